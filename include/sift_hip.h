@@ -1,0 +1,144 @@
+/*
+ * sift_hip.h — C ABI of the MI355X-native SIFT hot path (libsift_hip.so).
+ *
+ * This is the drop-in boundary for snowiow/SIFT's `sift::Sift::calculate()`
+ * (/root/reference/sift.hpp:78, sift.cpp:19-57; the only caller is main.cpp:56-57).
+ * Everything the reference does between receiving the greyscale float image and returning the
+ * `std::vector<InterestPoint>` — Gaussian pyramid, DoG, scale-space extrema, edge-response
+ * filter, gradient maps, orientation assignment, descriptors (sift.cpp + algorithms.cpp, which
+ * the reference runs through Vigra on one CPU thread) — runs here as hand-written HIP kernels
+ * for gfx950.  Plain pointers and sizes only; no C++ or torch types cross this boundary.  The
+ * C++ `sift::Sift` class in include/sift/sift.hpp and the Python mirror in sift_amd/ are thin
+ * hosts above these entry points.
+ *
+ * Image layout everywhere: float32, x fastest, img(x, y) = data[x + y*w] — the layout of the
+ * reference's vigra::MultiArray<2, float>.  Batches are n such frames back to back.
+ *
+ * Error model (reference: C++ exceptions out of calculate(), sift.cpp / Vigra preconditions):
+ * every call returns a status; SIFT_HIP_EPRECONDITION carries the text of the
+ * vigra::PreconditionViolation the reference would have thrown (e.g.
+ * "separableConvolveY(): kernel longer than line") in `err`; SIFT_HIP_EASSERT stands for the
+ * reference's assert()s (sift.cpp:382-383).
+ */
+#ifndef SIFT_HIP_H
+#define SIFT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIFT_HIP_OK 0
+#define SIFT_HIP_EPRECONDITION 1 /* vigra::PreconditionViolation analogue, message in err */
+#define SIFT_HIP_EASSERT 2       /* reference assert(): octaves == 0 or dogsPerEpoch < 3 */
+#define SIFT_HIP_EINVAL 3        /* bad argument to this API */
+#define SIFT_HIP_EHIP 4          /* HIP runtime failure, message in err */
+
+typedef struct sift_hip_ctx sift_hip_ctx;
+
+/* Constructor arguments of sift::Sift (sift.hpp:66-71), same meaning and order of magnitude
+ * defaults: dogsPerEpoch 3, octaves 3, sigma 1.6, k sqrt(2), subpixel false. */
+typedef struct sift_hip_params {
+    uint16_t dogs_per_epoch;
+    uint16_t octaves;
+    float sigma;
+    float k;
+    uint8_t subpixel;
+    uint8_t reserved[3];
+} sift_hip_params;
+
+/* POD image of sift::InterestPoint (interestpoint.hpp:13-63) without the descriptor vector;
+ * descriptors travel as a separate n x 128 float array (all zero and has_descriptor == 0 for a
+ * point the descriptor stage filtered, sift.cpp:65-70). */
+typedef struct sift_hip_keypoint {
+    float scale;
+    float orientation;
+    uint16_t x, y;      /* loc, octave coordinates */
+    uint16_t octave;
+    uint16_t index;     /* DoG index inside the octave */
+    uint8_t filtered;
+    uint8_t has_descriptor;
+    uint16_t reserved;
+} sift_hip_keypoint;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+/* One context per GPU / worker thread (a Sift instance is not re-entrant either, sift.hpp:46-56). */
+int sift_hip_create(int device, sift_hip_ctx** out, char* err, int errlen);
+void sift_hip_destroy(sift_hip_ctx* ctx);
+/* Option knobs: "fused_blur" (1 default: LDS-tiled single-kernel blur; 0: two-pass row/col
+ * kernels), "profile" (1: bracket the pyramid kernels with HIP events). Returns EINVAL if unknown. */
+int sift_hip_set_option(sift_hip_ctx* ctx, const char* name, int value);
+
+/* ---- Sift::calculate(), replaces sift.cpp:19-57 ---------------------------------------------- */
+/* n frames of w x h from HOST memory.  Results stay in the context until the next calculate. */
+int sift_hip_calculate_batch(sift_hip_ctx* ctx, const float* host_imgs, int n, int w, int h,
+                             const sift_hip_params* params, char* err, int errlen);
+/* Same, frames already resident in DEVICE memory of ctx's GPU (not modified). */
+int sift_hip_calculate_batch_device(sift_hip_ctx* ctx, const void* dev_imgs, int n, int w, int h,
+                                    const sift_hip_params* params, char* err, int errlen);
+
+/* Per-image status of the last batch (an image that "threw" has count 0). */
+int sift_hip_result_status(sift_hip_ctx* ctx, int32_t* status /* n */);
+/* Number of returned InterestPoints per image, and their sum. */
+int sift_hip_result_counts(sift_hip_ctx* ctx, int32_t* counts /* n */);
+int64_t sift_hip_result_total(sift_hip_ctx* ctx);
+/* Copy results to host: keypoints concatenated in image order, descriptors 128 floats each. */
+int sift_hip_result_copy(sift_hip_ctx* ctx, sift_hip_keypoint* keypoints, float* descriptors);
+/* Device-resident packed results (valid until the next calculate) for a GPU-side gather. */
+int sift_hip_result_device(sift_hip_ctx* ctx, const void** dev_keypoints, const void** dev_descriptors);
+/* The image calculate() leaves in the caller's MultiArray: when params.subpixel it is the
+ * sigma=1 blurred, 2x nearest-upsampled frame (sift.cpp:20-21); dims of it, then the pixels. */
+int sift_hip_image_dims(sift_hip_ctx* ctx, int* w, int* h);
+int sift_hip_image_copy(sift_hip_ctx* ctx, int image, float* out);
+
+/* ---- inspection of the last batch (parity tests) ------------------------------------------------ */
+/* kind: 0 gaussian (levels 0..D), 1 dog (0..D-1), 2 magnitude, 3 orientation (initial gradient
+ * maps, sift.cpp:130-160, only for levels some keypoint scale selects; 0x0 otherwise). */
+int sift_hip_level_dims(sift_hip_ctx* ctx, int kind, int octave, int level, int* w, int* h);
+int sift_hip_level_copy(sift_hip_ctx* ctx, int image, int kind, int octave, int level, float* out);
+float sift_hip_level_scale(sift_hip_ctx* ctx, int kind, int octave, int level);
+/* stage: 0 extrema candidates with edge-response flags (sift.cpp:33-34), 1 after first cleanup
+ * (:37-42), 2 after orientation assignment (:46), 3 after second cleanup (:49-54), 4 returned. */
+int sift_hip_stage_count(sift_hip_ctx* ctx, int image, int stage);
+int sift_hip_stage_copy(sift_hip_ctx* ctx, int image, int stage, sift_hip_keypoint* out);
+
+/* ---- sift::alg operators (algorithms.cpp) on single host images, for known-answer tests -------- */
+/* Kernel1D::initGaussian taps as the host side computes them; returns radius, -1 on bad sigma. */
+int sift_hip_gauss_taps(float sigma, float* taps, int cap);
+/* alg::convolveWithGauss (algorithms.cpp:10-22) */
+int sift_hip_convolve_with_gauss(sift_hip_ctx* ctx, const float* in, int w, int h, float sigma,
+                                 float* out, char* err, int errlen);
+/* alg::reduceToNextLevel (:24-36) -> ((w+1)/2, (h+1)/2); alg::increaseToNextLevel (:38-49) -> (2w, 2h) */
+int sift_hip_reduce_to_next_level(sift_hip_ctx* ctx, const float* in, int w, int h, float sigma,
+                                  float* out, char* err, int errlen);
+int sift_hip_increase_to_next_level(sift_hip_ctx* ctx, const float* in, int w, int h, float sigma,
+                                    float* out, char* err, int errlen);
+/* alg::dog (:52-64) */
+int sift_hip_dog(sift_hip_ctx* ctx, const float* lower, const float* higher, int w, int h, float* out);
+/* alg::gradientMagnitude / gradientOrientation over a whole level (:108-116, sift.cpp:130-160) */
+int sift_hip_gradient(sift_hip_ctx* ctx, const float* in, int w, int h, float* mag, float* ori);
+/* Per-point body of Sift::_eliminateEdgeResponses (sift.cpp:295-345) for m points on one DoG
+ * triple; flags[i] = 1 if the reference would set filtered. */
+int sift_hip_edge_responses(sift_hip_ctx* ctx, const float* dog0, const float* dog1, const float* dog2,
+                            int w, int h, const uint16_t* xs, const uint16_t* ys, int m, uint8_t* flags);
+/* alg::vertexParabola (:153-178) for m triples (x coords u16, y values f32). */
+int sift_hip_vertex_parabola(sift_hip_ctx* ctx, const uint16_t* lnx, const float* lny, const uint16_t* px,
+                             const float* py, const uint16_t* rnx, const float* rny, int m, float* out);
+/* The cleanup step (sift.cpp:37-42): permutation std::sort(cmpByFilter) applies to n flags;
+ * perm[i] = original index of the element ending at position i. */
+int sift_hip_sort_by_filter(sift_hip_ctx* ctx, const uint8_t* flags, int n, int32_t* perm);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+/* HIP-event timings of the pyramid kernels collected while option "profile" is 1.
+ * which: 0 = fused blur(+DoG) kernel, 1 = everything else in the pyramid stage.
+ * Returns accumulated milliseconds, launches and ALGORITHMIC bytes since reset. */
+int sift_hip_profile_get(sift_hip_ctx* ctx, int which, double* ms, int64_t* launches, double* bytes);
+int sift_hip_profile_reset(sift_hip_ctx* ctx);
+
+const char* sift_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIFT_HIP_H */

@@ -319,8 +319,8 @@ inline unsigned qrTransformToTriangularImpl(MV r, MV rhs, MV hh, std::vector<lon
         }
         qrHouseholderStep(k, r, rhs, hh);
         const float nv = std::fabs(r(k, k));
-        maxSV = (nv > maxSV) ? nv : maxSV;  // maxss/minss (bin@0x41e7eb-0x41e7fb)
-        minSV = (nv < minSV) ? nv : minSV;
+        maxSV = (nv < maxSV) ? maxSV : nv;  // std::max(nv, maxSV) — maxss (bin@0x41e7eb)
+        minSV = (minSV < nv) ? minSV : nv;  // std::min(nv, minSV) — minss (bin@0x41e7fb)
         if (epsilon == 0.0) tolerance = (double)((float)m * maxSV * FLT_EPSILON);
         if ((double)minSV > tolerance)
             ++rank;

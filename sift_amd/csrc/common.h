@@ -1,0 +1,108 @@
+// Shared declarations between the HIP kernels and the host-side context of libsift_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sift_hip.h"
+
+namespace sift_hip {
+
+constexpr int kMaxOctaves = 16;
+constexpr int kMaxDogs = 16;                       // dogsPerEpoch upper bound of this build
+constexpr int kMaxLevels = kMaxOctaves * (kMaxDogs + 1);
+constexpr int kMaxRadiusFused = 32;                // blur radii with a fused LDS-tiled kernel
+constexpr int kRegion = 8;                         // sift.cpp:61,164 `region`
+
+// Extrema candidate as the scan emits it (order: octave, dog, x outer, y inner; sift.cpp:352-373)
+struct Candidate {
+    uint16_t x, y;
+    uint16_t octave, index;
+};
+static_assert(sizeof(Candidate) == 8, "Candidate packing");
+
+// Device-resident description of the current plan (one per context, uploaded when the plan
+// changes).  Level buffers hold all n images of the batch back to back.
+struct DevPlan {
+    int n_images;
+    int octaves, dogs;               // O, D  (levels per octave: D + 1 gaussians, D dogs)
+    int w[kMaxOctaves], h[kMaxOctaves];
+    float* gauss[kMaxLevels];        // [o * (D+1) + j]
+    float* dog[kMaxLevels];          // [o * D + j]
+    float* mag[kMaxLevels];          // gradient maps, null unless the level is selected
+    float* ori[kMaxLevels];
+    float* w16[kMaxLevels];          // n x 256: top-left 16x16 of convolveWithGauss(level, 1.6)
+    float gauss_scale[kMaxLevels];
+    float dog_scale[kMaxLevels];
+    // _findNearestGaussian(dog_scale[o*D+i]) for every (octave, dog): level id o'*(D+1)+i'
+    int nearest_level[kMaxLevels];
+    // radius of the dead 16x16 blur (sift.cpp:184) per (octave, dog); > 15 => the reference throws
+    int dead_blur_radius[kMaxLevels];
+    // extrema bitmask geometry: per scanned (octave, middle dog) "scan level" s
+    int n_scan;
+    int scan_octave[kMaxLevels], scan_dog[kMaxLevels];
+    int scan_nyb[kMaxLevels];        // 64-row blocks per column
+    int scan_word_base[kMaxLevels];  // first mask word of the level inside one image
+    int words_per_image;
+    long long cand_capacity;         // per image
+};
+
+#define SIFT_HIP_CHECK(expr)                                                        \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) throw ::sift_hip::HipError(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+struct HipError {
+    hipError_t code;
+    const char* expr;
+    const char* file;
+    int line;
+    HipError(hipError_t c, const char* e, const char* f, int l) : code(c), expr(e), file(f), line(l) {}
+};
+
+// ---- kernel launchers (defined in the .hip files) ------------------------------------------------
+// Pyramid
+void launch_blur(hipStream_t s, bool fused, const float* in, float* tmp, float* out, float* dog, int w,
+                 int h, int n, const float* d_taps, int radius);
+void launch_resample(hipStream_t s, const float* src, float* dst, int ws, int hs, int wd, int hd, int n,
+                     const int* d_lutx, const int* d_luty);
+void launch_dog(hipStream_t s, const float* lower, const float* higher, float* out, size_t count);
+// Extrema + edge responses
+void launch_extrema_mask(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan,
+                         unsigned long long* d_masks, int* d_counts);
+void launch_extrema_scan(hipStream_t s, const DevPlan& plan, int* d_counts, int* d_totals);
+void launch_extrema_expand(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan,
+                           const unsigned long long* d_masks, const int* d_offsets, Candidate* d_cands);
+void launch_edge_filter(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const Candidate* d_cands,
+                        const int* d_totals, uint8_t* d_flags);
+void launch_edge_filter_points(hipStream_t s, const float* d0, const float* d1, const float* d2, int w, int h,
+                               const uint16_t* xs, const uint16_t* ys, int m, uint8_t* flags);
+void launch_vertex_parabola(hipStream_t s, const uint16_t* lnx, const float* lny, const uint16_t* px,
+                            const float* py, const uint16_t* rnx, const float* rny, int m, float* out);
+// Gradient maps + orientation assignment
+void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, int w, int h, int n);
+
+struct OrientIn {            // one entry per keypoint entering _orientationAssignment
+    uint32_t cand;           // index into the image's candidate array
+};
+struct OrientOut {
+    float orientation;       // *peaks.begin()
+    uint16_t npeaks;         // peaks.size()
+    uint8_t filtered;        // border test (sift.cpp:173-178)
+    uint8_t throws;          // dead blur would throw (sift.cpp:184, radius > 15)
+};
+void launch_orientation(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const Candidate* d_cands,
+                        const uint32_t* d_list, const int* d_list_off, const int* d_list_cnt,
+                        int max_cnt, OrientOut* d_out, float* d_peaks);
+// Descriptors
+struct FinalKp {             // one entry per keypoint entering _createDecriptors, vector order
+    uint32_t cand;
+    float orientation;
+};
+void launch_w16(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level, const float* d_taps16,
+                int radius16);
+void launch_descriptors(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level,
+                        const Candidate* d_cands, const FinalKp* d_final, const int* d_final_off,
+                        const int* d_final_cnt, sift_hip_keypoint* d_kp_out, float* d_desc_out);
+
+}  // namespace sift_hip

@@ -1,0 +1,35 @@
+// CPU build of the product's scalar math headers (the same code the HIP kernels inline), so the
+// `-m "not gpu"` tests can check them against libm and against the oracle without a GPU.
+// Not part of libsift_hip.so and never used by the product path.
+#include <stdint.h>
+
+#include "fdlibm_atan2f.h"
+#include "linalg3.h"
+
+extern "C" {
+float hostmath_atan2f(float y, float x) { return sift_hip::fdlibm_atan2f(y, x); }
+void hostmath_atan2f_array(const float* y, const float* x, int n, float* out) {
+    for (int i = 0; i < n; ++i) out[i] = sift_hip::fdlibm_atan2f(y[i], x[i]);
+}
+// matrices row-fastest like vigra::Matrix: a[i + 3*j] = A(i, j)
+int hostmath_inverse3(const float* a, float* res) {
+    float A[3][3], R[3][3] = {};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) A[i][j] = a[i + 3 * j];
+    const bool ok = sift_hip::inverse3(A, R);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) res[i + 3 * j] = R[i][j];
+    return ok ? 1 : 0;
+}
+int hostmath_solve3(const float* a, const float* b, float* res) {
+    float A[3][3], B[3] = {b[0], b[1], b[2]}, R[3] = {0, 0, 0};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) A[i][j] = a[i + 3 * j];
+    const bool ok = sift_hip::solve3<true>(A, B, R);
+    res[0] = R[0]; res[1] = R[1]; res[2] = R[2];
+    return ok ? 1 : 0;
+}
+float hostmath_vertex_parabola(uint16_t lnx, float lny, uint16_t px, float py, uint16_t rnx, float rny) {
+    return sift_hip::vertex_parabola(lnx, lny, px, py, rnx, rny);
+}
+}
