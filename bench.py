@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Headline benchmark: keypoints/sec of the Sift::calculate() hot path on synthetic 1920x1080
+greyscale frames, 4 octaves x 3 DoGs (BASELINE.json metric / config 4's per-GPU share).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (launched by torch.distributed.run for N > 1).  A "step" is one pass of the
+whole hot path (pyramid, DoG, extrema, edge filter, orientation, descriptors) over one batch of
+FRAMES_PER_GPU device-resident frames per GPU; for N > 1 the step ends with the RCCL gather of the
+keypoint lists (records + descriptors, never images) on rank 0.  Weak scaling: per-GPU work is
+fixed.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from multiprocessing.pool import ThreadPool
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FRAMES_PER_GPU = 32          # BASELINE config 4: 256 frames over 8 GPUs
+W, H = 1920, 1080
+DOGS, OCTAVES, SIGMA = 3, 4, 1.6
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+CPU_SAMPLE_FRAMES = 8
+
+
+def cpu_baseline(frames):
+    """Oracle (lean mode: identical results to the reference, redundant copies hoisted) on a
+    bounded sample of the same workload, 1 thread."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    kps, secs = 0, 0.0
+    for f in frames:
+        run = O.OracleRun(f, DOGS, OCTAVES, SIGMA)
+        secs += run.seconds
+        kps += run.points("final")[0].size
+        run.close()
+    return {"value": kps / secs, "unit": "keypoints/s", "cores": 1, "kind": "port",
+            "sample": f"{len(frames)} of the {FRAMES_PER_GPU} synthetic 1920x1080 frames, 4 oct x 3 DoG, oracle in lean mode "
+                      f"(reference's per-candidate image copies and per-keypoint re-blur hoisted; same results), "
+                      f"{secs:.1f} s CPU, {kps} keypoints"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    import torch
+    import torch.distributed as dist
+    from sift_amd import _lib
+    from sift_amd.sift import Context, K_SQRT2
+    from sift_amd.synthetic import synth_frame
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    nf = args.frames
+    seeds = [rank * nf + i + 1 for i in range(nf)]  # config 4: seeds 1..256 block-sharded
+    with ThreadPool(min(8, os.cpu_count() or 1)) as pool:
+        frames = np.stack(pool.map(lambda s: synth_frame(W, H, s), seeds))
+    d_frames = torch.from_numpy(frames).to(dev)
+    torch.cuda.synchronize()
+
+    ctx = Context(local_rank)
+    params = _lib.Params(DOGS, OCTAVES, SIGMA, K_SQRT2, 0)
+    L = ctx._L
+
+    def step():
+        ctx.calculate_batch_device(d_frames.data_ptr(), nf, W, H, params)
+        total = ctx.total()
+        if world > 1:
+            # RCCL gather of the keypoint lists only: counts, then variable-size records + descriptors
+            cnt = torch.tensor([total], dtype=torch.int64, device=dev)
+            allc = torch.empty(world, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(allc, cnt)
+            allc = allc.tolist()
+            kp = torch.empty(max(total, 1) * 20, dtype=torch.uint8, device=dev)
+            desc = torch.empty(max(total, 1) * 128, dtype=torch.float32, device=dev)
+            if total:
+                L.sift_hip_result_copy(ctx._h, C.c_void_p(kp.data_ptr()), C.c_void_p(desc.data_ptr()))
+            if rank == 0:
+                bufs, ops = [], []
+                for r in range(1, world):
+                    if allc[r]:
+                        bk = torch.empty(allc[r] * 20, dtype=torch.uint8, device=dev)
+                        bd = torch.empty(allc[r] * 128, dtype=torch.float32, device=dev)
+                        bufs.append((bk, bd))
+                        ops += [dist.P2POp(dist.irecv, bk, r), dist.P2POp(dist.irecv, bd, r)]
+                if ops:
+                    for w_ in dist.batch_isend_irecv(ops):
+                        w_.wait()
+            elif total:
+                for w_ in dist.batch_isend_irecv([dist.P2POp(dist.isend, kp[:total * 20], 0),
+                                                  dist.P2POp(dist.isend, desc[:total * 128], 0)]):
+                    w_.wait()
+        return total
+
+    for _ in range(args.warmup):
+        step()
+    ctx.set_option("profile", 1)
+    ctx.profile_reset()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    kps = 0
+    for _ in range(args.steps):
+        kps += step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ctx.set_option("profile", 0)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        k = torch.tensor([kps], dtype=torch.int64, device=dev)
+        dist.all_reduce(k, op=dist.ReduceOp.SUM)
+        kps = int(k.item())
+
+    if rank == 0:
+        ms, launches, nbytes = ctx.profile(0)
+        achieved = (nbytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+        out = {
+            "metric": "keypoints/sec, 1920x1080 4oct/3DoG",
+            "value": kps / dt,
+            "unit": "keypoints/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"batch of {nf} synthetic 1920x1080 greyscale frames per GPU, sigma 1.6, k sqrt2, "
+                                   f"4 octaves x 3 DoGs, subpixel off (BASELINE config 4 per-GPU share)",
+                       "frames_per_gpu": nf, "frames_total": nf * world, "keypoints_per_step": kps // max(args.steps, 1),
+                       "frames_per_s": nf * world * args.steps / dt,
+                       "gather": "RCCL p2p of keypoint records + descriptors to rank 0" if world > 1 else "none (1 GPU)"},
+            "roofline": {"kernel": "blur_fused_kernel (separable Gaussian + DoG, all pyramid levels)",
+                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launches": launches, "avg_launch_ms": ms / launches if launches else None,
+                         "algorithmic_bytes_per_launch": nbytes / launches if launches else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames[:CPU_SAMPLE_FRAMES])
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

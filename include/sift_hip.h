@@ -83,7 +83,8 @@ int sift_hip_result_status(sift_hip_ctx* ctx, int32_t* status /* n */);
 /* Number of returned InterestPoints per image, and their sum. */
 int sift_hip_result_counts(sift_hip_ctx* ctx, int32_t* counts /* n */);
 int64_t sift_hip_result_total(sift_hip_ctx* ctx);
-/* Copy results to host: keypoints concatenated in image order, descriptors 128 floats each. */
+/* Copy results (keypoints concatenated in image order, descriptors 128 floats each) to caller
+ * buffers, which may be host or device memory. */
 int sift_hip_result_copy(sift_hip_ctx* ctx, sift_hip_keypoint* keypoints, float* descriptors);
 /* Device-resident packed results (valid until the next calculate) for a GPU-side gather. */
 int sift_hip_result_device(sift_hip_ctx* ctx, const void** dev_keypoints, const void** dev_descriptors);

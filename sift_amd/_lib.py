@@ -1,0 +1,90 @@
+"""ctypes binding of libsift_hip.so — the C ABI declared in include/sift_hip.h.
+
+There is no fallback: if the HIP library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsift_hip.so")
+
+OK, EPRECONDITION, EASSERT, EINVAL, EHIP = 0, 1, 2, 3, 4
+
+# every symbol include/sift_hip.h declares
+SYMBOLS = [
+    "sift_hip_create", "sift_hip_destroy", "sift_hip_set_option", "sift_hip_calculate_batch",
+    "sift_hip_calculate_batch_device", "sift_hip_result_status", "sift_hip_result_counts",
+    "sift_hip_result_total", "sift_hip_result_copy", "sift_hip_result_device", "sift_hip_image_dims",
+    "sift_hip_image_copy", "sift_hip_level_dims", "sift_hip_level_copy", "sift_hip_level_scale",
+    "sift_hip_stage_count", "sift_hip_stage_copy", "sift_hip_gauss_taps", "sift_hip_convolve_with_gauss",
+    "sift_hip_reduce_to_next_level", "sift_hip_increase_to_next_level", "sift_hip_dog", "sift_hip_gradient",
+    "sift_hip_edge_responses", "sift_hip_vertex_parabola", "sift_hip_sort_by_filter", "sift_hip_profile_get",
+    "sift_hip_profile_reset", "sift_hip_version",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("dogs_per_epoch", C.c_uint16), ("octaves", C.c_uint16), ("sigma", C.c_float),
+                ("k", C.c_float), ("subpixel", C.c_uint8), ("reserved", C.c_uint8 * 3)]
+
+
+KEYPOINT_DTYPE = np.dtype([("scale", "<f4"), ("orientation", "<f4"), ("x", "<u2"), ("y", "<u2"),
+                           ("octave", "<u2"), ("index", "<u2"), ("filtered", "u1"),
+                           ("has_descriptor", "u1"), ("reserved", "<u2")])
+assert KEYPOINT_DTYPE.itemsize == 20
+
+_lib = None
+
+
+def load():
+    """Load libsift_hip.so and declare prototypes.  Raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the HIP path)")
+    L = C.CDLL(LIB_PATH)
+    fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
+    u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+    i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+    vp, ip, cs, ci = C.c_void_p, C.POINTER(C.c_int), C.c_char_p, C.c_int
+    L.sift_hip_version.restype = C.c_char_p
+    L.sift_hip_create.argtypes = [ci, C.POINTER(vp), cs, ci]
+    L.sift_hip_destroy.argtypes = [vp]
+    L.sift_hip_destroy.restype = None
+    L.sift_hip_set_option.argtypes = [vp, cs, ci]
+    L.sift_hip_calculate_batch.argtypes = [vp, fp, ci, ci, ci, C.POINTER(Params), cs, ci]
+    L.sift_hip_calculate_batch_device.argtypes = [vp, vp, ci, ci, ci, C.POINTER(Params), cs, ci]
+    L.sift_hip_result_status.argtypes = [vp, i32p]
+    L.sift_hip_result_counts.argtypes = [vp, i32p]
+    L.sift_hip_result_total.argtypes = [vp]
+    L.sift_hip_result_total.restype = C.c_int64
+    L.sift_hip_result_copy.argtypes = [vp, vp, vp]
+    L.sift_hip_result_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.sift_hip_image_dims.argtypes = [vp, ip, ip]
+    L.sift_hip_image_copy.argtypes = [vp, ci, fp]
+    L.sift_hip_level_dims.argtypes = [vp, ci, ci, ci, ip, ip]
+    L.sift_hip_level_copy.argtypes = [vp, ci, ci, ci, ci, fp]
+    L.sift_hip_level_scale.argtypes = [vp, ci, ci, ci]
+    L.sift_hip_level_scale.restype = C.c_float
+    L.sift_hip_stage_count.argtypes = [vp, ci, ci]
+    L.sift_hip_stage_copy.argtypes = [vp, ci, ci, vp]
+    L.sift_hip_gauss_taps.argtypes = [C.c_float, fp, ci]
+    L.sift_hip_convolve_with_gauss.argtypes = [vp, fp, ci, ci, C.c_float, fp, cs, ci]
+    L.sift_hip_reduce_to_next_level.argtypes = [vp, fp, ci, ci, C.c_float, fp, cs, ci]
+    L.sift_hip_increase_to_next_level.argtypes = [vp, fp, ci, ci, C.c_float, fp, cs, ci]
+    L.sift_hip_dog.argtypes = [vp, fp, fp, ci, ci, fp]
+    L.sift_hip_gradient.argtypes = [vp, fp, ci, ci, fp, fp]
+    L.sift_hip_edge_responses.argtypes = [vp, fp, fp, fp, ci, ci, u16p, u16p, ci, u8p]
+    L.sift_hip_vertex_parabola.argtypes = [vp, u16p, fp, u16p, fp, u16p, fp, ci, fp]
+    L.sift_hip_sort_by_filter.argtypes = [vp, u8p, ci, i32p]
+    L.sift_hip_profile_get.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    L.sift_hip_profile_reset.argtypes = [vp]
+    _lib = L
+    return L

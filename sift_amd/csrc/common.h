@@ -60,14 +60,29 @@ struct HipError {
     HipError(hipError_t c, const char* e, const char* f, int l) : code(c), expr(e), file(f), line(l) {}
 };
 
+// ---- records exchanged between host glue and kernels ------------------------------------------
+struct OrientOut {           // per keypoint entering _orientationAssignment
+    float orientation;       // *peaks.begin()
+    uint16_t npeaks;         // peaks.size()
+    uint8_t filtered;        // border test (sift.cpp:173-178)
+    uint8_t throws;          // dead blur would throw (sift.cpp:184): 0 no, 1 kernel longer, 2 sigma < 0
+};
+static_assert(sizeof(OrientOut) == 8, "OrientOut packing");
+
+struct FinalKp {             // one entry per keypoint entering _createDecriptors, vector order
+    uint32_t cand;
+    float orientation;
+    uint16_t x, y;
+    uint16_t octave, index;
+};
+static_assert(sizeof(FinalKp) == 16, "FinalKp packing");
+
 // ---- kernel launchers (defined in the .hip files) ------------------------------------------------
-// Pyramid
 void launch_blur(hipStream_t s, bool fused, const float* in, float* tmp, float* out, float* dog, int w,
                  int h, int n, const float* d_taps, int radius);
 void launch_resample(hipStream_t s, const float* src, float* dst, int ws, int hs, int wd, int hd, int n,
                      const int* d_lutx, const int* d_luty);
 void launch_dog(hipStream_t s, const float* lower, const float* higher, float* out, size_t count);
-// Extrema + edge responses
 void launch_extrema_mask(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan,
                          unsigned long long* d_masks, int* d_counts);
 void launch_extrema_scan(hipStream_t s, const DevPlan& plan, int* d_counts, int* d_totals);
@@ -79,30 +94,13 @@ void launch_edge_filter_points(hipStream_t s, const float* d0, const float* d1, 
                                const uint16_t* xs, const uint16_t* ys, int m, uint8_t* flags);
 void launch_vertex_parabola(hipStream_t s, const uint16_t* lnx, const float* lny, const uint16_t* px,
                             const float* py, const uint16_t* rnx, const float* rny, int m, float* out);
-// Gradient maps + orientation assignment
 void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, int w, int h, int n);
-
-struct OrientIn {            // one entry per keypoint entering _orientationAssignment
-    uint32_t cand;           // index into the image's candidate array
-};
-struct OrientOut {
-    float orientation;       // *peaks.begin()
-    uint16_t npeaks;         // peaks.size()
-    uint8_t filtered;        // border test (sift.cpp:173-178)
-    uint8_t throws;          // dead blur would throw (sift.cpp:184, radius > 15)
-};
 void launch_orientation(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const Candidate* d_cands,
-                        const uint32_t* d_list, const int* d_list_off, const int* d_list_cnt,
-                        int max_cnt, OrientOut* d_out, float* d_peaks);
-// Descriptors
-struct FinalKp {             // one entry per keypoint entering _createDecriptors, vector order
-    uint32_t cand;
-    float orientation;
-};
-void launch_w16(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level, const float* d_taps16,
-                int radius16);
+                        const uint32_t* d_list, const int* d_list_cnt, int list_cap, int max_cnt,
+                        OrientOut* d_out, float* d_peaks);
+void launch_w16(hipStream_t s, const DevPlan& plan, int level, const float* d_taps16, int radius16);
 void launch_descriptors(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level,
-                        const Candidate* d_cands, const FinalKp* d_final, const int* d_final_off,
-                        const int* d_final_cnt, sift_hip_keypoint* d_kp_out, float* d_desc_out);
+                        const FinalKp* d_final, const int* d_final_cnt, int final_cap,
+                        const long long* d_out_base, sift_hip_keypoint* d_kp_out, float* d_desc_out);
 
 }  // namespace sift_hip

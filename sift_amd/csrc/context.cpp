@@ -1,0 +1,1036 @@
+// libsift_hip.so host side: context, plan (pyramid geometry, scale schedule, tap tables), stage
+// orchestration of Sift::calculate() (/root/reference/sift.cpp:19-57) and the C ABI of
+// include/sift_hip.h.  All per-pixel and per-keypoint arithmetic runs in the HIP kernels; the
+// host keeps only the reference's order-defining glue (std::sort cleanup, u16 truncation,
+// appending extra orientation peaks).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+#include "host_glue.h"
+
+using namespace sift_hip;
+
+namespace {
+
+constexpr int kListCap = 65536;  // cleanup keeps at most 65535 points (u16_t size, sift.cpp:41)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) SIFT_HIP_CHECK(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        SIFT_HIP_CHECK(hipMalloc(&p, bytes));
+        cap = bytes;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct HostBuf {  // pinned
+    void* p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) SIFT_HIP_CHECK(hipHostFree(p));
+        p = nullptr;
+        cap = 0;
+        SIFT_HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+        cap = bytes;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct BlurOp {       // one alg::convolveWithGauss of the pyramid
+    int kind;         // 0 subpixel pre-blur, 1 g(0,0), 2 level blur (+DoG), 3 reduce blur
+    int octave, j;    // destination level for kind 2; source octave for kind 3
+    float sigma;
+    int radius;
+    size_t tap_off;   // float offset into the tap table
+    int w, h;         // image size the blur runs on
+};
+
+struct PointRec {     // host mirror of one vector<InterestPoint> element between stages
+    uint32_t cand;
+    float orientation;
+    uint8_t filtered;
+};
+
+struct Plan {
+    bool valid = false;
+    int n = 0, in_w = 0, in_h = 0;
+    sift_hip_params params{};
+    int bw = 0, bh = 0;  // base image (after optional 2x upsampling)
+    int O = 0, D = 0;
+    DevPlan dev{};
+    std::vector<BlurOp> ops;
+    std::vector<float> taps;          // all tap tables back to back
+    std::vector<int> luts;            // all index maps back to back
+    std::vector<size_t> lut_x_off, lut_y_off;  // per octave transition (index o -> o+1); [O] = subpixel
+    int fail_status = 0;              // plan-time precondition failure (depends only on sizes/params)
+    size_t fail_op = (size_t)-1;      // first op that cannot run
+    std::string fail_msg;
+    std::vector<int> grad_levels;     // levels some keypoint scale selects
+    std::vector<float> taps16;        // taps of convolveWithGauss(level, 1.6f) (sift.cpp:87)
+    int radius16 = 0;
+    size_t max_level_floats = 0;      // per image, largest level
+};
+
+}  // namespace
+
+struct sift_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool fused = true;
+    bool profile = false;
+    int host_threads = 0;
+    Plan plan;
+    DevBuf arena, d_plan, d_taps, d_luts, d_taps16, d_input, d_base, d_tmp, d_tmp2;
+    DevBuf d_masks, d_counts, d_totals, d_cands, d_flags;
+    DevBuf d_list, d_list_cnt, d_orient, d_peaks, d_final, d_final_cnt, d_out_base, d_kp, d_desc;
+    HostBuf h_flags, h_orient, h_peaks;
+    // results of the last batch
+    std::vector<int32_t> status, counts;
+    std::vector<std::string> messages;
+    std::vector<int> totals;                            // candidates per image
+    std::vector<size_t> flag_off;                       // offset of image's flags in h_flags
+    std::vector<std::vector<uint32_t>> list1;           // after first cleanup
+    std::vector<std::vector<PointRec>> after_orient;    // after _orientationAssignment
+    std::vector<std::vector<PointRec>> final_list;      // after second cleanup
+    std::vector<long long> out_base;
+    long long total = 0;
+    bool have_result = false;
+    bool have_pyramid = false;
+    // profiling
+    struct EvPair { hipEvent_t a, b; int which; double bytes; };
+    std::vector<EvPair> pending;
+    std::vector<hipEvent_t> event_pool;
+    double prof_ms[2] = {0, 0};
+    long long prof_launches[2] = {0, 0};
+    double prof_bytes[2] = {0, 0};
+};
+
+namespace {
+
+void set_err(char* err, int errlen, const std::string& msg) {
+    if (err && errlen > 0) {
+        std::snprintf(err, (size_t)errlen, "%s", msg.c_str());
+    }
+}
+
+std::string precondition(const char* text) { return std::string("Precondition violation!\n") + text; }
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+hipEvent_t get_event(sift_hip_ctx* c) {
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    SIFT_HIP_CHECK(hipEventCreate(&e));
+    return e;
+}
+
+void resolve_events(sift_hip_ctx* c) {
+    for (auto& p : c->pending) {
+        float ms = 0;
+        SIFT_HIP_CHECK(hipEventSynchronize(p.b));
+        SIFT_HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
+        c->prof_ms[p.which] += ms;
+        c->prof_launches[p.which] += 1;
+        c->prof_bytes[p.which] += p.bytes;
+        c->event_pool.push_back(p.a);
+        c->event_pool.push_back(p.b);
+    }
+    c->pending.clear();
+}
+
+// Blur with optional event bracket.  Algorithmic bytes: 4 B read + 4 B written per
+// pixel, + 4 B when the DoG is written too.
+void run_blur(sift_hip_ctx* c, const float* in, float* out, float* dog, int w, int h, int n, size_t tap_off,
+              int radius) {
+    const bool is_fused = c->fused && radius >= 1 && radius <= kMaxRadiusFused;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (c->profile) {
+        a = get_event(c);
+        b = get_event(c);
+        SIFT_HIP_CHECK(hipEventRecord(a, c->stream));
+    }
+    launch_blur(c->stream, c->fused, in, c->d_tmp.as<float>(), out, dog, w, h, n, c->d_taps.as<float>() + tap_off,
+                radius);
+    if (c->profile) {
+        SIFT_HIP_CHECK(hipEventRecord(b, c->stream));
+        const double px = (double)w * (double)h * (double)n;
+        c->pending.push_back({a, b, is_fused ? 0 : 1, px * (dog ? 12.0 : 8.0)});
+    }
+}
+
+// ---- plan -------------------------------------------------------------------------------------------
+// Mirrors Sift::_createDOGs' scale schedule (sift.cpp:388-411) and every Vigra precondition the
+// pyramid can trip, in execution order.
+int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm, std::string& msg) {
+    Plan& P = c->plan;
+    if (P.valid && P.n == n && P.in_w == w && P.in_h == h && std::memcmp(&P.params, &prm, sizeof(prm)) == 0)
+        return SIFT_HIP_OK;
+    P = Plan();
+    if (n <= 0 || w <= 0 || h <= 0 || w >= 32768 || h >= 32768) {  // i16 loop counters, sift.cpp:354-355
+        msg = "sift_hip: bad batch geometry";
+        return SIFT_HIP_EINVAL;
+    }
+    if (!(prm.octaves > 0)) { msg = "Assertion `_octaves > 0' failed."; return SIFT_HIP_EASSERT; }
+    if (!(prm.dogs_per_epoch >= 3)) { msg = "Assertion `_dogsPerEpoch >= 3' failed."; return SIFT_HIP_EASSERT; }
+    if (prm.octaves > kMaxOctaves || prm.dogs_per_epoch > kMaxDogs) {
+        msg = "sift_hip: this build supports at most 16 octaves and 16 DoGs per octave";
+        return SIFT_HIP_EINVAL;
+    }
+    P.n = n; P.in_w = w; P.in_h = h; P.params = prm;
+    const int O = P.O = prm.octaves, D = P.D = prm.dogs_per_epoch;
+    DevPlan& dv = P.dev;
+    std::memset(&dv, 0, sizeof(dv));
+    dv.n_images = n; dv.octaves = O; dv.dogs = D;
+
+    auto add_taps = [&](float sigma, int& radius, size_t& off) -> int {
+        std::vector<float> t;
+        if (!gauss_taps(sigma, t, radius)) return 2;
+        off = P.taps.size();
+        P.taps.insert(P.taps.end(), t.begin(), t.end());
+        return 0;
+    };
+    auto fail = [&](const std::string& m) {
+        if (P.fail_status == 0) {
+            P.fail_status = SIFT_HIP_EPRECONDITION;
+            P.fail_op = P.ops.size();
+            P.fail_msg = m;
+        }
+    };
+    // returns false when the op cannot run (precondition)
+    auto add_blur = [&](int kind, int o, int j, float sigma, int bw, int bh) -> bool {
+        BlurOp op{kind, o, j, sigma, 0, 0, bw, bh};
+        if (add_taps(sigma, op.radius, op.tap_off) != 0) {
+            fail(precondition("Kernel1D::initGaussian(): Standard deviation must be >= 0."));
+            return false;
+        }
+        if (!(bw >= op.radius + 1)) { fail(precondition("separableConvolveX(): kernel longer than line\n")); return false; }
+        if (!(bh >= op.radius + 1)) { fail(precondition("separableConvolveY(): kernel longer than line\n")); return false; }
+        P.ops.push_back(op);
+        return true;
+    };
+    auto add_lut = [&](int ws, int hs, int wd, int hd, size_t& xo, size_t& yo) -> bool {
+        if (!(ws > 1 && hs > 1)) { fail(precondition("resizeImageNoInterpolation(): Source image too small.\n")); return false; }
+        if (!(wd > 1 && hd > 1)) { fail(precondition("resizeImageNoInterpolation(): Destination image too small.\n")); return false; }
+        const std::vector<int> lx = resize_index_map(ws, wd), ly = resize_index_map(hs, hd);
+        xo = P.luts.size();
+        P.luts.insert(P.luts.end(), lx.begin(), lx.end());
+        yo = P.luts.size();
+        P.luts.insert(P.luts.end(), ly.begin(), ly.end());
+        return true;
+    };
+
+    P.lut_x_off.assign((size_t)O + 1, 0);
+    P.lut_y_off.assign((size_t)O + 1, 0);
+    P.bw = w; P.bh = h;
+    bool ok = true;
+    if (prm.subpixel) {  // sift.cpp:20-21: increaseToNextLevel(img, 1.0)
+        ok = add_blur(0, 0, 0, 1.0f, w, h) && add_lut(w, h, 2 * w, 2 * h, P.lut_x_off[(size_t)O], P.lut_y_off[(size_t)O]);
+        if (ok) { P.bw = 2 * w; P.bh = 2 * h; }
+    }
+    for (int o = 0; o < O; ++o) {
+        dv.w[o] = o == 0 ? P.bw : (dv.w[o - 1] + 1) / 2;
+        dv.h[o] = o == 0 ? P.bh : (dv.h[o - 1] + 1) / 2;
+    }
+    // scale schedule, sift.cpp:388-411 (u16 exp, pow in double, product with float sigma in double)
+    {
+        dv.gauss_scale[0] = prm.sigma;
+        uint16_t exp = 0;
+        for (int i = 0; i < O; ++i) {
+            for (int j = 1; j < D + 1; ++j) {
+                const float scale = (float)(std::pow((double)prm.k, (double)exp) * (double)prm.sigma);
+                dv.gauss_scale[i * (D + 1) + j] = scale;
+                dv.dog_scale[i * D + j - 1] = scale - dv.gauss_scale[i * (D + 1) + j - 1];
+                exp++;
+            }
+            if (i < O - 1) {
+                dv.gauss_scale[(i + 1) * (D + 1)] = dv.gauss_scale[i * (D + 1) + D - 1];
+                exp -= 2;
+            }
+        }
+    }
+    if (ok) ok = add_blur(1, 0, 0, prm.sigma, dv.w[0], dv.h[0]);
+    for (int o = 0; o < O && ok; ++o) {
+        for (int j = 1; j < D + 1 && ok; ++j) ok = add_blur(2, o, j, dv.gauss_scale[o * (D + 1) + j], dv.w[o], dv.h[o]);
+        if (ok && o < O - 1) {
+            ok = add_blur(3, o, D - 1, dv.gauss_scale[o * (D + 1) + D - 1], dv.w[o], dv.h[o]) &&
+                 add_lut(dv.w[o], dv.h[o], dv.w[o + 1], dv.h[o + 1], P.lut_x_off[(size_t)o], P.lut_y_off[(size_t)o]);
+        }
+    }
+    // _findNearestGaussian for every DoG scale (sift.cpp:205-218); dead 16x16 blur (sift.cpp:184)
+    for (int o = 0; o < O; ++o)
+        for (int i = 0; i < D; ++i) {
+            const float scale = dv.dog_scale[o * D + i];
+            float lowest = 100;
+            int best = 0;
+            for (int oo = 0; oo < O; ++oo)
+                for (int ii = 0; ii < D + 1; ++ii) {
+                    const float cur = std::abs(dv.gauss_scale[oo * (D + 1) + ii] - scale);
+                    if (cur < lowest) { lowest = cur; best = oo * (D + 1) + ii; }
+                }
+            dv.nearest_level[o * D + i] = best;
+            const float s = (float)(1.5 * (double)scale);
+            std::vector<float> t;
+            int r = 0;
+            if (!gauss_taps(s, t, r)) dv.dead_blur_radius[o * D + i] = 2;
+            else dv.dead_blur_radius[o * D + i] = (16 >= r + 1) ? 0 : 1;
+        }
+    // scanned DoG levels and mask geometry
+    dv.n_scan = 0;
+    int words = 0;
+    long long cap = 0;
+    for (int o = 0; o < O; ++o)
+        for (int i = 1; i < D - 1; ++i) {
+            const int s = dv.n_scan++;
+            dv.scan_octave[s] = o; dv.scan_dog[s] = i;
+            dv.scan_nyb[s] = (dv.h[o] + 63) / 64;
+            dv.scan_word_base[s] = words;
+            words += dv.w[o] * dv.scan_nyb[s];
+            cap += (long long)std::max(0, dv.w[o] - 2) * (long long)std::max(0, dv.h[o] - 2);
+            if (std::find(P.grad_levels.begin(), P.grad_levels.end(), dv.nearest_level[o * D + i]) == P.grad_levels.end())
+                P.grad_levels.push_back(dv.nearest_level[o * D + i]);
+        }
+    dv.words_per_image = std::max(words, 1);
+    dv.cand_capacity = std::max(cap, 1LL);
+    gauss_taps(1.6f, P.taps16, P.radius16);
+
+    // ---- device memory ----------------------------------------------------------------------------
+    size_t total = 0;
+    std::vector<size_t> goff((size_t)O * (D + 1)), doff((size_t)O * D), moff(P.grad_levels.size()), ooff(P.grad_levels.size()), woff(P.grad_levels.size());
+    P.max_level_floats = (size_t)std::max(w * (size_t)h, (size_t)P.bw * (size_t)P.bh);
+    auto carve = [&](size_t floats) { const size_t o = total; total = align_up(total + floats * sizeof(float), 256); return o; };
+    for (int o = 0; o < O; ++o) {
+        const size_t px = (size_t)dv.w[o] * (size_t)dv.h[o] * (size_t)n;
+        for (int j = 0; j < D + 1; ++j) goff[(size_t)(o * (D + 1) + j)] = carve(px);
+        for (int j = 0; j < D; ++j) doff[(size_t)(o * D + j)] = carve(px);
+    }
+    for (size_t g = 0; g < P.grad_levels.size(); ++g) {
+        const int o = P.grad_levels[g] / (D + 1);
+        const size_t px = (size_t)dv.w[o] * (size_t)dv.h[o] * (size_t)n;
+        moff[g] = carve(px);
+        ooff[g] = carve(px);
+        woff[g] = carve((size_t)256 * (size_t)n);
+    }
+    c->arena.ensure(total);
+    char* base = c->arena.as<char>();
+    for (size_t l = 0; l < goff.size(); ++l) dv.gauss[l] = reinterpret_cast<float*>(base + goff[l]);
+    for (size_t l = 0; l < doff.size(); ++l) dv.dog[l] = reinterpret_cast<float*>(base + doff[l]);
+    for (size_t g = 0; g < P.grad_levels.size(); ++g) {
+        dv.mag[P.grad_levels[g]] = reinterpret_cast<float*>(base + moff[g]);
+        dv.ori[P.grad_levels[g]] = reinterpret_cast<float*>(base + ooff[g]);
+        dv.w16[P.grad_levels[g]] = reinterpret_cast<float*>(base + woff[g]);
+    }
+    const size_t lvl_bytes = P.max_level_floats * (size_t)n * sizeof(float);
+    c->d_tmp.ensure(lvl_bytes);
+    c->d_tmp2.ensure(lvl_bytes);
+    if (prm.subpixel) c->d_base.ensure((size_t)P.bw * (size_t)P.bh * (size_t)n * sizeof(float));
+    c->d_plan.ensure(sizeof(DevPlan));
+    c->d_taps.ensure(std::max<size_t>(P.taps.size(), 1) * sizeof(float));
+    c->d_luts.ensure(std::max<size_t>(P.luts.size(), 1) * sizeof(int));
+    c->d_taps16.ensure(P.taps16.size() * sizeof(float));
+    SIFT_HIP_CHECK(hipMemcpyAsync(c->d_plan.p, &dv, sizeof(DevPlan), hipMemcpyHostToDevice, c->stream));
+    if (!P.taps.empty())
+        SIFT_HIP_CHECK(hipMemcpyAsync(c->d_taps.p, P.taps.data(), P.taps.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (!P.luts.empty())
+        SIFT_HIP_CHECK(hipMemcpyAsync(c->d_luts.p, P.luts.data(), P.luts.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    SIFT_HIP_CHECK(hipMemcpyAsync(c->d_taps16.p, P.taps16.data(), P.taps16.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    const size_t nw = (size_t)dv.words_per_image * (size_t)n;
+    c->d_masks.ensure(nw * sizeof(unsigned long long));
+    c->d_counts.ensure(nw * sizeof(int));
+    c->d_totals.ensure((size_t)n * sizeof(int));
+    c->d_cands.ensure((size_t)dv.cand_capacity * (size_t)n * sizeof(Candidate));
+    c->d_flags.ensure((size_t)dv.cand_capacity * (size_t)n);
+    c->d_list.ensure((size_t)kListCap * (size_t)n * sizeof(uint32_t));
+    c->d_list_cnt.ensure((size_t)n * sizeof(int));
+    c->d_orient.ensure((size_t)kListCap * (size_t)n * sizeof(OrientOut));
+    c->d_peaks.ensure((size_t)kListCap * (size_t)n * 36 * sizeof(float));
+    c->d_final.ensure((size_t)kListCap * (size_t)n * sizeof(FinalKp));
+    c->d_final_cnt.ensure((size_t)n * sizeof(int));
+    c->d_out_base.ensure((size_t)n * sizeof(long long));
+    SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
+    P.valid = true;
+    return SIFT_HIP_OK;
+}
+
+// ---- pyramid (Sift::_createDOGs, sift.cpp:381-417) ---------------------------------------------
+void run_pyramid(sift_hip_ctx* c, const float* d_in) {
+    Plan& P = c->plan;
+    const DevPlan& dv = P.dev;
+    const int n = P.n, O = P.O, D = P.D;
+    const float* base = d_in;
+    for (size_t k = 0; k < P.ops.size(); ++k) {
+        if (k >= P.fail_op) break;
+        const BlurOp& op = P.ops[k];
+        switch (op.kind) {
+            case 0: {  // increaseToNextLevel(img, 1.0): blur then 2x nearest upsample
+                run_blur(c, d_in, c->d_tmp2.as<float>(), nullptr, op.w, op.h, n, op.tap_off, op.radius);
+                launch_resample(c->stream, c->d_tmp2.as<float>(), c->d_base.as<float>(), op.w, op.h, P.bw, P.bh, n,
+                                c->d_luts.as<int>() + P.lut_x_off[(size_t)O], c->d_luts.as<int>() + P.lut_y_off[(size_t)O]);
+                base = c->d_base.as<float>();
+                break;
+            }
+            case 1:
+                run_blur(c, base, dv.gauss[0], nullptr, op.w, op.h, n, op.tap_off, op.radius);
+                break;
+            case 2: {
+                const int l = op.octave * (D + 1) + op.j;
+                run_blur(c, dv.gauss[l - 1], dv.gauss[l], dv.dog[op.octave * D + op.j - 1], op.w, op.h, n, op.tap_off, op.radius);
+                break;
+            }
+            case 3: {  // reduceToNextLevel(g(o, D-1), g(o, D-1).scale)
+                const int o = op.octave;
+                run_blur(c, dv.gauss[o * (D + 1) + D - 1], c->d_tmp2.as<float>(), nullptr, op.w, op.h, n, op.tap_off, op.radius);
+                launch_resample(c->stream, c->d_tmp2.as<float>(), dv.gauss[(o + 1) * (D + 1)], dv.w[o], dv.h[o], dv.w[o + 1],
+                                dv.h[o + 1], n, c->d_luts.as<int>() + P.lut_x_off[(size_t)o], c->d_luts.as<int>() + P.lut_y_off[(size_t)o]);
+                break;
+            }
+        }
+    }
+}
+
+struct Cleanup1Arg { sift_hip_ctx* c; };
+void cleanup1_fn(int img, void* a) {
+    sift_hip_ctx* c = static_cast<Cleanup1Arg*>(a)->c;
+    cleanup_survivors(c->h_flags.as<uint8_t>() + c->flag_off[(size_t)img], c->totals[(size_t)img], c->list1[(size_t)img]);
+}
+
+struct Cleanup2Arg { sift_hip_ctx* c; };
+void cleanup2_fn(int img, void* a) {
+    sift_hip_ctx* c = static_cast<Cleanup2Arg*>(a)->c;
+    const Plan& P = c->plan;
+    const std::vector<uint32_t>& l1 = c->list1[(size_t)img];
+    std::vector<PointRec>& ao = c->after_orient[(size_t)img];
+    std::vector<PointRec>& fin = c->final_list[(size_t)img];
+    ao.clear();
+    fin.clear();
+    const OrientOut* oo = c->h_orient.as<OrientOut>() + (size_t)img * kListCap;
+    const float* pk = c->h_peaks.as<float>() ? c->h_peaks.as<float>() + (size_t)img * kListCap * 36 : nullptr;
+    // sift.cpp:168-178, 184: a point past the border test whose dead blur cannot run throws
+    for (size_t k = 0; k < l1.size(); ++k) {
+        if (!oo[k].filtered && oo[k].throws) {
+            c->status[(size_t)img] = SIFT_HIP_EPRECONDITION;
+            c->messages[(size_t)img] = oo[k].throws == 2
+                ? precondition("Kernel1D::initGaussian(): Standard deviation must be >= 0.")
+                : precondition("separableConvolveX(): kernel longer than line\n");
+            return;
+        }
+    }
+    ao.reserve(l1.size());
+    std::vector<PointRec> additional;
+    for (size_t k = 0; k < l1.size(); ++k) {
+        PointRec p{l1[k], oo[k].orientation, oo[k].filtered};
+        ao.push_back(p);
+        if (!oo[k].filtered && oo[k].npeaks > 1 && pk) {
+            // sift.cpp:194-199: `peaks.begin()++` yields begin(), so every peak is appended
+            for (int j = 0; j < oo[k].npeaks; ++j) additional.push_back(PointRec{l1[k], pk[k * 36 + (size_t)j], 0});
+        }
+    }
+    ao.insert(ao.end(), additional.begin(), additional.end());
+    std::vector<uint8_t> flags(ao.size());
+    for (size_t k = 0; k < ao.size(); ++k) flags[k] = ao[k].filtered;
+    std::vector<uint32_t> surv;
+    cleanup_survivors(flags.data(), (int)flags.size(), surv);  // sift.cpp:49-54
+    fin.reserve(surv.size());
+    for (uint32_t s : surv) fin.push_back(ao[s]);
+    (void)P;
+}
+
+int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
+    Plan& P = c->plan;
+    const DevPlan& dv = P.dev;
+    const int n = P.n, D = P.D;
+    hipStream_t s = c->stream;
+    c->status.assign((size_t)n, 0);
+    c->counts.assign((size_t)n, 0);
+    c->messages.assign((size_t)n, std::string());
+    c->totals.assign((size_t)n, 0);
+    c->list1.assign((size_t)n, {});
+    c->after_orient.assign((size_t)n, {});
+    c->final_list.assign((size_t)n, {});
+    c->out_base.assign((size_t)n, 0);
+    c->total = 0;
+    c->have_result = false;
+    c->have_pyramid = false;
+
+    run_pyramid(c, d_in);
+    c->have_pyramid = true;
+    if (P.fail_status) {
+        SIFT_HIP_CHECK(hipStreamSynchronize(s));
+        resolve_events(c);
+        for (int i = 0; i < n; ++i) { c->status[(size_t)i] = P.fail_status; c->messages[(size_t)i] = P.fail_msg; }
+        c->have_result = true;
+        set_err(err, errlen, P.fail_msg);
+        return P.fail_status;
+    }
+
+    // extrema + edge responses (sift.cpp:33-34)
+    const DevPlan* dpl = c->d_plan.as<DevPlan>();
+    launch_extrema_mask(s, dpl, dv, c->d_masks.as<unsigned long long>(), c->d_counts.as<int>());
+    launch_extrema_scan(s, dv, c->d_counts.as<int>(), c->d_totals.as<int>());
+    launch_extrema_expand(s, dpl, dv, c->d_masks.as<unsigned long long>(), c->d_counts.as<int>(), c->d_cands.as<Candidate>());
+    launch_edge_filter(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_totals.as<int>(), c->d_flags.as<uint8_t>());
+    // gradient maps of the selected levels and W16 do not depend on the host glue: queue them now
+    for (int lvl : P.grad_levels) {
+        const int o = lvl / (D + 1);
+        launch_gradient(s, dv.gauss[lvl], dv.mag[lvl], dv.ori[lvl], dv.w[o], dv.h[o], n);
+        launch_w16(s, dv, lvl, c->d_taps16.as<float>(), P.radius16);
+    }
+    SIFT_HIP_CHECK(hipMemcpyAsync(c->totals.data(), c->d_totals.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+    SIFT_HIP_CHECK(hipStreamSynchronize(s));
+    resolve_events(c);
+
+    // first cleanup (sift.cpp:37-42) on the host: flags down, survivor lists up
+    c->flag_off.assign((size_t)n, 0);
+    size_t fl_total = 0;
+    for (int i = 0; i < n; ++i) { c->flag_off[(size_t)i] = fl_total; fl_total += (size_t)c->totals[(size_t)i]; }
+    c->h_flags.ensure(std::max<size_t>(fl_total, 1));
+    for (int i = 0; i < n; ++i)
+        if (c->totals[(size_t)i])
+            SIFT_HIP_CHECK(hipMemcpyAsync(c->h_flags.as<uint8_t>() + c->flag_off[(size_t)i],
+                                          c->d_flags.as<uint8_t>() + (size_t)i * (size_t)dv.cand_capacity,
+                                          (size_t)c->totals[(size_t)i], hipMemcpyDeviceToHost, s));
+    SIFT_HIP_CHECK(hipStreamSynchronize(s));
+    const int threads = c->host_threads > 0 ? c->host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    Cleanup1Arg a1{c};
+    parallel_for(n, threads, cleanup1_fn, &a1);
+
+    std::vector<int> cnt1((size_t)n);
+    int max_cnt = 0;
+    for (int i = 0; i < n; ++i) {
+        cnt1[(size_t)i] = (int)c->list1[(size_t)i].size();
+        max_cnt = std::max(max_cnt, cnt1[(size_t)i]);
+        if (cnt1[(size_t)i])
+            SIFT_HIP_CHECK(hipMemcpyAsync(c->d_list.as<uint32_t>() + (size_t)i * kListCap, c->list1[(size_t)i].data(),
+                                          (size_t)cnt1[(size_t)i] * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    }
+    SIFT_HIP_CHECK(hipMemcpyAsync(c->d_list_cnt.p, cnt1.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+
+    // orientation assignment (sift.cpp:44-46)
+    launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
+                       kListCap, max_cnt, c->d_orient.as<OrientOut>(), c->d_peaks.as<float>());
+    c->h_orient.ensure((size_t)n * kListCap * sizeof(OrientOut));
+    for (int i = 0; i < n; ++i)
+        if (cnt1[(size_t)i])
+            SIFT_HIP_CHECK(hipMemcpyAsync(c->h_orient.as<OrientOut>() + (size_t)i * kListCap,
+                                          c->d_orient.as<OrientOut>() + (size_t)i * kListCap,
+                                          (size_t)cnt1[(size_t)i] * sizeof(OrientOut), hipMemcpyDeviceToHost, s));
+    SIFT_HIP_CHECK(hipStreamSynchronize(s));
+    // extra peaks are rare (unreachable for non-negative images): fetch them only when present
+    bool any_multi = false;
+    for (int i = 0; i < n && !any_multi; ++i) {
+        const OrientOut* oo = c->h_orient.as<OrientOut>() + (size_t)i * kListCap;
+        for (int k = 0; k < cnt1[(size_t)i]; ++k)
+            if (oo[k].npeaks > 1) { any_multi = true; break; }
+    }
+    if (any_multi) {
+        c->h_peaks.ensure((size_t)n * kListCap * 36 * sizeof(float));
+        for (int i = 0; i < n; ++i)
+            if (cnt1[(size_t)i])
+                SIFT_HIP_CHECK(hipMemcpyAsync(c->h_peaks.as<float>() + (size_t)i * kListCap * 36,
+                                              c->d_peaks.as<float>() + (size_t)i * kListCap * 36,
+                                              (size_t)cnt1[(size_t)i] * 36 * sizeof(float), hipMemcpyDeviceToHost, s));
+        SIFT_HIP_CHECK(hipStreamSynchronize(s));
+    } else {
+        c->h_peaks.release();
+    }
+    Cleanup2Arg a2{c};
+    parallel_for(n, threads, cleanup2_fn, &a2);
+
+    // descriptors (sift.cpp:55)
+    std::vector<int> cnt2((size_t)n);
+    std::vector<FinalKp> up;
+    long long total = 0;
+    for (int i = 0; i < n; ++i) {
+        const auto& fin = c->final_list[(size_t)i];
+        cnt2[(size_t)i] = c->status[(size_t)i] ? 0 : (int)fin.size();
+        c->counts[(size_t)i] = cnt2[(size_t)i];
+        c->out_base[(size_t)i] = total;
+        total += cnt2[(size_t)i];
+    }
+    c->total = total;
+    c->d_kp.ensure(std::max<size_t>((size_t)total, 1) * sizeof(sift_hip_keypoint));
+    c->d_desc.ensure(std::max<size_t>((size_t)total, 1) * 128 * sizeof(float));
+    // candidate records are needed to fill FinalKp: fetch the referenced ones from the device copy
+    // (cheap: one gather per surviving keypoint) — done on the host from a downloaded candidate
+    // array only for the survivors' images.
+    {
+        std::vector<Candidate> hc;
+        for (int i = 0; i < n; ++i) {
+            if (!cnt2[(size_t)i]) continue;
+            hc.resize((size_t)c->totals[(size_t)i]);
+            SIFT_HIP_CHECK(hipMemcpyAsync(hc.data(), c->d_cands.as<Candidate>() + (size_t)i * (size_t)dv.cand_capacity,
+                                          hc.size() * sizeof(Candidate), hipMemcpyDeviceToHost, s));
+            SIFT_HIP_CHECK(hipStreamSynchronize(s));
+            const auto& fin = c->final_list[(size_t)i];
+            up.resize(fin.size());
+            for (size_t k = 0; k < fin.size(); ++k) {
+                const Candidate& cd = hc[fin[k].cand];
+                up[k] = FinalKp{fin[k].cand, fin[k].orientation, cd.x, cd.y, cd.octave, cd.index};
+            }
+            SIFT_HIP_CHECK(hipMemcpyAsync(c->d_final.as<FinalKp>() + (size_t)i * kListCap, up.data(), up.size() * sizeof(FinalKp),
+                                          hipMemcpyHostToDevice, s));
+            SIFT_HIP_CHECK(hipStreamSynchronize(s));
+        }
+    }
+    SIFT_HIP_CHECK(hipMemcpyAsync(c->d_final_cnt.p, cnt2.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+    SIFT_HIP_CHECK(hipMemcpyAsync(c->d_out_base.p, c->out_base.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice, s));
+    if (total > 0)
+        for (int lvl : P.grad_levels)
+            launch_descriptors(s, dpl, dv, lvl, c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(), kListCap,
+                               c->d_out_base.as<long long>(), c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>());
+    SIFT_HIP_CHECK(hipStreamSynchronize(s));
+    c->have_result = true;
+    int rc = SIFT_HIP_OK;
+    for (int i = 0; i < n; ++i)
+        if (c->status[(size_t)i]) {
+            rc = c->status[(size_t)i];
+            set_err(err, errlen, c->messages[(size_t)i]);
+            break;
+        }
+    return rc;
+}
+
+template <class F>
+int guarded(char* err, int errlen, F&& f) {
+    try {
+        return f();
+    } catch (const HipError& e) {
+        char buf[512];
+        std::snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s:%d: %s", (int)e.code, hipGetErrorString(e.code), e.file, e.line, e.expr);
+        set_err(err, errlen, buf);
+        return SIFT_HIP_EHIP;
+    } catch (const std::exception& e) {
+        set_err(err, errlen, e.what());
+        return SIFT_HIP_EHIP;
+    }
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+const char* sift_hip_version(void) { return "sift_hip 0.1 (gfx950)"; }
+
+int sift_hip_create(int device, sift_hip_ctx** out, char* err, int errlen) {
+    if (!out) return SIFT_HIP_EINVAL;
+    *out = nullptr;
+    return guarded(err, errlen, [&]() {
+        int count = 0;
+        SIFT_HIP_CHECK(hipGetDeviceCount(&count));
+        if (device < 0 || device >= count) {
+            set_err(err, errlen, "sift_hip_create: no such HIP device");
+            return SIFT_HIP_EINVAL;
+        }
+        SIFT_HIP_CHECK(hipSetDevice(device));
+        auto* c = new sift_hip_ctx();
+        c->device = device;
+        SIFT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        *out = c;
+        return SIFT_HIP_OK;
+    });
+}
+
+void sift_hip_destroy(sift_hip_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf* b : {&c->arena, &c->d_plan, &c->d_taps, &c->d_luts, &c->d_taps16, &c->d_input, &c->d_base, &c->d_tmp, &c->d_tmp2,
+                      &c->d_masks, &c->d_counts, &c->d_totals, &c->d_cands, &c->d_flags, &c->d_list, &c->d_list_cnt, &c->d_orient,
+                      &c->d_peaks, &c->d_final, &c->d_final_cnt, &c->d_out_base, &c->d_kp, &c->d_desc})
+        b->release();
+    for (HostBuf* b : {&c->h_flags, &c->h_orient, &c->h_peaks}) b->release();
+    for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
+    if (!c || !name) return SIFT_HIP_EINVAL;
+    if (!std::strcmp(name, "fused_blur")) { c->fused = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "profile")) { c->profile = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "host_threads")) { c->host_threads = value; return SIFT_HIP_OK; }
+    return SIFT_HIP_EINVAL;
+}
+
+int sift_hip_calculate_batch_device(sift_hip_ctx* c, const void* dev_imgs, int n, int w, int h,
+                                    const sift_hip_params* params, char* err, int errlen) {
+    if (!c || !dev_imgs || !params) return SIFT_HIP_EINVAL;
+    return guarded(err, errlen, [&]() {
+        SIFT_HIP_CHECK(hipSetDevice(c->device));
+        std::string msg;
+        const int rc = build_plan(c, n, w, h, *params, msg);
+        if (rc) { set_err(err, errlen, msg); return rc; }
+        return run_batch(c, static_cast<const float*>(dev_imgs), err, errlen);
+    });
+}
+
+int sift_hip_calculate_batch(sift_hip_ctx* c, const float* host_imgs, int n, int w, int h,
+                             const sift_hip_params* params, char* err, int errlen) {
+    if (!c || !host_imgs || !params || n <= 0 || w <= 0 || h <= 0) return SIFT_HIP_EINVAL;
+    return guarded(err, errlen, [&]() {
+        SIFT_HIP_CHECK(hipSetDevice(c->device));
+        const size_t bytes = (size_t)n * (size_t)w * (size_t)h * sizeof(float);
+        c->d_input.ensure(bytes);
+        SIFT_HIP_CHECK(hipMemcpyAsync(c->d_input.p, host_imgs, bytes, hipMemcpyHostToDevice, c->stream));
+        std::string msg;
+        const int rc = build_plan(c, n, w, h, *params, msg);
+        if (rc) { set_err(err, errlen, msg); return rc; }
+        return run_batch(c, c->d_input.as<float>(), err, errlen);
+    });
+}
+
+int sift_hip_result_status(sift_hip_ctx* c, int32_t* status) {
+    if (!c || !c->have_result) return SIFT_HIP_EINVAL;
+    std::copy(c->status.begin(), c->status.end(), status);
+    return SIFT_HIP_OK;
+}
+int sift_hip_result_counts(sift_hip_ctx* c, int32_t* counts) {
+    if (!c || !c->have_result) return SIFT_HIP_EINVAL;
+    std::copy(c->counts.begin(), c->counts.end(), counts);
+    return SIFT_HIP_OK;
+}
+int64_t sift_hip_result_total(sift_hip_ctx* c) { return (c && c->have_result) ? c->total : -1; }
+
+int sift_hip_result_copy(sift_hip_ctx* c, sift_hip_keypoint* kp, float* desc) {
+    if (!c || !c->have_result) return SIFT_HIP_EINVAL;
+    return guarded(nullptr, 0, [&]() {
+        SIFT_HIP_CHECK(hipSetDevice(c->device));
+        if (c->total > 0) {
+            if (kp) SIFT_HIP_CHECK(hipMemcpy(kp, c->d_kp.p, (size_t)c->total * sizeof(sift_hip_keypoint), hipMemcpyDefault));
+            if (desc) SIFT_HIP_CHECK(hipMemcpy(desc, c->d_desc.p, (size_t)c->total * 128 * sizeof(float), hipMemcpyDefault));
+        }
+        return SIFT_HIP_OK;
+    });
+}
+int sift_hip_result_device(sift_hip_ctx* c, const void** kp, const void** desc) {
+    if (!c || !c->have_result) return SIFT_HIP_EINVAL;
+    if (kp) *kp = c->d_kp.p;
+    if (desc) *desc = c->d_desc.p;
+    return SIFT_HIP_OK;
+}
+
+int sift_hip_image_dims(sift_hip_ctx* c, int* w, int* h) {
+    if (!c || !c->plan.valid) return SIFT_HIP_EINVAL;
+    const bool up = c->plan.params.subpixel && c->plan.fail_op > 0;
+    *w = up ? c->plan.bw : c->plan.in_w;
+    *h = up ? c->plan.bh : c->plan.in_h;
+    return SIFT_HIP_OK;
+}
+int sift_hip_image_copy(sift_hip_ctx* c, int image, float* out) {
+    if (!c || !c->plan.valid || !c->have_pyramid || image < 0 || image >= c->plan.n) return SIFT_HIP_EINVAL;
+    const bool up = c->plan.params.subpixel && c->plan.fail_op > 0;
+    if (!up) return SIFT_HIP_EINVAL;  // image unchanged: the caller still has it
+    return guarded(nullptr, 0, [&]() {
+        SIFT_HIP_CHECK(hipSetDevice(c->device));
+        const size_t px = (size_t)c->plan.bw * (size_t)c->plan.bh;
+        SIFT_HIP_CHECK(hipMemcpy(out, c->d_base.as<float>() + (size_t)image * px, px * sizeof(float), hipMemcpyDeviceToHost));
+        return SIFT_HIP_OK;
+    });
+}
+
+static float* level_ptr(sift_hip_ctx* c, int kind, int o, int i, int* w, int* h) {
+    const Plan& P = c->plan;
+    if (!P.valid || o < 0 || o >= P.O) return nullptr;
+    const int nl = kind == 1 ? P.D : P.D + 1;
+    if (i < 0 || i >= nl) return nullptr;
+    *w = P.dev.w[o];
+    *h = P.dev.h[o];
+    switch (kind) {
+        case 0: return P.dev.gauss[o * (P.D + 1) + i];
+        case 1: return P.dev.dog[o * P.D + i];
+        case 2: return P.dev.mag[o * (P.D + 1) + i];
+        case 3: return P.dev.ori[o * (P.D + 1) + i];
+    }
+    return nullptr;
+}
+int sift_hip_level_dims(sift_hip_ctx* c, int kind, int octave, int level, int* w, int* h) {
+    if (!c) return SIFT_HIP_EINVAL;
+    int ww = 0, hh = 0;
+    float* p = level_ptr(c, kind, octave, level, &ww, &hh);
+    *w = p ? ww : 0;
+    *h = p ? hh : 0;
+    return p ? SIFT_HIP_OK : SIFT_HIP_EINVAL;
+}
+int sift_hip_level_copy(sift_hip_ctx* c, int image, int kind, int octave, int level, float* out) {
+    if (!c || !c->have_pyramid || image < 0 || image >= c->plan.n) return SIFT_HIP_EINVAL;
+    int w = 0, h = 0;
+    float* p = level_ptr(c, kind, octave, level, &w, &h);
+    if (!p) return SIFT_HIP_EINVAL;
+    return guarded(nullptr, 0, [&]() {
+        SIFT_HIP_CHECK(hipSetDevice(c->device));
+        const size_t px = (size_t)w * (size_t)h;
+        SIFT_HIP_CHECK(hipMemcpy(out, p + (size_t)image * px, px * sizeof(float), hipMemcpyDeviceToHost));
+        return SIFT_HIP_OK;
+    });
+}
+float sift_hip_level_scale(sift_hip_ctx* c, int kind, int octave, int level) {
+    if (!c || !c->plan.valid) return NAN;
+    return kind == 1 ? c->plan.dev.dog_scale[octave * c->plan.D + level] : c->plan.dev.gauss_scale[octave * (c->plan.D + 1) + level];
+}
+
+int sift_hip_stage_count(sift_hip_ctx* c, int image, int stage) {
+    if (!c || !c->have_result || image < 0 || image >= c->plan.n) return -1;
+    switch (stage) {
+        case 0: return c->totals[(size_t)image];
+        case 1: return (int)c->list1[(size_t)image].size();
+        case 2: return (int)c->after_orient[(size_t)image].size();
+        case 3: return (int)c->final_list[(size_t)image].size();
+        case 4: return c->counts[(size_t)image];
+    }
+    return -1;
+}
+int sift_hip_stage_copy(sift_hip_ctx* c, int image, int stage, sift_hip_keypoint* out) {
+    const int cnt = sift_hip_stage_count(c, image, stage);
+    if (cnt < 0) return SIFT_HIP_EINVAL;
+    if (cnt == 0) return SIFT_HIP_OK;
+    return guarded(nullptr, 0, [&]() {
+        SIFT_HIP_CHECK(hipSetDevice(c->device));
+        const Plan& P = c->plan;
+        if (stage == 4) {
+            SIFT_HIP_CHECK(hipMemcpy(out, c->d_kp.as<sift_hip_keypoint>() + c->out_base[(size_t)image],
+                                     (size_t)cnt * sizeof(sift_hip_keypoint), hipMemcpyDeviceToHost));
+            return SIFT_HIP_OK;
+        }
+        std::vector<Candidate> hc((size_t)c->totals[(size_t)image]);
+        SIFT_HIP_CHECK(hipMemcpy(hc.data(), c->d_cands.as<Candidate>() + (size_t)image * (size_t)P.dev.cand_capacity,
+                                 hc.size() * sizeof(Candidate), hipMemcpyDeviceToHost));
+        auto fill = [&](sift_hip_keypoint& k, uint32_t cand, float orientation, uint8_t filtered) {
+            const Candidate& cd = hc[cand];
+            k.scale = P.dev.dog_scale[cd.octave * P.D + cd.index];
+            k.orientation = orientation;
+            k.x = cd.x; k.y = cd.y; k.octave = cd.octave; k.index = cd.index;
+            k.filtered = filtered; k.has_descriptor = 0; k.reserved = 0;
+        };
+        if (stage == 0) {
+            const uint8_t* fl = c->h_flags.as<uint8_t>() + c->flag_off[(size_t)image];
+            for (int i = 0; i < cnt; ++i) fill(out[i], (uint32_t)i, 0.0f, fl[i]);
+        } else if (stage == 1) {
+            const auto& l = c->list1[(size_t)image];
+            for (int i = 0; i < cnt; ++i) fill(out[i], l[(size_t)i], 0.0f, 0);
+        } else {
+            const auto& l = stage == 2 ? c->after_orient[(size_t)image] : c->final_list[(size_t)image];
+            for (int i = 0; i < cnt; ++i) fill(out[i], l[(size_t)i].cand, l[(size_t)i].orientation, l[(size_t)i].filtered);
+        }
+        return SIFT_HIP_OK;
+    });
+}
+
+// ---- single-image operators ---------------------------------------------------------------------------
+int sift_hip_gauss_taps(float sigma, float* taps, int cap) {
+    std::vector<float> t;
+    int r = 0;
+    if (!gauss_taps(sigma, t, r)) return -1;
+    for (int i = 0; i < (int)t.size() && i < cap; ++i) taps[i] = t[(size_t)i];
+    return r;
+}
+
+}  // extern "C"
+
+namespace {
+struct Scratch {
+    std::vector<void*> ptrs;
+    template <class T>
+    T* dev(size_t count) {
+        void* p = nullptr;
+        SIFT_HIP_CHECK(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+        ptrs.push_back(p);
+        return static_cast<T*>(p);
+    }
+    template <class T>
+    T* upload(const T* h, size_t count) {
+        T* d = dev<T>(count);
+        SIFT_HIP_CHECK(hipMemcpy(d, h, count * sizeof(T), hipMemcpyHostToDevice));
+        return d;
+    }
+    ~Scratch() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+};
+
+int blur_checks(float sigma, int w, int h, std::vector<float>& taps, int& r, std::string& msg) {
+    if (!gauss_taps(sigma, taps, r)) { msg = precondition("Kernel1D::initGaussian(): Standard deviation must be >= 0."); return SIFT_HIP_EPRECONDITION; }
+    if (!(w >= r + 1)) { msg = precondition("separableConvolveX(): kernel longer than line\n"); return SIFT_HIP_EPRECONDITION; }
+    if (!(h >= r + 1)) { msg = precondition("separableConvolveY(): kernel longer than line\n"); return SIFT_HIP_EPRECONDITION; }
+    return 0;
+}
+
+// blur then optional resample to (wd, hd)
+int op_blur_resample(sift_hip_ctx* c, const float* in, int w, int h, float sigma, int wd, int hd, float* out, char* err, int errlen) {
+    if (!c || !in || !out || w <= 0 || h <= 0) return SIFT_HIP_EINVAL;
+    return guarded(err, errlen, [&]() {
+        SIFT_HIP_CHECK(hipSetDevice(c->device));
+        std::vector<float> taps;
+        int r = 0;
+        std::string msg;
+        int rc = blur_checks(sigma, w, h, taps, r, msg);
+        if (rc) { set_err(err, errlen, msg); return rc; }
+        const bool resample = wd > 0;
+        if (resample) {
+            if (!(w > 1 && h > 1)) { set_err(err, errlen, precondition("resizeImageNoInterpolation(): Source image too small.\n")); return SIFT_HIP_EPRECONDITION; }
+            if (!(wd > 1 && hd > 1)) { set_err(err, errlen, precondition("resizeImageNoInterpolation(): Destination image too small.\n")); return SIFT_HIP_EPRECONDITION; }
+        }
+        Scratch s;
+        const size_t px = (size_t)w * (size_t)h;
+        float* d_in = s.upload(in, px);
+        float* d_tmp = s.dev<float>(px);
+        float* d_out = s.dev<float>(px);
+        float* d_taps = s.upload(taps.data(), taps.size());
+        launch_blur(c->stream, c->fused, d_in, d_tmp, d_out, nullptr, w, h, 1, d_taps, r);
+        if (resample) {
+            const std::vector<int> lx = resize_index_map(w, wd), ly = resize_index_map(h, hd);
+            int* d_lx = s.upload(lx.data(), lx.size());
+            int* d_ly = s.upload(ly.data(), ly.size());
+            float* d_rs = s.dev<float>((size_t)wd * (size_t)hd);
+            launch_resample(c->stream, d_out, d_rs, w, h, wd, hd, 1, d_lx, d_ly);
+            SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
+            SIFT_HIP_CHECK(hipMemcpy(out, d_rs, (size_t)wd * (size_t)hd * sizeof(float), hipMemcpyDeviceToHost));
+        } else {
+            SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
+            SIFT_HIP_CHECK(hipMemcpy(out, d_out, px * sizeof(float), hipMemcpyDeviceToHost));
+        }
+        return SIFT_HIP_OK;
+    });
+}
+}  // namespace
+
+extern "C" {
+
+int sift_hip_convolve_with_gauss(sift_hip_ctx* c, const float* in, int w, int h, float sigma, float* out, char* err, int errlen) {
+    return op_blur_resample(c, in, w, h, sigma, 0, 0, out, err, errlen);
+}
+int sift_hip_reduce_to_next_level(sift_hip_ctx* c, const float* in, int w, int h, float sigma, float* out, char* err, int errlen) {
+    return op_blur_resample(c, in, w, h, sigma, (w + 1) / 2, (h + 1) / 2, out, err, errlen);
+}
+int sift_hip_increase_to_next_level(sift_hip_ctx* c, const float* in, int w, int h, float sigma, float* out, char* err, int errlen) {
+    return op_blur_resample(c, in, w, h, sigma, 2 * w, 2 * h, out, err, errlen);
+}
+
+int sift_hip_dog(sift_hip_ctx* c, const float* lower, const float* higher, int w, int h, float* out) {
+    if (!c || !lower || !higher || !out || w <= 0 || h <= 0) return SIFT_HIP_EINVAL;
+    return guarded(nullptr, 0, [&]() {
+        SIFT_HIP_CHECK(hipSetDevice(c->device));
+        Scratch s;
+        const size_t px = (size_t)w * (size_t)h;
+        float* a = s.upload(lower, px);
+        float* b = s.upload(higher, px);
+        float* o = s.dev<float>(px);
+        launch_dog(c->stream, a, b, o, px);
+        SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
+        SIFT_HIP_CHECK(hipMemcpy(out, o, px * sizeof(float), hipMemcpyDeviceToHost));
+        return SIFT_HIP_OK;
+    });
+}
+
+int sift_hip_gradient(sift_hip_ctx* c, const float* in, int w, int h, float* mag, float* ori) {
+    if (!c || !in || !mag || !ori || w <= 0 || h <= 0) return SIFT_HIP_EINVAL;
+    return guarded(nullptr, 0, [&]() {
+        SIFT_HIP_CHECK(hipSetDevice(c->device));
+        Scratch s;
+        const size_t px = (size_t)w * (size_t)h;
+        float* a = s.upload(in, px);
+        float* m = s.dev<float>(px);
+        float* o = s.dev<float>(px);
+        launch_gradient(c->stream, a, m, o, w, h, 1);
+        SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
+        SIFT_HIP_CHECK(hipMemcpy(mag, m, px * sizeof(float), hipMemcpyDeviceToHost));
+        SIFT_HIP_CHECK(hipMemcpy(ori, o, px * sizeof(float), hipMemcpyDeviceToHost));
+        return SIFT_HIP_OK;
+    });
+}
+
+int sift_hip_edge_responses(sift_hip_ctx* c, const float* dog0, const float* dog1, const float* dog2, int w, int h,
+                            const uint16_t* xs, const uint16_t* ys, int m, uint8_t* flags) {
+    if (!c || !dog0 || !dog1 || !dog2 || !xs || !ys || !flags || w < 3 || h < 3 || m < 0) return SIFT_HIP_EINVAL;
+    for (int i = 0; i < m; ++i)
+        if (xs[i] < 1 || xs[i] > w - 2 || ys[i] < 1 || ys[i] > h - 2) return SIFT_HIP_EINVAL;
+    if (m == 0) return SIFT_HIP_OK;
+    return guarded(nullptr, 0, [&]() {
+        SIFT_HIP_CHECK(hipSetDevice(c->device));
+        Scratch s;
+        const size_t px = (size_t)w * (size_t)h;
+        float* a = s.upload(dog0, px);
+        float* b = s.upload(dog1, px);
+        float* d = s.upload(dog2, px);
+        uint16_t* dx = s.upload(xs, (size_t)m);
+        uint16_t* dy = s.upload(ys, (size_t)m);
+        uint8_t* df = s.dev<uint8_t>((size_t)m);
+        launch_edge_filter_points(c->stream, a, b, d, w, h, dx, dy, m, df);
+        SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
+        SIFT_HIP_CHECK(hipMemcpy(flags, df, (size_t)m, hipMemcpyDeviceToHost));
+        return SIFT_HIP_OK;
+    });
+}
+
+int sift_hip_vertex_parabola(sift_hip_ctx* c, const uint16_t* lnx, const float* lny, const uint16_t* px, const float* py,
+                             const uint16_t* rnx, const float* rny, int m, float* out) {
+    if (!c || m < 0) return SIFT_HIP_EINVAL;
+    if (m == 0) return SIFT_HIP_OK;
+    return guarded(nullptr, 0, [&]() {
+        SIFT_HIP_CHECK(hipSetDevice(c->device));
+        Scratch s;
+        uint16_t* a = s.upload(lnx, (size_t)m);
+        float* b = s.upload(lny, (size_t)m);
+        uint16_t* d = s.upload(px, (size_t)m);
+        float* e = s.upload(py, (size_t)m);
+        uint16_t* f = s.upload(rnx, (size_t)m);
+        float* g = s.upload(rny, (size_t)m);
+        float* o = s.dev<float>((size_t)m);
+        launch_vertex_parabola(c->stream, a, b, d, e, f, g, m, o);
+        SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
+        SIFT_HIP_CHECK(hipMemcpy(out, o, (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
+        return SIFT_HIP_OK;
+    });
+}
+
+int sift_hip_sort_by_filter(sift_hip_ctx* c, const uint8_t* flags, int n, int32_t* perm) {
+    (void)c;
+    if (!flags || !perm || n < 0) return SIFT_HIP_EINVAL;
+    std::vector<uint32_t> p;
+    sort_by_filter(flags, n, p);
+    for (int i = 0; i < n; ++i) perm[i] = (int32_t)p[(size_t)i];
+    return SIFT_HIP_OK;
+}
+
+int sift_hip_profile_get(sift_hip_ctx* c, int which, double* ms, int64_t* launches, double* bytes) {
+    if (!c || which < 0 || which > 1) return SIFT_HIP_EINVAL;
+    if (ms) *ms = c->prof_ms[which];
+    if (launches) *launches = c->prof_launches[which];
+    if (bytes) *bytes = c->prof_bytes[which];
+    return SIFT_HIP_OK;
+}
+int sift_hip_profile_reset(sift_hip_ctx* c) {
+    if (!c) return SIFT_HIP_EINVAL;
+    for (int i = 0; i < 2; ++i) { c->prof_ms[i] = 0; c->prof_launches[i] = 0; c->prof_bytes[i] = 0; }
+    return SIFT_HIP_OK;
+}
+
+}  // extern "C"

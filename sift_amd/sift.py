@@ -1,0 +1,272 @@
+"""Python mirror of the reference's `sift::Sift` / `sift::InterestPoint` API
+(/root/reference/sift.hpp:17-78, interestpoint.hpp:13-63) on top of the C ABI (include/sift_hip.h).
+
+Same constructor arguments, same meaning, same error behaviour: Vigra precondition failures the
+reference would throw surface as `PreconditionViolation`, its assert()s as `AssertionError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+
+K_SQRT2 = float(np.float32(np.sqrt(2.0)))
+
+KINDS = {"gaussian": 0, "dog": 1, "magnitude": 2, "orientation": 3}
+STAGES = {"candidates": 0, "after_sort1": 1, "after_orient": 2, "after_sort2": 3, "final": 4}
+
+
+class PreconditionViolation(RuntimeError):
+    """vigra::PreconditionViolation analogue; str() carries Vigra's message text."""
+
+
+class HipError(RuntimeError):
+    pass
+
+
+@dataclass
+class InterestPoint:  # interestpoint.hpp:13-63
+    scale: float
+    octave: int
+    index: int
+    filtered: bool
+    loc: tuple
+    orientation: float
+    descriptors: list = field(default_factory=list)
+
+
+def _raise(rc, err):
+    msg = err.value.decode(errors="replace")
+    if rc == _lib.EPRECONDITION:
+        raise PreconditionViolation(msg)
+    if rc == _lib.EASSERT:
+        raise AssertionError(msg)
+    if rc == _lib.EINVAL:
+        raise ValueError(msg or "sift_hip: invalid argument")
+    raise HipError(msg or f"sift_hip error {rc}")
+
+
+class Context:
+    """One sift_hip_ctx (one GPU, one stream)."""
+
+    def __init__(self, device: int = 0):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = self._L.sift_hip_create(device, C.byref(self._h), err, 512)
+        if rc:
+            self._h = C.c_void_p()
+            _raise(rc, err)
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.sift_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, name: str, value: int):
+        if self._L.sift_hip_set_option(self._h, name.encode(), int(value)):
+            raise ValueError(f"unknown option {name}")
+
+    # ---- Sift::calculate ---------------------------------------------------------------------
+    def calculate_batch(self, imgs, params, raise_on_error=True):
+        imgs = np.ascontiguousarray(imgs, dtype=np.float32)
+        if imgs.ndim == 2:
+            imgs = imgs[None]
+        n, h, w = imgs.shape
+        err = C.create_string_buffer(512)
+        rc = self._L.sift_hip_calculate_batch(self._h, imgs.reshape(-1), n, w, h, C.byref(params), err, 512)
+        self._n = n
+        if rc and raise_on_error:
+            _raise(rc, err)
+        return rc, err.value.decode(errors="replace")
+
+    def calculate_batch_device(self, dev_ptr: int, n: int, w: int, h: int, params, raise_on_error=True):
+        err = C.create_string_buffer(512)
+        rc = self._L.sift_hip_calculate_batch_device(self._h, C.c_void_p(dev_ptr), n, w, h, C.byref(params), err, 512)
+        self._n = n
+        if rc and raise_on_error:
+            _raise(rc, err)
+        return rc, err.value.decode(errors="replace")
+
+    def counts(self):
+        out = np.zeros(self._n, np.int32)
+        if self._L.sift_hip_result_counts(self._h, out):
+            raise HipError("no result")
+        return out
+
+    def status(self):
+        out = np.zeros(self._n, np.int32)
+        if self._L.sift_hip_result_status(self._h, out):
+            raise HipError("no result")
+        return out
+
+    def total(self) -> int:
+        return int(self._L.sift_hip_result_total(self._h))
+
+    def results(self):
+        t = self.total()
+        kp = np.zeros(max(t, 0), _lib.KEYPOINT_DTYPE)
+        desc = np.zeros((max(t, 0), 128), np.float32)
+        if t > 0 and self._L.sift_hip_result_copy(self._h, kp.ctypes.data, desc.ctypes.data):
+            raise HipError("sift_hip_result_copy failed")
+        return kp, desc
+
+    def result_device_ptrs(self):
+        a, b = C.c_void_p(), C.c_void_p()
+        if self._L.sift_hip_result_device(self._h, C.byref(a), C.byref(b)):
+            raise HipError("no result")
+        return a.value or 0, b.value or 0
+
+    def image(self, image: int = 0):
+        w, h = C.c_int(), C.c_int()
+        self._L.sift_hip_image_dims(self._h, C.byref(w), C.byref(h))
+        out = np.empty((h.value, w.value), np.float32)
+        if self._L.sift_hip_image_copy(self._h, image, out):
+            return None
+        return out
+
+    # ---- inspection ------------------------------------------------------------------------------
+    def level(self, kind: str, octave: int, level: int, image: int = 0):
+        w, h = C.c_int(), C.c_int()
+        if self._L.sift_hip_level_dims(self._h, KINDS[kind], octave, level, C.byref(w), C.byref(h)) or w.value == 0:
+            return None
+        out = np.empty((h.value, w.value), np.float32)
+        if self._L.sift_hip_level_copy(self._h, image, KINDS[kind], octave, level, out):
+            raise HipError("sift_hip_level_copy failed")
+        return out
+
+    def level_scale(self, kind: str, octave: int, level: int) -> float:
+        return float(self._L.sift_hip_level_scale(self._h, KINDS[kind], octave, level))
+
+    def stage(self, name: str, image: int = 0):
+        s = STAGES[name]
+        n = self._L.sift_hip_stage_count(self._h, image, s)
+        if n < 0:
+            raise HipError("no such stage")
+        out = np.zeros(n, _lib.KEYPOINT_DTYPE)
+        if n and self._L.sift_hip_stage_copy(self._h, image, s, out.ctypes.data):
+            raise HipError("sift_hip_stage_copy failed")
+        return out
+
+    # ---- sift::alg operators -------------------------------------------------------------------
+    def _op(self, fn, img, sigma, shape):
+        img = np.ascontiguousarray(img, np.float32)
+        h, w = img.shape
+        out = np.empty(shape, np.float32)
+        err = C.create_string_buffer(512)
+        rc = fn(self._h, img, w, h, sigma, out, err, 512)
+        if rc:
+            _raise(rc, err)
+        return out
+
+    def convolve_with_gauss(self, img, sigma):
+        return self._op(self._L.sift_hip_convolve_with_gauss, img, sigma, np.shape(img))
+
+    def reduce_to_next_level(self, img, sigma):
+        h, w = np.shape(img)
+        return self._op(self._L.sift_hip_reduce_to_next_level, img, sigma, ((h + 1) // 2, (w + 1) // 2))
+
+    def increase_to_next_level(self, img, sigma):
+        h, w = np.shape(img)
+        return self._op(self._L.sift_hip_increase_to_next_level, img, sigma, (2 * h, 2 * w))
+
+    def dog(self, lower, higher):
+        lower = np.ascontiguousarray(lower, np.float32)
+        higher = np.ascontiguousarray(higher, np.float32)
+        out = np.empty_like(lower)
+        if self._L.sift_hip_dog(self._h, lower, higher, lower.shape[1], lower.shape[0], out):
+            raise HipError("sift_hip_dog failed")
+        return out
+
+    def gradient(self, img):
+        img = np.ascontiguousarray(img, np.float32)
+        mag, ori = np.empty_like(img), np.empty_like(img)
+        if self._L.sift_hip_gradient(self._h, img, img.shape[1], img.shape[0], mag, ori):
+            raise HipError("sift_hip_gradient failed")
+        return mag, ori
+
+    def edge_responses(self, d0, d1, d2, xs, ys):
+        d0, d1, d2 = (np.ascontiguousarray(a, np.float32) for a in (d0, d1, d2))
+        xs = np.ascontiguousarray(xs, np.uint16)
+        ys = np.ascontiguousarray(ys, np.uint16)
+        flags = np.zeros(xs.size, np.uint8)
+        if self._L.sift_hip_edge_responses(self._h, d0, d1, d2, d0.shape[1], d0.shape[0], xs, ys, xs.size, flags):
+            raise HipError("sift_hip_edge_responses failed")
+        return flags
+
+    def vertex_parabola(self, lnx, lny, px, py, rnx, rny):
+        a = [np.ascontiguousarray(v, np.uint16) for v in (lnx, px, rnx)]
+        b = [np.ascontiguousarray(v, np.float32) for v in (lny, py, rny)]
+        out = np.zeros(a[0].size, np.float32)
+        if self._L.sift_hip_vertex_parabola(self._h, a[0], b[0], a[1], b[1], a[2], b[2], a[0].size, out):
+            raise HipError("sift_hip_vertex_parabola failed")
+        return out
+
+    def sort_by_filter(self, flags):
+        flags = np.ascontiguousarray(flags, np.uint8)
+        perm = np.zeros(flags.size, np.int32)
+        if self._L.sift_hip_sort_by_filter(self._h, flags, flags.size, perm):
+            raise HipError("sift_hip_sort_by_filter failed")
+        return perm
+
+    def profile(self, which: int):
+        ms, n, by = C.c_double(), C.c_int64(), C.c_double()
+        self._L.sift_hip_profile_get(self._h, which, C.byref(ms), C.byref(n), C.byref(by))
+        return ms.value, n.value, by.value
+
+    def profile_reset(self):
+        self._L.sift_hip_profile_reset(self._h)
+
+
+def gauss_taps(sigma: float):
+    L = _lib.load()
+    buf = np.zeros(8192, np.float32)
+    r = L.sift_hip_gauss_taps(sigma, buf, buf.size)
+    if r < 0:
+        raise PreconditionViolation("Kernel1D::initGaussian(): Standard deviation must be >= 0.")
+    return r, buf[:2 * r + 1].copy()
+
+
+class Sift:
+    """sift::Sift (sift.hpp:17-78): Sift(dogsPerEpoch=3, octaves=3, sigma=1.6, k=sqrt(2), subpixel=False)."""
+
+    def __init__(self, dogsPerEpoch: int = 3, octaves: int = 3, sigma: float = 1.6, k: float = K_SQRT2,
+                 subpixel: bool = False, device: int = 0, context: Context | None = None):
+        self.subpixel = bool(subpixel)
+        self._params = _lib.Params(dogsPerEpoch, octaves, sigma, k, 1 if subpixel else 0)
+        self.ctx = context or Context(device)
+
+    @property
+    def params(self):
+        return self._params
+
+    def calculate(self, img: np.ndarray):
+        """Returns (points, img): the InterestPoint list and the image the reference leaves in the
+        caller's array (the 2x upsampled one when subpixel, sift.cpp:20-21)."""
+        img = np.ascontiguousarray(img, np.float32)
+        try:
+            self.ctx.calculate_batch(img[None], self._params)
+        finally:
+            self.image = self.ctx.image(0) if self.subpixel else img
+        kp, desc = self.ctx.results()
+        pts = [InterestPoint(float(k["scale"]), int(k["octave"]), int(k["index"]), bool(k["filtered"]),
+                             (int(k["x"]), int(k["y"])), float(k["orientation"]),
+                             desc[i].tolist() if k["has_descriptor"] else [])
+               for i, k in enumerate(kp)]
+        return pts
+
+    def calculate_batch(self, imgs: np.ndarray):
+        """Batch of independent frames -> (counts, keypoints structured array, descriptors [N,128])."""
+        self.ctx.calculate_batch(imgs, self._params)
+        kp, desc = self.ctx.results()
+        return self.ctx.counts(), kp, desc

@@ -1,0 +1,285 @@
+"""GPU parity tests: the HIP path (through the C ABI of include/sift_hip.h) against the CPU oracle
+on the same seeded inputs.  Bit-exact for every float image, index and flag; descriptors are also
+required bit-exact (north_star tolerance: 1e-4 L2 — asserted as the fallback bound).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from sift_amd import _lib
+from sift_amd.sift import Context, PreconditionViolation, Sift, gauss_taps
+from sift_amd.synthetic import synth_frame
+
+pytestmark = pytest.mark.gpu
+
+DESC_TOL = 1e-4  # L2 per descriptor, BASELINE.json north_star
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_bits_equal(a, b, what, report=None):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    neq = bits(a) != bits(b)
+    # NaN payloads: treat NaN == NaN
+    neq &= ~(np.isnan(a) & np.isnan(b))
+    n = int(neq.sum())
+    if n:
+        idx = np.argwhere(neq)[:5]
+        detail = [(tuple(int(v) for v in i), float(a[tuple(i)]), float(b[tuple(i)])) for i in idx]
+        msg = f"{what}: {n}/{a.size} values differ; first: {detail}; max abs diff {float(np.nanmax(np.abs(a - b)))}"
+        if report is not None:
+            report.append(msg)
+        raise AssertionError(msg)
+
+
+# ------------------------------------------------------------------------------------------------
+# operator-level known-answer tests
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sigma", [1.0, 1.6, 2.2627418, 3.2, 4.5254836, 6.4, 9.050967, 12.8, 0.3, 0.0])
+@pytest.mark.parametrize("fused", [1, 0])
+def test_convolve_with_gauss(ctx, sigma, fused):
+    ctx.set_option("fused_blur", fused)
+    try:
+        for (w, h, seed) in [(200, 150, 3), (67, 131, 4), (64, 64, 5)]:
+            img = synth_frame(w, h, seed)
+            r, _ = O.gauss_taps(sigma)
+            if min(w, h) < r + 1:
+                with pytest.raises(PreconditionViolation):
+                    ctx.convolve_with_gauss(img, sigma)
+                continue
+            assert_bits_equal(ctx.convolve_with_gauss(img, sigma), O.convolve(img, sigma), f"blur s={sigma} {w}x{h} fused={fused}")
+    finally:
+        ctx.set_option("fused_blur", 1)
+
+
+def test_gauss_taps_match_oracle():
+    for sigma in [0.0, 0.2, 1.0, 1.6, 2.2627418, 3.2, 4.5254836, 6.4, 9.050967, 12.8, 18.101934, 50.0]:
+        r1, t1 = gauss_taps(sigma)
+        r2, t2 = O.gauss_taps(sigma)
+        assert r1 == r2
+        assert t1.tobytes() == t2.tobytes()
+
+
+def test_blur_precondition_messages(ctx):
+    img = synth_frame(40, 12, 1)
+    with pytest.raises(PreconditionViolation, match=r"separableConvolveY\(\): kernel longer than line"):
+        ctx.convolve_with_gauss(img, 4.5254836)  # r = 14 > 11
+    with pytest.raises(PreconditionViolation, match=r"separableConvolveX\(\): kernel longer than line"):
+        ctx.convolve_with_gauss(np.ascontiguousarray(img.T), 4.5254836)
+    with pytest.raises(PreconditionViolation, match="Standard deviation"):
+        ctx.convolve_with_gauss(img, -1.0)
+
+
+@pytest.mark.parametrize("shape", [(135, 240), (150, 201), (64, 64), (37, 90)])
+def test_resample(ctx, shape):
+    h, w = shape
+    img = synth_frame(w, h, 7)
+    assert_bits_equal(ctx.reduce_to_next_level(img, 1.6), O.resample(img, 1.6, 0), f"reduce {w}x{h}")
+    assert_bits_equal(ctx.increase_to_next_level(img, 1.0), O.resample(img, 1.0, 1), f"increase {w}x{h}")
+
+
+def test_dog_and_gradient(ctx):
+    a = synth_frame(173, 91, 11)
+    b = O.convolve(a, 1.6)
+    out = np.empty_like(a)
+    O.lib().oracle_dog(a, b, a.shape[1], a.shape[0], out)
+    assert_bits_equal(ctx.dog(a, b), out, "dog")
+    mag, ori = np.empty_like(b), np.empty_like(b)
+    O.lib().oracle_gradient(b, b.shape[1], b.shape[0], mag, ori)
+    gm, go = ctx.gradient(b)
+    assert_bits_equal(gm, mag, "gradient magnitude")
+    assert_bits_equal(go, ori, "gradient orientation")
+    # harsher inputs for atan2f / sqrt: random floats incl. tiny and huge differences
+    rng = np.random.default_rng(5)
+    c = (rng.standard_normal((64, 96)) * 10.0 ** rng.integers(-6, 6, (64, 96))).astype(np.float32)
+    O.lib().oracle_gradient(c, c.shape[1], c.shape[0], mag := np.empty_like(c), ori := np.empty_like(c))
+    gm, go = ctx.gradient(c)
+    assert_bits_equal(gm, mag, "gradient magnitude (wide range)")
+    assert_bits_equal(go, ori, "gradient orientation (wide range)")
+
+
+def test_edge_responses_and_parabola(ctx):
+    img = synth_frame(160, 120, 21)
+    g = [O.convolve(img, s) for s in (1.6, 2.2627418, 3.2, 4.5254836)]
+    d = []
+    for i in range(3):
+        out = np.empty_like(img)
+        O.lib().oracle_dog(g[i], g[i + 1], img.shape[1], img.shape[0], out)
+        d.append(out)
+    ys, xs = np.mgrid[1:119, 1:159]
+    xs, ys = xs.ravel().astype(np.uint16), ys.ravel().astype(np.uint16)
+    got = ctx.edge_responses(d[0], d[1], d[2], xs, ys)
+    want = np.array([O.lib().oracle_edge_filtered(d[0], d[1], d[2], 160, 120, int(x), int(y)) for x, y in zip(xs, ys)], np.uint8)
+    assert (got == want).all(), f"edge filter flags differ at {int((got != want).sum())} of {got.size} points"
+    assert 0 < want.sum() < want.size
+
+    rng = np.random.default_rng(2)
+    m = 5000
+    i = rng.integers(0, 36, m)
+    lnx = np.where(i == 0, 355, (i - 1) * 10 + 5).astype(np.uint16)
+    rnx = np.where(i == 35, 5, (i + 1) * 10 + 5).astype(np.uint16)
+    px = (i * 10 + 5).astype(np.uint16)
+    hs = (rng.random((3, m)) * 10.0 ** rng.integers(-3, 6, (3, m))).astype(np.float32)
+    hs[0, ::3] = 0
+    hs[2, ::3] = 0
+    got = ctx.vertex_parabola(lnx, hs[0], px, hs[1], rnx, hs[2])
+    want = np.array([O.lib().oracle_vertex_parabola(int(a), float(b), int(c), float(dd), int(e), float(f))
+                     for a, b, c, dd, e, f in zip(lnx, hs[0], px, hs[1], rnx, hs[2])], np.float32)
+    assert_bits_equal(got, want, "vertexParabola")
+
+
+# ------------------------------------------------------------------------------------------------
+# whole pipeline, stage by stage
+# ------------------------------------------------------------------------------------------------
+CASES = [
+    # name, w, h, seed, dogs, octaves, subpixel
+    ("synthetic 160x120 2oct", 160, 120, 1, 3, 2, False),
+    ("synthetic 640x480 4x3 (config 2)", 640, 480, 1, 3, 4, False),
+    ("synthetic 333x257 3oct odd sizes", 333, 257, 9, 3, 3, False),
+    ("synthetic 320x240 subpixel", 320, 240, 5, 3, 3, True),
+    ("synthetic 400x300 4 dogs", 400, 300, 6, 4, 2, False),
+]
+
+
+def compare_run(ctx, img, dogs, octaves, subpixel, name, report_dir, batch_of=1):
+    params = _lib.Params(dogs, octaves, 1.6, O.K_SQRT2, 1 if subpixel else 0)
+    run = O.OracleRun(img, dogs, octaves, subpixel=subpixel)
+    assert run.status == 0, run.error
+    imgs = np.stack([img] * batch_of)
+    ctx.calculate_batch(imgs, params)
+    rep = {"case": name}
+    for image in sorted({0, batch_of - 1}):
+        if subpixel:
+            assert_bits_equal(ctx.image(image), run.image(), f"{name}: replaced image")
+        for o in range(octaves):
+            for j in range(dogs + 1):
+                assert_bits_equal(ctx.level("gaussian", o, j, image), run.level("gaussian", o, j), f"{name}: gaussian({o},{j}) img{image}")
+                assert ctx.level_scale("gaussian", o, j) == run.scale("gaussian", o, j)
+            for j in range(dogs):
+                assert_bits_equal(ctx.level("dog", o, j, image), run.level("dog", o, j), f"{name}: dog({o},{j}) img{image}")
+                assert ctx.level_scale("dog", o, j) == run.scale("dog", o, j)
+        for stage in ("candidates", "after_sort1", "after_orient", "after_sort2", "final"):
+            got = ctx.stage(stage, image)
+            want, wdesc = run.points(stage)
+            rep[stage] = int(want.size)
+            assert got.size == want.size, f"{name}: {stage}: {got.size} points vs oracle {want.size}"
+            for f in ("x", "y", "octave", "index"):
+                assert (got[f] == want[f]).all(), f"{name}: {stage}: field {f} differs at {int((got[f] != want[f]).sum())} points"
+            assert (got["scale"] == want["scale"]).all(), f"{name}: {stage}: scale differs"
+            if stage in ("candidates", "after_orient", "after_sort2", "final"):
+                assert (got["filtered"].astype(bool) == want["filtered"].astype(bool)).all(), f"{name}: {stage}: filtered flags differ"
+            if stage in ("after_orient", "after_sort2", "final"):
+                m = ~want["filtered"].astype(bool)
+                assert_bits_equal(got["orientation"][m], want["orientation"][m], f"{name}: {stage}: orientation")
+    counts = ctx.counts()
+    kp, desc = ctx.results()
+    want, wdesc = run.points("final")
+    assert (counts == want.size).all()
+    for image in range(batch_of):
+        d = desc[image * want.size:(image + 1) * want.size]
+        l2 = np.sqrt(((d.astype(np.float64) - wdesc) ** 2).sum(axis=1)) if want.size else np.zeros(0)
+        rep["desc_max_l2"] = float(l2.max()) if l2.size else 0.0
+        rep["desc_bit_exact"] = bool(d.tobytes() == wdesc.tobytes())
+        assert (l2 <= DESC_TOL).all(), f"{name}: descriptors off by up to {l2.max()} (tol {DESC_TOL})"
+        assert rep["desc_bit_exact"], f"{name}: descriptors within tolerance but not bit-exact ({int((d != wdesc).sum())} values)"
+        k = kp[image * want.size:(image + 1) * want.size]
+        assert (k["has_descriptor"] == (want["n_desc"] == 128)).all()
+    with open(os.path.join(report_dir, "pipeline.jsonl"), "a") as f:
+        f.write(json.dumps(rep) + "\n")
+    return rep
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_pipeline_parity(ctx, report_dir, case):
+    name, w, h, seed, dogs, octaves, subpixel = case
+    rep = compare_run(ctx, synth_frame(w, h, seed), dogs, octaves, subpixel, name, report_dir)
+    assert rep["final"] > 0
+
+
+def test_pipeline_parity_two_pass_blur(ctx, report_dir):
+    ctx.set_option("fused_blur", 0)
+    try:
+        compare_run(ctx, synth_frame(200, 160, 2), 3, 2, False, "two-pass blur 200x160", report_dir)
+    finally:
+        ctx.set_option("fused_blur", 1)
+
+
+def test_batch_images_independent(ctx, report_dir):
+    """Every frame of a batch gets the single-frame result (frames differ)."""
+    params = _lib.Params(3, 3, 1.6, O.K_SQRT2, 0)
+    frames = np.stack([synth_frame(256, 192, s) for s in (1, 2, 3)])
+    ctx.calculate_batch(frames, params)
+    counts = ctx.counts()
+    kp, desc = ctx.results()
+    base = 0
+    for i in range(3):
+        want, wdesc = O.OracleRun(frames[i], 3, 3).points("final")
+        assert counts[i] == want.size
+        k = kp[base:base + counts[i]]
+        assert (k["x"] == want["x"]).all() and (k["y"] == want["y"]).all() and (k["octave"] == want["octave"]).all()
+        assert desc[base:base + counts[i]].tobytes() == wdesc.tobytes()
+        base += counts[i]
+
+
+def test_constant_image_has_no_keypoints(ctx):
+    """Every interior pixel ties => candidate; H = 0 => inverse fails => all filtered."""
+    img = np.full((96, 128), 77.0, np.float32)
+    params = _lib.Params(3, 2, 1.6, O.K_SQRT2, 0)
+    ctx.calculate_batch(img[None], params)
+    cand = ctx.stage("candidates")
+    run = O.OracleRun(img, 3, 2)
+    assert cand.size == run.points("candidates")[0].size == (128 - 2) * (96 - 2) + (64 - 2) * (48 - 2)
+    assert cand["filtered"].all()
+    assert ctx.counts()[0] == 0
+
+
+def test_exception_parity(ctx):
+    """B-13: pyramid level not larger than the kernel radius; asserts; B-14 dead 16x16 blur."""
+    img = synth_frame(160, 120, 1)
+    for (dogs, octaves) in [(3, 4), (5, 3)]:
+        run = O.OracleRun(img, dogs, octaves)
+        assert run.status == 1
+        with pytest.raises(PreconditionViolation) as e:
+            Sift(dogs, octaves, context=ctx).calculate(img)
+        assert str(e.value) == run.error
+    with pytest.raises(AssertionError):
+        Sift(2, 3, context=ctx).calculate(img)
+    with pytest.raises(AssertionError):
+        Sift(3, 0, context=ctx).calculate(img)
+    # B-14: 4 DoGs per octave, 3 octaves: DoG (2,2) has scale 3.2*... => dead blur radius > 15
+    big = synth_frame(512, 384, 3)
+    run = O.OracleRun(big, 4, 3)
+    if run.status == 1:
+        with pytest.raises(PreconditionViolation) as e:
+            Sift(4, 3, context=ctx).calculate(big)
+        assert str(e.value) == run.error
+    else:
+        compare_run(ctx, big, 4, 3, False, "512x384 4 dogs 3 oct", os.path.join(os.path.dirname(__file__), "..", "gpurun_out", "parity"))
+
+
+def test_full_size_properties(ctx):
+    """1920x1080, 4 oct x 3 DoG (bench workload): size-independent properties + oracle counts."""
+    img = synth_frame(1920, 1080, 1)
+    params = _lib.Params(3, 4, 1.6, O.K_SQRT2, 0)
+    ctx.calculate_batch(img[None], params)
+    kp, desc = ctx.results()
+    assert kp.size > 1000
+    # orientation is the rank-deficient parabola vertex ~177.4913 for every keypoint (B-9)
+    assert np.all(np.abs(kp["orientation"] - 177.4913) < 1e-3)
+    d = desc.reshape(-1, 16, 8)
+    assert np.all(d[:, :, 7] == 0)                      # bin 7 is never written (% 7)
+    s = d.sum(axis=2)
+    assert np.all((np.abs(s - 1) < 1e-5) | (s == 0))    # each cell L1-normalised
+    assert np.all(kp["x"] >= 8) and np.all(kp["y"] >= 8)
+    run = O.OracleRun(img, 3, 4)
+    want, wdesc = run.points("final")
+    assert kp.size == want.size
+    assert (kp["x"] == want["x"]).all() and (kp["y"] == want["y"]).all() and (kp["octave"] == want["octave"]).all()
+    assert desc.tobytes() == wdesc.tobytes()
