@@ -67,7 +67,8 @@ typedef struct sift_hip_keypoint {
 int sift_hip_create(int device, sift_hip_ctx** out, char* err, int errlen);
 void sift_hip_destroy(sift_hip_ctx* ctx);
 /* Option knobs: "fused_blur" (1 default: LDS-tiled single-kernel blur; 0: two-pass row/col
- * kernels), "profile" (1: bracket the pyramid kernels with HIP events). Returns EINVAL if unknown. */
+ * kernels), "gpu_cleanup" (1 default: cleanup steps as GPU kernels; 0: std::sort on the host),
+ * "host_threads", "profile" (1: bracket the pyramid kernels with HIP events). EINVAL if unknown. */
 int sift_hip_set_option(sift_hip_ctx* ctx, const char* name, int value);
 
 /* ---- Sift::calculate(), replaces sift.cpp:19-57 ---------------------------------------------- */
@@ -129,6 +130,11 @@ int sift_hip_vertex_parabola(sift_hip_ctx* ctx, const uint16_t* lnx, const float
 /* The cleanup step (sift.cpp:37-42): permutation std::sort(cmpByFilter) applies to n flags;
  * perm[i] = original index of the element ending at position i. */
 int sift_hip_sort_by_filter(sift_hip_ctx* ctx, const uint8_t* flags, int n, int32_t* perm);
+/* The whole cleanup (sift.cpp:37-42: sort, find first filtered, u16_t size, resize): original
+ * indices of the surviving points in their post-sort order.  on_gpu = 1 runs the cleanup kernel
+ * (kernels_cleanup.hip), 0 the host's std::sort glue; both must agree. */
+int sift_hip_cleanup_survivors(sift_hip_ctx* ctx, const uint8_t* flags, int n, int32_t* survivors,
+                               int32_t* count, int on_gpu);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* HIP-event timings of the pyramid kernels collected while option "profile" is 1.

@@ -22,7 +22,7 @@ SYMBOLS = [
     "sift_hip_image_copy", "sift_hip_level_dims", "sift_hip_level_copy", "sift_hip_level_scale",
     "sift_hip_stage_count", "sift_hip_stage_copy", "sift_hip_gauss_taps", "sift_hip_convolve_with_gauss",
     "sift_hip_reduce_to_next_level", "sift_hip_increase_to_next_level", "sift_hip_dog", "sift_hip_gradient",
-    "sift_hip_edge_responses", "sift_hip_vertex_parabola", "sift_hip_sort_by_filter", "sift_hip_profile_get",
+    "sift_hip_edge_responses", "sift_hip_vertex_parabola", "sift_hip_sort_by_filter", "sift_hip_cleanup_survivors", "sift_hip_profile_get",
     "sift_hip_profile_reset", "sift_hip_version",
 ]
 
@@ -84,6 +84,7 @@ def load():
     L.sift_hip_edge_responses.argtypes = [vp, fp, fp, fp, ci, ci, u16p, u16p, ci, u8p]
     L.sift_hip_vertex_parabola.argtypes = [vp, u16p, fp, u16p, fp, u16p, fp, ci, fp]
     L.sift_hip_sort_by_filter.argtypes = [vp, u8p, ci, i32p]
+    L.sift_hip_cleanup_survivors.argtypes = [vp, u8p, ci, i32p, C.POINTER(C.c_int32), ci]
     L.sift_hip_profile_get.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.sift_hip_profile_reset.argtypes = [vp]
     _lib = L

@@ -44,6 +44,9 @@ struct DevPlan {
     int scan_word_base[kMaxLevels];  // first mask word of the level inside one image
     int words_per_image;
     long long cand_capacity;         // per image
+    // descriptor tiles (64x64 core) of the levels some keypoint scale selects, per image
+    int desc_tile_base[kMaxLevels], desc_ntx[kMaxLevels], desc_nty[kMaxLevels];
+    int desc_tiles_per_image;
 };
 
 #define SIFT_HIP_CHECK(expr)                                                        \
@@ -96,11 +99,25 @@ void launch_vertex_parabola(hipStream_t s, const uint16_t* lnx, const float* lny
                             const float* py, const uint16_t* rnx, const float* rny, int m, float* out);
 void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, int w, int h, int n);
 void launch_orientation(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const Candidate* d_cands,
-                        const uint32_t* d_list, const int* d_list_cnt, int list_cap, int max_cnt,
-                        OrientOut* d_out, float* d_peaks);
+                        const uint32_t* d_list, const int* d_list_cnt, int list_cap, OrientOut* d_out,
+                        float* d_peaks);
+void launch_cleanup1(hipStream_t s, int n_images, const uint8_t* d_flags, const int* d_totals, long long cand_cap,
+                     uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, uint32_t* d_list, int list_cap,
+                     int* d_list_cnt, int* d_fallback);
+void launch_cleanup2(hipStream_t s, int n_images, const Candidate* d_cands, long long cand_cap,
+                     const uint32_t* d_list, const int* d_list_cnt, int list_cap, const OrientOut* d_orient,
+                     uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, FinalKp* d_final, int* d_final_cnt,
+                     int* d_status);
+void launch_cleanup_kat(hipStream_t s, const uint8_t* d_flags, int n, uint8_t* wk, uint32_t* wi, uint32_t* wi2,
+                        uint32_t* wp, uint32_t* d_out, int* d_info);
 void launch_w16(hipStream_t s, const DevPlan& plan, int level, const float* d_taps16, int radius16);
+// bins the final keypoints into per-tile lists (counts -> offsets -> fill), then one workgroup per tile
+void launch_desc_binning(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const FinalKp* d_final,
+                         const int* d_final_cnt, int final_cap, int* d_tile_cnt, int* d_tile_off,
+                         int* d_tile_cur, uint16_t* d_pool, int pool_cap);
 void launch_descriptors(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level,
                         const FinalKp* d_final, const int* d_final_cnt, int final_cap,
+                        const int* d_tile_cnt, const int* d_tile_off, const uint16_t* d_pool, int pool_cap,
                         const long long* d_out_base, sift_hip_keypoint* d_kp_out, float* d_desc_out);
 
 }  // namespace sift_hip

@@ -18,6 +18,7 @@ using namespace sift_hip;
 
 namespace {
 
+constexpr int kPoolCap = 4 * 65536;  // a 16x16 window touches at most 2x2 descriptor tiles
 constexpr int kListCap = 65536;  // cleanup keeps at most 65535 points (u16_t size, sift.cpp:41)
 
 struct DevBuf {
@@ -101,11 +102,13 @@ struct sift_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool fused = true;
+    bool gpu_cleanup = true;
     bool profile = false;
     int host_threads = 0;
     Plan plan;
     DevBuf arena, d_plan, d_taps, d_luts, d_taps16, d_input, d_base, d_tmp, d_tmp2;
     DevBuf d_masks, d_counts, d_totals, d_cands, d_flags;
+    DevBuf d_wk, d_wi, d_wi2, d_wp, d_status, d_tile, d_pool;
     DevBuf d_list, d_list_cnt, d_orient, d_peaks, d_final, d_final_cnt, d_out_base, d_kp, d_desc;
     HostBuf h_flags, h_orient, h_peaks;
     // results of the last batch
@@ -120,6 +123,7 @@ struct sift_hip_ctx {
     long long total = 0;
     bool have_result = false;
     bool have_pyramid = false;
+    bool stages_on_host = false;
     // profiling
     struct EvPair { hipEvent_t a, b; int which; double bytes; };
     std::vector<EvPair> pending;
@@ -317,6 +321,17 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
             if (std::find(P.grad_levels.begin(), P.grad_levels.end(), dv.nearest_level[o * D + i]) == P.grad_levels.end())
                 P.grad_levels.push_back(dv.nearest_level[o * D + i]);
         }
+    {
+        int tb = 0;
+        for (int lvl : P.grad_levels) {
+            const int o = lvl / (D + 1);
+            dv.desc_ntx[lvl] = (dv.w[o] + 63) / 64;
+            dv.desc_nty[lvl] = (dv.h[o] + 63) / 64;
+            dv.desc_tile_base[lvl] = tb;
+            tb += dv.desc_ntx[lvl] * dv.desc_nty[lvl];
+        }
+        dv.desc_tiles_per_image = std::max(tb, 1);
+    }
     dv.words_per_image = std::max(words, 1);
     dv.cand_capacity = std::max(cap, 1LL);
     gauss_taps(1.6f, P.taps16, P.radius16);
@@ -374,6 +389,8 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
     c->d_final.ensure((size_t)kListCap * (size_t)n * sizeof(FinalKp));
     c->d_final_cnt.ensure((size_t)n * sizeof(int));
     c->d_out_base.ensure((size_t)n * sizeof(long long));
+    c->d_tile.ensure((size_t)dv.desc_tiles_per_image * (size_t)n * 3 * sizeof(int));
+    c->d_pool.ensure((size_t)kPoolCap * (size_t)n * sizeof(uint16_t));
     SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
     P.valid = true;
     return SIFT_HIP_OK;
@@ -462,6 +479,179 @@ void cleanup2_fn(int img, void* a) {
     (void)P;
 }
 
+// ---- stages between the edge filter and the descriptors -----------------------------------------
+// Host-glue path: flags down, std::sort on the host (host_glue.cpp), lists up.  Exact by
+// construction (it IS libstdc++'s std::sort); used when option "gpu_cleanup" is 0 and as the
+// fallback for the cases the GPU cleanup flags (introsort depth limit, several orientation peaks).
+void mid_host(sift_hip_ctx* c) {
+    Plan& P = c->plan;
+    const DevPlan& dv = P.dev;
+    const int n = P.n;
+    hipStream_t s = c->stream;
+    const DevPlan* dpl = c->d_plan.as<DevPlan>();
+    SIFT_HIP_CHECK(hipMemcpyAsync(c->totals.data(), c->d_totals.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
+    SIFT_HIP_CHECK(hipStreamSynchronize(s));
+    c->flag_off.assign((size_t)n, 0);
+    size_t fl_total = 0;
+    for (int i = 0; i < n; ++i) { c->flag_off[(size_t)i] = fl_total; fl_total += (size_t)c->totals[(size_t)i]; }
+    c->h_flags.ensure(std::max<size_t>(fl_total, 1));
+    for (int i = 0; i < n; ++i)
+        if (c->totals[(size_t)i])
+            SIFT_HIP_CHECK(hipMemcpyAsync(c->h_flags.as<uint8_t>() + c->flag_off[(size_t)i],
+                                          c->d_flags.as<uint8_t>() + (size_t)i * (size_t)dv.cand_capacity,
+                                          (size_t)c->totals[(size_t)i], hipMemcpyDeviceToHost, s));
+    SIFT_HIP_CHECK(hipStreamSynchronize(s));
+    const int threads = c->host_threads > 0 ? c->host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+    Cleanup1Arg a1{c};
+    parallel_for(n, threads, cleanup1_fn, &a1);
+
+    std::vector<int> cnt1((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        cnt1[(size_t)i] = (int)c->list1[(size_t)i].size();
+        if (cnt1[(size_t)i])
+            SIFT_HIP_CHECK(hipMemcpyAsync(c->d_list.as<uint32_t>() + (size_t)i * kListCap, c->list1[(size_t)i].data(),
+                                          (size_t)cnt1[(size_t)i] * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    }
+    SIFT_HIP_CHECK(hipMemcpyAsync(c->d_list_cnt.p, cnt1.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+    launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
+                       kListCap, c->d_orient.as<OrientOut>(), c->d_peaks.as<float>());
+    c->h_orient.ensure((size_t)n * kListCap * sizeof(OrientOut));
+    for (int i = 0; i < n; ++i)
+        if (cnt1[(size_t)i])
+            SIFT_HIP_CHECK(hipMemcpyAsync(c->h_orient.as<OrientOut>() + (size_t)i * kListCap,
+                                          c->d_orient.as<OrientOut>() + (size_t)i * kListCap,
+                                          (size_t)cnt1[(size_t)i] * sizeof(OrientOut), hipMemcpyDeviceToHost, s));
+    SIFT_HIP_CHECK(hipStreamSynchronize(s));
+    bool any_multi = false;
+    for (int i = 0; i < n && !any_multi; ++i) {
+        const OrientOut* oo = c->h_orient.as<OrientOut>() + (size_t)i * kListCap;
+        for (int k = 0; k < cnt1[(size_t)i]; ++k)
+            if (!oo[k].filtered && oo[k].npeaks > 1) { any_multi = true; break; }
+    }
+    if (any_multi) {
+        c->h_peaks.ensure((size_t)n * kListCap * 36 * sizeof(float));
+        for (int i = 0; i < n; ++i)
+            if (cnt1[(size_t)i])
+                SIFT_HIP_CHECK(hipMemcpyAsync(c->h_peaks.as<float>() + (size_t)i * kListCap * 36,
+                                              c->d_peaks.as<float>() + (size_t)i * kListCap * 36,
+                                              (size_t)cnt1[(size_t)i] * 36 * sizeof(float), hipMemcpyDeviceToHost, s));
+        SIFT_HIP_CHECK(hipStreamSynchronize(s));
+    } else {
+        c->h_peaks.release();
+    }
+    Cleanup2Arg a2{c};
+    parallel_for(n, threads, cleanup2_fn, &a2);
+
+    std::vector<int> cnt2((size_t)n);
+    std::vector<FinalKp> up;
+    std::vector<Candidate> hc;
+    for (int i = 0; i < n; ++i) {
+        const auto& fin = c->final_list[(size_t)i];
+        cnt2[(size_t)i] = c->status[(size_t)i] ? 0 : (int)fin.size();
+        c->counts[(size_t)i] = cnt2[(size_t)i];
+        if (!cnt2[(size_t)i]) continue;
+        hc.resize((size_t)c->totals[(size_t)i]);
+        SIFT_HIP_CHECK(hipMemcpyAsync(hc.data(), c->d_cands.as<Candidate>() + (size_t)i * (size_t)dv.cand_capacity,
+                                      hc.size() * sizeof(Candidate), hipMemcpyDeviceToHost, s));
+        SIFT_HIP_CHECK(hipStreamSynchronize(s));
+        up.resize(fin.size());
+        for (size_t k = 0; k < fin.size(); ++k) {
+            const Candidate& cd = hc[fin[k].cand];
+            up[k] = FinalKp{fin[k].cand, fin[k].orientation, cd.x, cd.y, cd.octave, cd.index};
+        }
+        SIFT_HIP_CHECK(hipMemcpyAsync(c->d_final.as<FinalKp>() + (size_t)i * kListCap, up.data(), up.size() * sizeof(FinalKp),
+                                      hipMemcpyHostToDevice, s));
+        SIFT_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    SIFT_HIP_CHECK(hipMemcpyAsync(c->d_final_cnt.p, cnt2.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+    c->stages_on_host = true;
+}
+
+// GPU path: both cleanups as kernels (kernels_cleanup.hip); the host only reads 4 ints per image.
+// Returns false when some image needs the host path.
+bool mid_gpu(sift_hip_ctx* c) {
+    Plan& P = c->plan;
+    const DevPlan& dv = P.dev;
+    const int n = P.n;
+    hipStream_t s = c->stream;
+    const DevPlan* dpl = c->d_plan.as<DevPlan>();
+    const size_t per = (size_t)std::max<long long>(dv.cand_capacity, kListCap);
+    c->d_wk.ensure(per * (size_t)n);
+    c->d_wi.ensure(per * (size_t)n * sizeof(uint32_t));
+    c->d_wi2.ensure(per * (size_t)n * sizeof(uint32_t));
+    c->d_wp.ensure(per * (size_t)n * sizeof(uint32_t));
+    c->d_status.ensure((size_t)n * 5 * sizeof(int));
+    int* d_fb1 = c->d_status.as<int>() + (size_t)n * 4;
+    launch_cleanup1(s, n, c->d_flags.as<uint8_t>(), c->d_totals.as<int>(), dv.cand_capacity, c->d_wk.as<uint8_t>(),
+                    c->d_wi.as<uint32_t>(), c->d_wi2.as<uint32_t>(), c->d_wp.as<uint32_t>(), c->d_list.as<uint32_t>(),
+                    kListCap, c->d_list_cnt.as<int>(), d_fb1);
+    launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
+                       kListCap, c->d_orient.as<OrientOut>(), c->d_peaks.as<float>());
+    launch_cleanup2(s, n, c->d_cands.as<Candidate>(), dv.cand_capacity, c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
+                    kListCap, c->d_orient.as<OrientOut>(), c->d_wk.as<uint8_t>(), c->d_wi.as<uint32_t>(),
+                    c->d_wi2.as<uint32_t>(), c->d_wp.as<uint32_t>(), c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(),
+                    c->d_status.as<int>());
+    std::vector<int> st((size_t)n * 5);
+    SIFT_HIP_CHECK(hipMemcpyAsync(st.data(), c->d_status.p, st.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+    SIFT_HIP_CHECK(hipStreamSynchronize(s));
+    for (int i = 0; i < n; ++i)
+        if (st[(size_t)i * 4 + 1] || st[(size_t)n * 4 + (size_t)i]) return false;
+    for (int i = 0; i < n; ++i) {
+        c->counts[(size_t)i] = st[(size_t)i * 4 + 0];
+        if (st[(size_t)i * 4 + 2] != 0x7fffffff) {  // sift.cpp:184 would throw for this image
+            c->status[(size_t)i] = SIFT_HIP_EPRECONDITION;
+            c->messages[(size_t)i] = st[(size_t)i * 4 + 3] == 2
+                ? precondition("Kernel1D::initGaussian(): Standard deviation must be >= 0.")
+                : precondition("separableConvolveX(): kernel longer than line\n");
+            c->counts[(size_t)i] = 0;
+        }
+    }
+    c->stages_on_host = false;
+    return true;
+}
+
+// Fill the host-side stage vectors from the device buffers (inspection API after the GPU path).
+void ensure_host_stages(sift_hip_ctx* c) {
+    if (c->stages_on_host) return;
+    Plan& P = c->plan;
+    const DevPlan& dv = P.dev;
+    const int n = P.n;
+    SIFT_HIP_CHECK(hipMemcpy(c->totals.data(), c->d_totals.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    c->flag_off.assign((size_t)n, 0);
+    size_t fl_total = 0;
+    for (int i = 0; i < n; ++i) { c->flag_off[(size_t)i] = fl_total; fl_total += (size_t)c->totals[(size_t)i]; }
+    c->h_flags.ensure(std::max<size_t>(fl_total, 1));
+    std::vector<int> cnt1((size_t)n), cnt2((size_t)n);
+    SIFT_HIP_CHECK(hipMemcpy(cnt1.data(), c->d_list_cnt.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    SIFT_HIP_CHECK(hipMemcpy(cnt2.data(), c->d_final_cnt.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<OrientOut> oo;
+    std::vector<FinalKp> fk;
+    for (int i = 0; i < n; ++i) {
+        if (c->totals[(size_t)i])
+            SIFT_HIP_CHECK(hipMemcpy(c->h_flags.as<uint8_t>() + c->flag_off[(size_t)i],
+                                     c->d_flags.as<uint8_t>() + (size_t)i * (size_t)dv.cand_capacity,
+                                     (size_t)c->totals[(size_t)i], hipMemcpyDeviceToHost));
+        auto& l1 = c->list1[(size_t)i];
+        l1.resize((size_t)cnt1[(size_t)i]);
+        oo.resize(l1.size());
+        if (!l1.empty()) {
+            SIFT_HIP_CHECK(hipMemcpy(l1.data(), c->d_list.as<uint32_t>() + (size_t)i * kListCap, l1.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            SIFT_HIP_CHECK(hipMemcpy(oo.data(), c->d_orient.as<OrientOut>() + (size_t)i * kListCap, oo.size() * sizeof(OrientOut), hipMemcpyDeviceToHost));
+        }
+        auto& ao = c->after_orient[(size_t)i];
+        auto& fin = c->final_list[(size_t)i];
+        ao.clear();
+        fin.clear();
+        if (c->status[(size_t)i]) continue;  // the reference threw inside _orientationAssignment
+        for (size_t k = 0; k < l1.size(); ++k) ao.push_back(PointRec{l1[k], oo[k].orientation, oo[k].filtered});
+        fk.resize((size_t)cnt2[(size_t)i]);
+        if (!fk.empty())
+            SIFT_HIP_CHECK(hipMemcpy(fk.data(), c->d_final.as<FinalKp>() + (size_t)i * kListCap, fk.size() * sizeof(FinalKp), hipMemcpyDeviceToHost));
+        for (const FinalKp& f : fk) fin.push_back(PointRec{f.cand, f.orientation, 0});
+    }
+    c->stages_on_host = true;
+}
+
 int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     Plan& P = c->plan;
     const DevPlan& dv = P.dev;
@@ -478,6 +668,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     c->total = 0;
     c->have_result = false;
     c->have_pyramid = false;
+    c->stages_on_host = false;
 
     run_pyramid(c, d_in);
     c->have_pyramid = true;
@@ -486,125 +677,51 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
         resolve_events(c);
         for (int i = 0; i < n; ++i) { c->status[(size_t)i] = P.fail_status; c->messages[(size_t)i] = P.fail_msg; }
         c->have_result = true;
+        c->stages_on_host = true;
         set_err(err, errlen, P.fail_msg);
         return P.fail_status;
     }
 
-    // extrema + edge responses (sift.cpp:33-34)
+    // extrema + edge responses (sift.cpp:33-34); gradient maps of the selected levels and W16
     const DevPlan* dpl = c->d_plan.as<DevPlan>();
     launch_extrema_mask(s, dpl, dv, c->d_masks.as<unsigned long long>(), c->d_counts.as<int>());
     launch_extrema_scan(s, dv, c->d_counts.as<int>(), c->d_totals.as<int>());
     launch_extrema_expand(s, dpl, dv, c->d_masks.as<unsigned long long>(), c->d_counts.as<int>(), c->d_cands.as<Candidate>());
     launch_edge_filter(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_totals.as<int>(), c->d_flags.as<uint8_t>());
-    // gradient maps of the selected levels and W16 do not depend on the host glue: queue them now
     for (int lvl : P.grad_levels) {
         const int o = lvl / (D + 1);
         launch_gradient(s, dv.gauss[lvl], dv.mag[lvl], dv.ori[lvl], dv.w[o], dv.h[o], n);
         launch_w16(s, dv, lvl, c->d_taps16.as<float>(), P.radius16);
     }
-    SIFT_HIP_CHECK(hipMemcpyAsync(c->totals.data(), c->d_totals.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, s));
-    SIFT_HIP_CHECK(hipStreamSynchronize(s));
+    // cleanup, orientation assignment, cleanup (sift.cpp:37-54)
+    if (!(c->gpu_cleanup && mid_gpu(c))) {
+        for (int i = 0; i < n; ++i) { c->status[(size_t)i] = 0; c->messages[(size_t)i].clear(); }
+        mid_host(c);
+    }
     resolve_events(c);
 
-    // first cleanup (sift.cpp:37-42) on the host: flags down, survivor lists up
-    c->flag_off.assign((size_t)n, 0);
-    size_t fl_total = 0;
-    for (int i = 0; i < n; ++i) { c->flag_off[(size_t)i] = fl_total; fl_total += (size_t)c->totals[(size_t)i]; }
-    c->h_flags.ensure(std::max<size_t>(fl_total, 1));
-    for (int i = 0; i < n; ++i)
-        if (c->totals[(size_t)i])
-            SIFT_HIP_CHECK(hipMemcpyAsync(c->h_flags.as<uint8_t>() + c->flag_off[(size_t)i],
-                                          c->d_flags.as<uint8_t>() + (size_t)i * (size_t)dv.cand_capacity,
-                                          (size_t)c->totals[(size_t)i], hipMemcpyDeviceToHost, s));
-    SIFT_HIP_CHECK(hipStreamSynchronize(s));
-    const int threads = c->host_threads > 0 ? c->host_threads : (int)std::max(1u, std::thread::hardware_concurrency());
-    Cleanup1Arg a1{c};
-    parallel_for(n, threads, cleanup1_fn, &a1);
-
-    std::vector<int> cnt1((size_t)n);
-    int max_cnt = 0;
-    for (int i = 0; i < n; ++i) {
-        cnt1[(size_t)i] = (int)c->list1[(size_t)i].size();
-        max_cnt = std::max(max_cnt, cnt1[(size_t)i]);
-        if (cnt1[(size_t)i])
-            SIFT_HIP_CHECK(hipMemcpyAsync(c->d_list.as<uint32_t>() + (size_t)i * kListCap, c->list1[(size_t)i].data(),
-                                          (size_t)cnt1[(size_t)i] * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    }
-    SIFT_HIP_CHECK(hipMemcpyAsync(c->d_list_cnt.p, cnt1.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
-
-    // orientation assignment (sift.cpp:44-46)
-    launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
-                       kListCap, max_cnt, c->d_orient.as<OrientOut>(), c->d_peaks.as<float>());
-    c->h_orient.ensure((size_t)n * kListCap * sizeof(OrientOut));
-    for (int i = 0; i < n; ++i)
-        if (cnt1[(size_t)i])
-            SIFT_HIP_CHECK(hipMemcpyAsync(c->h_orient.as<OrientOut>() + (size_t)i * kListCap,
-                                          c->d_orient.as<OrientOut>() + (size_t)i * kListCap,
-                                          (size_t)cnt1[(size_t)i] * sizeof(OrientOut), hipMemcpyDeviceToHost, s));
-    SIFT_HIP_CHECK(hipStreamSynchronize(s));
-    // extra peaks are rare (unreachable for non-negative images): fetch them only when present
-    bool any_multi = false;
-    for (int i = 0; i < n && !any_multi; ++i) {
-        const OrientOut* oo = c->h_orient.as<OrientOut>() + (size_t)i * kListCap;
-        for (int k = 0; k < cnt1[(size_t)i]; ++k)
-            if (oo[k].npeaks > 1) { any_multi = true; break; }
-    }
-    if (any_multi) {
-        c->h_peaks.ensure((size_t)n * kListCap * 36 * sizeof(float));
-        for (int i = 0; i < n; ++i)
-            if (cnt1[(size_t)i])
-                SIFT_HIP_CHECK(hipMemcpyAsync(c->h_peaks.as<float>() + (size_t)i * kListCap * 36,
-                                              c->d_peaks.as<float>() + (size_t)i * kListCap * 36,
-                                              (size_t)cnt1[(size_t)i] * 36 * sizeof(float), hipMemcpyDeviceToHost, s));
-        SIFT_HIP_CHECK(hipStreamSynchronize(s));
-    } else {
-        c->h_peaks.release();
-    }
-    Cleanup2Arg a2{c};
-    parallel_for(n, threads, cleanup2_fn, &a2);
-
     // descriptors (sift.cpp:55)
-    std::vector<int> cnt2((size_t)n);
-    std::vector<FinalKp> up;
     long long total = 0;
     for (int i = 0; i < n; ++i) {
-        const auto& fin = c->final_list[(size_t)i];
-        cnt2[(size_t)i] = c->status[(size_t)i] ? 0 : (int)fin.size();
-        c->counts[(size_t)i] = cnt2[(size_t)i];
         c->out_base[(size_t)i] = total;
-        total += cnt2[(size_t)i];
+        total += c->counts[(size_t)i];
     }
     c->total = total;
     c->d_kp.ensure(std::max<size_t>((size_t)total, 1) * sizeof(sift_hip_keypoint));
     c->d_desc.ensure(std::max<size_t>((size_t)total, 1) * 128 * sizeof(float));
-    // candidate records are needed to fill FinalKp: fetch the referenced ones from the device copy
-    // (cheap: one gather per surviving keypoint) — done on the host from a downloaded candidate
-    // array only for the survivors' images.
-    {
-        std::vector<Candidate> hc;
-        for (int i = 0; i < n; ++i) {
-            if (!cnt2[(size_t)i]) continue;
-            hc.resize((size_t)c->totals[(size_t)i]);
-            SIFT_HIP_CHECK(hipMemcpyAsync(hc.data(), c->d_cands.as<Candidate>() + (size_t)i * (size_t)dv.cand_capacity,
-                                          hc.size() * sizeof(Candidate), hipMemcpyDeviceToHost, s));
-            SIFT_HIP_CHECK(hipStreamSynchronize(s));
-            const auto& fin = c->final_list[(size_t)i];
-            up.resize(fin.size());
-            for (size_t k = 0; k < fin.size(); ++k) {
-                const Candidate& cd = hc[fin[k].cand];
-                up[k] = FinalKp{fin[k].cand, fin[k].orientation, cd.x, cd.y, cd.octave, cd.index};
-            }
-            SIFT_HIP_CHECK(hipMemcpyAsync(c->d_final.as<FinalKp>() + (size_t)i * kListCap, up.data(), up.size() * sizeof(FinalKp),
-                                          hipMemcpyHostToDevice, s));
-            SIFT_HIP_CHECK(hipStreamSynchronize(s));
-        }
-    }
-    SIFT_HIP_CHECK(hipMemcpyAsync(c->d_final_cnt.p, cnt2.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
     SIFT_HIP_CHECK(hipMemcpyAsync(c->d_out_base.p, c->out_base.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice, s));
-    if (total > 0)
+    if (total > 0) {
+        const size_t nt = (size_t)dv.desc_tiles_per_image * (size_t)n;
+        int* t_cnt = c->d_tile.as<int>();
+        int* t_off = t_cnt + nt;
+        int* t_cur = t_off + nt;
+        launch_desc_binning(s, dpl, dv, c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(), kListCap, t_cnt, t_off, t_cur,
+                            c->d_pool.as<uint16_t>(), kPoolCap);
         for (int lvl : P.grad_levels)
-            launch_descriptors(s, dpl, dv, lvl, c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(), kListCap,
-                               c->d_out_base.as<long long>(), c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>());
+            launch_descriptors(s, dpl, dv, lvl, c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(), kListCap, t_cnt, t_off,
+                               c->d_pool.as<uint16_t>(), kPoolCap, c->d_out_base.as<long long>(),
+                               c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>());
+    }
     SIFT_HIP_CHECK(hipStreamSynchronize(s));
     c->have_result = true;
     int rc = SIFT_HIP_OK;
@@ -663,7 +780,7 @@ void sift_hip_destroy(sift_hip_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->arena, &c->d_plan, &c->d_taps, &c->d_luts, &c->d_taps16, &c->d_input, &c->d_base, &c->d_tmp, &c->d_tmp2,
-                      &c->d_masks, &c->d_counts, &c->d_totals, &c->d_cands, &c->d_flags, &c->d_list, &c->d_list_cnt, &c->d_orient,
+                      &c->d_wk, &c->d_wi, &c->d_wi2, &c->d_wp, &c->d_status, &c->d_tile, &c->d_pool, &c->d_masks, &c->d_counts, &c->d_totals, &c->d_cands, &c->d_flags, &c->d_list, &c->d_list_cnt, &c->d_orient,
                       &c->d_peaks, &c->d_final, &c->d_final_cnt, &c->d_out_base, &c->d_kp, &c->d_desc})
         b->release();
     for (HostBuf* b : {&c->h_flags, &c->h_orient, &c->h_peaks}) b->release();
@@ -676,6 +793,7 @@ void sift_hip_destroy(sift_hip_ctx* c) {
 int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     if (!c || !name) return SIFT_HIP_EINVAL;
     if (!std::strcmp(name, "fused_blur")) { c->fused = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "gpu_cleanup")) { c->gpu_cleanup = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "profile")) { c->profile = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "host_threads")) { c->host_threads = value; return SIFT_HIP_OK; }
     return SIFT_HIP_EINVAL;
@@ -799,6 +917,14 @@ float sift_hip_level_scale(sift_hip_ctx* c, int kind, int octave, int level) {
 
 int sift_hip_stage_count(sift_hip_ctx* c, int image, int stage) {
     if (!c || !c->have_result || image < 0 || image >= c->plan.n) return -1;
+    if (stage != 4) {
+        try {
+            SIFT_HIP_CHECK(hipSetDevice(c->device));
+            ensure_host_stages(c);
+        } catch (...) {
+            return -1;
+        }
+    }
     switch (stage) {
         case 0: return c->totals[(size_t)image];
         case 1: return (int)c->list1[(size_t)image].size();
@@ -1018,6 +1144,44 @@ int sift_hip_sort_by_filter(sift_hip_ctx* c, const uint8_t* flags, int n, int32_
     sort_by_filter(flags, n, p);
     for (int i = 0; i < n; ++i) perm[i] = (int32_t)p[(size_t)i];
     return SIFT_HIP_OK;
+}
+
+int sift_hip_cleanup_survivors(sift_hip_ctx* c, const uint8_t* flags, int n, int32_t* survivors, int32_t* count, int on_gpu) {
+    if (!flags || !survivors || !count || n < 0) return SIFT_HIP_EINVAL;
+    if (!on_gpu) {
+        std::vector<uint32_t> sv;
+        cleanup_survivors(flags, n, sv);
+        *count = (int32_t)sv.size();
+        for (size_t i = 0; i < sv.size(); ++i) survivors[i] = (int32_t)sv[i];
+        return SIFT_HIP_OK;
+    }
+    if (!c) return SIFT_HIP_EINVAL;
+    return guarded(nullptr, 0, [&]() {
+        SIFT_HIP_CHECK(hipSetDevice(c->device));
+        Scratch s;
+        const size_t m = (size_t)std::max(n, 1);
+        uint8_t* d_fl = s.upload(flags, m);
+        uint8_t* wk = s.dev<uint8_t>(m);
+        uint32_t* wi = s.dev<uint32_t>(m);
+        uint32_t* wi2 = s.dev<uint32_t>(m);
+        uint32_t* wp = s.dev<uint32_t>(m);
+        uint32_t* out = s.dev<uint32_t>(m);
+        int* info = s.dev<int>(2);
+        launch_cleanup_kat(c->stream, d_fl, n, wk, wi, wi2, wp, out, info);
+        SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
+        int h_info[2];
+        SIFT_HIP_CHECK(hipMemcpy(h_info, info, sizeof(h_info), hipMemcpyDeviceToHost));
+        if (h_info[1]) {  // introsort depth limit: the host's std::sort decides
+            std::vector<uint32_t> sv;
+            cleanup_survivors(flags, n, sv);
+            *count = (int32_t)sv.size();
+            for (size_t i = 0; i < sv.size(); ++i) survivors[i] = (int32_t)sv[i];
+            return SIFT_HIP_OK;
+        }
+        *count = h_info[0];
+        if (h_info[0]) SIFT_HIP_CHECK(hipMemcpy(survivors, out, (size_t)h_info[0] * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        return SIFT_HIP_OK;
+    });
 }
 
 int sift_hip_profile_get(sift_hip_ctx* c, int which, double* ms, int64_t* launches, double* bytes) {

@@ -1,0 +1,387 @@
+// The two "cleanup" steps of Sift::calculate (/root/reference/sift.cpp:37-42 and 49-54) on the GPU:
+//     std::sort(points, InterestPoint::cmpByFilter); find first filtered; u16_t size; resize(size)
+//
+// The order in which libstdc++'s UNSTABLE introsort leaves the surviving points feeds the
+// order-dependent descriptor stage, so it must be reproduced exactly.  With a two-valued key
+// (filtered or not) the algorithm's behaviour has a closed structure that needs no general sort:
+//   * __introsort_loop only ever carries ONE mixed range.  A partition around a "filtered" pivot
+//     moves the t-th filtered element from the left to position last-1-t while that is to its
+//     right; the right part is then all-filtered (dead: holds no survivor).  A partition around a
+//     "kept" pivot moves the t-th kept element from the right to first+t; the left part is then
+//     all-kept.
+//   * an all-kept range evolves independently of the data (every comparison is false): swap
+//     first<->middle, reverse [first+1, last), split — a closed-form position map per element.
+//   * __final_insertion_sort is a stable sort, i.e. a stable partition by key: survivors keep the
+//     position order they have after the loop.
+//   * depth_limit = 2*floor(log2 n); if it ever runs out (heapsort fallback) the image is flagged
+//     and the host's std::sort path (host_glue.cpp) redoes it.
+// One 1024-thread workgroup per image; ranks come from wavefront __ballot + popcount prefix sums.
+// tests/test_abi.py checks the host twin of this scheme, tests/test_gpu_parity.py this kernel,
+// against std::sort itself.
+#include "common.h"
+
+namespace sift_hip {
+
+constexpr int kCT = 1024;          // threads per cleanup workgroup
+constexpr int kMaxPure = 128;      // all-kept ranges spawned by one sort (<= rounds <= 2*31)
+
+struct PureRange {
+    int f, m, d;
+};
+
+struct CleanupShared {
+    int wc[2][16];
+    int flag;        // first failing position (min) of the current round
+    int T;
+    int f, l, d, p;
+    int npure;
+    int fallback;
+    PureRange pure[kMaxPure];
+};
+
+__device__ __forceinline__ int floor_log2(int n) { return 31 - __clz(n); }
+
+// Rank of this thread's element among the `hit` elements of the current 1024-element tile, plus
+// the tile's total.  Uses the double-buffered per-wave counters sh.wc[par].
+__device__ __forceinline__ int tile_rank(CleanupShared& sh, int par, bool hit, int& tile_total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) sh.wc[par][wv] = __popcll(m);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c = sh.wc[par][q];
+        before += (q < wv) ? c : 0;
+        total += c;
+    }
+    tile_total = total;
+    return before + __popcll(m & ((1ull << lane) - 1ull));
+}
+
+// Closed-form evolution of one element of an all-kept range [f, f+m) with depth budget d.
+// Returns the final position, or -1 if the depth limit would be hit with m > 16.
+__device__ __forceinline__ int pure_final_pos(int pos, int f, int m, int d) {
+    while (m > 16) {
+        if (d == 0) return -1;
+        --d;
+        const int l = f + m;
+        const int mid = f + m / 2;
+        if (pos == f) pos = mid;           // __move_median_to_first: every compare false -> swap(first, mid)
+        else if (pos == mid) pos = f;
+        if (pos >= f + 1) pos = f + l - pos;  // __unguarded_partition with an equal pivot: reverse [f+1, l)
+        const int cut = f + ((m & 1) ? (m + 1) / 2 : m / 2);
+        if (pos < cut) {
+            m = cut - f;
+        } else {
+            f = cut;
+            m = l - cut;
+        }
+    }
+    return pos;
+}
+
+// Core: K[0..n) keys (0 kept, 1 filtered) and I[0..n) payload are permuted in global memory like
+// __introsort_loop would; I2 receives the arrangement after the all-kept ranges' evolution.
+// P is scratch for swap sources (n/2 + 1 entries).  Returns via sh.fallback.
+__device__ void introsort_binary(CleanupShared& sh, int n, uint8_t* __restrict__ K, uint32_t* __restrict__ I,
+                                 uint32_t* __restrict__ I2, uint32_t* __restrict__ P) {
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        sh.f = 0;
+        sh.l = n;
+        sh.d = n > 0 ? 2 * floor_log2(n) : 0;
+        sh.npure = 0;
+        sh.fallback = 0;
+    }
+    __syncthreads();
+    while (true) {
+        const int f = sh.f, l = sh.l;
+        if (l - f <= 16 || sh.fallback) break;
+        __syncthreads();
+        if (tid == 0) {
+            if (sh.d == 0) {
+                sh.fallback = 1;
+            } else {
+                sh.d -= 1;
+                // __move_median_to_first(f, f+1, mid, l-1)
+                const int a = f + 1, b = f + (l - f) / 2, c = l - 1;
+                const int ka = K[a], kb = K[b], kc = K[c];
+                auto comp = [](int x, int y) { return x == 0 && y == 1; };
+                int s;
+                if (comp(ka, kb)) {
+                    if (comp(kb, kc)) s = b;
+                    else if (comp(ka, kc)) s = c;
+                    else s = a;
+                } else if (comp(ka, kc)) s = a;
+                else if (comp(kb, kc)) s = c;
+                else s = b;
+                const uint8_t kf = K[f], ks = K[s];
+                K[f] = ks;
+                K[s] = kf;
+                const uint32_t jf = I[f], js = I[s];
+                I[f] = js;
+                I[s] = jf;
+                sh.p = ks;
+                sh.flag = 0x7fffffff;
+                sh.T = 0x7fffffff;
+            }
+        }
+        __syncthreads();
+        if (sh.fallback) break;
+        const int p = sh.p;
+        const int F = f + 1, L = l;
+        int running = 0;  // hits seen in earlier tiles (block-uniform)
+        int par = 0;
+        if (p == 1) {
+            // t-th filtered element from the left goes to L-1-t while it lies left of it
+            for (int base = F; base < L; base += kCT) {
+                const int pos = base + tid;
+                const bool hit = pos < L && K[pos] == 1;
+                int tile_total;
+                const int t = running + tile_rank(sh, par, hit, tile_total);
+                if (hit) {
+                    if (pos < L - 1 - t) {
+                        P[t] = (uint32_t)pos;
+                    } else {  // participants are a prefix of the hits: the smallest failing rank is T
+                        atomicMin(&sh.T, t);
+                        atomicMin(&sh.flag, pos);
+                    }
+                }
+                running += tile_total;
+                par ^= 1;
+                __syncthreads();
+                if (sh.T != 0x7fffffff) break;
+            }
+        } else {
+            // t-th kept element from the right goes to F+t while it lies right of it
+            for (int base = L - 1; base >= F; base -= kCT) {
+                const int pos = base - tid;
+                const bool hit = pos >= F && K[pos] == 0;
+                int tile_total;
+                const int t = running + tile_rank(sh, par, hit, tile_total);
+                if (hit) {
+                    if (F + t < pos) P[t] = (uint32_t)pos;
+                    else atomicMin(&sh.T, t);
+                }
+                running += tile_total;
+                par ^= 1;
+                __syncthreads();
+                if (sh.T != 0x7fffffff) break;
+            }
+        }
+        __syncthreads();
+        const int T = (sh.T == 0x7fffffff) ? running : sh.T;
+        __syncthreads();
+        // apply the T disjoint swaps
+        for (int t = tid; t < T; t += kCT) {
+            const int a = (int)P[t];
+            const int b = p == 1 ? (L - 1 - t) : (F + t);
+            const uint8_t ka = K[a], kb = K[b];
+            K[a] = kb;
+            K[b] = ka;
+            const uint32_t ia = I[a], ib = I[b];
+            I[a] = ib;
+            I[b] = ia;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (p == 1) {
+                const int fail = sh.flag;
+                const int cut = (fail != 0x7fffffff && fail == L - 1 - T) ? L - 1 - T : L - T;
+                sh.l = cut;  // right part [cut, l) is all filtered: dead
+            } else {
+                const int cut = F + T;
+                if (sh.npure < kMaxPure) {
+                    sh.pure[sh.npure] = PureRange{f, cut - f, sh.d};
+                    sh.npure += 1;
+                } else {
+                    sh.fallback = 1;
+                }
+                sh.f = cut;  // left part [f, cut) is all kept
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    // evolve the all-kept ranges; everything else stays where it is
+    const int npure = sh.npure;
+    for (int i = tid; i < n; i += kCT) {
+        int dest = i;
+        for (int r = 0; r < npure; ++r) {
+            const PureRange pr = sh.pure[r];
+            if (i >= pr.f && i < pr.f + pr.m) {
+                dest = pure_final_pos(i, pr.f, pr.m, pr.d);
+                break;
+            }
+        }
+        if (dest < 0) {
+            sh.fallback = 1;
+            dest = i;
+        }
+        I2[dest] = I[i];
+    }
+    __syncthreads();
+}
+
+// Stable partition: kept elements in position order -> out[0..size), size = count mod 65536.
+// `emit(rank, payload)` is called for rank < size.
+template <class Emit>
+__device__ int compact_kept(CleanupShared& sh, int n, const uint8_t* __restrict__ K,
+                            const uint32_t* __restrict__ I2, Emit emit) {
+    const int tid = threadIdx.x;
+    // total first (needed for the u16 truncation)
+    int cnt = 0;
+    for (int i = tid; i < n; i += kCT) cnt += K[i] == 0;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if (tid == 0) sh.T = 0;
+    __syncthreads();
+    if ((tid & 63) == 0) atomicAdd(&sh.T, cnt);
+    __syncthreads();
+    const int total = sh.T;
+    const int size = total & 0xffff;  // u16_t size (sift.cpp:41,53)
+    __syncthreads();
+    int running = 0, par = 0;
+    for (int base = 0; base < n && running < size; base += kCT) {
+        const int pos = base + tid;
+        const bool hit = pos < n && K[pos] == 0;
+        int tile_total;
+        const int r = running + tile_rank(sh, par, hit, tile_total);
+        if (hit && r < size) emit(r, I2[pos]);
+        running += tile_total;
+        par ^= 1;
+    }
+    __syncthreads();
+    return size;
+}
+
+// ---- cleanup 1: flags of the extrema candidates -> ordered survivor list ---------------------
+__global__ __launch_bounds__(kCT) void cleanup1_kernel(const uint8_t* __restrict__ flags,
+                                                       const int* __restrict__ totals, long long cand_cap,
+                                                       uint8_t* __restrict__ wk, uint32_t* __restrict__ wi,
+                                                       uint32_t* __restrict__ wi2, uint32_t* __restrict__ wp,
+                                                       uint32_t* __restrict__ list, int list_cap,
+                                                       int* __restrict__ list_cnt, int* __restrict__ fallback) {
+    __shared__ CleanupShared sh;
+    const int img = blockIdx.x;
+    const int n = totals[img];
+    const size_t off = (size_t)img * (size_t)cand_cap;
+    uint8_t* K = wk + off;
+    uint32_t* I = wi + off;
+    uint32_t* I2 = wi2 + off;
+    uint32_t* P = wp + off;
+    const uint8_t* fl = flags + off;
+    for (int i = threadIdx.x; i < n; i += kCT) {
+        K[i] = fl[i] ? 1 : 0;
+        I[i] = (uint32_t)i;
+    }
+    __syncthreads();
+    introsort_binary(sh, n, K, I, I2, P);
+    uint32_t* out = list + (size_t)img * (size_t)list_cap;
+    const int size = compact_kept(sh, n, K, I2, [&](int r, uint32_t id) { out[r] = id; });
+    if (threadIdx.x == 0) {
+        list_cnt[img] = size;
+        fallback[img] = sh.fallback;
+    }
+}
+
+// ---- cleanup 2: after orientation assignment -> FinalKp list ---------------------------------------
+// status[img*4 + {0: count, 1: fallback (depth limit or a point with several orientation peaks),
+//                 2: index of the first point whose dead blur throws (or INT_MAX), 3: its code}]
+__global__ __launch_bounds__(kCT) void cleanup2_kernel(const Candidate* __restrict__ cands, long long cand_cap,
+                                                       const uint32_t* __restrict__ list,
+                                                       const int* __restrict__ list_cnt, int list_cap,
+                                                       const OrientOut* __restrict__ orient,
+                                                       uint8_t* __restrict__ wk, uint32_t* __restrict__ wi,
+                                                       uint32_t* __restrict__ wi2, uint32_t* __restrict__ wp,
+                                                       FinalKp* __restrict__ finals, int* __restrict__ final_cnt,
+                                                       int* __restrict__ status) {
+    __shared__ CleanupShared sh;
+    __shared__ int s_multi, s_throw;
+    const int img = blockIdx.x;
+    const int n = list_cnt[img];
+    const size_t off = (size_t)img * (size_t)list_cap;
+    uint8_t* K = wk + off;
+    uint32_t* I = wi + off;
+    uint32_t* I2 = wi2 + off;
+    uint32_t* P = wp + off;
+    const OrientOut* oo = orient + off;
+    if (threadIdx.x == 0) {
+        s_multi = 0;
+        s_throw = 0x7fffffff;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += kCT) {
+        const OrientOut o = oo[i];
+        K[i] = o.filtered ? 1 : 0;
+        I[i] = (uint32_t)i;
+        if (!o.filtered && o.npeaks > 1) s_multi = 1;
+        if (!o.filtered && o.throws) atomicMin(&s_throw, i);
+    }
+    __syncthreads();
+    introsort_binary(sh, n, K, I, I2, P);
+    const uint32_t* l1 = list + off;
+    const Candidate* cd = cands + (size_t)img * (size_t)cand_cap;
+    FinalKp* out = finals + off;
+    const int size = compact_kept(sh, n, K, I2, [&](int r, uint32_t id) {
+        const uint32_t c = l1[id];
+        const Candidate k = cd[c];
+        FinalKp f;
+        f.cand = c;
+        f.orientation = oo[id].orientation;
+        f.x = k.x;
+        f.y = k.y;
+        f.octave = k.octave;
+        f.index = k.index;
+        out[r] = f;
+    });
+    if (threadIdx.x == 0) {
+        const bool thr = s_throw != 0x7fffffff;
+        final_cnt[img] = thr ? 0 : size;
+        status[img * 4 + 0] = thr ? 0 : size;
+        status[img * 4 + 1] = (sh.fallback || s_multi) ? 1 : 0;
+        status[img * 4 + 2] = s_throw;
+        status[img * 4 + 3] = thr ? oo[s_throw].throws : 0;
+    }
+}
+
+// KAT entry: flags -> survivor order (whole kept prefix, no u16 truncation applied by the caller)
+__global__ __launch_bounds__(kCT) void cleanup_kat_kernel(const uint8_t* __restrict__ flags, int n,
+                                                          uint8_t* __restrict__ K, uint32_t* __restrict__ I,
+                                                          uint32_t* __restrict__ I2, uint32_t* __restrict__ P,
+                                                          uint32_t* __restrict__ out, int* __restrict__ info) {
+    __shared__ CleanupShared sh;
+    for (int i = threadIdx.x; i < n; i += kCT) {
+        K[i] = flags[i] ? 1 : 0;
+        I[i] = (uint32_t)i;
+    }
+    __syncthreads();
+    introsort_binary(sh, n, K, I, I2, P);
+    const int size = compact_kept(sh, n, K, I2, [&](int r, uint32_t id) { out[r] = id; });
+    if (threadIdx.x == 0) {
+        info[0] = size;
+        info[1] = sh.fallback;
+    }
+}
+
+void launch_cleanup1(hipStream_t s, int n_images, const uint8_t* d_flags, const int* d_totals, long long cand_cap,
+                     uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, uint32_t* d_list, int list_cap,
+                     int* d_list_cnt, int* d_fallback) {
+    hipLaunchKernelGGL(cleanup1_kernel, dim3((unsigned)n_images), dim3(kCT), 0, s, d_flags, d_totals, cand_cap, wk,
+                       wi, wi2, wp, d_list, list_cap, d_list_cnt, d_fallback);
+}
+
+void launch_cleanup2(hipStream_t s, int n_images, const Candidate* d_cands, long long cand_cap,
+                     const uint32_t* d_list, const int* d_list_cnt, int list_cap, const OrientOut* d_orient,
+                     uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, FinalKp* d_final, int* d_final_cnt,
+                     int* d_status) {
+    hipLaunchKernelGGL(cleanup2_kernel, dim3((unsigned)n_images), dim3(kCT), 0, s, d_cands, cand_cap, d_list,
+                       d_list_cnt, list_cap, d_orient, wk, wi, wi2, wp, d_final, d_final_cnt, d_status);
+}
+
+void launch_cleanup_kat(hipStream_t s, const uint8_t* d_flags, int n, uint8_t* wk, uint32_t* wi, uint32_t* wi2,
+                        uint32_t* wp, uint32_t* d_out, int* d_info) {
+    hipLaunchKernelGGL(cleanup_kat_kernel, dim3(1), dim3(kCT), 0, s, d_flags, n, wk, wi, wi2, wp, d_out, d_info);
+}
+
+}  // namespace sift_hip

@@ -66,22 +66,94 @@ __global__ __launch_bounds__(256) void w16_kernel(const float* __restrict__ leve
 
 constexpr int kCore = 64;
 constexpr int kExt = kCore + 2 * kRegion;  // 80
-constexpr int kListCap = 1024;
+constexpr int kTileListCap = 2048;         // per-tile list held (and sorted) in LDS
 
+// ---- binning: which keypoints touch which extended tile ------------------------------------------
+// A 16x16 window touches the extended regions of at most 2x2 tiles.  Counts, an exclusive scan per
+// image and an atomic fill give every tile its (unordered) list; the descriptor kernel sorts its
+// list by vector index in LDS, because the order IS the semantics (cumulative mutation).
+__device__ __forceinline__ void tile_span(int v, int ntiles, int& lo, int& hi) {
+    // tiles t with t*64 - 8 < v + 8 and v - 8 < t*64 + 72  <=>  v - 80 < t*64 < v + 16
+    lo = (v - 80) / kCore + 1;          // smallest t with t*64 > v - 80 (v - 80 may be negative)
+    if (v - 80 < 0) lo = 0;
+    hi = (v + 15) / kCore;              // largest t with t*64 < v + 16
+    if (hi > ntiles - 1) hi = ntiles - 1;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void desc_bin_kernel(const DevPlan* __restrict__ plan,
+                                                       const FinalKp* __restrict__ finals,
+                                                       const int* __restrict__ final_cnt, int final_cap,
+                                                       int* __restrict__ tile_cnt, const int* __restrict__ tile_off,
+                                                       int* __restrict__ tile_cur, uint16_t* __restrict__ pool,
+                                                       int pool_cap) {
+    const int img = blockIdx.y;
+    const int K = final_cnt[img];
+    const int D = plan->dogs;
+    const int tpi = plan->desc_tiles_per_image;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+        const FinalKp f = finals[(size_t)img * (size_t)final_cap + k];
+        const int level = plan->nearest_level[f.octave * D + f.index];
+        const int ntx = plan->desc_ntx[level], nty = plan->desc_nty[level];
+        int x0, x1, y0, y1;
+        tile_span(f.x, ntx, x0, x1);
+        tile_span(f.y, nty, y0, y1);
+        for (int ty = y0; ty <= y1; ++ty)
+            for (int tx = x0; tx <= x1; ++tx) {
+                const int t = img * tpi + plan->desc_tile_base[level] + ty * ntx + tx;
+                if (!FILL) {
+                    atomicAdd(&tile_cnt[t], 1);
+                } else {
+                    const int p = atomicAdd(&tile_cur[t], 1);
+                    pool[(size_t)img * (size_t)pool_cap + (size_t)tile_off[t] + (size_t)p] = (uint16_t)k;
+                }
+            }
+    }
+}
+
+// exclusive scan of one image's tile counts (one workgroup per image, chunked)
+__global__ __launch_bounds__(1024) void desc_tile_scan_kernel(const int* __restrict__ tile_cnt,
+                                                              int* __restrict__ tile_off, int tpi) {
+    __shared__ int s_part[1024];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int* c = tile_cnt + (size_t)img * tpi;
+    int* o = tile_off + (size_t)img * tpi;
+    const int chunk = (tpi + 1023) / 1024;
+    const int lo = tid * chunk, hi = min(lo + chunk, tpi);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += c[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = (tid >= off) ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = s_part[tid] - sum;
+    for (int i = lo; i < hi; ++i) {
+        o[i] = run;
+        run += c[i];
+    }
+}
+
+// ---- the tile kernel ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restrict__ plan, int level,
                                                          const FinalKp* __restrict__ finals,
                                                          const int* __restrict__ final_cnt, int final_cap,
+                                                         const int* __restrict__ tile_cnt,
+                                                         const int* __restrict__ tile_off,
+                                                         const uint16_t* __restrict__ pool, int pool_cap,
                                                          const long long* __restrict__ out_base,
                                                          sift_hip_keypoint* __restrict__ kp_out,
                                                          float* __restrict__ desc_out) {
     __shared__ float s_ori[kExt * kExt];
     __shared__ float s_mag[kExt * kExt];
     __shared__ float s_w16[256];
-    __shared__ unsigned short s_list[kListCap];
-    __shared__ float s_val[256];
-    __shared__ unsigned char s_bin[256];
-    __shared__ float s_hist[128];
-    __shared__ float s_len[16];
+    __shared__ unsigned short s_raw[kTileListCap];
+    __shared__ unsigned short s_list[kTileListCap];
+    __shared__ float s_val[2][256];
+    __shared__ unsigned char s_bin[2][256];
     __shared__ int s_wcnt[4];
     __shared__ int s_n;
 
@@ -93,6 +165,9 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
     const int w = plan->w[oct], h = plan->h[oct];
     const int cx0 = blockIdx.x * kCore, cy0 = blockIdx.y * kCore;
     const int ex0 = cx0 - kRegion, ey0 = cy0 - kRegion;
+    const int tile = img * plan->desc_tiles_per_image + plan->desc_tile_base[level] + blockIdx.y * gridDim.x + blockIdx.x;
+    const int n_tile = tile_cnt[tile];
+    if (n_tile == 0) return;  // no window touches this tile: nothing to mutate, nothing to emit
     const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
     const float* __restrict__ gm = plan->mag[level] + img_off;
     const float* __restrict__ go = plan->ori[level] + img_off;
@@ -111,18 +186,106 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
         s_mag[idx] = ok ? gm[o] : 0.0f;
     }
     s_w16[tid] = plan->w16[level][(size_t)img * 256 + tid];
-    __syncthreads();
 
     const int wlx = tid & 15, wly = tid >> 4;  // this thread's pixel inside a keypoint window
+    const int slot = ((wlx >> 2) * 4 + (wly >> 2)) * 16 + (wlx & 3) * 4 + (wly & 3);
 
+    // One keypoint of the ordered list: update the resident pixels, stage the histogram inputs of an
+    // owned keypoint (phase A), then 128 threads build its 16x8 histogram (phase B).  s_val/s_bin
+    // are double-buffered so one barrier per keypoint suffices.
+    auto process = [&](int e, int k) {
+        const FinalKp f = fin[k];
+        const int kx = f.x, ky = f.y;
+        // sift.cpp:65-70 (never newly true after the orientation stage's stricter test)
+        const bool kfilt = kx < kRegion || kx > w - kRegion || ky < kRegion || ky > h - kRegion;
+        const bool owned = kx >= cx0 && kx < cx0 + kCore && ky >= cy0 && ky < cy0 + kCore;
+        const int buf = e & 1;
+        if (!kfilt) {
+            const int X = kx - kRegion + wlx, Y = ky - kRegion + wly;
+            const int ex = X - ex0, ey = Y - ey0;
+            const bool inside = ex >= 0 && ex < kExt && ey >= 0 && ey < kExt;
+            float o = 0.0f, mg = 0.0f;
+            if (inside) {
+                const int idx = ey * kExt + ex;
+                o = s_ori[idx] + f.orientation;   // sift.cpp:82
+                s_ori[idx] = o;
+                mg = s_mag[idx] + s_w16[tid];     // sift.cpp:90, weighting(x, y) window-local
+                s_mag[idx] = mg;
+            }
+            if (owned) {
+                // alg::orientationHistogram8 inputs in descriptor order: cell = (x/4)*4 + y/4
+                // (x outer, sift.cpp:95-96), inside a cell x outer, y inner
+                const float sum = mg * gg[(size_t)Y * (size_t)w + (size_t)X];
+                unsigned i = f32_to_u16_x86_d(__builtin_floorf(o / 45.0f));
+                i = i % 7u;
+                s_val[buf][slot] = sum;
+                s_bin[buf][slot] = (unsigned char)i;
+            }
+        }
+        __syncthreads();
+        if (owned) {
+            const long long ok = obase + k;
+            if (tid < 128) {
+                float out = 0.0f;
+                if (!kfilt) {
+                    const int cell = tid >> 3, b = tid & 7;
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const float v = s_val[buf][cell * 16 + q];
+                        acc = (s_bin[buf][cell * 16 + q] == b) ? acc + v : acc;
+                    }
+                    // alg::normalizeVector: length = b0 + b1 + ... + b7 sequentially, from the 8 lanes
+                    float length = 0.0f;
+#pragma unroll
+                    for (int b2 = 0; b2 < 8; ++b2) length += __shfl(acc, (lane & ~7) + b2);
+                    out = (length == 0.0f) ? acc : acc / length;
+                }
+                desc_out[(size_t)ok * 128 + tid] = out;
+            }
+            if (tid == 128) {
+                sift_hip_keypoint r;
+                r.scale = plan->dog_scale[f.octave * D + f.index];
+                r.orientation = f.orientation;
+                r.x = f.x;
+                r.y = f.y;
+                r.octave = f.octave;
+                r.index = f.index;
+                r.filtered = kfilt ? 1 : 0;
+                r.has_descriptor = kfilt ? 0 : 1;
+                r.reserved = 0;
+                kp_out[ok] = r;
+            }
+        }
+    };
+
+    if (n_tile <= kTileListCap) {
+        // fetch the tile's list and rank-sort it by vector index (indices are unique)
+        const uint16_t* __restrict__ src = pool + (size_t)img * (size_t)pool_cap + (size_t)tile_off[tile];
+        for (int i = tid; i < n_tile; i += 256) s_raw[i] = src[i];
+        __syncthreads();
+        for (int i = tid; i < n_tile; i += 256) {
+            const unsigned short v = s_raw[i];
+            int r = 0;
+            for (int j = 0; j < n_tile; ++j) r += s_raw[j] < v;
+            s_list[r] = v;
+        }
+        __syncthreads();
+        for (int e = 0; e < n_tile; ++e) process(e, (int)s_list[e]);
+        return;
+    }
+
+    // oversized list (> kTileListCap keypoints touch this tile): walk ALL keypoints of the image in
+    // order, ballot-compacting the ones that touch the tile, in segments that fit s_list
+    __syncthreads();
+    int e_total = 0;
     for (int k0 = 0; k0 < K;) {
-        // ---- ordered, ballot-compacted list of the next keypoints that touch this tile ----------
         if (tid == 0) s_n = 0;
         __syncthreads();
         int k_next = k0;
         for (; k_next < K; k_next += 256) {
             const int n_before = s_n;
-            if (n_before + 256 > kListCap) break;  // list full: process it, then resume the scan here
+            if (n_before + 256 > kTileListCap) break;
             const int k = k_next + tid;
             bool hit = false;
             if (k < K) {
@@ -143,84 +306,9 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
             __syncthreads();
         }
         const int n_list = s_n;
-
-        // ---- walk the list in vector order --------------------------------------------------------
-        for (int e = 0; e < n_list; ++e) {
-            const int k = k0 + (int)s_list[e];
-            const FinalKp f = fin[k];
-            const int kx = f.x, ky = f.y;
-            // sift.cpp:65-70 (never newly true after the orientation stage's stricter test)
-            const bool kfilt = kx < kRegion || kx > w - kRegion || ky < kRegion || ky > h - kRegion;
-            const bool owned = kx >= cx0 && kx < cx0 + kCore && ky >= cy0 && ky < cy0 + kCore;
-            if (!kfilt) {
-                const int X = kx - kRegion + wlx, Y = ky - kRegion + wly;
-                const int ex = X - ex0, ey = Y - ey0;
-                const bool inside = ex >= 0 && ex < kExt && ey >= 0 && ey < kExt;
-                float o = 0.0f, mg = 0.0f;
-                if (inside) {
-                    const int idx = ey * kExt + ex;
-                    o = s_ori[idx] + f.orientation;   // sift.cpp:82
-                    s_ori[idx] = o;
-                    mg = s_mag[idx] + s_w16[tid];     // sift.cpp:90, weighting(x, y) window-local
-                    s_mag[idx] = mg;
-                }
-                if (owned) {
-                    // alg::orientationHistogram8 inputs, staged in descriptor order:
-                    // cell = (x/4)*4 + y/4 (x outer, sift.cpp:95-96), inside a cell x outer, y inner
-                    const float sum = mg * gg[(size_t)Y * (size_t)w + (size_t)X];
-                    unsigned i = f32_to_u16_x86_d(__builtin_floorf(o / 45.0f));
-                    i = i % 7u;
-                    const int slot = ((wlx >> 2) * 4 + (wly >> 2)) * 16 + (wlx & 3) * 4 + (wly & 3);
-                    s_val[slot] = sum;
-                    s_bin[slot] = (unsigned char)i;
-                }
-            }
-            __syncthreads();
-            if (owned) {
-                const long long ok = obase + k;
-                if (!kfilt) {
-                    if (tid < 128) {
-                        const int cell = tid >> 3, b = tid & 7;
-                        float acc = 0.0f;
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) {
-                            const float v = s_val[cell * 16 + q];
-                            acc = (s_bin[cell * 16 + q] == b) ? acc + v : acc;
-                        }
-                        s_hist[tid] = acc;
-                    }
-                    __syncthreads();
-                    if (tid < 16) {  // alg::normalizeVector: length = sum of the 8 bins, sequential
-                        float length = 0.0f;
-#pragma unroll
-                        for (int b = 0; b < 8; ++b) length += s_hist[tid * 8 + b];
-                        s_len[tid] = length;
-                    }
-                    __syncthreads();
-                    if (tid < 128) {
-                        const float length = s_len[tid >> 3];
-                        const float v = s_hist[tid];
-                        desc_out[(size_t)ok * 128 + tid] = (length == 0.0f) ? v : v / length;
-                    }
-                } else if (tid < 128) {
-                    desc_out[(size_t)ok * 128 + tid] = 0.0f;
-                }
-                if (tid == 0) {
-                    sift_hip_keypoint r;
-                    r.scale = plan->dog_scale[f.octave * D + f.index];
-                    r.orientation = f.orientation;
-                    r.x = f.x;
-                    r.y = f.y;
-                    r.octave = f.octave;
-                    r.index = f.index;
-                    r.filtered = kfilt ? 1 : 0;
-                    r.has_descriptor = kfilt ? 0 : 1;
-                    r.reserved = 0;
-                    kp_out[ok] = r;
-                }
-                __syncthreads();
-            }
-        }
+        for (int e = 0; e < n_list; ++e) process(e_total + e, k0 + (int)s_list[e]);
+        e_total += n_list;
+        __syncthreads();
         k0 = k_next;
     }
 }
@@ -232,14 +320,28 @@ void launch_w16(hipStream_t s, const DevPlan& plan, int level, const float* d_ta
                        radius16);
 }
 
+void launch_desc_binning(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const FinalKp* d_final,
+                         const int* d_final_cnt, int final_cap, int* d_tile_cnt, int* d_tile_off,
+                         int* d_tile_cur, uint16_t* d_pool, int pool_cap) {
+    const size_t nt = (size_t)plan.desc_tiles_per_image * (size_t)plan.n_images;
+    (void)hipMemsetAsync(d_tile_cnt, 0, nt * sizeof(int), s);
+    (void)hipMemsetAsync(d_tile_cur, 0, nt * sizeof(int), s);
+    const dim3 grid(64, (unsigned)plan.n_images);
+    hipLaunchKernelGGL(desc_bin_kernel<false>, grid, dim3(256), 0, s, d_plan, d_final, d_final_cnt, final_cap,
+                       d_tile_cnt, (const int*)d_tile_off, d_tile_cur, d_pool, pool_cap);
+    hipLaunchKernelGGL(desc_tile_scan_kernel, dim3((unsigned)plan.n_images), dim3(1024), 0, s,
+                       (const int*)d_tile_cnt, d_tile_off, plan.desc_tiles_per_image);
+    hipLaunchKernelGGL(desc_bin_kernel<true>, grid, dim3(256), 0, s, d_plan, d_final, d_final_cnt, final_cap,
+                       d_tile_cnt, (const int*)d_tile_off, d_tile_cur, d_pool, pool_cap);
+}
+
 void launch_descriptors(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level,
                         const FinalKp* d_final, const int* d_final_cnt, int final_cap,
+                        const int* d_tile_cnt, const int* d_tile_off, const uint16_t* d_pool, int pool_cap,
                         const long long* d_out_base, sift_hip_keypoint* d_kp_out, float* d_desc_out) {
-    const int oct = level / (plan.dogs + 1);
-    const dim3 grid((unsigned)((plan.w[oct] + kCore - 1) / kCore), (unsigned)((plan.h[oct] + kCore - 1) / kCore),
-                    (unsigned)plan.n_images);
+    const dim3 grid((unsigned)plan.desc_ntx[level], (unsigned)plan.desc_nty[level], (unsigned)plan.n_images);
     hipLaunchKernelGGL(descriptor_kernel, grid, dim3(256), 0, s, d_plan, level, d_final, d_final_cnt, final_cap,
-                       d_out_base, d_kp_out, d_desc_out);
+                       d_tile_cnt, d_tile_off, d_pool, pool_cap, d_out_base, d_kp_out, d_desc_out);
 }
 
 }  // namespace sift_hip

@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
                                                           const int* __restrict__ list_cnt, int list_cap,
                                                           OrientOut* __restrict__ out,
                                                           float* __restrict__ peaks_out) {
-    __shared__ float s_prod[4][256];
-    __shared__ unsigned char s_bin[4][256];
+    __shared__ __attribute__((aligned(16))) float s_prod[4][256];
+    __shared__ __attribute__((aligned(16))) unsigned char s_bin[4][256];
     __shared__ float s_hist[4][36];
     __shared__ float s_only[4][36];
     __shared__ float s_set[4][36];
@@ -71,10 +71,12 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int img = blockIdx.y;
-    const int kp = blockIdx.x * 4 + wv;
     const int cnt = list_cnt[img];
-    const bool active = kp < cnt;
     const int D = plan->dogs;
+    // the survivor count lives on the device: a fixed grid strides over the groups of 4 keypoints
+    for (int grp = blockIdx.x; grp * 4 < cnt; grp += gridDim.x) {
+    const int kp = grp * 4 + wv;
+    const bool active = kp < cnt;
 
     int x = 0, y = 0, lvl = 0, w = 1, h = 1, l = 0;
     bool border = true;
@@ -113,9 +115,17 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
     __syncthreads();
     if (run && throws == 0 && lane < 36) {
         float acc = 0.0f;
-        for (int q = 0; q < 256; ++q) {
-            const float v = s_prod[wv][q];
-            acc = (s_bin[wv][q] == lane) ? acc + v : acc;
+        const float4* __restrict__ pv = reinterpret_cast<const float4*>(s_prod[wv]);
+        const unsigned* __restrict__ pb = reinterpret_cast<const unsigned*>(s_bin[wv]);
+        const unsigned me = (unsigned)lane;
+#pragma unroll 4
+        for (int q = 0; q < 64; ++q) {  // 4 samples per LDS read, still strictly in sample order
+            const float4 v = pv[q];
+            const unsigned b = pb[q];
+            acc = ((b & 0xffu) == me) ? acc + v.x : acc;
+            acc = (((b >> 8) & 0xffu) == me) ? acc + v.y : acc;
+            acc = (((b >> 16) & 0xffu) == me) ? acc + v.z : acc;
+            acc = ((b >> 24) == me) ? acc + v.w : acc;
         }
         s_hist[wv][lane] = acc;
         s_only[wv][lane] = acc;
@@ -185,6 +195,8 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
         }
         out[(size_t)img * (size_t)list_cap + (size_t)kp] = r;
     }
+    __syncthreads();
+    }
 }
 
 void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, int w, int h, int n) {
@@ -193,10 +205,9 @@ void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, int 
 }
 
 void launch_orientation(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const Candidate* d_cands,
-                        const uint32_t* d_list, const int* d_list_cnt, int list_cap, int max_cnt,
-                        OrientOut* d_out, float* d_peaks) {
-    if (max_cnt <= 0) return;
-    const dim3 grid((unsigned)((max_cnt + 3) / 4), (unsigned)plan.n_images);
+                        const uint32_t* d_list, const int* d_list_cnt, int list_cap, OrientOut* d_out,
+                        float* d_peaks) {
+    const dim3 grid(1024, (unsigned)plan.n_images);
     hipLaunchKernelGGL(orientation_kernel, grid, dim3(256), 0, s, d_plan, d_cands, d_list, d_list_cnt, list_cap,
                        d_out, d_peaks);
 }

@@ -283,3 +283,69 @@ def test_full_size_properties(ctx):
     assert kp.size == want.size
     assert (kp["x"] == want["x"]).all() and (kp["y"] == want["y"]).all() and (kp["octave"] == want["octave"]).all()
     assert desc.tobytes() == wdesc.tobytes()
+
+
+# ------------------------------------------------------------------------------------------------
+# committed golden fixtures (tests/golden/, made by make_golden.py in the dev container)
+# ------------------------------------------------------------------------------------------------
+from golden_util import CASES as GOLDEN_CASES, load_case, sha  # noqa: E402
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_hip_matches_golden(ctx, name):
+    g, img, dogs, octaves, subpixel = load_case(name)
+    ctx.calculate_batch(img[None], _lib.Params(dogs, octaves, 1.6, O.K_SQRT2, 1 if subpixel else 0))
+    for k, want in zip(g["level_names"], g["level_sha"]):
+        kind = "gaussian" if k[0] == "g" else "dog"
+        o, j = map(int, k[1:].split("_"))
+        assert sha(ctx.level(kind, o, j)) == want, k
+    got = [ctx.stage(s).size for s in ("candidates", "after_sort1", "after_orient", "after_sort2", "final")]
+    assert got == g["counts"].tolist()
+    cand = ctx.stage("candidates")
+    assert sha(cand["filtered"].astype(np.uint8)) == str(g["cand_flags_sha"])
+    kp, desc = ctx.results()
+    assert (kp["x"] == g["kp_x"]).all() and (kp["y"] == g["kp_y"]).all() and (kp["octave"] == g["kp_octave"]).all()
+    assert kp["orientation"].tobytes() == g["kp_orientation"].tobytes()
+    assert desc.tobytes() == g["descriptors"].tobytes()
+
+
+# ------------------------------------------------------------------------------------------------
+# cleanup (std::sort + u16 truncation) as a GPU kernel vs libstdc++ itself
+# ------------------------------------------------------------------------------------------------
+def _survivors(ctx, flags, on_gpu):
+    import ctypes as C
+    flags = np.ascontiguousarray(flags, np.uint8)
+    out = np.zeros(max(flags.size, 1), np.int32)
+    cnt = C.c_int32()
+    rc = ctx._L.sift_hip_cleanup_survivors(ctx._h, flags, flags.size, out, C.byref(cnt), on_gpu)
+    assert rc == 0
+    return out[:cnt.value].copy()
+
+
+def test_cleanup_kernel_matches_std_sort(ctx):
+    rng = np.random.default_rng(7)
+    cases = []
+    for n in list(range(0, 40)) + [63, 64, 65, 100, 257, 1000, 1023, 1024, 1025, 2049, 5000, 20000, 70000, 200000]:
+        for p in (0.0, 0.03, 0.2, 0.5, 0.8, 0.9, 0.97, 1.0):
+            cases.append((rng.random(n) < p).astype(np.uint8))
+    for n in (100, 1000, 4097, 66000):   # structured inputs
+        a = np.zeros(n, np.uint8); a[n // 2:] = 1; cases.append(a)
+        cases.append(a[::-1].copy())
+        b = np.zeros(n, np.uint8); b[::2] = 1; cases.append(b)
+        c = np.ones(n, np.uint8); c[::17] = 0; cases.append(c)
+    for flags in cases:
+        perm = O.sort_by_filter(flags)
+        nz = int((flags == 0).sum())
+        want = perm[:nz & 0xffff]                       # u16_t size (sift.cpp:41)
+        host = _survivors(ctx, flags, 0)
+        gpu = _survivors(ctx, flags, 1)
+        assert host.size == want.size and (host == want).all(), (flags.size, "host glue")
+        assert gpu.size == want.size and (gpu == want).all(), (flags.size, float(flags.mean()) if flags.size else 0, "gpu kernel")
+
+
+def test_pipeline_parity_host_glue_path(ctx, report_dir):
+    ctx.set_option("gpu_cleanup", 0)
+    try:
+        compare_run(ctx, synth_frame(333, 257, 9), 3, 3, False, "host-glue path 333x257", report_dir)
+    finally:
+        ctx.set_option("gpu_cleanup", 1)

@@ -1,0 +1,91 @@
+"""CPU build of the scalar math the HIP kernels inline (fdlibm atan2f restatement, register
+3x3 Householder QR) against libm and the oracle's Vigra-style generic restatement."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hm():
+    path = os.path.join(ROOT, "sift_amd", "lib", "libsift_hostmath.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "sift_amd", "csrc"), "../lib/libsift_hostmath.so"])
+    H = C.CDLL(path)
+    fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    H.hostmath_atan2f_array.argtypes = [fp, fp, C.c_int, fp]
+    H.hostmath_inverse3.argtypes = [fp, fp]
+    H.hostmath_solve3.argtypes = [fp, fp, fp]
+    H.hostmath_vertex_parabola.restype = C.c_float
+    H.hostmath_vertex_parabola.argtypes = [C.c_uint16, C.c_float, C.c_uint16, C.c_float, C.c_uint16, C.c_float]
+    return H
+
+
+def test_atan2f_matches_libm(hm):
+    rng = np.random.default_rng(1)
+    n = 2_000_000
+    y = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    x = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    # image-like differences too
+    y[::2] = (rng.integers(-2550, 2550, n // 2) / rng.integers(1, 64, n // 2)).astype(np.float32)
+    x[::2] = (rng.integers(-2550, 2550, n // 2) / rng.integers(1, 64, n // 2)).astype(np.float32)
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 3.4e38], np.float32)
+    ys, xs = np.meshgrid(special, special)
+    y = np.ascontiguousarray(np.concatenate([y, ys.ravel()]))
+    x = np.ascontiguousarray(np.concatenate([x, xs.ravel()]))
+    got = np.empty_like(y)
+    hm.hostmath_atan2f_array(y, x, y.size, got)
+    want = np.array([O.lib().oracle_atan2f(float(a), float(b)) for a, b in zip(y[-100:], x[-100:])], np.float32)
+    assert (got[-100:].view(np.uint32) == want.view(np.uint32))[~np.isnan(want)].all()
+    ref = np.arctan2(y.astype(np.float64), x.astype(np.float64))
+    ok = np.isnan(ref) | (np.abs(got - ref) <= 4e-7 * np.maximum(1.0, np.abs(ref)))
+    assert ok.all()
+    # bit-for-bit against glibc's atan2f on a 200k sample through the oracle library
+    idx = rng.integers(0, y.size, 200_000)
+    want = np.array([O.lib().oracle_atan2f(float(a), float(b)) for a, b in zip(y[idx], x[idx])], np.float32)
+    g = got[idx]
+    same = (g.view(np.uint32) == want.view(np.uint32)) | (np.isnan(g) & np.isnan(want))
+    assert same.all()
+
+
+def test_linalg3_matches_oracle(hm):
+    rng = np.random.default_rng(0)
+    L = O.lib()
+    rankdef = 0
+    for t in range(20000):
+        kind = t % 5
+        a = (rng.standard_normal(9) * 10.0 ** rng.integers(-3, 3)).astype(np.float32)
+        if kind == 1:
+            a[6:9] = 0
+        if kind == 2:
+            a[3:6] = a[0:3] * 2
+        if kind == 3:
+            a = np.round(a).astype(np.float32)
+        if kind == 4:
+            m = a.reshape(3, 3)
+            a = (m + m.T).astype(np.float32).reshape(-1).copy()
+        b = rng.standard_normal(3).astype(np.float32)
+        r1, r2 = np.zeros(9, np.float32), np.zeros(9, np.float32)
+        o1, o2 = L.oracle_inverse3(a, r1), hm.hostmath_inverse3(a, r2)
+        assert o1 == o2 and (not o1 or r1.tobytes() == r2.tobytes())
+        s1, s2 = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        q1, q2 = L.oracle_solve3(a, b, s1), hm.hostmath_solve3(a, b, s2)
+        rankdef += not q1
+        assert q1 == q2 and s1.tobytes() == s2.tobytes()
+    assert rankdef > 1000  # the minimum-norm path is exercised
+
+
+def test_vertex_parabola_kat(hm):
+    # (355,0),(5,h0),(15,0) -> rank 2, ~177.4913 for any h0 > 0
+    for h0 in (1.0, 37.5, 1234.567, 98765.4):
+        v = hm.hostmath_vertex_parabola(355, 0.0, 5, h0, 15, 0.0)
+        assert v == O.lib().oracle_vertex_parabola(355, 0.0, 5, h0, 15, 0.0)
+        assert abs(v - 177.4913) < 1e-3
+    assert np.isnan(hm.hostmath_vertex_parabola(355, 0.0, 5, 0.0, 15, 0.0))
+    assert hm.hostmath_vertex_parabola(355, 0.0, 5, 37.5, 15, 0.0) == np.float32(177.49134826660156)
