@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void w16_kernel(const float* __restrict__ leve
 
 constexpr int kCore = 64;
 constexpr int kExt = kCore + 2 * kRegion;  // 80
-constexpr int kTileListCap = 2048;         // per-tile list held (and sorted) in LDS
+constexpr int kTileListCap = 1024;         // per-tile list held (and sorted) in LDS
 
 // ---- binning: which keypoints touch which extended tile ------------------------------------------
 // A 16x16 window touches the extended regions of at most 2x2 tiles.  Counts, an exclusive scan per
@@ -152,6 +152,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
     __shared__ float s_w16[256];
     __shared__ unsigned short s_raw[kTileListCap];
     __shared__ unsigned short s_list[kTileListCap];
+    __shared__ FinalKp s_fin[kTileListCap];
     __shared__ float s_val[2][256];
     __shared__ unsigned char s_bin[2][256];
     __shared__ int s_wcnt[4];
@@ -193,8 +194,17 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
     // One keypoint of the ordered list: update the resident pixels, stage the histogram inputs of an
     // owned keypoint (phase A), then 128 threads build its 16x8 histogram (phase B).  s_val/s_bin
     // are double-buffered so one barrier per keypoint suffices.
-    auto process = [&](int e, int k) {
-        const FinalKp f = fin[k];
+    // LDS-only barrier: keeps the prefetched global loads of the next keypoint in flight
+    auto lds_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // Gaussian value under this thread's window pixel of keypoint f (0 when not needed)
+    auto gauss_at = [&](const FinalKp& f) -> float {
+        const int kx = f.x, ky = f.y;
+        const bool kfilt = kx < kRegion || kx > w - kRegion || ky < kRegion || ky > h - kRegion;
+        const bool owned = kx >= cx0 && kx < cx0 + kCore && ky >= cy0 && ky < cy0 + kCore;
+        if (kfilt || !owned) return 0.0f;
+        return gg[(size_t)(ky - kRegion + wly) * (size_t)w + (size_t)(kx - kRegion + wlx)];
+    };
+    auto process = [&](int e, int k, const FinalKp f, const float gval) {
         const int kx = f.x, ky = f.y;
         // sift.cpp:65-70 (never newly true after the orientation stage's stricter test)
         const bool kfilt = kx < kRegion || kx > w - kRegion || ky < kRegion || ky > h - kRegion;
@@ -215,14 +225,14 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
             if (owned) {
                 // alg::orientationHistogram8 inputs in descriptor order: cell = (x/4)*4 + y/4
                 // (x outer, sift.cpp:95-96), inside a cell x outer, y inner
-                const float sum = mg * gg[(size_t)Y * (size_t)w + (size_t)X];
+                const float sum = mg * gval;
                 unsigned i = f32_to_u16_x86_d(__builtin_floorf(o / 45.0f));
                 i = i % 7u;
                 s_val[buf][slot] = sum;
                 s_bin[buf][slot] = (unsigned char)i;
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (owned) {
             const long long ok = obase + k;
             if (tid < 128) {
@@ -269,9 +279,19 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
             int r = 0;
             for (int j = 0; j < n_tile; ++j) r += s_raw[j] < v;
             s_list[r] = v;
+            s_fin[r] = fin[v];
         }
         __syncthreads();
-        for (int e = 0; e < n_tile; ++e) process(e, (int)s_list[e]);
+        FinalKp f = s_fin[0];
+        float g = gauss_at(f);
+        for (int e = 0; e < n_tile; ++e) {
+            const int nx = (e + 1 < n_tile) ? e + 1 : e;
+            const FinalKp fn = s_fin[nx];
+            const float gn = gauss_at(fn);     // in flight across this keypoint's barrier
+            process(e, (int)s_list[e], f, g);
+            f = fn;
+            g = gn;
+        }
         return;
     }
 
@@ -306,7 +326,11 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
             __syncthreads();
         }
         const int n_list = s_n;
-        for (int e = 0; e < n_list; ++e) process(e_total + e, k0 + (int)s_list[e]);
+        for (int e = 0; e < n_list; ++e) {
+            const int k = k0 + (int)s_list[e];
+            const FinalKp f = fin[k];
+            process(e_total + e, k, f, gauss_at(f));
+        }
         e_total += n_list;
         __syncthreads();
         k0 = k_next;

@@ -52,10 +52,15 @@ __global__ __launch_bounds__(256) void gradient_kernel(const float* __restrict__
     ori[o] = a;
 }
 
-// One wave per keypoint.  The 16x16 window of orientation / magnitude / Gaussian is fetched with
-// row-coalesced loads, the 256 (bin, magnitude*gauss) pairs are staged in LDS in the reference's
-// summation order (x outer, y inner), lane b < 36 then accumulates bin b sequentially in that
-// order, and lane 0 runs the short serial peak search.
+// Two phases per workgroup of 128 keypoints:
+//  1. histogram: one WAVE per keypoint (each wave walks 32 keypoints).  The 16x16 window of
+//     orientation / magnitude / Gaussian is fetched with row-coalesced loads, the 256
+//     (bin, magnitude*gauss) pairs are staged in LDS in the reference's summation order (x outer,
+//     y inner) and lane b < 36 accumulates bin b sequentially in that order.
+//  2. peaks: one THREAD per keypoint runs the serial Sift::_findPeaks / vertexParabola logic on its
+//     histogram column in LDS, so 128 dependent chains run side by side instead of one per wave.
+constexpr int kOrientGroup = 128;
+
 __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restrict__ plan,
                                                           const Candidate* __restrict__ cands,
                                                           const uint32_t* __restrict__ list,
@@ -64,138 +69,153 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
                                                           float* __restrict__ peaks_out) {
     __shared__ __attribute__((aligned(16))) float s_prod[4][256];
     __shared__ __attribute__((aligned(16))) unsigned char s_bin[4][256];
-    __shared__ float s_hist[4][36];
-    __shared__ float s_only[4][36];
-    __shared__ float s_set[4][36];
+    __shared__ float s_hist[36][kOrientGroup];
+    __shared__ float s_set[36][kOrientGroup];
+    __shared__ unsigned char s_state[kOrientGroup];  // bit0 border-filtered, bits 1-2 throw code, bit7 run
 
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
     const int img = blockIdx.y;
     const int cnt = list_cnt[img];
     const int D = plan->dogs;
-    // the survivor count lives on the device: a fixed grid strides over the groups of 4 keypoints
-    for (int grp = blockIdx.x; grp * 4 < cnt; grp += gridDim.x) {
-    const int kp = grp * 4 + wv;
-    const bool active = kp < cnt;
-
-    int x = 0, y = 0, lvl = 0, w = 1, h = 1, l = 0;
-    bool border = true;
-    if (active) {
-        const Candidate cd = cands[(size_t)img * (size_t)plan->cand_capacity + list[(size_t)img * list_cap + kp]];
-        x = cd.x;
-        y = cd.y;
-        l = cd.octave * D + cd.index;
-        lvl = plan->nearest_level[l];
-        const int no = lvl / (D + 1);
-        w = plan->w[no];
-        h = plan->h[no];
-        border = (x < kRegion || x >= w - kRegion) || (y < kRegion || y >= h - kRegion);  // sift.cpp:173-174
-    }
-    const bool run = active && !border;
-    const int throws = run ? plan->dead_blur_radius[l] : 0;  // sift.cpp:184 (0 ok, else error code)
-
-    if (run && throws == 0) {
-        const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
-        const float* __restrict__ gm = plan->mag[lvl] + img_off;
-        const float* __restrict__ go = plan->ori[lvl] + img_off;
-        const float* __restrict__ gg = plan->gauss[lvl] + img_off;
-        const int x0 = x - kRegion, y0 = y - kRegion;
+    const size_t cbase = (size_t)img * (size_t)plan->cand_capacity;
+    const size_t lbase = (size_t)img * (size_t)list_cap;
+    // the survivor count lives on the device: a fixed grid strides over the groups of keypoints
+    for (int grp = blockIdx.x; grp * kOrientGroup < cnt; grp += gridDim.x) {
+        // ---- phase 1 --------------------------------------------------------------------------
+        for (int j = 0; j < kOrientGroup / 4; ++j) {
+            const int slot = wv * (kOrientGroup / 4) + j;
+            const int kp = grp * kOrientGroup + slot;
+            if (kp >= cnt) break;  // wave-uniform
+            const Candidate cd = cands[cbase + list[lbase + kp]];
+            const int x = cd.x, y = cd.y;
+            const int l = cd.octave * D + cd.index;
+            const int lvl = plan->nearest_level[l];
+            const int no = lvl / (D + 1);
+            const int w = plan->w[no], h = plan->h[no];
+            const bool border = (x < kRegion || x >= w - kRegion) || (y < kRegion || y >= h - kRegion);  // sift.cpp:173-174
+            const int throws = border ? 0 : plan->dead_blur_radius[l];  // sift.cpp:184 (0 ok, else error code)
+            const bool run = !border && throws == 0;
+            if (lane == 0) s_state[slot] = (unsigned char)((border ? 1 : 0) | (throws << 1) | (run ? 0x80 : 0));
+            if (!run) continue;
+            const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
+            const float* __restrict__ gm = plan->mag[lvl] + img_off;
+            const float* __restrict__ go = plan->ori[lvl] + img_off;
+            const float* __restrict__ gg = plan->gauss[lvl] + img_off;
+            const int x0 = x - kRegion, y0 = y - kRegion;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int ly = it * 4 + (lane >> 4);
-            const int lx = lane & 15;
-            const size_t o = (size_t)(y0 + ly) * (size_t)w + (size_t)(x0 + lx);
-            const float sum = gm[o] * gg[o];
-            unsigned i = f32_to_u16_x86(__builtin_floorf(go[o] / 10.0f));
-            i = i % 35u;
-            s_prod[wv][lx * 16 + ly] = sum;
-            s_bin[wv][lx * 16 + ly] = (unsigned char)i;
-        }
-    }
-    __syncthreads();
-    if (run && throws == 0 && lane < 36) {
-        float acc = 0.0f;
-        const float4* __restrict__ pv = reinterpret_cast<const float4*>(s_prod[wv]);
-        const unsigned* __restrict__ pb = reinterpret_cast<const unsigned*>(s_bin[wv]);
-        const unsigned me = (unsigned)lane;
+            for (int it = 0; it < 4; ++it) {
+                const int ly = it * 4 + (lane >> 4);
+                const int lx = lane & 15;
+                const size_t o = (size_t)(y0 + ly) * (size_t)w + (size_t)(x0 + lx);
+                const float sum = gm[o] * gg[o];
+                unsigned i = f32_to_u16_x86(__builtin_floorf(go[o] / 10.0f));
+                i = i % 35u;
+                s_prod[wv][lx * 16 + ly] = sum;
+                s_bin[wv][lx * 16 + ly] = (unsigned char)i;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < 36) {
+                float acc = 0.0f;
+                const float4* __restrict__ pv = reinterpret_cast<const float4*>(s_prod[wv]);
+                const unsigned* __restrict__ pb = reinterpret_cast<const unsigned*>(s_bin[wv]);
+                const unsigned me = (unsigned)lane;
 #pragma unroll 4
-        for (int q = 0; q < 64; ++q) {  // 4 samples per LDS read, still strictly in sample order
-            const float4 v = pv[q];
-            const unsigned b = pb[q];
-            acc = ((b & 0xffu) == me) ? acc + v.x : acc;
-            acc = (((b >> 8) & 0xffu) == me) ? acc + v.y : acc;
-            acc = (((b >> 16) & 0xffu) == me) ? acc + v.z : acc;
-            acc = ((b >> 24) == me) ? acc + v.w : acc;
-        }
-        s_hist[wv][lane] = acc;
-        s_only[wv][lane] = acc;
-    }
-    __syncthreads();
-    if (active && lane == 0) {
-        OrientOut r;
-        r.orientation = 0.0f;
-        r.npeaks = 0;
-        r.filtered = border ? 1 : 0;
-        r.throws = (unsigned char)throws;
-        if (run && throws == 0) {
-            float* histo = s_hist[wv];
-            float* only = s_only[wv];
-            float* set = s_set[wv];
-            // Sift::_findPeaks (sift.cpp:220-286)
-            int max_index = 0;
-            for (int i = 1; i < 36; ++i)
-                if (only[max_index] < only[i]) max_index = i;  // std::max_element: first largest
-            const float range = (float)((double)histo[max_index] * 0.8);
-            for (int i = 0; i < 36; ++i)
-                if (only[i] < range) only[i] = -1.0f;
-            for (int i = 1; i < 35; ++i)
-                if (only[i] < only[i - 1] || only[i] < only[i + 1]) only[i] = -1.0f;
-            int n = 0;
-            bool nan_first = false;
-            for (int pass = 0; pass < 37; ++pass) {
-                int i;
-                if (pass == 0) {
-                    i = max_index;
-                } else {
-                    i = pass - 1;
-                    if (!(only[i] > -1.0f) || i == max_index) continue;
+                for (int q = 0; q < 64; ++q) {  // 4 samples per LDS read, still strictly in sample order
+                    const float4 v = pv[q];
+                    const unsigned b = pb[q];
+                    acc = ((b & 0xffu) == me) ? acc + v.x : acc;
+                    acc = (((b >> 8) & 0xffu) == me) ? acc + v.y : acc;
+                    acc = (((b >> 16) & 0xffu) == me) ? acc + v.z : acc;
+                    acc = ((b >> 24) == me) ? acc + v.w : acc;
                 }
-                unsigned short lnx, rnx;
-                float lny, rny;
-                const unsigned short px = (unsigned short)(i * 10 + 5);
-                const float py = histo[i];
-                if (i == 0) { lnx = 355; lny = histo[35]; }
-                else        { lnx = (unsigned short)((i - 1) * 10 + 5); lny = histo[i - 1]; }
-                if (i == 35) { rnx = 5; rny = histo[0]; }
-                else         { rnx = (unsigned short)((i + 1) * 10 + 5); rny = histo[i + 1]; }
-                const float v = vertex_parabola(lnx, lny, px, py, rnx, rny);
+                s_hist[lane][slot] = acc;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        __syncthreads();
+        // ---- phase 2 --------------------------------------------------------------------------
+        const int kp = grp * kOrientGroup + tid;
+        if (tid < kOrientGroup && kp < cnt) {
+            const unsigned st = s_state[tid];
+            OrientOut r;
+            r.orientation = 0.0f;
+            r.npeaks = 0;
+            r.filtered = (unsigned char)(st & 1u);
+            r.throws = (unsigned char)((st >> 1) & 3u);
+            if (st & 0x80u) {
+                // Sift::_findPeaks (sift.cpp:220-286) on histogram column `tid`
+                int max_index = 0;
+                float hmax = s_hist[0][tid];
+                for (int i = 1; i < 36; ++i) {
+                    const float v = s_hist[i][tid];
+                    if (hmax < v) { hmax = v; max_index = i; }  // std::max_element: first largest
+                }
+                const float range = (float)((double)hmax * 0.8);
+                auto thresholded = [&](int i) {
+                    const float v = s_hist[i][tid];
+                    return (v < range) ? -1.0f : v;
+                };
+                auto vertex_at = [&](int i) {
+                    unsigned short lnx, rnx;
+                    float lny, rny;
+                    const unsigned short px = (unsigned short)(i * 10 + 5);
+                    const float py = s_hist[i][tid];
+                    if (i == 0) { lnx = 355; lny = s_hist[35][tid]; }
+                    else        { lnx = (unsigned short)((i - 1) * 10 + 5); lny = s_hist[i - 1][tid]; }
+                    if (i == 35) { rnx = 5; rny = s_hist[0][tid]; }
+                    else         { rnx = (unsigned short)((i + 1) * 10 + 5); rny = s_hist[i + 1][tid]; }
+                    return vertex_parabola(lnx, lny, px, py, rnx, rny);
+                };
                 // std::set<float>::emplace: a NaN first element blocks every later insert (no key
                 // compares less than it and it compares less than none); a later NaN is never
                 // inserted; numbers insert sorted and unique.
-                if (pass == 0) {
-                    set[0] = v;
-                    n = 1;
-                    nan_first = (v != v);
-                } else if (!nan_first && v == v) {
-                    int pos = 0;
-                    while (pos < n && set[pos] < v) ++pos;
-                    if (!(pos < n && !(v < set[pos]))) {  // not equivalent to an existing key
-                        for (int j = n; j > pos; --j) set[j] = set[j - 1];
-                        set[pos] = v;
-                        ++n;
+                const float v0 = vertex_at(max_index);
+                s_set[0][tid] = v0;
+                int n = 1;
+                const bool nan_first = (v0 != v0);
+                // peaks_only after the 80% threshold and the in-place local-maximum sweep
+                // (i = 1..34 uses the already updated left neighbour and the not yet updated right)
+                float left = thresholded(0);      // peaks_only[0], never touched by the sweep
+                float cur = thresholded(1);
+                for (int i = 0; i < 36; ++i) {
+                    float only_i;
+                    if (i == 0) {
+                        only_i = left;
+                    } else {
+                        const float right = (i < 35) ? thresholded(i + 1) : 0.0f;
+                        only_i = cur;
+                        if (i < 35 && (cur < left || cur < right)) only_i = -1.0f;
+                        left = only_i;
+                        cur = right;
+                    }
+                    if (!(only_i > -1.0f) || i == max_index) continue;
+                    const float v = vertex_at(i);
+                    if (!nan_first && v == v) {
+                        int pos = 0;
+                        while (pos < n && s_set[pos][tid] < v) ++pos;
+                        if (!(pos < n && !(v < s_set[pos][tid]))) {  // not equivalent to an existing key
+                            for (int j = n; j > pos; --j) s_set[j][tid] = s_set[j - 1][tid];
+                            s_set[pos][tid] = v;
+                            ++n;
+                        }
                     }
                 }
+                r.orientation = s_set[0][tid];
+                r.npeaks = (unsigned short)n;
+                if (n > 1) {
+                    float* po = peaks_out + (lbase + (size_t)kp) * 36;
+                    for (int j = 0; j < n; ++j) po[j] = s_set[j][tid];
+                }
             }
-            r.orientation = set[0];
-            r.npeaks = (unsigned short)n;
-            if (n > 1) {
-                float* po = peaks_out + ((size_t)img * (size_t)list_cap + (size_t)kp) * 36;
-                for (int j = 0; j < n; ++j) po[j] = set[j];
-            }
+            out[lbase + (size_t)kp] = r;
         }
-        out[(size_t)img * (size_t)list_cap + (size_t)kp] = r;
-    }
-    __syncthreads();
+        __syncthreads();
     }
 }
 
@@ -207,7 +227,7 @@ void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, int 
 void launch_orientation(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const Candidate* d_cands,
                         const uint32_t* d_list, const int* d_list_cnt, int list_cap, OrientOut* d_out,
                         float* d_peaks) {
-    const dim3 grid(1024, (unsigned)plan.n_images);
+    const dim3 grid(128, (unsigned)plan.n_images);
     hipLaunchKernelGGL(orientation_kernel, grid, dim3(256), 0, s, d_plan, d_cands, d_list, d_list_cnt, list_cap,
                        d_out, d_peaks);
 }

@@ -25,117 +25,195 @@ __device__ __forceinline__ int reflect_clamp(int p, int n) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused blur: one workgroup produces a 64 x TH output tile.
-//   1. row-coalesced HBM loads of the (64+2R) x (TH+2R) source tile (halo reflected at the image
-//      border) into LDS,
-//   2. row pass LDS -> registers (each thread 4 consecutive outputs, ds_read_b128 windows) -> LDS,
-//   3. column pass LDS -> registers (each thread TH/4 consecutive rows of one column, conflict-free
-//      ds_read_b32), DoG = 128 + (blurred - source) from the source tile still in LDS,
-//   4. coalesced stores.
+// Fused blur.  A persistent workgroup walks 64x64 output tiles:
+//   1. the (64+2*RA) x (64+2R) source tile (RA = R rounded up to 4, halo reflected at the image
+//      border) is fetched with row-coalesced 16-byte HBM loads into REGISTERS one tile ahead, so the
+//      HBM latency of tile t+1 hides under the arithmetic of tile t, then written to LDS;
+//   2. row pass LDS -> registers (4 consecutive outputs per thread from ds_read_b128 windows) -> LDS;
+//   3. column pass LDS -> registers (4 columns x 4 rows per thread, conflict-free ds_read_b128);
+//      DoG = 128 + (blurred - source) from the source tile still in LDS;
+//   4. 16-byte coalesced stores.
 // The intermediate never touches HBM: 4 B read + 4 B (8 B with DoG) written per pixel.
+// Barriers are LDS-only (s_waitcnt lgkmcnt(0); s_barrier) so the prefetch stays in flight.
 // Taps are read with wave-uniform constant indices => scalar loads into SGPRs.
-// Workgroup ids are remapped so that each XCD (ids dealt round-robin over 8 XCDs) walks a
+// Workgroup ids are dealt round-robin over the 8 XCDs, so each XCD (= ids equal mod 8) is given a
 // contiguous run of tiles: neighbouring tiles' halos then hit that XCD's L2.
+// Tiles that touch the image border, or images whose rows are not 16-byte aligned, take a scalar
+// load / store path with per-element reflection.
 // ---------------------------------------------------------------------------------------------
-template <int R, int TH, bool DOG>
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int R, bool DOG>
 __global__ __launch_bounds__(256) void blur_fused_kernel(const float* __restrict__ in,
                                                          float* __restrict__ out,
                                                          float* __restrict__ dog, int w, int h,
-                                                         int tiles_x, int tiles_y,
-                                                         const float* __restrict__ taps) {
-    constexpr int TW = 64;
-    constexpr int SW = TW + 2 * R;
+                                                         int tiles_x, int tiles_y, int total_tiles,
+                                                         int vec_ok, const float* __restrict__ taps) {
+    constexpr int TW = 64, TH = 64;
+    constexpr int RA = (R + 3) & ~3;
+    constexpr int PAD = RA - R;
+    constexpr int SWA = TW + 2 * RA;       // LDS row length, multiple of 4
     constexpr int SH = TH + 2 * R;
-    constexpr int SWP = (SW + 3) & ~3;
+    constexpr int ROW4 = SWA / 4;          // float4 per source row
+    constexpr int NL4 = SH * ROW4;         // float4 per source tile
+    constexpr int NLD = (NL4 + 255) / 256; // prefetch registers (float4) per thread
     constexpr int NT = 2 * R + 1;
-    constexpr int PY = TH / 4;
-    __shared__ __attribute__((aligned(16))) float s_src[SH * SWP];
+    __shared__ __attribute__((aligned(16))) float s_src[SH * SWA];
     __shared__ __attribute__((aligned(16))) float s_mid[SH * TW];
+    float4* s_src4 = reinterpret_cast<float4*>(s_src);
+    float4* s_mid4 = reinterpret_cast<float4*>(s_mid);
 
     const int tid = threadIdx.x;
-    // XCD-aware remap of the linear workgroup id
-    const unsigned nblk = gridDim.x;
-    const unsigned chunk = nblk >> 3;
-    unsigned lin = blockIdx.x;
-    if (lin < (chunk << 3)) lin = (lin & 7u) * chunk + (lin >> 3);
-    const unsigned tiles = (unsigned)(tiles_x * tiles_y);
-    const unsigned img = lin / tiles;
-    const unsigned t2 = lin - img * tiles;
-    const int ty = (int)(t2 / (unsigned)tiles_x);
-    const int tx = (int)(t2 - (unsigned)ty * (unsigned)tiles_x);
-    const int x0 = tx * TW, y0 = ty * TH;
-    const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
-    const float* __restrict__ src = in + img_off;
-
-    // 1. source tile -> LDS
-    for (int idx = tid; idx < SH * SW; idx += 256) {
-        const int ly = idx / SW;
-        const int lx = idx - ly * SW;
-        const int gy = reflect_clamp(y0 - R + ly, h);
-        const int gx = reflect_clamp(x0 - R + lx, w);
-        s_src[ly * SWP + lx] = src[(size_t)gy * (size_t)w + (size_t)gx];
+    // tile schedule: XCD x (= id mod 8) owns tiles [x*chunk, (x+1)*chunk)
+    int t, t_end, t_step;
+    if ((gridDim.x & 7u) == 0) {
+        const int chunk = (total_tiles + 7) >> 3;
+        const int xcd = blockIdx.x & 7;
+        t = xcd * chunk + (int)(blockIdx.x >> 3);
+        t_end = min(xcd * chunk + chunk, total_tiles);
+        t_step = (int)(gridDim.x >> 3);
+    } else {
+        t = blockIdx.x;
+        t_end = total_tiles;
+        t_step = gridDim.x;
     }
-    __syncthreads();
+    const int tiles = tiles_x * tiles_y;
 
-    // 2. row pass
-    for (int it = tid; it < SH * (TW / 4); it += 256) {
-        const int ly = it >> 4;
-        const int q = it & 15;
-        constexpr int NV = 4 + 2 * R;
-        constexpr int NV4 = (NV + 3) / 4;
-        float v[NV4 * 4];
-        const float4* p4 = reinterpret_cast<const float4*>(&s_src[ly * SWP + 4 * q]);
+    float4 pre[NLD];
+    auto load_tile = [&](int tile) {
+        const int img = tile / tiles;
+        const int t2 = tile - img * tiles;
+        const int ty = t2 / tiles_x, tx = t2 - ty * tiles_x;
+        const int x0 = tx * TW, y0 = ty * TH;
+        const float* __restrict__ src = in + (size_t)img * (size_t)w * (size_t)h;
+        const bool interior = vec_ok && x0 - RA >= 0 && x0 + TW + RA <= w && y0 - R >= 0 && y0 + TH + R <= h;
+        if (interior) {
+            const float* __restrict__ base = src + (size_t)(y0 - R) * (size_t)w + (size_t)(x0 - RA);
 #pragma unroll
-        for (int c = 0; c < NV4; ++c) {
-            const float4 f = p4[c];
-            v[4 * c + 0] = f.x;
-            v[4 * c + 1] = f.y;
-            v[4 * c + 2] = f.z;
-            v[4 * c + 3] = f.w;
-        }
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+            for (int i = 0; i < NLD; ++i) {
+                const int e = tid + 256 * i;
+                if (e < NL4) {
+                    const int ly = e / ROW4, c4 = e - ly * ROW4;
+                    pre[i] = *reinterpret_cast<const float4*>(base + (size_t)ly * (size_t)w + (size_t)(4 * c4));
+                }
+            }
+        } else {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float k = taps[NT - 1 - t];
-            a0 += k * v[t];
-            a1 += k * v[t + 1];
-            a2 += k * v[t + 2];
-            a3 += k * v[t + 3];
-        }
-        *reinterpret_cast<float4*>(&s_mid[ly * TW + 4 * q]) = make_float4(a0, a1, a2, a3);
-    }
-    __syncthreads();
-
-    // 3. column pass
-    const int c = tid & 63;
-    const int g = tid >> 6;
-    float acc[PY];
-#pragma unroll
-    for (int i = 0; i < PY; ++i) acc[i] = 0.0f;
-#pragma unroll
-    for (int t = 0; t < PY + 2 * R; ++t) {
-        const float v = s_mid[(g * PY + t) * TW + c];
-#pragma unroll
-        for (int i = 0; i < PY; ++i) {
-            if (t - i >= 0 && t - i <= 2 * R) acc[i] += taps[NT - 1 - (t - i)] * v;
-        }
-    }
-    // 4. stores
-    const int x = x0 + c;
-    if (x < w) {
-#pragma unroll
-        for (int i = 0; i < PY; ++i) {
-            const int y = y0 + g * PY + i;
-            if (y < h) {
-                const size_t o = img_off + (size_t)y * (size_t)w + (size_t)x;
-                out[o] = acc[i];
-                if (DOG) {
-                    const float prev = s_src[(R + g * PY + i) * SWP + R + c];
-                    const float dif = acc[i] - prev;
-                    dog[o] = 128.0f + dif;
+            for (int i = 0; i < NLD; ++i) {
+                const int e = tid + 256 * i;
+                if (e < NL4) {
+                    const int ly = e / ROW4, c4 = e - ly * ROW4;
+                    const size_t row = (size_t)reflect_clamp(y0 - R + ly, h) * (size_t)w;
+                    const int gx = x0 - RA + 4 * c4;
+                    pre[i].x = src[row + (size_t)reflect_clamp(gx + 0, w)];
+                    pre[i].y = src[row + (size_t)reflect_clamp(gx + 1, w)];
+                    pre[i].z = src[row + (size_t)reflect_clamp(gx + 2, w)];
+                    pre[i].w = src[row + (size_t)reflect_clamp(gx + 3, w)];
                 }
             }
         }
+    };
+
+    if (t < t_end) load_tile(t);
+    while (t < t_end) {
+        // 1. prefetched source tile -> LDS
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + 256 * i;
+            if (e < NL4) s_src4[e] = pre[i];
+        }
+        lds_barrier();
+        const int tn = t + t_step;
+        if (tn < t_end) load_tile(tn);  // stays in flight through both passes
+
+        // 2. row pass
+#pragma unroll 1
+        for (int it = tid; it < SH * (TW / 4); it += 256) {
+            const int ly = it >> 4;
+            const int q = it & 15;
+            constexpr int NV = PAD + 4 + 2 * R;
+            constexpr int NV4 = (NV + 3) / 4;
+            float v[NV4 * 4];
+            const float4* p4 = &s_src4[ly * ROW4 + q];
+#pragma unroll
+            for (int c = 0; c < NV4; ++c) {
+                const float4 f = p4[c];
+                v[4 * c + 0] = f.x;
+                v[4 * c + 1] = f.y;
+                v[4 * c + 2] = f.z;
+                v[4 * c + 3] = f.w;
+            }
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                const float tap = taps[NT - 1 - k];
+                a0 += tap * v[PAD + k];
+                a1 += tap * v[PAD + k + 1];
+                a2 += tap * v[PAD + k + 2];
+                a3 += tap * v[PAD + k + 3];
+            }
+            s_mid4[ly * (TW / 4) + q] = make_float4(a0, a1, a2, a3);
+        }
+        lds_barrier();
+
+        // 3. column pass: 4 columns x 4 rows per thread
+        const int cg = tid & 15, rg = tid >> 4;
+        float4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int k = 0; k < 4 + 2 * R; ++k) {
+            const float4 m = s_mid4[(rg * 4 + k) * (TW / 4) + cg];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (k - i >= 0 && k - i <= 2 * R) {
+                    const float tap = taps[NT - 1 - (k - i)];
+                    acc[i].x += tap * m.x;
+                    acc[i].y += tap * m.y;
+                    acc[i].z += tap * m.z;
+                    acc[i].w += tap * m.w;
+                }
+            }
+            // keep the unrolled loop from hoisting every LDS read to the top (VGPR blow-up)
+            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        // 4. stores
+        {
+            const int img = t / tiles;
+            const int t2 = t - img * tiles;
+            const int ty = t2 / tiles_x, tx = t2 - ty * tiles_x;
+            const int x = tx * TW + 4 * cg;
+            const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int y = ty * TH + rg * 4 + i;
+                if (y < h && x < w) {
+                    const size_t o = img_off + (size_t)y * (size_t)w + (size_t)x;
+                    float4 d4;
+                    if (DOG) {
+                        const float4 prev = s_src4[(R + rg * 4 + i) * ROW4 + (RA / 4) + cg];
+                        const float dx = acc[i].x - prev.x, dy = acc[i].y - prev.y;
+                        const float dz = acc[i].z - prev.z, dw = acc[i].w - prev.w;
+                        d4 = make_float4(128.0f + dx, 128.0f + dy, 128.0f + dz, 128.0f + dw);
+                    }
+                    if (vec_ok && x + 3 < w) {
+                        *reinterpret_cast<float4*>(out + o) = acc[i];
+                        if (DOG) *reinterpret_cast<float4*>(dog + o) = d4;
+                    } else {
+                        const float av[4] = {acc[i].x, acc[i].y, acc[i].z, acc[i].w};
+                        const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (x + j < w) {
+                                out[o + j] = av[j];
+                                if (DOG) dog[o + j] = dv[j];
+                            }
+                    }
+                }
+            }
+        }
+        lds_barrier();  // s_src / s_mid are rewritten by the next tile
+        t = tn;
     }
 }
 
@@ -209,15 +287,18 @@ __global__ void dog_kernel(const float* __restrict__ lower, const float* __restr
 template <int R>
 static void launch_fused_r(hipStream_t s, const float* in, float* out, float* dog, int w, int h, int n,
                            const float* d_taps) {
-    constexpr int TH = 64;
-    const int tiles_x = (w + 63) / 64, tiles_y = (h + TH - 1) / TH;
-    const unsigned grid = (unsigned)(tiles_x * tiles_y * n);
+    const int tiles_x = (w + 63) / 64, tiles_y = (h + 63) / 64;
+    const int total = tiles_x * tiles_y * n;
+    int grid = total < 1024 ? total : 1024;  // persistent workgroups, 4 per CU offered
+    if (grid >= 8) grid &= ~7;
+    const bool aligned = (((uintptr_t)in | (uintptr_t)out | (uintptr_t)dog) & 15u) == 0;
+    const int vec_ok = (w % 4 == 0 && aligned) ? 1 : 0;
     if (dog)
-        hipLaunchKernelGGL((blur_fused_kernel<R, TH, true>), dim3(grid), dim3(256), 0, s, in, out, dog, w, h,
-                           tiles_x, tiles_y, d_taps);
+        hipLaunchKernelGGL((blur_fused_kernel<R, true>), dim3((unsigned)grid), dim3(256), 0, s, in, out, dog, w, h,
+                           tiles_x, tiles_y, total, vec_ok, d_taps);
     else
-        hipLaunchKernelGGL((blur_fused_kernel<R, TH, false>), dim3(grid), dim3(256), 0, s, in, out, dog, w, h,
-                           tiles_x, tiles_y, d_taps);
+        hipLaunchKernelGGL((blur_fused_kernel<R, false>), dim3((unsigned)grid), dim3(256), 0, s, in, out, dog, w, h,
+                           tiles_x, tiles_y, total, vec_ok, d_taps);
 }
 
 #define SIFT_FUSED_CASE(R) \
