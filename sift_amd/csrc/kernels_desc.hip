@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void w16_kernel(const float* __restrict__ leve
 
 constexpr int kCore = 64;
 constexpr int kExt = kCore + 2 * kRegion;  // 80
-constexpr int kTileListCap = 1024;         // per-tile list held (and sorted) in LDS
+constexpr int kTileListCap = 768;          // per-tile list held (and sorted) in LDS
 
 // ---- binning: which keypoints touch which extended tile ------------------------------------------
 // A 16x16 window touches the extended regions of at most 2x2 tiles.  Counts, an exclusive scan per
@@ -138,6 +138,15 @@ __global__ __launch_bounds__(1024) void desc_tile_scan_kernel(const int* __restr
 }
 
 // ---- the tile kernel ---------------------------------------------------------------------------------
+// Pixel ownership by residue: thread t owns every pixel (X, Y) of the extended tile with
+// (X mod 16, Y mod 16) == (t mod 16, t / 16).  Any 16x16 window contains exactly one pixel of each
+// residue class, so for every keypoint each thread updates exactly ONE pixel — always one of its
+// own.  A pixel's whole chain of float additions therefore runs in one thread's program order and
+// the cumulative mutation needs no barrier at all.  Only the 4x4x8 histograms need other threads'
+// values: they are staged per keypoint in LDS, kDescBatch keypoints at a time (two barriers per
+// batch), and built by all 256 threads, two keypoints at once.
+constexpr int kDescBatch = 8;
+
 __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restrict__ plan, int level,
                                                          const FinalKp* __restrict__ finals,
                                                          const int* __restrict__ final_cnt, int final_cap,
@@ -151,10 +160,10 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
     __shared__ float s_mag[kExt * kExt];
     __shared__ float s_w16[256];
     __shared__ unsigned short s_raw[kTileListCap];
-    __shared__ unsigned short s_list[kTileListCap];
+    __shared__ unsigned short s_list[kTileListCap];   // vector index k of each list entry, ascending
     __shared__ FinalKp s_fin[kTileListCap];
-    __shared__ float s_val[2][256];
-    __shared__ unsigned char s_bin[2][256];
+    __shared__ float s_val[kDescBatch][256];
+    __shared__ unsigned char s_bin[kDescBatch][256];
     __shared__ int s_wcnt[4];
     __shared__ int s_n;
 
@@ -188,84 +197,115 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
     }
     s_w16[tid] = plan->w16[level][(size_t)img * 256 + tid];
 
-    const int wlx = tid & 15, wly = tid >> 4;  // this thread's pixel inside a keypoint window
-    const int slot = ((wlx >> 2) * 4 + (wly >> 2)) * 16 + (wlx & 3) * 4 + (wly & 3);
+    const int rx = tid & 15, ry = tid >> 4;  // residues of the pixels this thread owns
 
-    // One keypoint of the ordered list: update the resident pixels, stage the histogram inputs of an
-    // owned keypoint (phase A), then 128 threads build its 16x8 histogram (phase B).  s_val/s_bin
-    // are double-buffered so one barrier per keypoint suffices.
-    // LDS-only barrier: keeps the prefetched global loads of the next keypoint in flight
-    auto lds_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    // Gaussian value under this thread's window pixel of keypoint f (0 when not needed)
-    auto gauss_at = [&](const FinalKp& f) -> float {
-        const int kx = f.x, ky = f.y;
-        const bool kfilt = kx < kRegion || kx > w - kRegion || ky < kRegion || ky > h - kRegion;
-        const bool owned = kx >= cx0 && kx < cx0 + kCore && ky >= cy0 && ky < cy0 + kCore;
-        if (kfilt || !owned) return 0.0f;
-        return gg[(size_t)(ky - kRegion + wly) * (size_t)w + (size_t)(kx - kRegion + wlx)];
+    struct Geo {   // this thread's pixel inside keypoint f's window
+        bool kfilt, owned, inside;
+        int lx, ly, X, Y;
     };
-    auto process = [&](int e, int k, const FinalKp f, const float gval) {
+    auto geometry = [&](const FinalKp& f) {
+        Geo g;
         const int kx = f.x, ky = f.y;
         // sift.cpp:65-70 (never newly true after the orientation stage's stricter test)
-        const bool kfilt = kx < kRegion || kx > w - kRegion || ky < kRegion || ky > h - kRegion;
-        const bool owned = kx >= cx0 && kx < cx0 + kCore && ky >= cy0 && ky < cy0 + kCore;
-        const int buf = e & 1;
-        if (!kfilt) {
-            const int X = kx - kRegion + wlx, Y = ky - kRegion + wly;
-            const int ex = X - ex0, ey = Y - ey0;
-            const bool inside = ex >= 0 && ex < kExt && ey >= 0 && ey < kExt;
-            float o = 0.0f, mg = 0.0f;
-            if (inside) {
-                const int idx = ey * kExt + ex;
-                o = s_ori[idx] + f.orientation;   // sift.cpp:82
-                s_ori[idx] = o;
-                mg = s_mag[idx] + s_w16[tid];     // sift.cpp:90, weighting(x, y) window-local
-                s_mag[idx] = mg;
-            }
-            if (owned) {
-                // alg::orientationHistogram8 inputs in descriptor order: cell = (x/4)*4 + y/4
-                // (x outer, sift.cpp:95-96), inside a cell x outer, y inner
-                const float sum = mg * gval;
-                unsigned i = f32_to_u16_x86_d(__builtin_floorf(o / 45.0f));
-                i = i % 7u;
-                s_val[buf][slot] = sum;
-                s_bin[buf][slot] = (unsigned char)i;
-            }
-        }
-        lds_barrier();
-        if (owned) {
-            const long long ok = obase + k;
-            if (tid < 128) {
-                float out = 0.0f;
-                if (!kfilt) {
-                    const int cell = tid >> 3, b = tid & 7;
-                    float acc = 0.0f;
+        g.kfilt = kx < kRegion || kx > w - kRegion || ky < kRegion || ky > h - kRegion;
+        g.owned = kx >= cx0 && kx < cx0 + kCore && ky >= cy0 && ky < cy0 + kCore;
+        g.lx = (rx - (kx - kRegion)) & 15;   // window-local x of the pixel with X = rx (mod 16)
+        g.ly = (ry - (ky - kRegion)) & 15;
+        g.X = kx - kRegion + g.lx;
+        g.Y = ky - kRegion + g.ly;
+        const int ex = g.X - ex0, ey = g.Y - ey0;
+        g.inside = ex >= 0 && ex < kExt && ey >= 0 && ey < kExt;
+        return g;
+    };
+
+    // Processes the ordered entries s_fin[0..n_seg) / s_list[0..n_seg).
+    auto run_segment = [&](int n_seg) {
+        for (int e0 = 0; e0 < n_seg; e0 += kDescBatch) {
+            // ---- phase A: per-pixel chains, no barrier -------------------------------------------------
+            float gv[kDescBatch];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const float v = s_val[buf][cell * 16 + q];
-                        acc = (s_bin[buf][cell * 16 + q] == b) ? acc + v : acc;
-                    }
-                    // alg::normalizeVector: length = b0 + b1 + ... + b7 sequentially, from the 8 lanes
-                    float length = 0.0f;
-#pragma unroll
-                    for (int b2 = 0; b2 < 8; ++b2) length += __shfl(acc, (lane & ~7) + b2);
-                    out = (length == 0.0f) ? acc : acc / length;
+            for (int m = 0; m < kDescBatch; ++m) {   // Gaussian values first: independent loads in flight
+                gv[m] = 0.0f;
+                if (e0 + m < n_seg) {
+                    const FinalKp f = s_fin[e0 + m];
+                    const Geo g = geometry(f);
+                    if (g.owned && !g.kfilt) gv[m] = gg[(size_t)g.Y * (size_t)w + (size_t)g.X];
                 }
-                desc_out[(size_t)ok * 128 + tid] = out;
             }
-            if (tid == 128) {
-                sift_hip_keypoint r;
-                r.scale = plan->dog_scale[f.octave * D + f.index];
-                r.orientation = f.orientation;
-                r.x = f.x;
-                r.y = f.y;
-                r.octave = f.octave;
-                r.index = f.index;
-                r.filtered = kfilt ? 1 : 0;
-                r.has_descriptor = kfilt ? 0 : 1;
-                r.reserved = 0;
-                kp_out[ok] = r;
+#pragma unroll
+            for (int m = 0; m < kDescBatch; ++m) {
+                if (e0 + m < n_seg) {
+                    const FinalKp f = s_fin[e0 + m];
+                    const Geo g = geometry(f);
+                    if (!g.kfilt) {
+                        float o = 0.0f, mg = 0.0f;
+                        if (g.inside) {
+                            const int idx = (g.Y - ey0) * kExt + (g.X - ex0);
+                            o = s_ori[idx] + f.orientation;            // sift.cpp:82
+                            s_ori[idx] = o;
+                            mg = s_mag[idx] + s_w16[g.lx + 16 * g.ly];  // sift.cpp:90, weighting(x, y) window-local
+                            s_mag[idx] = mg;
+                        }
+                        if (g.owned) {
+                            // alg::orientationHistogram8 inputs in descriptor order: cell = (x/4)*4 + y/4
+                            // (x outer, sift.cpp:95-96), inside a cell x outer, y inner
+                            const float sum = mg * gv[m];
+                            unsigned i = f32_to_u16_x86_d(__builtin_floorf(o / 45.0f));
+                            i = i % 7u;
+                            const int slot = ((g.lx >> 2) * 4 + (g.ly >> 2)) * 16 + (g.lx & 3) * 4 + (g.ly & 3);
+                            s_val[m][slot] = sum;
+                            s_bin[m][slot] = (unsigned char)i;
+                        }
+                    }
+                }
             }
+            __syncthreads();
+            // ---- phase B: histograms, two keypoints at a time over 256 threads ------------------------
+#pragma unroll
+            for (int j = 0; j < kDescBatch / 2; ++j) {
+                const int m = 2 * j + (tid >> 7);
+                const int e = e0 + m;
+                if (e < n_seg) {
+                    const FinalKp f = s_fin[e];
+                    const int kx = f.x, ky = f.y;
+                    const bool kfilt = kx < kRegion || kx > w - kRegion || ky < kRegion || ky > h - kRegion;
+                    const bool owned = kx >= cx0 && kx < cx0 + kCore && ky >= cy0 && ky < cy0 + kCore;
+                    if (owned) {
+                        const int c = tid & 127;
+                        const long long ok = obase + (long long)s_list[e];
+                        float outv = 0.0f;
+                        if (!kfilt) {
+                            const int cell = c >> 3, b = c & 7;
+                            float acc = 0.0f;
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) {
+                                const float v = s_val[m][cell * 16 + q];
+                                acc = (s_bin[m][cell * 16 + q] == b) ? acc + v : acc;
+                            }
+                            // alg::normalizeVector: length = b0 + b1 + ... + b7 sequentially, from the 8 lanes
+                            float length = 0.0f;
+#pragma unroll
+                            for (int b2 = 0; b2 < 8; ++b2) length += __shfl(acc, (lane & ~7) + b2);
+                            outv = (length == 0.0f) ? acc : acc / length;
+                        }
+                        desc_out[(size_t)ok * 128 + c] = outv;
+                        if (c == 0) {
+                            sift_hip_keypoint r;
+                            r.scale = plan->dog_scale[f.octave * D + f.index];
+                            r.orientation = f.orientation;
+                            r.x = f.x;
+                            r.y = f.y;
+                            r.octave = f.octave;
+                            r.index = f.index;
+                            r.filtered = kfilt ? 1 : 0;
+                            r.has_descriptor = kfilt ? 0 : 1;
+                            r.reserved = 0;
+                            kp_out[ok] = r;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
         }
     };
 
@@ -282,23 +322,13 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
             s_fin[r] = fin[v];
         }
         __syncthreads();
-        FinalKp f = s_fin[0];
-        float g = gauss_at(f);
-        for (int e = 0; e < n_tile; ++e) {
-            const int nx = (e + 1 < n_tile) ? e + 1 : e;
-            const FinalKp fn = s_fin[nx];
-            const float gn = gauss_at(fn);     // in flight across this keypoint's barrier
-            process(e, (int)s_list[e], f, g);
-            f = fn;
-            g = gn;
-        }
+        run_segment(n_tile);
         return;
     }
 
     // oversized list (> kTileListCap keypoints touch this tile): walk ALL keypoints of the image in
-    // order, ballot-compacting the ones that touch the tile, in segments that fit s_list
+    // order, ballot-compacting the ones that touch the tile, in segments that fit the LDS list
     __syncthreads();
-    int e_total = 0;
     for (int k0 = 0; k0 < K;) {
         if (tid == 0) s_n = 0;
         __syncthreads();
@@ -308,8 +338,9 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
             if (n_before + 256 > kTileListCap) break;
             const int k = k_next + tid;
             bool hit = false;
+            FinalKp f;
             if (k < K) {
-                const FinalKp f = fin[k];
+                f = fin[k];
                 const int l = f.octave * D + f.index;
                 hit = plan->nearest_level[l] == level && (int)f.x + kRegion > ex0 &&
                       (int)f.x - kRegion < ex0 + kExt && (int)f.y + kRegion > ey0 &&
@@ -320,18 +351,16 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
             __syncthreads();
             int off = n_before;
             for (int q = 0; q < wv; ++q) off += s_wcnt[q];
-            if (hit) s_list[off + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(k - k0);
+            if (hit) {
+                const int p = off + __popcll(m & ((1ull << lane) - 1ull));
+                s_list[p] = (unsigned short)k;
+                s_fin[p] = f;
+            }
             __syncthreads();
             if (tid == 0) s_n = n_before + s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
             __syncthreads();
         }
-        const int n_list = s_n;
-        for (int e = 0; e < n_list; ++e) {
-            const int k = k0 + (int)s_list[e];
-            const FinalKp f = fin[k];
-            process(e_total + e, k, f, gauss_at(f));
-        }
-        e_total += n_list;
+        run_segment(s_n);
         __syncthreads();
         k0 = k_next;
     }

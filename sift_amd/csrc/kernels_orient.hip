@@ -118,7 +118,24 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane < 36) {
+            // all 256 samples in one bin (always the case for the reference's radians-as-degrees
+            // orientations): one serial chain, 4 samples per LDS read, instead of 36 masked ones
+            const unsigned b0 = s_bin[wv][0];
+            const unsigned w4 = reinterpret_cast<const unsigned*>(s_bin[wv])[lane];
+            const bool uniform = __all(w4 == b0 * 0x01010101u);
+            if (uniform) {
+                float acc = 0.0f;
+                const float4* __restrict__ pv = reinterpret_cast<const float4*>(s_prod[wv]);
+#pragma unroll 8
+                for (int q = 0; q < 64; ++q) {
+                    const float4 v = pv[q];
+                    acc += v.x;
+                    acc += v.y;
+                    acc += v.z;
+                    acc += v.w;
+                }
+                if (lane < 36) s_hist[lane][slot] = ((unsigned)lane == b0) ? acc : 0.0f;
+            } else if (lane < 36) {
                 float acc = 0.0f;
                 const float4* __restrict__ pv = reinterpret_cast<const float4*>(s_prod[wv]);
                 const unsigned* __restrict__ pb = reinterpret_cast<const unsigned*>(s_bin[wv]);
