@@ -12,6 +12,7 @@ constexpr int kMaxDogs = 16;                       // dogsPerEpoch upper bound o
 constexpr int kMaxLevels = kMaxOctaves * (kMaxDogs + 1);
 constexpr int kMaxRadiusFused = 32;                // blur radii with a fused LDS-tiled kernel
 constexpr int kRegion = 8;                         // sift.cpp:61,164 `region`
+constexpr int kDescCore = 48;                      // descriptor tile core (kernels_desc.hip)
 
 // Extrema candidate as the scan emits it (order: octave, dog, x outer, y inner; sift.cpp:352-373)
 struct Candidate {

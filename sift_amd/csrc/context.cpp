@@ -325,8 +325,8 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
         int tb = 0;
         for (int lvl : P.grad_levels) {
             const int o = lvl / (D + 1);
-            dv.desc_ntx[lvl] = (dv.w[o] + 63) / 64;
-            dv.desc_nty[lvl] = (dv.h[o] + 63) / 64;
+            dv.desc_ntx[lvl] = (dv.w[o] + kDescCore - 1) / kDescCore;
+            dv.desc_nty[lvl] = (dv.h[o] + kDescCore - 1) / kDescCore;
             dv.desc_tile_base[lvl] = tb;
             tb += dv.desc_ntx[lvl] * dv.desc_nty[lvl];
         }

@@ -64,19 +64,20 @@ __global__ __launch_bounds__(256) void w16_kernel(const float* __restrict__ leve
     w16[(size_t)img * 256 + (size_t)(lx + 16 * ly)] = out;
 }
 
-constexpr int kCore = 64;
-constexpr int kExt = kCore + 2 * kRegion;  // 80
-constexpr int kTileListCap = 768;          // per-tile list held (and sorted) in LDS
+constexpr int kCore = kDescCore;
+constexpr int kExt = kCore + 2 * kRegion;  // 64
+constexpr int kTileListCap = 768;         // per-tile list held (and sorted) in LDS
 
 // ---- binning: which keypoints touch which extended tile ------------------------------------------
 // A 16x16 window touches the extended regions of at most 2x2 tiles.  Counts, an exclusive scan per
 // image and an atomic fill give every tile its (unordered) list; the descriptor kernel sorts its
 // list by vector index in LDS, because the order IS the semantics (cumulative mutation).
 __device__ __forceinline__ void tile_span(int v, int ntiles, int& lo, int& hi) {
-    // tiles t with t*64 - 8 < v + 8 and v - 8 < t*64 + 72  <=>  v - 80 < t*64 < v + 16
-    lo = (v - 80) / kCore + 1;          // smallest t with t*64 > v - 80 (v - 80 may be negative)
-    if (v - 80 < 0) lo = 0;
-    hi = (v + 15) / kCore;              // largest t with t*64 < v + 16
+    // tiles t whose extended region [t*C - 8, t*C + C + 8) meets the window [v - 8, v + 8):
+    //   v - C - 16 < t*C < v + 16
+    const int a = v - kCore - 16;
+    lo = a < 0 ? 0 : a / kCore + 1;     // smallest t with t*C > a
+    hi = (v + 15) / kCore;              // largest t with t*C < v + 16
     if (hi > ntiles - 1) hi = ntiles - 1;
 }
 
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
                                                          float* __restrict__ desc_out) {
     __shared__ float s_ori[kExt * kExt];
     __shared__ float s_mag[kExt * kExt];
+    __shared__ float s_gau[kExt * kExt];
     __shared__ float s_w16[256];
     __shared__ unsigned short s_raw[kTileListCap];
     __shared__ unsigned short s_list[kTileListCap];   // vector index k of each list entry, ascending
@@ -194,6 +196,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
         const size_t o = (size_t)(ok ? Y : 0) * (size_t)w + (size_t)(ok ? X : 0);
         s_ori[idx] = ok ? go[o] : 0.0f;
         s_mag[idx] = ok ? gm[o] : 0.0f;
+        s_gau[idx] = ok ? gg[o] : 0.0f;
     }
     s_w16[tid] = plan->w16[level][(size_t)img * 256 + tid];
 
@@ -219,19 +222,11 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
     };
 
     // Processes the ordered entries s_fin[0..n_seg) / s_list[0..n_seg).
+    // cross-thread data only moves through LDS here: do not drain the output stores at barriers
+    auto lds_only_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     auto run_segment = [&](int n_seg) {
         for (int e0 = 0; e0 < n_seg; e0 += kDescBatch) {
             // ---- phase A: per-pixel chains, no barrier -------------------------------------------------
-            float gv[kDescBatch];
-#pragma unroll
-            for (int m = 0; m < kDescBatch; ++m) {   // Gaussian values first: independent loads in flight
-                gv[m] = 0.0f;
-                if (e0 + m < n_seg) {
-                    const FinalKp f = s_fin[e0 + m];
-                    const Geo g = geometry(f);
-                    if (g.owned && !g.kfilt) gv[m] = gg[(size_t)g.Y * (size_t)w + (size_t)g.X];
-                }
-            }
 #pragma unroll
             for (int m = 0; m < kDescBatch; ++m) {
                 if (e0 + m < n_seg) {
@@ -249,7 +244,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
                         if (g.owned) {
                             // alg::orientationHistogram8 inputs in descriptor order: cell = (x/4)*4 + y/4
                             // (x outer, sift.cpp:95-96), inside a cell x outer, y inner
-                            const float sum = mg * gv[m];
+                            const float sum = mg * s_gau[(g.Y - ey0) * kExt + (g.X - ex0)];
                             unsigned i = f32_to_u16_x86_d(__builtin_floorf(o / 45.0f));
                             i = i % 7u;
                             const int slot = ((g.lx >> 2) * 4 + (g.ly >> 2)) * 16 + (g.lx & 3) * 4 + (g.ly & 3);
@@ -259,7 +254,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
                     }
                 }
             }
-            __syncthreads();
+            lds_only_barrier();
             // ---- phase B: histograms, two keypoints at a time over 256 threads ------------------------
 #pragma unroll
             for (int j = 0; j < kDescBatch / 2; ++j) {
@@ -305,7 +300,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
                     }
                 }
             }
-            __syncthreads();
+            lds_only_barrier();
         }
     };
 
