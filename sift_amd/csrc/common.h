@@ -119,6 +119,6 @@ void launch_desc_binning(hipStream_t s, const DevPlan* d_plan, const DevPlan& pl
 void launch_descriptors(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level,
                         const FinalKp* d_final, const int* d_final_cnt, int final_cap,
                         const int* d_tile_cnt, const int* d_tile_off, const uint16_t* d_pool, int pool_cap,
-                        const long long* d_out_base, sift_hip_keypoint* d_kp_out, float* d_desc_out);
+                        const long long* d_out_base, sift_hip_keypoint* d_kp_out, float* d_desc_out, int dbg = 0);
 
 }  // namespace sift_hip

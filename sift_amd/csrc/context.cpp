@@ -101,10 +101,13 @@ struct Plan {
 struct sift_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;          // side stream: work that can overlap the 1-block-per-image cleanup
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool fused = true;
     bool gpu_cleanup = true;
     bool profile = false;
     int host_threads = 0;
+    int desc_dbg = 0;
     Plan plan;
     DevBuf arena, d_plan, d_taps, d_luts, d_taps16, d_input, d_base, d_tmp, d_tmp2;
     DevBuf d_masks, d_counts, d_totals, d_cands, d_flags;
@@ -513,6 +516,7 @@ void mid_host(sift_hip_ctx* c) {
                                           (size_t)cnt1[(size_t)i] * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     }
     SIFT_HIP_CHECK(hipMemcpyAsync(c->d_list_cnt.p, cnt1.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
+    SIFT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
     launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
                        kListCap, c->d_orient.as<OrientOut>(), c->d_peaks.as<float>());
     c->h_orient.ensure((size_t)n * kListCap * sizeof(OrientOut));
@@ -585,6 +589,7 @@ bool mid_gpu(sift_hip_ctx* c) {
     launch_cleanup1(s, n, c->d_flags.as<uint8_t>(), c->d_totals.as<int>(), dv.cand_capacity, c->d_wk.as<uint8_t>(),
                     c->d_wi.as<uint32_t>(), c->d_wi2.as<uint32_t>(), c->d_wp.as<uint32_t>(), c->d_list.as<uint32_t>(),
                     kListCap, c->d_list_cnt.as<int>(), d_fb1);
+    SIFT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
     launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
                        kListCap, c->d_orient.as<OrientOut>(), c->d_peaks.as<float>());
     launch_cleanup2(s, n, c->d_cands.as<Candidate>(), dv.cand_capacity, c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
@@ -688,11 +693,16 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     launch_extrema_scan(s, dv, c->d_counts.as<int>(), c->d_totals.as<int>());
     launch_extrema_expand(s, dpl, dv, c->d_masks.as<unsigned long long>(), c->d_counts.as<int>(), c->d_cands.as<Candidate>());
     launch_edge_filter(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_totals.as<int>(), c->d_flags.as<uint8_t>());
+    // Gradient maps and W16 only need the pyramid: they run on the side stream so that they fill the
+    // CUs the one-workgroup-per-image cleanup kernel leaves idle.
+    SIFT_HIP_CHECK(hipEventRecord(c->ev_fork, s));
+    SIFT_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     for (int lvl : P.grad_levels) {
         const int o = lvl / (D + 1);
-        launch_gradient(s, dv.gauss[lvl], dv.mag[lvl], dv.ori[lvl], dv.w[o], dv.h[o], n);
-        launch_w16(s, dv, lvl, c->d_taps16.as<float>(), P.radius16);
+        launch_gradient(c->stream2, dv.gauss[lvl], dv.mag[lvl], dv.ori[lvl], dv.w[o], dv.h[o], n);
+        launch_w16(c->stream2, dv, lvl, c->d_taps16.as<float>(), P.radius16);
     }
+    SIFT_HIP_CHECK(hipEventRecord(c->ev_join, c->stream2));
     // cleanup, orientation assignment, cleanup (sift.cpp:37-54)
     if (!(c->gpu_cleanup && mid_gpu(c))) {
         for (int i = 0; i < n; ++i) { c->status[(size_t)i] = 0; c->messages[(size_t)i].clear(); }
@@ -720,7 +730,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
         for (int lvl : P.grad_levels)
             launch_descriptors(s, dpl, dv, lvl, c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(), kListCap, t_cnt, t_off,
                                c->d_pool.as<uint16_t>(), kPoolCap, c->d_out_base.as<long long>(),
-                               c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>());
+                               c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->desc_dbg);
     }
     SIFT_HIP_CHECK(hipStreamSynchronize(s));
     c->have_result = true;
@@ -770,6 +780,9 @@ int sift_hip_create(int device, sift_hip_ctx** out, char* err, int errlen) {
         auto* c = new sift_hip_ctx();
         c->device = device;
         SIFT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        SIFT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
         *out = c;
         return SIFT_HIP_OK;
     });
@@ -786,6 +799,9 @@ void sift_hip_destroy(sift_hip_ctx* c) {
     for (HostBuf* b : {&c->h_flags, &c->h_orient, &c->h_peaks}) b->release();
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(c->ev_fork);
+    (void)hipEventDestroy(c->ev_join);
+    (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -793,6 +809,7 @@ void sift_hip_destroy(sift_hip_ctx* c) {
 int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     if (!c || !name) return SIFT_HIP_EINVAL;
     if (!std::strcmp(name, "fused_blur")) { c->fused = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "desc_dbg")) { c->desc_dbg = value; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "gpu_cleanup")) { c->gpu_cleanup = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "profile")) { c->profile = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "host_threads")) { c->host_threads = value; return SIFT_HIP_OK; }

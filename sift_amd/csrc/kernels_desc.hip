@@ -156,10 +156,10 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
                                                          const uint16_t* __restrict__ pool, int pool_cap,
                                                          const long long* __restrict__ out_base,
                                                          sift_hip_keypoint* __restrict__ kp_out,
-                                                         float* __restrict__ desc_out) {
-    __shared__ float s_ori[kExt * kExt];
-    __shared__ float s_mag[kExt * kExt];
-    __shared__ float s_gau[kExt * kExt];
+                                                         float* __restrict__ desc_out, int dbg) {
+    __shared__ __attribute__((aligned(16))) float s_ori[kExt * kExt];
+    __shared__ __attribute__((aligned(16))) float s_mag[kExt * kExt];
+    __shared__ __attribute__((aligned(16))) float s_gau[kExt * kExt];
     __shared__ float s_w16[256];
     __shared__ unsigned short s_raw[kTileListCap];
     __shared__ unsigned short s_list[kTileListCap];   // vector index k of each list entry, ascending
@@ -188,15 +188,47 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
     const int K = final_cnt[img];
     const long long obase = out_base[img];
 
-    // initial gradient values of the extended tile
-    for (int idx = tid; idx < kExt * kExt; idx += 256) {
-        const int ly = idx / kExt, lx = idx - ly * kExt;
-        const int X = ex0 + lx, Y = ey0 + ly;
-        const bool ok = X >= 0 && X < w && Y >= 0 && Y < h;
-        const size_t o = (size_t)(ok ? Y : 0) * (size_t)w + (size_t)(ok ? X : 0);
-        s_ori[idx] = ok ? go[o] : 0.0f;
-        s_mag[idx] = ok ? gm[o] : 0.0f;
-        s_gau[idx] = ok ? gg[o] : 0.0f;
+    // initial gradient / Gaussian values of the extended tile: 16-byte loads (all issued before the
+    // LDS stores) when rows are 16-byte aligned, scalar otherwise
+    if (!(dbg & 4)) {
+        const bool vec = (w & 3) == 0 && ((((uintptr_t)gm | (uintptr_t)go | (uintptr_t)gg) & 15u) == 0);
+        if (vec) {
+            constexpr int R4 = kExt / 4;                 // float4 per tile row
+            constexpr int N4 = kExt * R4;
+            constexpr int NI = (N4 + 255) / 256;
+            float4 vo[NI], vm[NI], vg[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int e = tid + 256 * i;
+                const int ly = e / R4, c4 = e - ly * R4;
+                const int X = ex0 + 4 * c4, Y = ey0 + ly;
+                const bool ok = e < N4 && X >= 0 && X < w && Y >= 0 && Y < h;   // ex0, w multiples of 4
+                const size_t o = (size_t)(ok ? Y : 0) * (size_t)w + (size_t)(ok ? X : 0);
+                const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                vo[i] = ok ? *reinterpret_cast<const float4*>(go + o) : z;
+                vm[i] = ok ? *reinterpret_cast<const float4*>(gm + o) : z;
+                vg[i] = ok ? *reinterpret_cast<const float4*>(gg + o) : z;
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int e = tid + 256 * i;
+                if (e < N4) {
+                    reinterpret_cast<float4*>(s_ori)[e] = vo[i];
+                    reinterpret_cast<float4*>(s_mag)[e] = vm[i];
+                    reinterpret_cast<float4*>(s_gau)[e] = vg[i];
+                }
+            }
+        } else {
+            for (int idx = tid; idx < kExt * kExt; idx += 256) {
+                const int ly = idx / kExt, lx = idx - ly * kExt;
+                const int X = ex0 + lx, Y = ey0 + ly;
+                const bool ok = X >= 0 && X < w && Y >= 0 && Y < h;
+                const size_t o = (size_t)(ok ? Y : 0) * (size_t)w + (size_t)(ok ? X : 0);
+                s_ori[idx] = ok ? go[o] : 0.0f;
+                s_mag[idx] = ok ? gm[o] : 0.0f;
+                s_gau[idx] = ok ? gg[o] : 0.0f;
+            }
+        }
     }
     s_w16[tid] = plan->w16[level][(size_t)img * 256 + tid];
 
@@ -206,12 +238,21 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
         bool kfilt, owned, inside;
         int lx, ly, X, Y;
     };
+    // The LDS copy of a record reuses `cand` for two per-tile flags: bit 0 = the descriptor stage's
+    // own bounds test fails (sift.cpp:65-70; never newly true after the orientation stage's
+    // stricter test), bit 1 = the keypoint's location lies in this tile's core (it is emitted here).
+    auto with_flags = [&](FinalKp f) {
+        const int kx = f.x, ky = f.y;
+        const bool kfilt = kx < kRegion || kx > w - kRegion || ky < kRegion || ky > h - kRegion;
+        const bool owned = kx >= cx0 && kx < cx0 + kCore && ky >= cy0 && ky < cy0 + kCore;
+        f.cand = (kfilt ? 1u : 0u) | (owned ? 2u : 0u);
+        return f;
+    };
     auto geometry = [&](const FinalKp& f) {
         Geo g;
         const int kx = f.x, ky = f.y;
-        // sift.cpp:65-70 (never newly true after the orientation stage's stricter test)
-        g.kfilt = kx < kRegion || kx > w - kRegion || ky < kRegion || ky > h - kRegion;
-        g.owned = kx >= cx0 && kx < cx0 + kCore && ky >= cy0 && ky < cy0 + kCore;
+        g.kfilt = (f.cand & 1u) != 0;
+        g.owned = (f.cand & 2u) != 0;
         g.lx = (rx - (kx - kRegion)) & 15;   // window-local x of the pixel with X = rx (mod 16)
         g.ly = (ry - (ky - kRegion)) & 15;
         g.X = kx - kRegion + g.lx;
@@ -226,6 +267,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
     auto lds_only_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     auto run_segment = [&](int n_seg) {
         for (int e0 = 0; e0 < n_seg; e0 += kDescBatch) {
+            if (!(dbg & 1))
             // ---- phase A: per-pixel chains, no barrier -------------------------------------------------
 #pragma unroll
             for (int m = 0; m < kDescBatch; ++m) {
@@ -256,15 +298,15 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
             }
             lds_only_barrier();
             // ---- phase B: histograms, two keypoints at a time over 256 threads ------------------------
+            if (!(dbg & 2))
 #pragma unroll
             for (int j = 0; j < kDescBatch / 2; ++j) {
                 const int m = 2 * j + (tid >> 7);
                 const int e = e0 + m;
                 if (e < n_seg) {
                     const FinalKp f = s_fin[e];
-                    const int kx = f.x, ky = f.y;
-                    const bool kfilt = kx < kRegion || kx > w - kRegion || ky < kRegion || ky > h - kRegion;
-                    const bool owned = kx >= cx0 && kx < cx0 + kCore && ky >= cy0 && ky < cy0 + kCore;
+                    const bool kfilt = (f.cand & 1u) != 0;
+                    const bool owned = (f.cand & 2u) != 0;
                     if (owned) {
                         const int c = tid & 127;
                         const long long ok = obase + (long long)s_list[e];
@@ -314,10 +356,10 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
             int r = 0;
             for (int j = 0; j < n_tile; ++j) r += s_raw[j] < v;
             s_list[r] = v;
-            s_fin[r] = fin[v];
+            s_fin[r] = with_flags(fin[v]);
         }
         __syncthreads();
-        run_segment(n_tile);
+        if (!(dbg & 8)) run_segment(n_tile);
         return;
     }
 
@@ -349,7 +391,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
             if (hit) {
                 const int p = off + __popcll(m & ((1ull << lane) - 1ull));
                 s_list[p] = (unsigned short)k;
-                s_fin[p] = f;
+                s_fin[p] = with_flags(f);
             }
             __syncthreads();
             if (tid == 0) s_n = n_before + s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
@@ -386,10 +428,10 @@ void launch_desc_binning(hipStream_t s, const DevPlan* d_plan, const DevPlan& pl
 void launch_descriptors(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level,
                         const FinalKp* d_final, const int* d_final_cnt, int final_cap,
                         const int* d_tile_cnt, const int* d_tile_off, const uint16_t* d_pool, int pool_cap,
-                        const long long* d_out_base, sift_hip_keypoint* d_kp_out, float* d_desc_out) {
+                        const long long* d_out_base, sift_hip_keypoint* d_kp_out, float* d_desc_out, int dbg) {
     const dim3 grid((unsigned)plan.desc_ntx[level], (unsigned)plan.desc_nty[level], (unsigned)plan.n_images);
     hipLaunchKernelGGL(descriptor_kernel, grid, dim3(256), 0, s, d_plan, level, d_final, d_final_cnt, final_cap,
-                       d_tile_cnt, d_tile_off, d_pool, pool_cap, d_out_base, d_kp_out, d_desc_out);
+                       d_tile_cnt, d_tile_off, d_pool, pool_cap, d_out_base, d_kp_out, d_desc_out, dbg);
 }
 
 }  // namespace sift_hip

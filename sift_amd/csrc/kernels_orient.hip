@@ -84,10 +84,22 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
     // the survivor count lives on the device: a fixed grid strides over the groups of keypoints
     for (int grp = blockIdx.x; grp * kOrientGroup < cnt; grp += gridDim.x) {
         // ---- phase 1 --------------------------------------------------------------------------
-        for (int j = 0; j < kOrientGroup / 4; ++j) {
-            const int slot = wv * (kOrientGroup / 4) + j;
-            const int kp = grp * kOrientGroup + slot;
-            if (kp >= cnt) break;  // wave-uniform
+        // Window samples of keypoint j+1 are fetched into registers while keypoint j is accumulated.
+        struct Win {
+            float pm[4], po[4], pg[4];
+            bool valid, run;
+            unsigned char state;
+        };
+        auto fetch = [&](int j) {
+            Win wn;
+            wn.valid = false;
+            wn.run = false;
+            wn.state = 0;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) wn.pm[it] = wn.po[it] = wn.pg[it] = 0.0f;
+            const int kp = grp * kOrientGroup + wv * (kOrientGroup / 4) + j;
+            if (j >= kOrientGroup / 4 || kp >= cnt) return wn;  // wave-uniform
+            wn.valid = true;
             const Candidate cd = cands[cbase + list[lbase + kp]];
             const int x = cd.x, y = cd.y;
             const int l = cd.octave * D + cd.index;
@@ -96,64 +108,84 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
             const int w = plan->w[no], h = plan->h[no];
             const bool border = (x < kRegion || x >= w - kRegion) || (y < kRegion || y >= h - kRegion);  // sift.cpp:173-174
             const int throws = border ? 0 : plan->dead_blur_radius[l];  // sift.cpp:184 (0 ok, else error code)
-            const bool run = !border && throws == 0;
-            if (lane == 0) s_state[slot] = (unsigned char)((border ? 1 : 0) | (throws << 1) | (run ? 0x80 : 0));
-            if (!run) continue;
-            const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
-            const float* __restrict__ gm = plan->mag[lvl] + img_off;
-            const float* __restrict__ go = plan->ori[lvl] + img_off;
-            const float* __restrict__ gg = plan->gauss[lvl] + img_off;
-            const int x0 = x - kRegion, y0 = y - kRegion;
+            wn.run = !border && throws == 0;
+            wn.state = (unsigned char)((border ? 1 : 0) | (throws << 1) | (wn.run ? 0x80 : 0));
+            if (wn.run) {
+                const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
+                const float* __restrict__ gm = plan->mag[lvl] + img_off;
+                const float* __restrict__ go = plan->ori[lvl] + img_off;
+                const float* __restrict__ gg = plan->gauss[lvl] + img_off;
+                const int x0 = x - kRegion, y0 = y - kRegion;
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int ly = it * 4 + (lane >> 4);
-                const int lx = lane & 15;
-                const size_t o = (size_t)(y0 + ly) * (size_t)w + (size_t)(x0 + lx);
-                const float sum = gm[o] * gg[o];
-                unsigned i = f32_to_u16_x86(__builtin_floorf(go[o] / 10.0f));
-                i = i % 35u;
-                s_prod[wv][lx * 16 + ly] = sum;
-                s_bin[wv][lx * 16 + ly] = (unsigned char)i;
+                for (int it = 0; it < 4; ++it) {
+                    const int ly = it * 4 + (lane >> 4);
+                    const int lx = lane & 15;
+                    const size_t o = (size_t)(y0 + ly) * (size_t)w + (size_t)(x0 + lx);
+                    wn.pm[it] = gm[o];
+                    wn.po[it] = go[o];
+                    wn.pg[it] = gg[o];
+                }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // all 256 samples in one bin (always the case for the reference's radians-as-degrees
-            // orientations): one serial chain, 4 samples per LDS read, instead of 36 masked ones
-            const unsigned b0 = s_bin[wv][0];
-            const unsigned w4 = reinterpret_cast<const unsigned*>(s_bin[wv])[lane];
-            const bool uniform = __all(w4 == b0 * 0x01010101u);
-            if (uniform) {
-                float acc = 0.0f;
-                const float4* __restrict__ pv = reinterpret_cast<const float4*>(s_prod[wv]);
+            return wn;
+        };
+        Win cur = fetch(0);
+        for (int j = 0; j < kOrientGroup / 4; ++j) {
+            if (!cur.valid) break;  // wave-uniform
+            const Win nxt = fetch(j + 1);
+            const int slot = wv * (kOrientGroup / 4) + j;
+            if (lane == 0) s_state[slot] = cur.state;
+            if (cur.run) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int ly = it * 4 + (lane >> 4);
+                    const int lx = lane & 15;
+                    const float sum = cur.pm[it] * cur.pg[it];
+                    unsigned i = f32_to_u16_x86(__builtin_floorf(cur.po[it] / 10.0f));
+                    i = i % 35u;
+                    s_prod[wv][lx * 16 + ly] = sum;
+                    s_bin[wv][lx * 16 + ly] = (unsigned char)i;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // all 256 samples in one bin (always the case for the reference's radians-as-degrees
+                // orientations): one serial chain, 4 samples per LDS read, instead of 36 masked ones
+                const unsigned b0 = s_bin[wv][0];
+                const unsigned w4 = reinterpret_cast<const unsigned*>(s_bin[wv])[lane];
+                const bool uniform = __all(w4 == b0 * 0x01010101u);
+                if (uniform) {
+                    float acc = 0.0f;
+                    const float4* __restrict__ pv = reinterpret_cast<const float4*>(s_prod[wv]);
 #pragma unroll 8
-                for (int q = 0; q < 64; ++q) {
-                    const float4 v = pv[q];
-                    acc += v.x;
-                    acc += v.y;
-                    acc += v.z;
-                    acc += v.w;
-                }
-                if (lane < 36) s_hist[lane][slot] = ((unsigned)lane == b0) ? acc : 0.0f;
-            } else if (lane < 36) {
-                float acc = 0.0f;
-                const float4* __restrict__ pv = reinterpret_cast<const float4*>(s_prod[wv]);
-                const unsigned* __restrict__ pb = reinterpret_cast<const unsigned*>(s_bin[wv]);
-                const unsigned me = (unsigned)lane;
+                    for (int q = 0; q < 64; ++q) {
+                        const float4 v = pv[q];
+                        acc += v.x;
+                        acc += v.y;
+                        acc += v.z;
+                        acc += v.w;
+                    }
+                    if (lane < 36) s_hist[lane][slot] = ((unsigned)lane == b0) ? acc : 0.0f;
+                } else if (lane < 36) {
+                    float acc = 0.0f;
+                    const float4* __restrict__ pv = reinterpret_cast<const float4*>(s_prod[wv]);
+                    const unsigned* __restrict__ pb = reinterpret_cast<const unsigned*>(s_bin[wv]);
+                    const unsigned me = (unsigned)lane;
 #pragma unroll 4
-                for (int q = 0; q < 64; ++q) {  // 4 samples per LDS read, still strictly in sample order
-                    const float4 v = pv[q];
-                    const unsigned b = pb[q];
-                    acc = ((b & 0xffu) == me) ? acc + v.x : acc;
-                    acc = (((b >> 8) & 0xffu) == me) ? acc + v.y : acc;
-                    acc = (((b >> 16) & 0xffu) == me) ? acc + v.z : acc;
-                    acc = ((b >> 24) == me) ? acc + v.w : acc;
+                    for (int q = 0; q < 64; ++q) {  // 4 samples per LDS read, still strictly in sample order
+                        const float4 v = pv[q];
+                        const unsigned b = pb[q];
+                        acc = ((b & 0xffu) == me) ? acc + v.x : acc;
+                        acc = (((b >> 8) & 0xffu) == me) ? acc + v.y : acc;
+                        acc = (((b >> 16) & 0xffu) == me) ? acc + v.z : acc;
+                        acc = ((b >> 24) == me) ? acc + v.w : acc;
+                    }
+                    s_hist[lane][slot] = acc;
                 }
-                s_hist[lane][slot] = acc;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            cur = nxt;
         }
         __syncthreads();
         // ---- phase 2 --------------------------------------------------------------------------
