@@ -164,8 +164,10 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
     __shared__ unsigned short s_raw[kTileListCap];
     __shared__ unsigned short s_list[kTileListCap];   // vector index k of each list entry, ascending
     __shared__ FinalKp s_fin[kTileListCap];
-    __shared__ float s_val[kDescBatch][256];
-    __shared__ unsigned char s_bin[kDescBatch][256];
+    // histogram inputs of a batch, laid out [sample-in-cell q][cell][keypoint m]: the phase-B reader
+    // (thread = (m, cell), q marching) then touches 128 consecutive words per read
+    __shared__ float s_val[16 * 16 * kDescBatch];
+    __shared__ unsigned char s_bin[16 * 16 * kDescBatch];
     __shared__ int s_wcnt[4];
     __shared__ int s_n;
 
@@ -194,30 +196,32 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
         const bool vec = (w & 3) == 0 && ((((uintptr_t)gm | (uintptr_t)go | (uintptr_t)gg) & 15u) == 0);
         if (vec) {
             constexpr int R4 = kExt / 4;                 // float4 per tile row
-            constexpr int N4 = kExt * R4;
-            constexpr int NI = (N4 + 255) / 256;
-            float4 vo[NI], vm[NI], vg[NI];
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int e = tid + 256 * i;
-                const int ly = e / R4, c4 = e - ly * R4;
-                const int X = ex0 + 4 * c4, Y = ey0 + ly;
-                const bool ok = e < N4 && X >= 0 && X < w && Y >= 0 && Y < h;   // ex0, w multiples of 4
-                const size_t o = (size_t)(ok ? Y : 0) * (size_t)w + (size_t)(ok ? X : 0);
-                const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                vo[i] = ok ? *reinterpret_cast<const float4*>(go + o) : z;
-                vm[i] = ok ? *reinterpret_cast<const float4*>(gm + o) : z;
-                vg[i] = ok ? *reinterpret_cast<const float4*>(gg + o) : z;
+            static_assert(kExt * R4 == 4 * 256, "tile init assumes 4 float4 per thread and array");
+            const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            float4 o0 = z, o1 = z, o2 = z, o3 = z, m0 = z, m1 = z, m2 = z, m3 = z, g0 = z, g1 = z, g2 = z, g3 = z;
+#define SIFT_TILE_LOAD(i, vo, vm, vg)                                                             \
+            {                                                                                     \
+                const int e = tid + 256 * (i);                                                    \
+                const int ly = e / R4, c4 = e - ly * R4;                                          \
+                const int X = ex0 + 4 * c4, Y = ey0 + ly;                                         \
+                if (X >= 0 && X < w && Y >= 0 && Y < h) { /* ex0 and w are multiples of 4 */       \
+                    const size_t o = (size_t)Y * (size_t)w + (size_t)X;                           \
+                    vo = *reinterpret_cast<const float4*>(go + o);                                \
+                    vm = *reinterpret_cast<const float4*>(gm + o);                                \
+                    vg = *reinterpret_cast<const float4*>(gg + o);                                \
+                }                                                                                 \
             }
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int e = tid + 256 * i;
-                if (e < N4) {
-                    reinterpret_cast<float4*>(s_ori)[e] = vo[i];
-                    reinterpret_cast<float4*>(s_mag)[e] = vm[i];
-                    reinterpret_cast<float4*>(s_gau)[e] = vg[i];
-                }
-            }
+            SIFT_TILE_LOAD(0, o0, m0, g0)
+            SIFT_TILE_LOAD(1, o1, m1, g1)
+            SIFT_TILE_LOAD(2, o2, m2, g2)
+            SIFT_TILE_LOAD(3, o3, m3, g3)
+#undef SIFT_TILE_LOAD
+            float4* po = reinterpret_cast<float4*>(s_ori);
+            float4* pm = reinterpret_cast<float4*>(s_mag);
+            float4* pg = reinterpret_cast<float4*>(s_gau);
+            po[tid] = o0; po[tid + 256] = o1; po[tid + 512] = o2; po[tid + 768] = o3;
+            pm[tid] = m0; pm[tid + 256] = m1; pm[tid + 512] = m2; pm[tid + 768] = m3;
+            pg[tid] = g0; pg[tid + 256] = g1; pg[tid + 512] = g2; pg[tid + 768] = g3;
         } else {
             for (int idx = tid; idx < kExt * kExt; idx += 256) {
                 const int ly = idx / kExt, lx = idx - ly * kExt;
@@ -289,44 +293,54 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
                             const float sum = mg * s_gau[(g.Y - ey0) * kExt + (g.X - ex0)];
                             unsigned i = f32_to_u16_x86_d(__builtin_floorf(o / 45.0f));
                             i = i % 7u;
-                            const int slot = ((g.lx >> 2) * 4 + (g.ly >> 2)) * 16 + (g.lx & 3) * 4 + (g.ly & 3);
-                            s_val[m][slot] = sum;
-                            s_bin[m][slot] = (unsigned char)i;
+                            const int cell = (g.lx >> 2) * 4 + (g.ly >> 2), q = (g.lx & 3) * 4 + (g.ly & 3);
+                            const int slot = (q * 16 + cell) * kDescBatch + m;
+                            s_val[slot] = sum;
+                            s_bin[slot] = (unsigned char)i;
                         }
                     }
                 }
             }
             lds_only_barrier();
-            // ---- phase B: histograms, two keypoints at a time over 256 threads ------------------------
-            if (!(dbg & 2))
-#pragma unroll
-            for (int j = 0; j < kDescBatch / 2; ++j) {
-                const int m = 2 * j + (tid >> 7);
+            // ---- phase B: one thread per (keypoint of the batch, cell): 8 bins in registers --------------
+            if (!(dbg & 2) && tid < 16 * kDescBatch) {
+                const int m = tid & (kDescBatch - 1), cell = tid / kDescBatch;
                 const int e = e0 + m;
                 if (e < n_seg) {
                     const FinalKp f = s_fin[e];
                     const bool kfilt = (f.cand & 1u) != 0;
                     const bool owned = (f.cand & 2u) != 0;
                     if (owned) {
-                        const int c = tid & 127;
                         const long long ok = obase + (long long)s_list[e];
-                        float outv = 0.0f;
+                        float h0 = 0.0f, h1 = 0.0f, h2 = 0.0f, h3 = 0.0f, h4 = 0.0f, h5 = 0.0f, h6 = 0.0f;
+                        float h7 = 0.0f;  // bin 7 is never written (the index is taken % 7) but is normalised
                         if (!kfilt) {
-                            const int cell = c >> 3, b = c & 7;
-                            float acc = 0.0f;
+                            // alg::orientationHistogram8: samples of the cell in x-outer / y-inner order
 #pragma unroll
                             for (int q = 0; q < 16; ++q) {
-                                const float v = s_val[m][cell * 16 + q];
-                                acc = (s_bin[m][cell * 16 + q] == b) ? acc + v : acc;
+                                const float v = s_val[(q * 16 + cell) * kDescBatch + m];
+                                const unsigned b = s_bin[(q * 16 + cell) * kDescBatch + m];
+                                h0 = (b == 0u) ? h0 + v : h0;
+                                h1 = (b == 1u) ? h1 + v : h1;
+                                h2 = (b == 2u) ? h2 + v : h2;
+                                h3 = (b == 3u) ? h3 + v : h3;
+                                h4 = (b == 4u) ? h4 + v : h4;
+                                h5 = (b == 5u) ? h5 + v : h5;
+                                h6 = (b == 6u) ? h6 + v : h6;
                             }
-                            // alg::normalizeVector: length = b0 + b1 + ... + b7 sequentially, from the 8 lanes
+                            // alg::normalizeVector: length = b0 + ... + b7 sequentially; skip if 0
                             float length = 0.0f;
-#pragma unroll
-                            for (int b2 = 0; b2 < 8; ++b2) length += __shfl(acc, (lane & ~7) + b2);
-                            outv = (length == 0.0f) ? acc : acc / length;
+                            length += h0; length += h1; length += h2; length += h3;
+                            length += h4; length += h5; length += h6; length += h7;
+                            if (!(length == 0.0f)) {
+                                h0 = h0 / length; h1 = h1 / length; h2 = h2 / length; h3 = h3 / length;
+                                h4 = h4 / length; h5 = h5 / length; h6 = h6 / length; h7 = h7 / length;
+                            }
                         }
-                        desc_out[(size_t)ok * 128 + c] = outv;
-                        if (c == 0) {
+                        float4* dst = reinterpret_cast<float4*>(desc_out + (size_t)ok * 128 + (size_t)cell * 8);
+                        dst[0] = make_float4(h0, h1, h2, h3);
+                        dst[1] = make_float4(h4, h5, h6, h7);
+                        if (cell == 0) {
                             sift_hip_keypoint r;
                             r.scale = plan->dog_scale[f.octave * D + f.index];
                             r.orientation = f.orientation;

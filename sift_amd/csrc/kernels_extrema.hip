@@ -21,88 +21,76 @@
 namespace sift_hip {
 
 // ---------------------------------------------------------------------------------------------
-// Mask kernel: one workgroup = 64 rows x 64 columns of one image of one scanned DoG level.
-// The three DoG tiles (65 x 65 with the x-1 / y-1 fringe) are staged in LDS with row-coalesced
-// loads; each wave then walks 16 columns with lane = row, so one __ballot per column is the
-// column's candidate mask in y order.
+// Mask kernel.  One WAVE owns 63 output columns x one 64-row block of one image of one scanned DoG
+// level: lane l holds column x = 63*group + l (lane 0 only supplies the x-1 neighbour of lane 1).
+// The wave walks the 65 rows top to bottom with row-coalesced loads straight from HBM/L2 (every
+// pixel is fetched once per wave, no LDS, no barrier), keeps the previous row in registers, gets
+// the x-1 values with a wavefront shuffle and ORs one candidate bit per row into a 64-bit column
+// mask.  Rows are unrolled four at a time so 12 independent loads are in flight per lane.
 // ---------------------------------------------------------------------------------------------
-constexpr int kExTile = 64;
-constexpr int kExStride = kExTile + 1;  // 65 floats: lanes (rows) hit distinct banks
+constexpr int kExCols = 63;
 
 __global__ __launch_bounds__(256) void extrema_mask_kernel(const float* __restrict__ d0,
                                                            const float* __restrict__ d1,
                                                            const float* __restrict__ d2, int w, int h,
-                                                           int nyb, int word_base, int words_per_image,
+                                                           int nyb, int ngroups, int word_base,
+                                                           int words_per_image,
                                                            unsigned long long* __restrict__ masks,
                                                            int* __restrict__ counts) {
-    __shared__ float s[3][kExStride * kExStride];
-    const int tid = threadIdx.x;
-    const int xa = blockIdx.x * kExTile;  // first column of the tile
+    const int lane = threadIdx.x & 63;
+    const int grp = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (grp >= ngroups) return;  // whole wave
     const int yb = blockIdx.y;
-    const int ya = yb * kExTile;
     const int img = blockIdx.z;
+    const int x = grp * kExCols + lane;
+    const int xc = x < w ? x : w - 1;  // clamped column for loads
     const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
-    const float* __restrict__ src[3] = {d0 + img_off, d1 + img_off, d2 + img_off};
+    const float* __restrict__ s0 = d0 + img_off + xc;
+    const float* __restrict__ s1 = d1 + img_off + xc;
+    const float* __restrict__ s2 = d2 + img_off + xc;
+    const int ya = yb * 64;
+    const bool x_ok = lane >= 1 && x >= 1 && x <= w - 2;
 
-    for (int idx = tid; idx < kExStride * kExStride; idx += 256) {
-        const int ly = idx / kExStride;
-        const int lx = idx - ly * kExStride;
-        const int gx = xa - 1 + lx, gy = ya - 1 + ly;
-        const bool ok = gx >= 0 && gx < w && gy >= 0 && gy < h;
-        const size_t o = (size_t)(ok ? gy : 0) * (size_t)w + (size_t)(ok ? gx : 0);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) s[k][idx] = ok ? src[k][o] : 0.0f;
-    }
-    __syncthreads();
-
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int ly = lane + 1;
-    const int y = ya + lane;
-    const bool y_ok = y >= 1 && y <= h - 2;
-    // values of the previous column (x-1): [image][0 = row y-1, 1 = row y]
-    float pv[3][2];
+    auto row_off = [&](int y) { return (size_t)(y < 0 ? 0 : (y >= h ? h - 1 : y)) * (size_t)w; };
+    // previous row (own column and x-1 column), starting with row ya-1
+    float po0, po1, po2, pl0, pl1, pl2;
     {
-        const int lx0 = wave * 16;  // column left of this wave's first column
+        const size_t o = row_off(ya - 1);
+        po0 = s0[o]; po1 = s1[o]; po2 = s2[o];
+        pl0 = __shfl_up(po0, 1); pl1 = __shfl_up(po1, 1); pl2 = __shfl_up(po2, 1);
+    }
+    unsigned long long mask = 0ull;
+#pragma unroll 1
+    for (int j0 = 0; j0 < 64; j0 += 4) {
+        float c0[4], c1[4], c2[4];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            pv[k][0] = s[k][(ly - 1) * kExStride + lx0];
-            pv[k][1] = s[k][ly * kExStride + lx0];
+        for (int u = 0; u < 4; ++u) {
+            const size_t o = row_off(ya + j0 + u);
+            c0[u] = s0[o];
+            c1[u] = s1[o];
+            c2[u] = s2[o];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float l0 = __shfl_up(c0[u], 1), l1 = __shfl_up(c1[u], 1), l2 = __shfl_up(c2[u], 1);
+            const float c = c1[u];
+            const bool any_gt = (pl0 > c) || (po0 > c) || (l0 > c) || (c0[u] > c) || (pl1 > c) || (po1 > c) ||
+                                (l1 > c) || (pl2 > c) || (po2 > c) || (l2 > c) || (c2[u] > c);
+            const bool any_lt = (pl0 < c) || (po0 < c) || (l0 < c) || (c0[u] < c) || (pl1 < c) || (po1 < c) ||
+                                (l1 < c) || (pl2 < c) || (po2 < c) || (l2 < c) || (c2[u] < c);
+            const int y = ya + j0 + u;
+            const bool cand = x_ok && y >= 1 && y <= h - 2 && (!any_gt || !any_lt);
+            mask |= (unsigned long long)(cand ? 1u : 0u) << (j0 + u);
+            po0 = c0[u]; po1 = c1[u]; po2 = c2[u];
+            pl0 = l0; pl1 = l1; pl2 = l2;
         }
     }
-#pragma unroll 4
-    for (int j = 0; j < 16; ++j) {
-        const int lx = wave * 16 + j + 1;
-        const int x = xa + lx - 1;
-        float cv[3][2];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            cv[k][0] = s[k][(ly - 1) * kExStride + lx];
-            cv[k][1] = s[k][ly * kExStride + lx];
-        }
-        const float c = cv[1][1];
-        bool any_gt = false, any_lt = false;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                any_gt = any_gt || (pv[k][r] > c) || (cv[k][r] > c);
-                any_lt = any_lt || (pv[k][r] < c) || (cv[k][r] < c);
-            }
-        }
-        const bool cand = y_ok && x >= 1 && x <= w - 2 && (!any_gt || !any_lt);
-        const unsigned long long m = __ballot(cand);
-        if (lane == 0 && x < w) {
-            const size_t wi = (size_t)img * (size_t)words_per_image + (size_t)word_base +
-                              (size_t)x * (size_t)nyb + (size_t)yb;
-            masks[wi] = m;
-            counts[wi] = __popcll(m);
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            pv[k][0] = cv[k][0];
-            pv[k][1] = cv[k][1];
-        }
+    // lane 0 of group 0 is column 0 (never a candidate, its word must still be written)
+    if ((lane >= 1 || grp == 0) && x < w) {
+        const size_t wi = (size_t)img * (size_t)words_per_image + (size_t)word_base + (size_t)x * (size_t)nyb +
+                          (size_t)yb;
+        masks[wi] = mask;
+        counts[wi] = __popcll(mask);
     }
 }
 
@@ -137,18 +125,17 @@ __global__ __launch_bounds__(1024) void extrema_scan_kernel(int* __restrict__ co
     if (tid == 1023) totals[img] = s_part[1023];
 }
 
-// Expansion: one wave per mask word, set bits -> Candidate records at offset + rank.
+// Expansion: one thread per mask word walks its set bits (y ascending) and writes the Candidate
+// records at the word's offset: consecutive threads write consecutive runs of the output.
 __global__ __launch_bounds__(256) void extrema_expand_kernel(const DevPlan* __restrict__ plan,
                                                              const unsigned long long* __restrict__ masks,
                                                              const int* __restrict__ offsets,
                                                              Candidate* __restrict__ cands) {
-    const int lane = threadIdx.x & 63;
     const int words = plan->words_per_image;
     const long long total_words = (long long)words * plan->n_images;
-    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
-    for (long long wi = wave0; wi < total_words; wi += nwaves) {
-        const unsigned long long m = masks[wi];
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long wi = (long long)blockIdx.x * blockDim.x + threadIdx.x; wi < total_words; wi += stride) {
+        unsigned long long m = masks[wi];
         if (m == 0ull) continue;
         const int img = (int)(wi / words);
         const int lw = (int)(wi - (long long)img * words);
@@ -159,14 +146,16 @@ __global__ __launch_bounds__(256) void extrema_expand_kernel(const DevPlan* __re
         const int rel = lw - plan->scan_word_base[sl];
         const int x = rel / nyb;
         const int yb = rel - x * nyb;
-        if ((m >> lane) & 1ull) {
-            const int rank = __popcll(m & ((1ull << lane) - 1ull));
-            Candidate c;
-            c.x = (uint16_t)x;
-            c.y = (uint16_t)(yb * 64 + lane);
-            c.octave = (uint16_t)plan->scan_octave[sl];
-            c.index = (uint16_t)plan->scan_dog[sl];
-            cands[(size_t)img * (size_t)plan->cand_capacity + (size_t)offsets[wi] + (size_t)rank] = c;
+        Candidate c;
+        c.x = (uint16_t)x;
+        c.octave = (uint16_t)plan->scan_octave[sl];
+        c.index = (uint16_t)plan->scan_dog[sl];
+        Candidate* out = cands + (size_t)img * (size_t)plan->cand_capacity + (size_t)offsets[wi];
+        while (m) {
+            const int bit = __ffsll((long long)m) - 1;
+            c.y = (uint16_t)(yb * 64 + bit);
+            *out++ = c;
+            m &= m - 1ull;
         }
     }
 }
@@ -263,10 +252,10 @@ void launch_extrema_mask(hipStream_t s, const DevPlan* d_plan, const DevPlan& pl
         const int o = plan.scan_octave[k], i = plan.scan_dog[k];
         const int w = plan.w[o], h = plan.h[o];
         const int l = o * plan.dogs + i;
-        const dim3 grid((unsigned)((w + kExTile - 1) / kExTile), (unsigned)plan.scan_nyb[k],
-                        (unsigned)plan.n_images);
+        const int ngroups = (w + kExCols - 1) / kExCols;  // lanes 1..63 of group g cover x = 63g+1 .. 63g+63
+        const dim3 grid((unsigned)((ngroups + 3) / 4), (unsigned)plan.scan_nyb[k], (unsigned)plan.n_images);
         hipLaunchKernelGGL(extrema_mask_kernel, grid, dim3(256), 0, s, (const float*)plan.dog[l - 1],
-                           (const float*)plan.dog[l], (const float*)plan.dog[l + 1], w, h, plan.scan_nyb[k],
+                           (const float*)plan.dog[l], (const float*)plan.dog[l + 1], w, h, plan.scan_nyb[k], ngroups,
                            plan.scan_word_base[k], plan.words_per_image, d_masks, d_counts);
     }
 }
@@ -279,8 +268,8 @@ void launch_extrema_scan(hipStream_t s, const DevPlan& plan, int* d_counts, int*
 void launch_extrema_expand(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan,
                            const unsigned long long* d_masks, const int* d_offsets, Candidate* d_cands) {
     const long long total_words = (long long)plan.words_per_image * plan.n_images;
-    long long blocks = (total_words + 3) / 4;  // 4 waves per block, one word per wave per trip
-    if (blocks > 8192) blocks = 8192;
+    long long blocks = (total_words + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(extrema_expand_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d_plan, d_masks,
                        d_offsets, d_cands);
