@@ -1,0 +1,123 @@
+// sift::Sift — drop-in for the reference's class (/root/reference/sift.hpp:17-78): same public
+// member `subpixel`, same constructor arguments and defaults, same `calculate(image&)` returning
+// std::vector<InterestPoint> by value, same side effect on the caller's image when subpixel
+// (sift.cpp:20-21), exceptions with Vigra's message text where the reference throws
+// vigra::PreconditionViolation.  Header-only host code above the C ABI of libsift_hip.so
+// (include/sift_hip.h); every stage runs in HIP kernels on the GPU.
+#ifndef SIFT_AMD_SIFT_HPP
+#define SIFT_AMD_SIFT_HPP
+#include <cassert>
+#include <cmath>
+#include <exception>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../sift_hip.h"
+#include "image2f.hpp"
+#include "interestpoint.hpp"
+#include "types.hpp"
+#ifdef SIFT_WITH_VIGRA
+#include <vigra/multi_array.hxx>
+#endif
+
+namespace sift {
+
+// vigra::PreconditionViolation analogue (also a std::exception); what() carries Vigra's text.
+class PreconditionViolation : public std::runtime_error {
+public:
+    explicit PreconditionViolation(const std::string& m) : std::runtime_error(m) {}
+};
+
+class Sift {
+public:
+    const bool subpixel;
+
+    explicit Sift(u16_t dogsPerEpoch = 3, u16_t octaves = 3, f32_t sigma = 1.6, f32_t k = std::sqrt(2),
+                  bool subpixel_ = false, int device = 0)
+        : subpixel(subpixel_), _sigma(sigma), _k(k), _dogsPerEpoch(dogsPerEpoch), _octaves(octaves) {
+        char err[512] = "";
+        if (sift_hip_create(device, &_ctx, err, sizeof(err)) != SIFT_HIP_OK)
+            throw std::runtime_error(std::string("sift_hip_create: ") + err);
+    }
+    Sift(const Sift&) = delete;
+    Sift& operator=(const Sift&) = delete;
+    ~Sift() { sift_hip_destroy(_ctx); }
+
+    std::vector<InterestPoint> calculate(Image2f& img) {
+        const int w = (int)img.width(), h = (int)img.height();
+        const int rc = run(img.data(), w, h);
+        if (subpixel) {  // the reference overwrites the caller's image before anything can throw
+            int nw = 0, nh = 0;
+            if (sift_hip_image_dims(_ctx, &nw, &nh) == SIFT_HIP_OK && (nw != w || nh != h)) {
+                Image2f up(nw, nh);
+                if (sift_hip_image_copy(_ctx, 0, up.data()) == SIFT_HIP_OK) img = up;
+            }
+        }
+        raise(rc);
+        return collect();
+    }
+
+#ifdef SIFT_WITH_VIGRA
+    std::vector<InterestPoint> calculate(vigra::MultiArray<2, f32_t>& img) {
+        const int w = (int)img.width(), h = (int)img.height();
+        const int rc = run(img.data(), w, h);
+        if (subpixel) {
+            int nw = 0, nh = 0;
+            if (sift_hip_image_dims(_ctx, &nw, &nh) == SIFT_HIP_OK && (nw != w || nh != h)) {
+                vigra::MultiArray<2, f32_t> up(vigra::Shape2(nw, nh));
+                if (sift_hip_image_copy(_ctx, 0, up.data()) == SIFT_HIP_OK) img = up;
+            }
+        }
+        raise(rc);
+        return collect();
+    }
+#endif
+
+private:
+    const f32_t _sigma, _k;
+    const u16_t _dogsPerEpoch, _octaves;
+    sift_hip_ctx* _ctx = nullptr;
+    char _err[512] = "";
+
+    int run(const float* data, int w, int h) {
+        sift_hip_params p{};
+        p.dogs_per_epoch = _dogsPerEpoch;
+        p.octaves = _octaves;
+        p.sigma = _sigma;
+        p.k = _k;
+        p.subpixel = subpixel ? 1 : 0;
+        return sift_hip_calculate_batch(_ctx, data, 1, w, h, &p, _err, sizeof(_err));
+    }
+    void raise(int rc) const {
+        if (rc == SIFT_HIP_OK) return;
+        if (rc == SIFT_HIP_EPRECONDITION) throw PreconditionViolation(_err);
+        if (rc == SIFT_HIP_EASSERT) {  // the reference assert()s (sift.cpp:382-383)
+            assert(!"sift::Sift: octaves > 0 && dogsPerEpoch >= 3");
+            throw std::logic_error(_err);
+        }
+        throw std::runtime_error(_err);
+    }
+    std::vector<InterestPoint> collect() {
+        const long long n = sift_hip_result_total(_ctx);
+        std::vector<sift_hip_keypoint> kp((size_t)(n > 0 ? n : 0));
+        std::vector<float> desc((size_t)(n > 0 ? n : 0) * 128);
+        if (n > 0 && sift_hip_result_copy(_ctx, kp.data(), desc.data()) != SIFT_HIP_OK)
+            throw std::runtime_error("sift_hip_result_copy failed");
+        std::vector<InterestPoint> out((size_t)(n > 0 ? n : 0));
+        for (size_t i = 0; i < out.size(); ++i) {
+            InterestPoint& p = out[i];
+            p.scale = kp[i].scale;
+            p.octave = kp[i].octave;
+            p.index = kp[i].index;
+            p.filtered = kp[i].filtered != 0;
+            p.loc = Point<u16_t, u16_t>(kp[i].x, kp[i].y);
+            p.orientation = kp[i].orientation;
+            if (kp[i].has_descriptor) p.descriptors.assign(desc.begin() + (std::ptrdiff_t)i * 128, desc.begin() + (std::ptrdiff_t)(i + 1) * 128);
+        }
+        return out;
+    }
+};
+
+}  // namespace sift
+#endif

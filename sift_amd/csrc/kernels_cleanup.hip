@@ -204,22 +204,20 @@ __device__ void introsort_binary(CleanupShared& sh, int n, uint8_t* __restrict__
         __syncthreads();
     }
     __syncthreads();
-    // evolve the all-kept ranges; everything else stays where it is
+    // Only kept elements are ever read back.  Outside the all-kept ranges they stay where the loop
+    // left them; inside, each one moves to its closed-form final position.
+    for (int i = tid; i < n; i += kCT)
+        if (K[i] == 0) I2[i] = I[i];
+    __syncthreads();
     const int npure = sh.npure;
-    for (int i = tid; i < n; i += kCT) {
-        int dest = i;
-        for (int r = 0; r < npure; ++r) {
-            const PureRange pr = sh.pure[r];
-            if (i >= pr.f && i < pr.f + pr.m) {
-                dest = pure_final_pos(i, pr.f, pr.m, pr.d);
-                break;
-            }
+    for (int r = 0; r < npure; ++r) {
+        const PureRange pr = sh.pure[r];
+        if (pr.m <= 16) continue;  // already final
+        for (int j = tid; j < pr.m; j += kCT) {
+            const int dest = pure_final_pos(pr.f + j, pr.f, pr.m, pr.d);
+            if (dest < 0) sh.fallback = 1;
+            else I2[dest] = I[pr.f + j];
         }
-        if (dest < 0) {
-            sh.fallback = 1;
-            dest = i;
-        }
-        I2[dest] = I[i];
     }
     __syncthreads();
 }

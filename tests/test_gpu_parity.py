@@ -349,3 +349,29 @@ def test_pipeline_parity_host_glue_path(ctx, report_dir):
         compare_run(ctx, synth_frame(333, 257, 9), 3, 3, False, "host-glue path 333x257", report_dir)
     finally:
         ctx.set_option("gpu_cleanup", 1)
+
+
+def test_cpp_dropin_example(ctx, tmp_path):
+    """examples/sift_points.cpp (the C++ sift::Sift drop-in over the C ABI) on the parrot fixture."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "sift_points"
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "sift_points.cpp"), "-L" + os.path.join(root, "sift_amd", "lib"),
+                           "-lsift_hip", "-Wl,-rpath," + os.path.join(root, "sift_amd", "lib"), "-o", str(exe)])
+    out = subprocess.run([str(exe), os.path.join(root, "tests", "golden", "parrot_r.pgm"), "4", "3", "0"],
+                         cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    g = np.load(os.path.join(root, "tests", "golden", "case_parrot.npz"))
+    lines = open(tmp_path / "interstpoints.txt").read().splitlines()
+    assert lines[0] == "Location\tscale\torientation\tdescriptors"
+    assert len(lines) - 1 == int(g["counts"][-1])
+    first = lines[1].split("\t")
+    assert first[0] == f"[{int(g['kp_x'][0])}, {int(g['kp_y'][0])}]"
+    # exception text reaches the caller like vigra's would: 160x120 cannot carry 4 octaves
+    from sift_amd.synthetic import synth_frame
+    small = synth_frame(160, 120, 1).astype(np.uint8)
+    with open(tmp_path / "small.pgm", "wb") as f:
+        f.write(b"P5\n160 120\n255\n" + small.tobytes())
+    out = subprocess.run([str(exe), "small.pgm", "4", "3", "0"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert "kernel longer than line" in out.stderr
