@@ -53,13 +53,18 @@ __global__ __launch_bounds__(256) void gradient_kernel(const float* __restrict__
 }
 
 // Two phases per workgroup of 128 keypoints:
-//  1. histogram: one WAVE per keypoint (each wave walks 32 keypoints).  The 16x16 window of
-//     orientation / magnitude / Gaussian is fetched with row-coalesced loads, the 256
-//     (bin, magnitude*gauss) pairs are staged in LDS in the reference's summation order (x outer,
-//     y inner) and lane b < 36 accumulates bin b sequentially in that order.
+//  1. histogram.  Each wave takes 32 keypoints, 8 at a time: the 16x16 windows of orientation /
+//     magnitude / Gaussian are fetched with row-coalesced loads and the 256 (bin, magnitude*gauss)
+//     pairs of each keypoint are staged in LDS in the reference's summation order (x outer, y inner);
+//     then LANE k runs keypoint k's ordered sum, so 8 dependent chains advance side by side.  All
+//     256 samples of a keypoint normally share one bin (the reference feeds radians where degrees
+//     were meant), which makes the sum a single register chain; a keypoint with mixed bins takes
+//     the general path (ordered read-modify-write of its 36 bins).
 //  2. peaks: one THREAD per keypoint runs the serial Sift::_findPeaks / vertexParabola logic on its
 //     histogram column in LDS, so 128 dependent chains run side by side instead of one per wave.
 constexpr int kOrientGroup = 128;
+constexpr int kOrientSub = 8;       // keypoints staged per wave at a time
+constexpr int kOrientStride = 260;  // floats (and bytes) between staged keypoints: conflict-free
 
 __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restrict__ plan,
                                                           const Candidate* __restrict__ cands,
@@ -67,11 +72,13 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
                                                           const int* __restrict__ list_cnt, int list_cap,
                                                           OrientOut* __restrict__ out,
                                                           float* __restrict__ peaks_out) {
-    __shared__ __attribute__((aligned(16))) float s_prod[4][256];
-    __shared__ __attribute__((aligned(16))) unsigned char s_bin[4][256];
+    // staging (phase 1) and the peak sets (phase 2) are never live together: they share storage
+    __shared__ __attribute__((aligned(16))) float s_stage[4 * kOrientSub * kOrientStride];
+    __shared__ __attribute__((aligned(16))) unsigned char s_sbin[4 * kOrientSub * kOrientStride];
     __shared__ float s_hist[36][kOrientGroup];
-    __shared__ float s_set[36][kOrientGroup];
     __shared__ unsigned char s_state[kOrientGroup];  // bit0 border-filtered, bits 1-2 throw code, bit7 run
+    static_assert(sizeof(float) * 4 * kOrientSub * kOrientStride >= sizeof(float) * 36 * kOrientGroup, "s_set overlay");
+    float (*s_set)[kOrientGroup] = reinterpret_cast<float (*)[kOrientGroup]>(s_stage);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -81,111 +88,97 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
     const int D = plan->dogs;
     const size_t cbase = (size_t)img * (size_t)plan->cand_capacity;
     const size_t lbase = (size_t)img * (size_t)list_cap;
+    float* __restrict__ wprod = s_stage + wv * kOrientSub * kOrientStride;
+    unsigned char* __restrict__ wbin = s_sbin + wv * kOrientSub * kOrientStride;
     // the survivor count lives on the device: a fixed grid strides over the groups of keypoints
     for (int grp = blockIdx.x; grp * kOrientGroup < cnt; grp += gridDim.x) {
         // ---- phase 1 --------------------------------------------------------------------------
-        // Window samples of keypoint j+1 are fetched into registers while keypoint j is accumulated.
-        struct Win {
-            float pm[4], po[4], pg[4];
-            bool valid, run;
-            unsigned char state;
-        };
-        auto fetch = [&](int j) {
-            Win wn;
-            wn.valid = false;
-            wn.run = false;
-            wn.state = 0;
-#pragma unroll
-            for (int it = 0; it < 4; ++it) wn.pm[it] = wn.po[it] = wn.pg[it] = 0.0f;
-            const int kp = grp * kOrientGroup + wv * (kOrientGroup / 4) + j;
-            if (j >= kOrientGroup / 4 || kp >= cnt) return wn;  // wave-uniform
-            wn.valid = true;
-            const Candidate cd = cands[cbase + list[lbase + kp]];
-            const int x = cd.x, y = cd.y;
-            const int l = cd.octave * D + cd.index;
-            const int lvl = plan->nearest_level[l];
-            const int no = lvl / (D + 1);
-            const int w = plan->w[no], h = plan->h[no];
-            const bool border = (x < kRegion || x >= w - kRegion) || (y < kRegion || y >= h - kRegion);  // sift.cpp:173-174
-            const int throws = border ? 0 : plan->dead_blur_radius[l];  // sift.cpp:184 (0 ok, else error code)
-            wn.run = !border && throws == 0;
-            wn.state = (unsigned char)((border ? 1 : 0) | (throws << 1) | (wn.run ? 0x80 : 0));
-            if (wn.run) {
+        for (int sb = 0; sb < kOrientGroup / 4 / kOrientSub; ++sb) {
+            const int slot0 = wv * (kOrientGroup / 4) + sb * kOrientSub;
+            if (grp * kOrientGroup + slot0 >= cnt) break;  // wave-uniform
+            unsigned runmask = 0, unimask = 0;             // wave-uniform bit per staged keypoint
+#pragma unroll 2
+            for (int k = 0; k < kOrientSub; ++k) {
+                const int slot = slot0 + k;
+                const int kp = grp * kOrientGroup + slot;
+                if (kp >= cnt) break;  // wave-uniform
+                const Candidate cd = cands[cbase + list[lbase + kp]];
+                const int x = cd.x, y = cd.y;
+                const int l = cd.octave * D + cd.index;
+                const int lvl = plan->nearest_level[l];
+                const int no = lvl / (D + 1);
+                const int w = plan->w[no], h = plan->h[no];
+                const bool border = (x < kRegion || x >= w - kRegion) || (y < kRegion || y >= h - kRegion);  // sift.cpp:173-174
+                const int throws = border ? 0 : plan->dead_blur_radius[l];  // sift.cpp:184 (0 ok, else error code)
+                const bool run = !border && throws == 0;
+                if (lane == 0) s_state[slot] = (unsigned char)((border ? 1 : 0) | (throws << 1) | (run ? 0x80 : 0));
+                if (!run) continue;
+                runmask |= 1u << k;
                 const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
                 const float* __restrict__ gm = plan->mag[lvl] + img_off;
                 const float* __restrict__ go = plan->ori[lvl] + img_off;
                 const float* __restrict__ gg = plan->gauss[lvl] + img_off;
                 const int x0 = x - kRegion, y0 = y - kRegion;
+                unsigned first_bin = 0;
+                bool same = true;
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int ly = it * 4 + (lane >> 4);
                     const int lx = lane & 15;
                     const size_t o = (size_t)(y0 + ly) * (size_t)w + (size_t)(x0 + lx);
-                    wn.pm[it] = gm[o];
-                    wn.po[it] = go[o];
-                    wn.pg[it] = gg[o];
-                }
-            }
-            return wn;
-        };
-        Win cur = fetch(0);
-        for (int j = 0; j < kOrientGroup / 4; ++j) {
-            if (!cur.valid) break;  // wave-uniform
-            const Win nxt = fetch(j + 1);
-            const int slot = wv * (kOrientGroup / 4) + j;
-            if (lane == 0) s_state[slot] = cur.state;
-            if (cur.run) {
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int ly = it * 4 + (lane >> 4);
-                    const int lx = lane & 15;
-                    const float sum = cur.pm[it] * cur.pg[it];
-                    unsigned i = f32_to_u16_x86(__builtin_floorf(cur.po[it] / 10.0f));
+                    const float sum = gm[o] * gg[o];
+                    unsigned i = f32_to_u16_x86(__builtin_floorf(go[o] / 10.0f));
                     i = i % 35u;
-                    s_prod[wv][lx * 16 + ly] = sum;
-                    s_bin[wv][lx * 16 + ly] = (unsigned char)i;
+                    wprod[k * kOrientStride + lx * 16 + ly] = sum;
+                    wbin[k * kOrientStride + lx * 16 + ly] = (unsigned char)i;
+                    if (it == 0) first_bin = __shfl(i, 0);
+                    same = same && (i == first_bin);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                // all 256 samples in one bin (always the case for the reference's radians-as-degrees
-                // orientations): one serial chain, 4 samples per LDS read, instead of 36 masked ones
-                const unsigned b0 = s_bin[wv][0];
-                const unsigned w4 = reinterpret_cast<const unsigned*>(s_bin[wv])[lane];
-                const bool uniform = __all(w4 == b0 * 0x01010101u);
-                if (uniform) {
-                    float acc = 0.0f;
-                    const float4* __restrict__ pv = reinterpret_cast<const float4*>(s_prod[wv]);
-#pragma unroll 8
-                    for (int q = 0; q < 64; ++q) {
-                        const float4 v = pv[q];
-                        acc += v.x;
-                        acc += v.y;
-                        acc += v.z;
-                        acc += v.w;
-                    }
-                    if (lane < 36) s_hist[lane][slot] = ((unsigned)lane == b0) ? acc : 0.0f;
-                } else if (lane < 36) {
-                    float acc = 0.0f;
-                    const float4* __restrict__ pv = reinterpret_cast<const float4*>(s_prod[wv]);
-                    const unsigned* __restrict__ pb = reinterpret_cast<const unsigned*>(s_bin[wv]);
-                    const unsigned me = (unsigned)lane;
-#pragma unroll 4
-                    for (int q = 0; q < 64; ++q) {  // 4 samples per LDS read, still strictly in sample order
-                        const float4 v = pv[q];
-                        const unsigned b = pb[q];
-                        acc = ((b & 0xffu) == me) ? acc + v.x : acc;
-                        acc = (((b >> 8) & 0xffu) == me) ? acc + v.y : acc;
-                        acc = (((b >> 16) & 0xffu) == me) ? acc + v.z : acc;
-                        acc = ((b >> 24) == me) ? acc + v.w : acc;
-                    }
-                    s_hist[lane][slot] = acc;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (__all(same)) unimask |= 1u << k;
             }
-            cur = nxt;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // lane k: ordered sum of keypoint k (x outer, y inner == staging order)
+            float acc = 0.0f;
+            unsigned b0 = 0;
+            if (lane < kOrientSub && ((runmask & unimask) >> lane) & 1u) {
+                const float4* __restrict__ pv = reinterpret_cast<const float4*>(wprod + lane * kOrientStride);
+                b0 = wbin[lane * kOrientStride];
+#pragma unroll 8
+                for (int q = 0; q < 64; ++q) {
+                    const float4 v = pv[q];
+                    acc += v.x;
+                    acc += v.y;
+                    acc += v.z;
+                    acc += v.w;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kOrientSub; ++k) {
+                if (!((runmask >> k) & 1u)) continue;  // wave-uniform
+                const int slot = slot0 + k;
+                if ((unimask >> k) & 1u) {
+                    const float a = __shfl(acc, k);
+                    const unsigned b = __shfl(b0, k);
+                    if (lane < 36) s_hist[lane][slot] = ((unsigned)lane == b) ? a : 0.0f;
+                } else {
+                    // mixed bins: bins[i] += sum sample by sample, in order (one lane, LDS resident)
+                    if (lane < 36) s_hist[lane][slot] = 0.0f;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (lane == 0) {
+                        for (int q = 0; q < 256; ++q) {
+                            const unsigned b = wbin[k * kOrientStride + q];
+                            s_hist[b][slot] = s_hist[b][slot] + wprod[k * kOrientStride + q];
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         __syncthreads();
         // ---- phase 2 --------------------------------------------------------------------------
