@@ -97,37 +97,55 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
             const int slot0 = wv * (kOrientGroup / 4) + sb * kOrientSub;
             if (grp * kOrientGroup + slot0 >= cnt) break;  // wave-uniform
             unsigned runmask = 0, unimask = 0;             // wave-uniform bit per staged keypoint
-#pragma unroll 2
+            // all window loads of the 8 keypoints are issued before any of them is consumed
+            float pm[kOrientSub][4], po[kOrientSub][4], pg[kOrientSub][4];
+#pragma unroll
             for (int k = 0; k < kOrientSub; ++k) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) pm[k][it] = po[k][it] = pg[k][it] = 0.0f;
                 const int slot = slot0 + k;
                 const int kp = grp * kOrientGroup + slot;
-                if (kp >= cnt) break;  // wave-uniform
-                const Candidate cd = cands[cbase + list[lbase + kp]];
-                const int x = cd.x, y = cd.y;
-                const int l = cd.octave * D + cd.index;
-                const int lvl = plan->nearest_level[l];
-                const int no = lvl / (D + 1);
-                const int w = plan->w[no], h = plan->h[no];
-                const bool border = (x < kRegion || x >= w - kRegion) || (y < kRegion || y >= h - kRegion);  // sift.cpp:173-174
-                const int throws = border ? 0 : plan->dead_blur_radius[l];  // sift.cpp:184 (0 ok, else error code)
-                const bool run = !border && throws == 0;
-                if (lane == 0) s_state[slot] = (unsigned char)((border ? 1 : 0) | (throws << 1) | (run ? 0x80 : 0));
-                if (!run) continue;
-                runmask |= 1u << k;
-                const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
-                const float* __restrict__ gm = plan->mag[lvl] + img_off;
-                const float* __restrict__ go = plan->ori[lvl] + img_off;
-                const float* __restrict__ gg = plan->gauss[lvl] + img_off;
-                const int x0 = x - kRegion, y0 = y - kRegion;
+                if (kp < cnt) {  // wave-uniform
+                    const Candidate cd = cands[cbase + list[lbase + kp]];
+                    const int x = cd.x, y = cd.y;
+                    const int l = cd.octave * D + cd.index;
+                    const int lvl = plan->nearest_level[l];
+                    const int no = lvl / (D + 1);
+                    const int w = plan->w[no], h = plan->h[no];
+                    const bool border = (x < kRegion || x >= w - kRegion) || (y < kRegion || y >= h - kRegion);  // sift.cpp:173-174
+                    const int throws = border ? 0 : plan->dead_blur_radius[l];  // sift.cpp:184 (0 ok, else error code)
+                    const bool run = !border && throws == 0;
+                    if (lane == 0) s_state[slot] = (unsigned char)((border ? 1 : 0) | (throws << 1) | (run ? 0x80 : 0));
+                    if (run) {
+                        runmask |= 1u << k;
+                        const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
+                        const float* __restrict__ gm = plan->mag[lvl] + img_off;
+                        const float* __restrict__ go = plan->ori[lvl] + img_off;
+                        const float* __restrict__ gg = plan->gauss[lvl] + img_off;
+                        const int x0 = x - kRegion, y0 = y - kRegion;
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            const int ly = it * 4 + (lane >> 4);
+                            const int lx = lane & 15;
+                            const size_t o = (size_t)(y0 + ly) * (size_t)w + (size_t)(x0 + lx);
+                            pm[k][it] = gm[o];
+                            po[k][it] = go[o];
+                            pg[k][it] = gg[o];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kOrientSub; ++k) {
+                if (!((runmask >> k) & 1u)) continue;  // wave-uniform
                 unsigned first_bin = 0;
                 bool same = true;
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int ly = it * 4 + (lane >> 4);
                     const int lx = lane & 15;
-                    const size_t o = (size_t)(y0 + ly) * (size_t)w + (size_t)(x0 + lx);
-                    const float sum = gm[o] * gg[o];
-                    unsigned i = f32_to_u16_x86(__builtin_floorf(go[o] / 10.0f));
+                    const float sum = pm[k][it] * pg[k][it];
+                    unsigned i = f32_to_u16_x86(__builtin_floorf(po[k][it] / 10.0f));
                     i = i % 35u;
                     wprod[k * kOrientStride + lx * 16 + ly] = sum;
                     wbin[k * kOrientStride + lx * 16 + ly] = (unsigned char)i;

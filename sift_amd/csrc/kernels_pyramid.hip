@@ -44,7 +44,7 @@ __device__ __forceinline__ int reflect_clamp(int p, int n) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int R, bool DOG>
-__global__ __launch_bounds__(256, (R <= 12 ? 3 : (R <= 24 ? 2 : 1))) void blur_fused_kernel(const float* __restrict__ in,
+__global__ __launch_bounds__(256, (R <= 8 ? 3 : (R <= 24 ? 2 : 1))) void blur_fused_kernel(const float* __restrict__ in,
                                                          float* __restrict__ out,
                                                          float* __restrict__ dog, int w, int h,
                                                          int tiles_x, int tiles_y, int total_tiles,
