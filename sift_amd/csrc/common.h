@@ -31,6 +31,8 @@ struct DevPlan {
     float* dog[kMaxLevels];          // [o * D + j]
     float* mag[kMaxLevels];          // gradient maps, null unless the level is selected
     float* ori[kMaxLevels];
+    float* prod[kMaxLevels];         // magnitude * gaussian of the initial maps (orientationHistogram36 weight)
+    uint8_t* obin[kMaxLevels];       // (u16)floor(ori/10) % 35 of the initial orientation map
     float* w16[kMaxLevels];          // n x 256: top-left 16x16 of convolveWithGauss(level, 1.6)
     float gauss_scale[kMaxLevels];
     float dog_scale[kMaxLevels];
@@ -98,13 +100,15 @@ void launch_edge_filter_points(hipStream_t s, const float* d0, const float* d1, 
                                const uint16_t* xs, const uint16_t* ys, int m, uint8_t* flags);
 void launch_vertex_parabola(hipStream_t s, const uint16_t* lnx, const float* lny, const uint16_t* px,
                             const float* py, const uint16_t* rnx, const float* rny, int m, float* out);
-void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, int w, int h, int n);
+void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, float* prod, uint8_t* obin, int w, int h,
+                     int n);
 void launch_orientation(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const Candidate* d_cands,
-                        const uint32_t* d_list, const int* d_list_cnt, int list_cap, OrientOut* d_out,
-                        float* d_peaks);
+                        const uint32_t* d_list, const uint32_t* d_order, const int* d_list_cnt, int list_cap,
+                        OrientOut* d_out, float* d_peaks);
+void launch_iota(hipStream_t s, uint32_t* d, int per_image, int n_images);
 void launch_cleanup1(hipStream_t s, int n_images, const uint8_t* d_flags, const int* d_totals, long long cand_cap,
-                     uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, uint32_t* d_list, int list_cap,
-                     int* d_list_cnt, int* d_fallback);
+                     uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, uint32_t* d_list, uint32_t* d_order,
+                     int list_cap, int* d_list_cnt, int* d_fallback);
 void launch_cleanup2(hipStream_t s, int n_images, const Candidate* d_cands, long long cand_cap,
                      const uint32_t* d_list, const int* d_list_cnt, int list_cap, const OrientOut* d_orient,
                      uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, FinalKp* d_final, int* d_final_cnt,

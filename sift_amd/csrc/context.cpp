@@ -112,6 +112,7 @@ struct sift_hip_ctx {
     DevBuf arena, d_plan, d_taps, d_luts, d_taps16, d_input, d_base, d_tmp, d_tmp2;
     DevBuf d_masks, d_counts, d_totals, d_cands, d_flags;
     DevBuf d_wk, d_wi, d_wi2, d_wp, d_status, d_tile, d_pool;
+    DevBuf d_order;
     DevBuf d_list, d_list_cnt, d_orient, d_peaks, d_final, d_final_cnt, d_out_base, d_kp, d_desc;
     HostBuf h_flags, h_orient, h_peaks;
     // results of the last batch
@@ -341,7 +342,7 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
 
     // ---- device memory ----------------------------------------------------------------------------
     size_t total = 0;
-    std::vector<size_t> goff((size_t)O * (D + 1)), doff((size_t)O * D), moff(P.grad_levels.size()), ooff(P.grad_levels.size()), woff(P.grad_levels.size());
+    std::vector<size_t> goff((size_t)O * (D + 1)), doff((size_t)O * D), moff(P.grad_levels.size()), ooff(P.grad_levels.size()), woff(P.grad_levels.size()), poff(P.grad_levels.size()), boff(P.grad_levels.size());
     P.max_level_floats = (size_t)std::max(w * (size_t)h, (size_t)P.bw * (size_t)P.bh);
     auto carve = [&](size_t floats) { const size_t o = total; total = align_up(total + floats * sizeof(float), 256); return o; };
     for (int o = 0; o < O; ++o) {
@@ -355,6 +356,8 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
         moff[g] = carve(px);
         ooff[g] = carve(px);
         woff[g] = carve((size_t)256 * (size_t)n);
+        poff[g] = carve(px);
+        boff[g] = carve((px + 3) / 4);
     }
     c->arena.ensure(total);
     char* base = c->arena.as<char>();
@@ -364,6 +367,8 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
         dv.mag[P.grad_levels[g]] = reinterpret_cast<float*>(base + moff[g]);
         dv.ori[P.grad_levels[g]] = reinterpret_cast<float*>(base + ooff[g]);
         dv.w16[P.grad_levels[g]] = reinterpret_cast<float*>(base + woff[g]);
+        dv.prod[P.grad_levels[g]] = reinterpret_cast<float*>(base + poff[g]);
+        dv.obin[P.grad_levels[g]] = reinterpret_cast<uint8_t*>(base + boff[g]);
     }
     const size_t lvl_bytes = P.max_level_floats * (size_t)n * sizeof(float);
     c->d_tmp.ensure(lvl_bytes);
@@ -387,6 +392,7 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
     c->d_flags.ensure((size_t)dv.cand_capacity * (size_t)n);
     c->d_list.ensure((size_t)kListCap * (size_t)n * sizeof(uint32_t));
     c->d_list_cnt.ensure((size_t)n * sizeof(int));
+    c->d_order.ensure((size_t)kListCap * (size_t)n * sizeof(uint32_t));
     c->d_orient.ensure((size_t)kListCap * (size_t)n * sizeof(OrientOut));
     c->d_peaks.ensure((size_t)kListCap * (size_t)n * 36 * sizeof(float));
     c->d_final.ensure((size_t)kListCap * (size_t)n * sizeof(FinalKp));
@@ -517,8 +523,9 @@ void mid_host(sift_hip_ctx* c) {
     }
     SIFT_HIP_CHECK(hipMemcpyAsync(c->d_list_cnt.p, cnt1.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
     SIFT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
-    launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
-                       kListCap, c->d_orient.as<OrientOut>(), c->d_peaks.as<float>());
+    launch_iota(s, c->d_order.as<uint32_t>(), kListCap, n);
+    launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_list.as<uint32_t>(), c->d_order.as<uint32_t>(),
+                       c->d_list_cnt.as<int>(), kListCap, c->d_orient.as<OrientOut>(), c->d_peaks.as<float>());
     c->h_orient.ensure((size_t)n * kListCap * sizeof(OrientOut));
     for (int i = 0; i < n; ++i)
         if (cnt1[(size_t)i])
@@ -588,10 +595,10 @@ bool mid_gpu(sift_hip_ctx* c) {
     int* d_fb1 = c->d_status.as<int>() + (size_t)n * 4;
     launch_cleanup1(s, n, c->d_flags.as<uint8_t>(), c->d_totals.as<int>(), dv.cand_capacity, c->d_wk.as<uint8_t>(),
                     c->d_wi.as<uint32_t>(), c->d_wi2.as<uint32_t>(), c->d_wp.as<uint32_t>(), c->d_list.as<uint32_t>(),
-                    kListCap, c->d_list_cnt.as<int>(), d_fb1);
+                    c->d_order.as<uint32_t>(), kListCap, c->d_list_cnt.as<int>(), d_fb1);
     SIFT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
-    launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
-                       kListCap, c->d_orient.as<OrientOut>(), c->d_peaks.as<float>());
+    launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_list.as<uint32_t>(), c->d_order.as<uint32_t>(),
+                       c->d_list_cnt.as<int>(), kListCap, c->d_orient.as<OrientOut>(), c->d_peaks.as<float>());
     launch_cleanup2(s, n, c->d_cands.as<Candidate>(), dv.cand_capacity, c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
                     kListCap, c->d_orient.as<OrientOut>(), c->d_wk.as<uint8_t>(), c->d_wi.as<uint32_t>(),
                     c->d_wi2.as<uint32_t>(), c->d_wp.as<uint32_t>(), c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(),
@@ -699,7 +706,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     SIFT_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     for (int lvl : P.grad_levels) {
         const int o = lvl / (D + 1);
-        launch_gradient(c->stream2, dv.gauss[lvl], dv.mag[lvl], dv.ori[lvl], dv.w[o], dv.h[o], n);
+        launch_gradient(c->stream2, dv.gauss[lvl], dv.mag[lvl], dv.ori[lvl], dv.prod[lvl], dv.obin[lvl], dv.w[o], dv.h[o], n);
         launch_w16(c->stream2, dv, lvl, c->d_taps16.as<float>(), P.radius16);
     }
     SIFT_HIP_CHECK(hipEventRecord(c->ev_join, c->stream2));
@@ -793,7 +800,7 @@ void sift_hip_destroy(sift_hip_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->arena, &c->d_plan, &c->d_taps, &c->d_luts, &c->d_taps16, &c->d_input, &c->d_base, &c->d_tmp, &c->d_tmp2,
-                      &c->d_wk, &c->d_wi, &c->d_wi2, &c->d_wp, &c->d_status, &c->d_tile, &c->d_pool, &c->d_masks, &c->d_counts, &c->d_totals, &c->d_cands, &c->d_flags, &c->d_list, &c->d_list_cnt, &c->d_orient,
+                      &c->d_wk, &c->d_wi, &c->d_wi2, &c->d_wp, &c->d_status, &c->d_tile, &c->d_pool, &c->d_order, &c->d_masks, &c->d_counts, &c->d_totals, &c->d_cands, &c->d_flags, &c->d_list, &c->d_list_cnt, &c->d_orient,
                       &c->d_peaks, &c->d_final, &c->d_final_cnt, &c->d_out_base, &c->d_kp, &c->d_desc})
         b->release();
     for (HostBuf* b : {&c->h_flags, &c->h_orient, &c->h_peaks}) b->release();
@@ -1102,7 +1109,9 @@ int sift_hip_gradient(sift_hip_ctx* c, const float* in, int w, int h, float* mag
         float* a = s.upload(in, px);
         float* m = s.dev<float>(px);
         float* o = s.dev<float>(px);
-        launch_gradient(c->stream, a, m, o, w, h, 1);
+        float* pr = s.dev<float>(px);
+        uint8_t* ob = s.dev<uint8_t>(px);
+        launch_gradient(c->stream, a, m, o, pr, ob, w, h, 1);
         SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
         SIFT_HIP_CHECK(hipMemcpy(mag, m, px * sizeof(float), hipMemcpyDeviceToHost));
         SIFT_HIP_CHECK(hipMemcpy(ori, o, px * sizeof(float), hipMemcpyDeviceToHost));

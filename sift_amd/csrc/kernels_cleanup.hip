@@ -226,7 +226,7 @@ __device__ void introsort_binary(CleanupShared& sh, int n, uint8_t* __restrict__
 // `emit(rank, payload)` is called for rank < size.
 template <class Emit>
 __device__ int compact_kept(CleanupShared& sh, int n, const uint8_t* __restrict__ K,
-                            const uint32_t* __restrict__ I2, Emit emit) {
+                            const uint32_t* __restrict__ I2, Emit emit, int* total_out = nullptr) {
     const int tid = threadIdx.x;
     // total first (needed for the u16 truncation)
     int cnt = 0;
@@ -238,6 +238,7 @@ __device__ int compact_kept(CleanupShared& sh, int n, const uint8_t* __restrict_
     __syncthreads();
     const int total = sh.T;
     const int size = total & 0xffff;  // u16_t size (sift.cpp:41,53)
+    if (total_out) *total_out = total;
     __syncthreads();
     int running = 0, par = 0;
     for (int base = 0; base < n && running < size; base += kCT) {
@@ -258,7 +259,8 @@ __global__ __launch_bounds__(kCT) void cleanup1_kernel(const uint8_t* __restrict
                                                        const int* __restrict__ totals, long long cand_cap,
                                                        uint8_t* __restrict__ wk, uint32_t* __restrict__ wi,
                                                        uint32_t* __restrict__ wi2, uint32_t* __restrict__ wp,
-                                                       uint32_t* __restrict__ list, int list_cap,
+                                                       uint32_t* __restrict__ list,
+                                                       uint32_t* __restrict__ order, int list_cap,
                                                        int* __restrict__ list_cnt, int* __restrict__ fallback) {
     __shared__ CleanupShared sh;
     const int img = blockIdx.x;
@@ -276,11 +278,36 @@ __global__ __launch_bounds__(kCT) void cleanup1_kernel(const uint8_t* __restrict
     __syncthreads();
     introsort_binary(sh, n, K, I, I2, P);
     uint32_t* out = list + (size_t)img * (size_t)list_cap;
-    const int size = compact_kept(sh, n, K, I2, [&](int r, uint32_t id) { out[r] = id; });
+    uint32_t* ord = order + (size_t)img * (size_t)list_cap;
+    int total = 0;
+    // I is free from here on: it records each survivor's list position by candidate index
+    const int size = compact_kept(sh, n, K, I2, [&](int r, uint32_t id) { out[r] = id; I[id] = (uint32_t)r; }, &total);
+    __syncthreads();
+    // Processing order for the (order-independent) orientation stage: ascending candidate index,
+    // i.e. the scan's spatial order, so that consecutive keypoints share most of their window.
+    if (total == size) {
+        int running = 0, par = 0;
+        for (int base = 0; base < n; base += kCT) {
+            const int pos = base + (int)threadIdx.x;
+            const bool hit = pos < n && fl[pos] == 0;
+            int tile_total;
+            const int r = running + tile_rank(sh, par, hit, tile_total);
+            if (hit) ord[r] = I[pos];
+            running += tile_total;
+            par ^= 1;
+        }
+    } else {  // u16 truncation dropped survivors: keep list order
+        for (int r = threadIdx.x; r < size; r += kCT) ord[r] = (uint32_t)r;
+    }
     if (threadIdx.x == 0) {
         list_cnt[img] = size;
         fallback[img] = sh.fallback;
     }
+}
+
+__global__ void iota_kernel(uint32_t* __restrict__ d, int per_image) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < per_image) d[(size_t)blockIdx.y * (size_t)per_image + i] = (uint32_t)i;
 }
 
 // ---- cleanup 2: after orientation assignment -> FinalKp list ---------------------------------------
@@ -363,10 +390,15 @@ __global__ __launch_bounds__(kCT) void cleanup_kat_kernel(const uint8_t* __restr
 }
 
 void launch_cleanup1(hipStream_t s, int n_images, const uint8_t* d_flags, const int* d_totals, long long cand_cap,
-                     uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, uint32_t* d_list, int list_cap,
-                     int* d_list_cnt, int* d_fallback) {
+                     uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, uint32_t* d_list, uint32_t* d_order,
+                     int list_cap, int* d_list_cnt, int* d_fallback) {
     hipLaunchKernelGGL(cleanup1_kernel, dim3((unsigned)n_images), dim3(kCT), 0, s, d_flags, d_totals, cand_cap, wk,
-                       wi, wi2, wp, d_list, list_cap, d_list_cnt, d_fallback);
+                       wi, wi2, wp, d_list, d_order, list_cap, d_list_cnt, d_fallback);
+}
+
+void launch_iota(hipStream_t s, uint32_t* d, int per_image, int n_images) {
+    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((per_image + 255) / 256), (unsigned)n_images), dim3(256), 0, s, d,
+                       per_image);
 }
 
 void launch_cleanup2(hipStream_t s, int n_images, const Candidate* d_cands, long long cand_cap,

@@ -30,7 +30,8 @@ __device__ __forceinline__ unsigned f32_to_u16_x86(float v) {
 
 // sift.cpp:130-160: interior pixels only, border stays 0.
 __global__ __launch_bounds__(256) void gradient_kernel(const float* __restrict__ g, float* __restrict__ mag,
-                                                       float* __restrict__ ori, int w, int h) {
+                                                       float* __restrict__ ori, float* __restrict__ prod,
+                                                       uint8_t* __restrict__ obin, int w, int h) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= w) return;
@@ -50,6 +51,10 @@ __global__ __launch_bounds__(256) void gradient_kernel(const float* __restrict__
     }
     mag[o] = m;
     ori[o] = a;
+    // per-pixel inputs of alg::orientationHistogram36 (algorithms.cpp:126-128), which reads the
+    // INITIAL maps: weight = magnitude * gaussian, bin = (u16)floor(orientation / 10) % 35
+    prod[o] = m * g[o];
+    obin[o] = (uint8_t)(f32_to_u16_x86(__builtin_floorf(a / 10.0f)) % 35u);
 }
 
 // Two phases per workgroup of 128 keypoints:
@@ -69,6 +74,7 @@ constexpr int kOrientStride = 260;  // floats (and bytes) between staged keypoin
 __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restrict__ plan,
                                                           const Candidate* __restrict__ cands,
                                                           const uint32_t* __restrict__ list,
+                                                          const uint32_t* __restrict__ order,
                                                           const int* __restrict__ list_cnt, int list_cap,
                                                           OrientOut* __restrict__ out,
                                                           float* __restrict__ peaks_out) {
@@ -76,6 +82,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
     __shared__ __attribute__((aligned(16))) float s_stage[4 * kOrientSub * kOrientStride];
     __shared__ __attribute__((aligned(16))) unsigned char s_sbin[4 * kOrientSub * kOrientStride];
     __shared__ float s_hist[36][kOrientGroup];
+    __shared__ unsigned short s_kp[kOrientGroup];    // survivor-list position of each slot
     __shared__ unsigned char s_state[kOrientGroup];  // bit0 border-filtered, bits 1-2 throw code, bit7 run
     static_assert(sizeof(float) * 4 * kOrientSub * kOrientStride >= sizeof(float) * 36 * kOrientGroup, "s_set overlay");
     float (*s_set)[kOrientGroup] = reinterpret_cast<float (*)[kOrientGroup]>(s_stage);
@@ -98,14 +105,17 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
             if (grp * kOrientGroup + slot0 >= cnt) break;  // wave-uniform
             unsigned runmask = 0, unimask = 0;             // wave-uniform bit per staged keypoint
             // all window loads of the 8 keypoints are issued before any of them is consumed
-            float pm[kOrientSub][4], po[kOrientSub][4], pg[kOrientSub][4];
+            float pp[kOrientSub][4];
+            unsigned pb[kOrientSub][4];
 #pragma unroll
             for (int k = 0; k < kOrientSub; ++k) {
 #pragma unroll
-                for (int it = 0; it < 4; ++it) pm[k][it] = po[k][it] = pg[k][it] = 0.0f;
+                for (int it = 0; it < 4; ++it) { pp[k][it] = 0.0f; pb[k][it] = 0u; }
                 const int slot = slot0 + k;
-                const int kp = grp * kOrientGroup + slot;
-                if (kp < cnt) {  // wave-uniform
+                const int j = grp * kOrientGroup + slot;   // processing position (spatial order)
+                if (j < cnt) {  // wave-uniform
+                    const int kp = (int)order[lbase + j];  // position in the survivor list
+                    if (lane == 0) s_kp[slot] = (unsigned short)kp;
                     const Candidate cd = cands[cbase + list[lbase + kp]];
                     const int x = cd.x, y = cd.y;
                     const int l = cd.octave * D + cd.index;
@@ -119,18 +129,16 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
                     if (run) {
                         runmask |= 1u << k;
                         const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
-                        const float* __restrict__ gm = plan->mag[lvl] + img_off;
-                        const float* __restrict__ go = plan->ori[lvl] + img_off;
-                        const float* __restrict__ gg = plan->gauss[lvl] + img_off;
+                        const float* __restrict__ gp = plan->prod[lvl] + img_off;
+                        const uint8_t* __restrict__ gb = plan->obin[lvl] + img_off;
                         const int x0 = x - kRegion, y0 = y - kRegion;
 #pragma unroll
                         for (int it = 0; it < 4; ++it) {
                             const int ly = it * 4 + (lane >> 4);
                             const int lx = lane & 15;
                             const size_t o = (size_t)(y0 + ly) * (size_t)w + (size_t)(x0 + lx);
-                            pm[k][it] = gm[o];
-                            po[k][it] = go[o];
-                            pg[k][it] = gg[o];
+                            pp[k][it] = gp[o];
+                            pb[k][it] = gb[o];
                         }
                     }
                 }
@@ -144,9 +152,8 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
                 for (int it = 0; it < 4; ++it) {
                     const int ly = it * 4 + (lane >> 4);
                     const int lx = lane & 15;
-                    const float sum = pm[k][it] * pg[k][it];
-                    unsigned i = f32_to_u16_x86(__builtin_floorf(po[k][it] / 10.0f));
-                    i = i % 35u;
+                    const float sum = pp[k][it];
+                    const unsigned i = pb[k][it];
                     wprod[k * kOrientStride + lx * 16 + ly] = sum;
                     wbin[k * kOrientStride + lx * 16 + ly] = (unsigned char)i;
                     if (it == 0) first_bin = __shfl(i, 0);
@@ -200,8 +207,8 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
         }
         __syncthreads();
         // ---- phase 2 --------------------------------------------------------------------------
-        const int kp = grp * kOrientGroup + tid;
-        if (tid < kOrientGroup && kp < cnt) {
+        if (tid < kOrientGroup && grp * kOrientGroup + tid < cnt) {
+            const int kp = (int)s_kp[tid];
             const unsigned st = s_state[tid];
             OrientOut r;
             r.orientation = 0.0f;
@@ -279,17 +286,18 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
     }
 }
 
-void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, int w, int h, int n) {
+void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, float* prod, uint8_t* obin, int w, int h,
+                     int n) {
     const dim3 grid((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)n);
-    hipLaunchKernelGGL(gradient_kernel, grid, dim3(256), 0, s, g, mag, ori, w, h);
+    hipLaunchKernelGGL(gradient_kernel, grid, dim3(256), 0, s, g, mag, ori, prod, obin, w, h);
 }
 
 void launch_orientation(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const Candidate* d_cands,
-                        const uint32_t* d_list, const int* d_list_cnt, int list_cap, OrientOut* d_out,
-                        float* d_peaks) {
+                        const uint32_t* d_list, const uint32_t* d_order, const int* d_list_cnt, int list_cap,
+                        OrientOut* d_out, float* d_peaks) {
     const dim3 grid(128, (unsigned)plan.n_images);
-    hipLaunchKernelGGL(orientation_kernel, grid, dim3(256), 0, s, d_plan, d_cands, d_list, d_list_cnt, list_cap,
-                       d_out, d_peaks);
+    hipLaunchKernelGGL(orientation_kernel, grid, dim3(256), 0, s, d_plan, d_cands, d_list, d_order, d_list_cnt,
+                       list_cap, d_out, d_peaks);
 }
 
 }  // namespace sift_hip
