@@ -75,6 +75,15 @@ struct OrientOut {           // per keypoint entering _orientationAssignment
 };
 static_assert(sizeof(OrientOut) == 8, "OrientOut packing");
 
+// One keypoint of the orientation stage, in processing (spatial) order
+struct OrientIn {
+    uint16_t x, y;
+    uint16_t octave, index;
+    uint32_t kp;             // position in the survivor list (where the result goes)
+    uint32_t pad;
+};
+static_assert(sizeof(OrientIn) == 16, "OrientIn packing");
+
 struct FinalKp {             // one entry per keypoint entering _createDecriptors, vector order
     uint32_t cand;
     float orientation;
@@ -103,12 +112,14 @@ void launch_vertex_parabola(hipStream_t s, const uint16_t* lnx, const float* lny
 void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, float* prod, uint8_t* obin, int w, int h,
                      int n);
 void launch_orientation(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const Candidate* d_cands,
-                        const uint32_t* d_list, const uint32_t* d_order, const int* d_list_cnt, int list_cap,
-                        OrientOut* d_out, float* d_peaks);
-void launch_iota(hipStream_t s, uint32_t* d, int per_image, int n_images);
+                        const OrientIn* d_oin, const int* d_list_cnt, int list_cap, OrientOut* d_out,
+                        float* d_peaks);
+// host-glue path: orientation inputs in list order from an uploaded survivor list
+void launch_build_orient_in(hipStream_t s, const Candidate* d_cands, long long cand_cap, const uint32_t* d_list,
+                            const int* d_list_cnt, int list_cap, int n_images, OrientIn* d_oin);
 void launch_cleanup1(hipStream_t s, int n_images, const uint8_t* d_flags, const int* d_totals, long long cand_cap,
-                     uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, uint32_t* d_list, uint32_t* d_order,
-                     int list_cap, int* d_list_cnt, int* d_fallback);
+                     uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, uint32_t* d_list, OrientIn* d_oin,
+                     const Candidate* d_cands, int list_cap, int* d_list_cnt, int* d_fallback);
 void launch_cleanup2(hipStream_t s, int n_images, const Candidate* d_cands, long long cand_cap,
                      const uint32_t* d_list, const int* d_list_cnt, int list_cap, const OrientOut* d_orient,
                      uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, FinalKp* d_final, int* d_final_cnt,

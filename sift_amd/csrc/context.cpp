@@ -392,7 +392,7 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
     c->d_flags.ensure((size_t)dv.cand_capacity * (size_t)n);
     c->d_list.ensure((size_t)kListCap * (size_t)n * sizeof(uint32_t));
     c->d_list_cnt.ensure((size_t)n * sizeof(int));
-    c->d_order.ensure((size_t)kListCap * (size_t)n * sizeof(uint32_t));
+    c->d_order.ensure((size_t)kListCap * (size_t)n * sizeof(OrientIn));
     c->d_orient.ensure((size_t)kListCap * (size_t)n * sizeof(OrientOut));
     c->d_peaks.ensure((size_t)kListCap * (size_t)n * 36 * sizeof(float));
     c->d_final.ensure((size_t)kListCap * (size_t)n * sizeof(FinalKp));
@@ -523,9 +523,10 @@ void mid_host(sift_hip_ctx* c) {
     }
     SIFT_HIP_CHECK(hipMemcpyAsync(c->d_list_cnt.p, cnt1.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s));
     SIFT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
-    launch_iota(s, c->d_order.as<uint32_t>(), kListCap, n);
-    launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_list.as<uint32_t>(), c->d_order.as<uint32_t>(),
-                       c->d_list_cnt.as<int>(), kListCap, c->d_orient.as<OrientOut>(), c->d_peaks.as<float>());
+    launch_build_orient_in(s, c->d_cands.as<Candidate>(), dv.cand_capacity, c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
+                           kListCap, n, c->d_order.as<OrientIn>());
+    launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_order.as<OrientIn>(), c->d_list_cnt.as<int>(), kListCap,
+                       c->d_orient.as<OrientOut>(), c->d_peaks.as<float>());
     c->h_orient.ensure((size_t)n * kListCap * sizeof(OrientOut));
     for (int i = 0; i < n; ++i)
         if (cnt1[(size_t)i])
@@ -595,10 +596,10 @@ bool mid_gpu(sift_hip_ctx* c) {
     int* d_fb1 = c->d_status.as<int>() + (size_t)n * 4;
     launch_cleanup1(s, n, c->d_flags.as<uint8_t>(), c->d_totals.as<int>(), dv.cand_capacity, c->d_wk.as<uint8_t>(),
                     c->d_wi.as<uint32_t>(), c->d_wi2.as<uint32_t>(), c->d_wp.as<uint32_t>(), c->d_list.as<uint32_t>(),
-                    c->d_order.as<uint32_t>(), kListCap, c->d_list_cnt.as<int>(), d_fb1);
+                    c->d_order.as<OrientIn>(), c->d_cands.as<Candidate>(), kListCap, c->d_list_cnt.as<int>(), d_fb1);
     SIFT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
-    launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_list.as<uint32_t>(), c->d_order.as<uint32_t>(),
-                       c->d_list_cnt.as<int>(), kListCap, c->d_orient.as<OrientOut>(), c->d_peaks.as<float>());
+    launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_order.as<OrientIn>(), c->d_list_cnt.as<int>(), kListCap,
+                       c->d_orient.as<OrientOut>(), c->d_peaks.as<float>());
     launch_cleanup2(s, n, c->d_cands.as<Candidate>(), dv.cand_capacity, c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
                     kListCap, c->d_orient.as<OrientOut>(), c->d_wk.as<uint8_t>(), c->d_wi.as<uint32_t>(),
                     c->d_wi2.as<uint32_t>(), c->d_wp.as<uint32_t>(), c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(),

@@ -260,7 +260,8 @@ __global__ __launch_bounds__(kCT) void cleanup1_kernel(const uint8_t* __restrict
                                                        uint8_t* __restrict__ wk, uint32_t* __restrict__ wi,
                                                        uint32_t* __restrict__ wi2, uint32_t* __restrict__ wp,
                                                        uint32_t* __restrict__ list,
-                                                       uint32_t* __restrict__ order, int list_cap,
+                                                       OrientIn* __restrict__ oin,
+                                                       const Candidate* __restrict__ cands, int list_cap,
                                                        int* __restrict__ list_cnt, int* __restrict__ fallback) {
     __shared__ CleanupShared sh;
     const int img = blockIdx.x;
@@ -278,7 +279,14 @@ __global__ __launch_bounds__(kCT) void cleanup1_kernel(const uint8_t* __restrict
     __syncthreads();
     introsort_binary(sh, n, K, I, I2, P);
     uint32_t* out = list + (size_t)img * (size_t)list_cap;
-    uint32_t* ord = order + (size_t)img * (size_t)list_cap;
+    OrientIn* ord = oin + (size_t)img * (size_t)list_cap;
+    const Candidate* cd = cands + off;
+    auto make_in = [&](uint32_t cand, uint32_t kp) {
+        const Candidate c = cd[cand];
+        OrientIn o;
+        o.x = c.x; o.y = c.y; o.octave = c.octave; o.index = c.index; o.kp = kp; o.pad = 0;
+        return o;
+    };
     int total = 0;
     // I is free from here on: it records each survivor's list position by candidate index
     const int size = compact_kept(sh, n, K, I2, [&](int r, uint32_t id) { out[r] = id; I[id] = (uint32_t)r; }, &total);
@@ -292,12 +300,12 @@ __global__ __launch_bounds__(kCT) void cleanup1_kernel(const uint8_t* __restrict
             const bool hit = pos < n && fl[pos] == 0;
             int tile_total;
             const int r = running + tile_rank(sh, par, hit, tile_total);
-            if (hit) ord[r] = I[pos];
+            if (hit) ord[r] = make_in((uint32_t)pos, I[pos]);
             running += tile_total;
             par ^= 1;
         }
     } else {  // u16 truncation dropped survivors: keep list order
-        for (int r = threadIdx.x; r < size; r += kCT) ord[r] = (uint32_t)r;
+        for (int r = threadIdx.x; r < size; r += kCT) ord[r] = make_in(out[r], (uint32_t)r);
     }
     if (threadIdx.x == 0) {
         list_cnt[img] = size;
@@ -305,9 +313,16 @@ __global__ __launch_bounds__(kCT) void cleanup1_kernel(const uint8_t* __restrict
     }
 }
 
-__global__ void iota_kernel(uint32_t* __restrict__ d, int per_image) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < per_image) d[(size_t)blockIdx.y * (size_t)per_image + i] = (uint32_t)i;
+__global__ void build_orient_in_kernel(const Candidate* __restrict__ cands, long long cand_cap,
+                                       const uint32_t* __restrict__ list, const int* __restrict__ list_cnt,
+                                       int list_cap, OrientIn* __restrict__ oin) {
+    const int img = blockIdx.y;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= list_cnt[img]) return;
+    const Candidate c = cands[(size_t)img * (size_t)cand_cap + list[(size_t)img * (size_t)list_cap + r]];
+    OrientIn o;
+    o.x = c.x; o.y = c.y; o.octave = c.octave; o.index = c.index; o.kp = (uint32_t)r; o.pad = 0;
+    oin[(size_t)img * (size_t)list_cap + r] = o;
 }
 
 // ---- cleanup 2: after orientation assignment -> FinalKp list ---------------------------------------
@@ -390,15 +405,16 @@ __global__ __launch_bounds__(kCT) void cleanup_kat_kernel(const uint8_t* __restr
 }
 
 void launch_cleanup1(hipStream_t s, int n_images, const uint8_t* d_flags, const int* d_totals, long long cand_cap,
-                     uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, uint32_t* d_list, uint32_t* d_order,
-                     int list_cap, int* d_list_cnt, int* d_fallback) {
+                     uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, uint32_t* d_list, OrientIn* d_oin,
+                     const Candidate* d_cands, int list_cap, int* d_list_cnt, int* d_fallback) {
     hipLaunchKernelGGL(cleanup1_kernel, dim3((unsigned)n_images), dim3(kCT), 0, s, d_flags, d_totals, cand_cap, wk,
-                       wi, wi2, wp, d_list, d_order, list_cap, d_list_cnt, d_fallback);
+                       wi, wi2, wp, d_list, d_oin, d_cands, list_cap, d_list_cnt, d_fallback);
 }
 
-void launch_iota(hipStream_t s, uint32_t* d, int per_image, int n_images) {
-    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((per_image + 255) / 256), (unsigned)n_images), dim3(256), 0, s, d,
-                       per_image);
+void launch_build_orient_in(hipStream_t s, const Candidate* d_cands, long long cand_cap, const uint32_t* d_list,
+                            const int* d_list_cnt, int list_cap, int n_images, OrientIn* d_oin) {
+    hipLaunchKernelGGL(build_orient_in_kernel, dim3((unsigned)((list_cap + 255) / 256), (unsigned)n_images), dim3(256), 0,
+                       s, d_cands, cand_cap, d_list, d_list_cnt, list_cap, d_oin);
 }
 
 void launch_cleanup2(hipStream_t s, int n_images, const Candidate* d_cands, long long cand_cap,

@@ -72,9 +72,7 @@ constexpr int kOrientSub = 8;       // keypoints staged per wave at a time
 constexpr int kOrientStride = 260;  // floats (and bytes) between staged keypoints: conflict-free
 
 __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restrict__ plan,
-                                                          const Candidate* __restrict__ cands,
-                                                          const uint32_t* __restrict__ list,
-                                                          const uint32_t* __restrict__ order,
+                                                          const OrientIn* __restrict__ oin,
                                                           const int* __restrict__ list_cnt, int list_cap,
                                                           OrientOut* __restrict__ out,
                                                           float* __restrict__ peaks_out) {
@@ -93,7 +91,6 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
     const int img = blockIdx.y;
     const int cnt = list_cnt[img];
     const int D = plan->dogs;
-    const size_t cbase = (size_t)img * (size_t)plan->cand_capacity;
     const size_t lbase = (size_t)img * (size_t)list_cap;
     float* __restrict__ wprod = s_stage + wv * kOrientSub * kOrientStride;
     unsigned char* __restrict__ wbin = s_sbin + wv * kOrientSub * kOrientStride;
@@ -107,6 +104,15 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
             // all window loads of the 8 keypoints are issued before any of them is consumed
             float pp[kOrientSub][4];
             unsigned pb[kOrientSub][4];
+            // one coalesced fetch brings the 8 keypoint records; fields are then wave-uniform
+            // scalars (readfirstlane) so the plan lookups become scalar loads
+            OrientIn rec;
+            rec.x = rec.y = rec.octave = rec.index = 0;
+            rec.kp = 0;
+            {
+                const int j = grp * kOrientGroup + slot0 + (lane & (kOrientSub - 1));
+                if (j < cnt) rec = oin[lbase + j];
+            }
 #pragma unroll
             for (int k = 0; k < kOrientSub; ++k) {
 #pragma unroll
@@ -114,11 +120,12 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
                 const int slot = slot0 + k;
                 const int j = grp * kOrientGroup + slot;   // processing position (spatial order)
                 if (j < cnt) {  // wave-uniform
-                    const int kp = (int)order[lbase + j];  // position in the survivor list
+                    const unsigned xy = __builtin_amdgcn_readfirstlane(__shfl((unsigned)rec.x | ((unsigned)rec.y << 16), k));
+                    const unsigned oi = __builtin_amdgcn_readfirstlane(__shfl((unsigned)rec.octave | ((unsigned)rec.index << 16), k));
+                    const int kp = (int)__builtin_amdgcn_readfirstlane(__shfl(rec.kp, k));  // survivor-list position
                     if (lane == 0) s_kp[slot] = (unsigned short)kp;
-                    const Candidate cd = cands[cbase + list[lbase + kp]];
-                    const int x = cd.x, y = cd.y;
-                    const int l = cd.octave * D + cd.index;
+                    const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+                    const int l = (int)(oi & 0xffffu) * D + (int)(oi >> 16);
                     const int lvl = plan->nearest_level[l];
                     const int no = lvl / (D + 1);
                     const int w = plan->w[no], h = plan->h[no];
@@ -293,11 +300,12 @@ void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, floa
 }
 
 void launch_orientation(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const Candidate* d_cands,
-                        const uint32_t* d_list, const uint32_t* d_order, const int* d_list_cnt, int list_cap,
-                        OrientOut* d_out, float* d_peaks) {
+                        const OrientIn* d_oin, const int* d_list_cnt, int list_cap, OrientOut* d_out,
+                        float* d_peaks) {
+    (void)d_cands;
     const dim3 grid(128, (unsigned)plan.n_images);
-    hipLaunchKernelGGL(orientation_kernel, grid, dim3(256), 0, s, d_plan, d_cands, d_list, d_order, d_list_cnt,
-                       list_cap, d_out, d_peaks);
+    hipLaunchKernelGGL(orientation_kernel, grid, dim3(256), 0, s, d_plan, d_oin, d_list_cnt, list_cap, d_out,
+                       d_peaks);
 }
 
 }  // namespace sift_hip
