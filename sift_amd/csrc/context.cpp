@@ -399,7 +399,7 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
     c->d_final_cnt.ensure((size_t)n * sizeof(int));
     c->d_out_base.ensure((size_t)n * sizeof(long long));
     c->d_tile.ensure((size_t)dv.desc_tiles_per_image * (size_t)n * 3 * sizeof(int));
-    c->d_pool.ensure((size_t)kPoolCap * (size_t)n * sizeof(uint16_t));
+    c->d_pool.ensure((size_t)kPoolCap * (size_t)n * sizeof(FinalKp));
     SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
     P.valid = true;
     return SIFT_HIP_OK;
@@ -734,10 +734,10 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
         int* t_off = t_cnt + nt;
         int* t_cur = t_off + nt;
         launch_desc_binning(s, dpl, dv, c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(), kListCap, t_cnt, t_off, t_cur,
-                            c->d_pool.as<uint16_t>(), kPoolCap);
+                            c->d_pool.as<FinalKp>(), kPoolCap);
         for (int lvl : P.grad_levels)
             launch_descriptors(s, dpl, dv, lvl, c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(), kListCap, t_cnt, t_off,
-                               c->d_pool.as<uint16_t>(), kPoolCap, c->d_out_base.as<long long>(),
+                               c->d_pool.as<FinalKp>(), kPoolCap, c->d_out_base.as<long long>(),
                                c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->desc_dbg);
     }
     SIFT_HIP_CHECK(hipStreamSynchronize(s));

@@ -30,7 +30,7 @@ struct PureRange {
 };
 
 struct CleanupShared {
-    int wc[2][16];
+    int wc[2][4][16];
     int flag;        // first failing position (min) of the current round
     int T;
     int f, l, d, p;
@@ -41,22 +41,33 @@ struct CleanupShared {
 
 __device__ __forceinline__ int floor_log2(int n) { return 31 - __clz(n); }
 
-// Rank of this thread's element among the `hit` elements of the current 1024-element tile, plus
-// the tile's total.  Uses the double-buffered per-wave counters sh.wc[par].
-__device__ __forceinline__ int tile_rank(CleanupShared& sh, int par, bool hit, int& tile_total) {
+// Ranks of this thread's four elements (one in each of four consecutive 1024-element chunks, so the
+// four loads that produced `hit` are coalesced and in flight together) among the hits of the
+// current 4096-element tile, plus the tile's total.  Double-buffered per-wave counters sh.wc[par].
+__device__ __forceinline__ void tile_rank4(CleanupShared& sh, int par, const bool (&hit)[4], int (&rank)[4],
+                                           int& tile_total) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const unsigned long long m = __ballot(hit);
-    if (lane == 0) sh.wc[par][wv] = __popcll(m);
-    __syncthreads();
-    int before = 0, total = 0;
+    unsigned long long m[4];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int c = sh.wc[par][q];
-        before += (q < wv) ? c : 0;
-        total += c;
+    for (int u = 0; u < 4; ++u) {
+        m[u] = __ballot(hit[u]);
+        if (lane == 0) sh.wc[par][u][wv] = __popcll(m[u]);
     }
-    tile_total = total;
-    return before + __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();
+    int run = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        int before = 0, total = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int c = sh.wc[par][u][q];
+            before += (q < wv) ? c : 0;
+            total += c;
+        }
+        rank[u] = run + before + __popcll(m[u] & ((1ull << lane) - 1ull));
+        run += total;
+    }
+    tile_total = run;
 }
 
 // Closed-form evolution of one element of an all-kept range [f, f+m) with depth budget d.
@@ -135,17 +146,26 @@ __device__ void introsort_binary(CleanupShared& sh, int n, uint8_t* __restrict__
         int par = 0;
         if (p == 1) {
             // t-th filtered element from the left goes to L-1-t while it lies left of it
-            for (int base = F; base < L; base += kCT) {
-                const int pos = base + tid;
-                const bool hit = pos < L && K[pos] == 1;
+            for (int base = F; base < L; base += 4 * kCT) {
+                bool hit[4];
+                int pos[4], rk[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    pos[u] = base + u * kCT + tid;
+                    hit[u] = pos[u] < L && K[pos[u]] == 1;
+                }
                 int tile_total;
-                const int t = running + tile_rank(sh, par, hit, tile_total);
-                if (hit) {
-                    if (pos < L - 1 - t) {
-                        P[t] = (uint32_t)pos;
-                    } else {  // participants are a prefix of the hits: the smallest failing rank is T
-                        atomicMin(&sh.T, t);
-                        atomicMin(&sh.flag, pos);
+                tile_rank4(sh, par, hit, rk, tile_total);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (hit[u]) {
+                        const int t = running + rk[u];
+                        if (pos[u] < L - 1 - t) {
+                            P[t] = (uint32_t)pos[u];
+                        } else {  // participants are a prefix of the hits: the smallest failing rank is T
+                            atomicMin(&sh.T, t);
+                            atomicMin(&sh.flag, pos[u]);
+                        }
                     }
                 }
                 running += tile_total;
@@ -155,14 +175,23 @@ __device__ void introsort_binary(CleanupShared& sh, int n, uint8_t* __restrict__
             }
         } else {
             // t-th kept element from the right goes to F+t while it lies right of it
-            for (int base = L - 1; base >= F; base -= kCT) {
-                const int pos = base - tid;
-                const bool hit = pos >= F && K[pos] == 0;
+            for (int base = L - 1; base >= F; base -= 4 * kCT) {
+                bool hit[4];
+                int pos[4], rk[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    pos[u] = base - u * kCT - tid;
+                    hit[u] = pos[u] >= F && K[pos[u]] == 0;
+                }
                 int tile_total;
-                const int t = running + tile_rank(sh, par, hit, tile_total);
-                if (hit) {
-                    if (F + t < pos) P[t] = (uint32_t)pos;
-                    else atomicMin(&sh.T, t);
+                tile_rank4(sh, par, hit, rk, tile_total);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (hit[u]) {
+                        const int t = running + rk[u];
+                        if (F + t < pos[u]) P[t] = (uint32_t)pos[u];
+                        else atomicMin(&sh.T, t);
+                    }
                 }
                 running += tile_total;
                 par ^= 1;
@@ -206,6 +235,7 @@ __device__ void introsort_binary(CleanupShared& sh, int n, uint8_t* __restrict__
     __syncthreads();
     // Only kept elements are ever read back.  Outside the all-kept ranges they stay where the loop
     // left them; inside, each one moves to its closed-form final position.
+#pragma unroll 4
     for (int i = tid; i < n; i += kCT)
         if (K[i] == 0) I2[i] = I[i];
     __syncthreads();
@@ -230,6 +260,7 @@ __device__ int compact_kept(CleanupShared& sh, int n, const uint8_t* __restrict_
     const int tid = threadIdx.x;
     // total first (needed for the u16 truncation)
     int cnt = 0;
+#pragma unroll 4
     for (int i = tid; i < n; i += kCT) cnt += K[i] == 0;
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
     if (tid == 0) sh.T = 0;
@@ -241,12 +272,19 @@ __device__ int compact_kept(CleanupShared& sh, int n, const uint8_t* __restrict_
     if (total_out) *total_out = total;
     __syncthreads();
     int running = 0, par = 0;
-    for (int base = 0; base < n && running < size; base += kCT) {
-        const int pos = base + tid;
-        const bool hit = pos < n && K[pos] == 0;
+    for (int base = 0; base < n && running < size; base += 4 * kCT) {
+        bool hit[4];
+        int pos[4], rk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            pos[u] = base + u * kCT + tid;
+            hit[u] = pos[u] < n && K[pos[u]] == 0;
+        }
         int tile_total;
-        const int r = running + tile_rank(sh, par, hit, tile_total);
-        if (hit && r < size) emit(r, I2[pos]);
+        tile_rank4(sh, par, hit, rk, tile_total);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (hit[u] && running + rk[u] < size) emit(running + rk[u], I2[pos[u]]);
         running += tile_total;
         par ^= 1;
     }
@@ -272,6 +310,7 @@ __global__ __launch_bounds__(kCT) void cleanup1_kernel(const uint8_t* __restrict
     uint32_t* I2 = wi2 + off;
     uint32_t* P = wp + off;
     const uint8_t* fl = flags + off;
+#pragma unroll 4
     for (int i = threadIdx.x; i < n; i += kCT) {
         K[i] = fl[i] ? 1 : 0;
         I[i] = (uint32_t)i;
@@ -295,12 +334,19 @@ __global__ __launch_bounds__(kCT) void cleanup1_kernel(const uint8_t* __restrict
     // i.e. the scan's spatial order, so that consecutive keypoints share most of their window.
     if (total == size) {
         int running = 0, par = 0;
-        for (int base = 0; base < n; base += kCT) {
-            const int pos = base + (int)threadIdx.x;
-            const bool hit = pos < n && fl[pos] == 0;
+        for (int base = 0; base < n; base += 4 * kCT) {
+            bool hit[4];
+            int pos[4], rk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                pos[u] = base + u * kCT + (int)threadIdx.x;
+                hit[u] = pos[u] < n && fl[pos[u]] == 0;
+            }
             int tile_total;
-            const int r = running + tile_rank(sh, par, hit, tile_total);
-            if (hit) ord[r] = make_in((uint32_t)pos, I[pos]);
+            tile_rank4(sh, par, hit, rk, tile_total);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (hit[u]) ord[running + rk[u]] = make_in((uint32_t)pos[u], I[pos[u]]);
             running += tile_total;
             par ^= 1;
         }

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void w16_kernel(const float* __restrict__ leve
 
 constexpr int kCore = kDescCore;
 constexpr int kExt = kCore + 2 * kRegion;  // 64
-constexpr int kTileListCap = 768;         // per-tile list held (and sorted) in LDS
+constexpr int kTileListCap = 512;         // per-tile list held (and sorted) in LDS
 
 // ---- binning: which keypoints touch which extended tile ------------------------------------------
 // A 16x16 window touches the extended regions of at most 2x2 tiles.  Counts, an exclusive scan per
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void desc_bin_kernel(const DevPlan* __restrict
                                                        const FinalKp* __restrict__ finals,
                                                        const int* __restrict__ final_cnt, int final_cap,
                                                        int* __restrict__ tile_cnt, const int* __restrict__ tile_off,
-                                                       int* __restrict__ tile_cur, uint16_t* __restrict__ pool,
+                                                       int* __restrict__ tile_cur, FinalKp* __restrict__ pool,
                                                        int pool_cap) {
     const int img = blockIdx.y;
     const int K = final_cnt[img];
@@ -106,7 +106,9 @@ __global__ __launch_bounds__(256) void desc_bin_kernel(const DevPlan* __restrict
                     atomicAdd(&tile_cnt[t], 1);
                 } else {
                     const int p = atomicAdd(&tile_cur[t], 1);
-                    pool[(size_t)img * (size_t)pool_cap + (size_t)tile_off[t] + (size_t)p] = (uint16_t)k;
+                    FinalKp rec = f;
+                    rec.cand = (uint32_t)k;  // the tile kernel sorts by this; the candidate id is not needed there
+                    pool[(size_t)img * (size_t)pool_cap + (size_t)tile_off[t] + (size_t)p] = rec;
                 }
             }
     }
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
                                                          const int* __restrict__ final_cnt, int final_cap,
                                                          const int* __restrict__ tile_cnt,
                                                          const int* __restrict__ tile_off,
-                                                         const uint16_t* __restrict__ pool, int pool_cap,
+                                                         const FinalKp* __restrict__ pool, int pool_cap,
                                                          const long long* __restrict__ out_base,
                                                          sift_hip_keypoint* __restrict__ kp_out,
                                                          float* __restrict__ desc_out, int dbg) {
@@ -161,12 +163,11 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
     __shared__ __attribute__((aligned(16))) float s_mag[kExt * kExt];
     __shared__ __attribute__((aligned(16))) float s_gau[kExt * kExt];
     __shared__ float s_w16[256];
-    __shared__ unsigned short s_raw[kTileListCap];
     __shared__ unsigned short s_list[kTileListCap];   // vector index k of each list entry, ascending
     __shared__ FinalKp s_fin[kTileListCap];
     // histogram inputs of a batch, laid out [sample-in-cell q][cell][keypoint m]: the phase-B reader
     // (thread = (m, cell), q marching) then touches 128 consecutive words per read
-    __shared__ float s_val[16 * 16 * kDescBatch];
+    __shared__ __attribute__((aligned(16))) float s_val[16 * 16 * kDescBatch];
     __shared__ unsigned char s_bin[16 * 16 * kDescBatch];
     __shared__ int s_wcnt[4];
     __shared__ int s_n;
@@ -360,17 +361,21 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
         }
     };
 
+    // the unsorted records are staged in the (not yet used) histogram staging area
+    static_assert(sizeof(FinalKp) * kTileListCap <= sizeof(float) * 16 * 16 * kDescBatch, "s_raw overlay");
+    FinalKp* s_raw = reinterpret_cast<FinalKp*>(s_val);
     if (n_tile <= kTileListCap) {
         // fetch the tile's list and rank-sort it by vector index (indices are unique)
-        const uint16_t* __restrict__ src = pool + (size_t)img * (size_t)pool_cap + (size_t)tile_off[tile];
+        const FinalKp* __restrict__ src = pool + (size_t)img * (size_t)pool_cap + (size_t)tile_off[tile];
         for (int i = tid; i < n_tile; i += 256) s_raw[i] = src[i];
         __syncthreads();
         for (int i = tid; i < n_tile; i += 256) {
-            const unsigned short v = s_raw[i];
+            const FinalKp rec = s_raw[i];
+            const uint32_t v = rec.cand;
             int r = 0;
-            for (int j = 0; j < n_tile; ++j) r += s_raw[j] < v;
-            s_list[r] = v;
-            s_fin[r] = with_flags(fin[v]);
+            for (int j = 0; j < n_tile; ++j) r += s_raw[j].cand < v;
+            s_list[r] = (unsigned short)v;
+            s_fin[r] = with_flags(rec);
         }
         __syncthreads();
         if (!(dbg & 8)) run_segment(n_tile);
@@ -426,7 +431,7 @@ void launch_w16(hipStream_t s, const DevPlan& plan, int level, const float* d_ta
 
 void launch_desc_binning(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const FinalKp* d_final,
                          const int* d_final_cnt, int final_cap, int* d_tile_cnt, int* d_tile_off,
-                         int* d_tile_cur, uint16_t* d_pool, int pool_cap) {
+                         int* d_tile_cur, FinalKp* d_pool, int pool_cap) {
     const size_t nt = (size_t)plan.desc_tiles_per_image * (size_t)plan.n_images;
     (void)hipMemsetAsync(d_tile_cnt, 0, nt * sizeof(int), s);
     (void)hipMemsetAsync(d_tile_cur, 0, nt * sizeof(int), s);
@@ -441,7 +446,7 @@ void launch_desc_binning(hipStream_t s, const DevPlan* d_plan, const DevPlan& pl
 
 void launch_descriptors(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level,
                         const FinalKp* d_final, const int* d_final_cnt, int final_cap,
-                        const int* d_tile_cnt, const int* d_tile_off, const uint16_t* d_pool, int pool_cap,
+                        const int* d_tile_cnt, const int* d_tile_off, const FinalKp* d_pool, int pool_cap,
                         const long long* d_out_base, sift_hip_keypoint* d_kp_out, float* d_desc_out, int dbg) {
     const dim3 grid((unsigned)plan.desc_ntx[level], (unsigned)plan.desc_nty[level], (unsigned)plan.n_images);
     hipLaunchKernelGGL(descriptor_kernel, grid, dim3(256), 0, s, d_plan, level, d_final, d_final_cnt, final_cap,
