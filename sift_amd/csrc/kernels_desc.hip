@@ -149,6 +149,8 @@ __global__ __launch_bounds__(1024) void desc_tile_scan_kernel(const int* __restr
 // values: they are staged per keypoint in LDS, kDescBatch keypoints at a time (two barriers per
 // batch), and built by all 256 threads, two keypoints at once.
 constexpr int kDescBatch = 8;
+constexpr int kStageRow = 20;                       // staged window row: 16 samples + pad
+constexpr int kStageStride = 16 * kStageRow + 1;    // per keypoint: odd, so batch neighbours shift banks by one
 
 __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restrict__ plan, int level,
                                                          const FinalKp* __restrict__ finals,
@@ -167,8 +169,8 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
     __shared__ FinalKp s_fin[kTileListCap];
     // histogram inputs of a batch, laid out [sample-in-cell q][cell][keypoint m]: the phase-B reader
     // (thread = (m, cell), q marching) then touches 128 consecutive words per read
-    __shared__ __attribute__((aligned(16))) float s_val[16 * 16 * kDescBatch];
-    __shared__ unsigned char s_bin[16 * 16 * kDescBatch];
+    __shared__ __attribute__((aligned(16))) float s_val[kStageStride * kDescBatch];
+    __shared__ unsigned char s_bin[kStageStride * kDescBatch];
     __shared__ int s_wcnt[4];
     __shared__ int s_n;
 
@@ -191,6 +193,9 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
     const int K = final_cnt[img];
     const long long obase = out_base[img];
 
+    // LDS tile index of pixel (ex, ey): odd rows have their two 16-column halves swapped in every
+    // 32-column group, so the two window rows a half-wave touches fall on disjoint banks
+    auto tile_idx = [](int ex, int ey) { return ey * kExt + (ex ^ ((ey & 1) << 4)); };
     // initial gradient / Gaussian values of the extended tile: 16-byte loads (all issued before the
     // LDS stores) when rows are 16-byte aligned, scalar otherwise
     if (!(dbg & 4)) {
@@ -220,18 +225,19 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
             float4* po = reinterpret_cast<float4*>(s_ori);
             float4* pm = reinterpret_cast<float4*>(s_mag);
             float4* pg = reinterpret_cast<float4*>(s_gau);
-            po[tid] = o0; po[tid + 256] = o1; po[tid + 512] = o2; po[tid + 768] = o3;
-            pm[tid] = m0; pm[tid + 256] = m1; pm[tid + 512] = m2; pm[tid + 768] = m3;
-            pg[tid] = g0; pg[tid + 256] = g1; pg[tid + 512] = g2; pg[tid + 768] = g3;
+            auto sw4 = [](int e) { const int ly = e / R4; return e ^ ((ly & 1) << 2); };  // same swizzle, float4 units
+            po[sw4(tid)] = o0; po[sw4(tid + 256)] = o1; po[sw4(tid + 512)] = o2; po[sw4(tid + 768)] = o3;
+            pm[sw4(tid)] = m0; pm[sw4(tid + 256)] = m1; pm[sw4(tid + 512)] = m2; pm[sw4(tid + 768)] = m3;
+            pg[sw4(tid)] = g0; pg[sw4(tid + 256)] = g1; pg[sw4(tid + 512)] = g2; pg[sw4(tid + 768)] = g3;
         } else {
             for (int idx = tid; idx < kExt * kExt; idx += 256) {
                 const int ly = idx / kExt, lx = idx - ly * kExt;
                 const int X = ex0 + lx, Y = ey0 + ly;
                 const bool ok = X >= 0 && X < w && Y >= 0 && Y < h;
                 const size_t o = (size_t)(ok ? Y : 0) * (size_t)w + (size_t)(ok ? X : 0);
-                s_ori[idx] = ok ? go[o] : 0.0f;
-                s_mag[idx] = ok ? gm[o] : 0.0f;
-                s_gau[idx] = ok ? gg[o] : 0.0f;
+                s_ori[tile_idx(lx, ly)] = ok ? go[o] : 0.0f;
+                s_mag[tile_idx(lx, ly)] = ok ? gm[o] : 0.0f;
+                s_gau[tile_idx(lx, ly)] = ok ? gg[o] : 0.0f;
             }
         }
     }
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
                     if (!g.kfilt) {
                         float o = 0.0f, mg = 0.0f;
                         if (g.inside) {
-                            const int idx = (g.Y - ey0) * kExt + (g.X - ex0);
+                            const int idx = tile_idx(g.X - ex0, g.Y - ey0);
                             o = s_ori[idx] + f.orientation;            // sift.cpp:82
                             s_ori[idx] = o;
                             mg = s_mag[idx] + s_w16[g.lx + 16 * g.ly];  // sift.cpp:90, weighting(x, y) window-local
@@ -291,11 +297,10 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
                         if (g.owned) {
                             // alg::orientationHistogram8 inputs in descriptor order: cell = (x/4)*4 + y/4
                             // (x outer, sift.cpp:95-96), inside a cell x outer, y inner
-                            const float sum = mg * s_gau[(g.Y - ey0) * kExt + (g.X - ex0)];
+                            const float sum = mg * s_gau[tile_idx(g.X - ex0, g.Y - ey0)];
                             unsigned i = f32_to_u16_x86_d(__builtin_floorf(o / 45.0f));
                             i = i % 7u;
-                            const int cell = (g.lx >> 2) * 4 + (g.ly >> 2), q = (g.lx & 3) * 4 + (g.ly & 3);
-                            const int slot = (q * 16 + cell) * kDescBatch + m;
+                            const int slot = m * kStageStride + g.ly * kStageRow + g.lx;  // window layout, padded rows
                             s_val[slot] = sum;
                             s_bin[slot] = (unsigned char)i;
                         }
@@ -305,7 +310,8 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
             lds_only_barrier();
             // ---- phase B: one thread per (keypoint of the batch, cell): 8 bins in registers --------------
             if (!(dbg & 2) && tid < 16 * kDescBatch) {
-                const int m = tid & (kDescBatch - 1), cell = tid / kDescBatch;
+                const int m = tid >> 4, cell = tid & 15;   // cell = (x/4)*4 + y/4, sift.cpp:95-96
+                const int sbase = m * kStageStride + (cell & 3) * 4 * kStageRow + (cell >> 2) * 4;
                 const int e = e0 + m;
                 if (e < n_seg) {
                     const FinalKp f = s_fin[e];
@@ -319,8 +325,9 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
                             // alg::orientationHistogram8: samples of the cell in x-outer / y-inner order
 #pragma unroll
                             for (int q = 0; q < 16; ++q) {
-                                const float v = s_val[(q * 16 + cell) * kDescBatch + m];
-                                const unsigned b = s_bin[(q * 16 + cell) * kDescBatch + m];
+                                const int at = sbase + (q & 3) * kStageRow + (q >> 2);   // x outer, y inner
+                                const float v = s_val[at];
+                                const unsigned b = s_bin[at];
                                 h0 = (b == 0u) ? h0 + v : h0;
                                 h1 = (b == 1u) ? h1 + v : h1;
                                 h2 = (b == 2u) ? h2 + v : h2;
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
     };
 
     // the unsorted records are staged in the (not yet used) histogram staging area
-    static_assert(sizeof(FinalKp) * kTileListCap <= sizeof(float) * 16 * 16 * kDescBatch, "s_raw overlay");
+    static_assert(sizeof(FinalKp) * kTileListCap <= sizeof(float) * kStageStride * kDescBatch, "s_raw overlay");
     FinalKp* s_raw = reinterpret_cast<FinalKp*>(s_val);
     if (n_tile <= kTileListCap) {
         // fetch the tile's list and rank-sort it by vector index (indices are unique)

@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256) void gradient_kernel(const float* __restrict__
 //     histogram column in LDS, so 128 dependent chains run side by side instead of one per wave.
 constexpr int kOrientGroup = 128;
 constexpr int kOrientSub = 8;       // keypoints staged per wave at a time
-constexpr int kOrientStride = 260;  // floats (and bytes) between staged keypoints: conflict-free
+constexpr int kOrientCol = 20;      // staged samples of one window column (16 + pad: 2-way instead of 8-way write conflicts)
+constexpr int kOrientStride = 324;  // floats (and bytes) between staged keypoints: lane k reads 16-byte words at bank 4k
 
 __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restrict__ plan,
                                                           const OrientIn* __restrict__ oin,
@@ -161,8 +162,8 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
                     const int lx = lane & 15;
                     const float sum = pp[k][it];
                     const unsigned i = pb[k][it];
-                    wprod[k * kOrientStride + lx * 16 + ly] = sum;
-                    wbin[k * kOrientStride + lx * 16 + ly] = (unsigned char)i;
+                    wprod[k * kOrientStride + lx * kOrientCol + ly] = sum;
+                    wbin[k * kOrientStride + lx * kOrientCol + ly] = (unsigned char)i;
                     if (it == 0) first_bin = __shfl(i, 0);
                     same = same && (i == first_bin);
                 }
@@ -177,13 +178,16 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
             if (lane < kOrientSub && ((runmask & unimask) >> lane) & 1u) {
                 const float4* __restrict__ pv = reinterpret_cast<const float4*>(wprod + lane * kOrientStride);
                 b0 = wbin[lane * kOrientStride];
-#pragma unroll 8
-                for (int q = 0; q < 64; ++q) {
-                    const float4 v = pv[q];
-                    acc += v.x;
-                    acc += v.y;
-                    acc += v.z;
-                    acc += v.w;
+#pragma unroll 4
+                for (int cx = 0; cx < 16; ++cx) {   // x outer, y inner: column cx, rows 0..15
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float4 v = pv[cx * (kOrientCol / 4) + j];
+                        acc += v.x;
+                        acc += v.y;
+                        acc += v.z;
+                        acc += v.w;
+                    }
                 }
             }
 #pragma unroll
@@ -202,8 +206,9 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     if (lane == 0) {
                         for (int q = 0; q < 256; ++q) {
-                            const unsigned b = wbin[k * kOrientStride + q];
-                            s_hist[b][slot] = s_hist[b][slot] + wprod[k * kOrientStride + q];
+                            const int at = k * kOrientStride + (q >> 4) * kOrientCol + (q & 15);
+                            const unsigned b = wbin[at];
+                            s_hist[b][slot] = s_hist[b][slot] + wprod[at];
                         }
                     }
                 }
