@@ -41,6 +41,8 @@ __device__ __forceinline__ int reflect_clamp(int p, int n) {
 // Tiles that touch the image border, or images whose rows are not 16-byte aligned, take a scalar
 // load / store path with per-element reflection.
 // ---------------------------------------------------------------------------------------------
+constexpr int gcd_ce(int a, int b) { return b == 0 ? a : gcd_ce(b, a % b); }
+
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int R, bool DOG>
@@ -126,11 +128,16 @@ __global__ __launch_bounds__(256, (R <= 8 ? 3 : (R <= 24 ? 2 : 1))) void blur_fu
         const int tn = t + t_step;
         if (tn < t_end) load_tile(tn);  // stays in flight through both passes
 
-        // 2. row pass
+        // 2. row pass.  A wave reads 4 rows x 16 float4 per instruction; the rows are taken RG apart so
+        // that their LDS offsets agree modulo 256 B, the row spacing the ds_read_b128 lane groups are
+        // conflict-free for.
+        constexpr int RG = 16 / gcd_ce(ROW4, 16);
+        constexpr int NBLK = (SH + 4 * RG - 1) / (4 * RG);      // blocks of 4*RG rows
 #pragma unroll 1
-        for (int it = tid; it < SH * (TW / 4); it += 256) {
-            const int ly = it >> 4;
-            const int q = it & 15;
+        for (int wi = tid >> 6; wi < NBLK * RG; wi += 4) {
+            const int ly = (wi / RG) * (4 * RG) + (wi % RG) + RG * ((tid >> 4) & 3);
+            const int q = tid & 15;
+            if (ly >= SH) continue;
             constexpr int NV = PAD + 4 + 2 * R;
             constexpr int NV4 = (NV + 3) / 4;
             float v[NV4 * 4];
