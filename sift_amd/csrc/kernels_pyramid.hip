@@ -43,6 +43,19 @@ __device__ __forceinline__ int reflect_clamp(int p, int n) {
 // ---------------------------------------------------------------------------------------------
 constexpr int gcd_ce(int a, int b) { return b == 0 ? a : gcd_ce(b, a % b); }
 
+// 16-byte LDS read that the optimiser cannot split into narrower (slower, conflicting) reads of just
+// the elements it can prove are used.  The caller waits with lds_wait() before touching the result.
+__device__ __forceinline__ float4 lds_read_b128(const float4* p) {
+    float4 r;
+    const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ void lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int R, bool DOG>
@@ -142,9 +155,13 @@ __global__ __launch_bounds__(256, (R <= 8 ? 3 : (R <= 24 ? 2 : 1))) void blur_fu
             constexpr int NV4 = (NV + 3) / 4;
             float v[NV4 * 4];
             const float4* p4 = &s_src4[ly * ROW4 + q];
+            float4 f4[NV4];
+#pragma unroll
+            for (int c = 0; c < NV4; ++c) f4[c] = lds_read_b128(p4 + c);
+            lds_wait();
 #pragma unroll
             for (int c = 0; c < NV4; ++c) {
-                const float4 f = p4[c];
+                const float4 f = f4[c];
                 v[4 * c + 0] = f.x;
                 v[4 * c + 1] = f.y;
                 v[4 * c + 2] = f.z;
