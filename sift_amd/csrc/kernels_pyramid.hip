@@ -11,6 +11,8 @@
 // compiled with -ffp-contract=off and repeats it in a pragma), the row pass result is rounded to
 // float before the column pass consumes it (the reference stores it in `tmp`), and
 // reflect(p) = -p for p < 0, 2(w-1)-p for p >= w.
+#include <cstdlib>
+
 #include "common.h"
 
 #pragma clang fp contract(off)
@@ -78,13 +80,13 @@ __device__ __forceinline__ void lds_read_window(const float4* p, float4 (&f)[N])
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int R, bool DOG>
-__global__ __launch_bounds__(256, (R <= 8 ? 3 : (R <= 24 ? 2 : 1))) void blur_fused_kernel(const float* __restrict__ in,
+template <int R, bool DOG, int TH = 64>
+__global__ __launch_bounds__(256, (TH == 32 ? 4 : (R <= 8 ? 3 : (R <= 24 ? 2 : 1)))) void blur_fused_kernel(const float* __restrict__ in,
                                                          float* __restrict__ out,
                                                          float* __restrict__ dog, int w, int h,
                                                          int tiles_x, int tiles_y, int total_tiles,
                                                          int vec_ok, const float* __restrict__ taps) {
-    constexpr int TW = 64, TH = 64;
+    constexpr int TW = 64;
     constexpr int RA = (R + 3) & ~3;
     constexpr int PAD = RA - R;
     constexpr int SWA = TW + 2 * RA;       // LDS row length, multiple of 4
@@ -198,16 +200,17 @@ __global__ __launch_bounds__(256, (R <= 8 ? 3 : (R <= 24 ? 2 : 1))) void blur_fu
         }
         lds_barrier();
 
-        // 3. column pass: 4 columns x 4 rows per thread
+        // 3. column pass: 4 columns x PY rows per thread
+        constexpr int PY = TH / 16;
         const int cg = tid & 15, rg = tid >> 4;
-        float4 acc[4];
+        float4 acc[PY];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int i = 0; i < PY; ++i) acc[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
-        for (int k = 0; k < 4 + 2 * R; ++k) {
-            const float4 m = s_mid4[(rg * 4 + k) * (TW / 4) + cg];
+        for (int k = 0; k < PY + 2 * R; ++k) {
+            const float4 m = s_mid4[(rg * PY + k) * (TW / 4) + cg];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < PY; ++i) {
                 if (k - i >= 0 && k - i <= 2 * R) {
                     const float tap = taps[NT - 1 - (k - i)];
                     acc[i].x += tap * m.x;
@@ -227,13 +230,13 @@ __global__ __launch_bounds__(256, (R <= 8 ? 3 : (R <= 24 ? 2 : 1))) void blur_fu
             const int x = tx * TW + 4 * cg;
             const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int y = ty * TH + rg * 4 + i;
+            for (int i = 0; i < PY; ++i) {
+                const int y = ty * TH + rg * PY + i;
                 if (y < h && x < w) {
                     const size_t o = img_off + (size_t)y * (size_t)w + (size_t)x;
                     float4 d4;
                     if (DOG) {
-                        const float4 prev = s_src4[(R + rg * 4 + i) * ROW4 + (RA / 4) + cg];
+                        const float4 prev = s_src4[(R + rg * PY + i) * ROW4 + (RA / 4) + cg];
                         const float dx = acc[i].x - prev.x, dy = acc[i].y - prev.y;
                         const float dz = acc[i].z - prev.z, dw = acc[i].w - prev.w;
                         d4 = make_float4(128.0f + dx, 128.0f + dy, 128.0f + dz, 128.0f + dw);
@@ -326,21 +329,39 @@ __global__ void dog_kernel(const float* __restrict__ lower, const float* __restr
     out[i] = 128.0f + dif;
 }
 
-template <int R>
-static void launch_fused_r(hipStream_t s, const float* in, float* out, float* dog, int w, int h, int n,
-                           const float* d_taps) {
-    const int tiles_x = (w + 63) / 64, tiles_y = (h + 63) / 64;
+static int blur_th() {
+    static int th = [] { const char* e = getenv("SIFT_BLUR_TH"); return e ? atoi(e) : 64; }();
+    return th;
+}
+
+template <int R, int TH>
+static void launch_fused_rt(hipStream_t s, const float* in, float* out, float* dog, int w, int h, int n,
+                            const float* d_taps) {
+    const int tiles_x = (w + 63) / 64, tiles_y = (h + TH - 1) / TH;
     const int total = tiles_x * tiles_y * n;
-    int grid = total < 1024 ? total : 1024;  // persistent workgroups, 4 per CU offered
+    const int cap = TH == 32 ? 1536 : 1024;  // persistent workgroups offered per launch
+    int grid = total < cap ? total : cap;
     if (grid >= 8) grid &= ~7;
     const bool aligned = (((uintptr_t)in | (uintptr_t)out | (uintptr_t)dog) & 15u) == 0;
     const int vec_ok = (w % 4 == 0 && aligned) ? 1 : 0;
     if (dog)
-        hipLaunchKernelGGL((blur_fused_kernel<R, true>), dim3((unsigned)grid), dim3(256), 0, s, in, out, dog, w, h,
+        hipLaunchKernelGGL((blur_fused_kernel<R, true, TH>), dim3((unsigned)grid), dim3(256), 0, s, in, out, dog, w, h,
                            tiles_x, tiles_y, total, vec_ok, d_taps);
     else
-        hipLaunchKernelGGL((blur_fused_kernel<R, false>), dim3((unsigned)grid), dim3(256), 0, s, in, out, dog, w, h,
+        hipLaunchKernelGGL((blur_fused_kernel<R, false, TH>), dim3((unsigned)grid), dim3(256), 0, s, in, out, dog, w, h,
                            tiles_x, tiles_y, total, vec_ok, d_taps);
+}
+
+template <int R>
+static void launch_fused_r(hipStream_t s, const float* in, float* out, float* dog, int w, int h, int n,
+                           const float* d_taps) {
+    if constexpr (R == 5 || R == 7 || R == 10) {
+        if (blur_th() == 32) {
+            launch_fused_rt<R, 32>(s, in, out, dog, w, h, n, d_taps);
+            return;
+        }
+    }
+    launch_fused_rt<R, 64>(s, in, out, dog, w, h, n, d_taps);
 }
 
 #define SIFT_FUSED_CASE(R) \
