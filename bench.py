@@ -47,6 +47,16 @@ def cpu_baseline(frames):
                       f"{secs:.1f} s CPU, {kps} keypoints"}
 
 
+def pmc_traffic():
+    """HBM bytes per blur launch from the committed rocprofv3 PMC pass (tools/pmc_round.sh; FETCH_SIZE x2
+    corrected + WRITE_SIZE, MI355X_MICROARCH.md section HBM).  bench.py itself cannot read PMC counters."""
+    p = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    try:
+        return json.load(open(p))["_blur_fused_all"]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,34 +95,19 @@ def main():
     params = _lib.Params(DOGS, OCTAVES, SIGMA, K_SQRT2, 0)
     L = ctx._L
 
+    from sift_amd.gather import gather_keypoints
+
     def step():
         ctx.calculate_batch_device(d_frames.data_ptr(), nf, W, H, params)
         total = ctx.total()
         if world > 1:
-            # RCCL gather of the keypoint lists only: counts, then variable-size records + descriptors
-            cnt = torch.tensor([total], dtype=torch.int64, device=dev)
-            allc = torch.empty(world, dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(allc, cnt)
-            allc = allc.tolist()
+            # RCCL gather of the keypoint lists only (counts, then records + descriptors to rank 0)
             kp = torch.empty(max(total, 1) * 20, dtype=torch.uint8, device=dev)
             desc = torch.empty(max(total, 1) * 128, dtype=torch.float32, device=dev)
             if total:
                 L.sift_hip_result_copy(ctx._h, C.c_void_p(kp.data_ptr()), C.c_void_p(desc.data_ptr()))
-            if rank == 0:
-                bufs, ops = [], []
-                for r in range(1, world):
-                    if allc[r]:
-                        bk = torch.empty(allc[r] * 20, dtype=torch.uint8, device=dev)
-                        bd = torch.empty(allc[r] * 128, dtype=torch.float32, device=dev)
-                        bufs.append((bk, bd))
-                        ops += [dist.P2POp(dist.irecv, bk, r), dist.P2POp(dist.irecv, bd, r)]
-                if ops:
-                    for w_ in dist.batch_isend_irecv(ops):
-                        w_.wait()
-            elif total:
-                for w_ in dist.batch_isend_irecv([dist.P2POp(dist.isend, kp[:total * 20], 0),
-                                                  dist.P2POp(dist.isend, desc[:total * 128], 0)]):
-                    w_.wait()
+            counts = torch.from_numpy(ctx.counts()).to(dev)
+            gather_keypoints(kp, desc, counts, dst=0)
         return total
 
     for _ in range(args.warmup):
@@ -163,7 +158,8 @@ def main():
                        "gather": "RCCL p2p of keypoint records + descriptors to rank 0" if world > 1 else "none (1 GPU)"},
             "roofline": {"kernel": "blur_fused_kernel (separable Gaussian + DoG, all pyramid levels)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
+                         "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench)",
                          "launches": launches, "avg_launch_ms": ms / launches if launches else None,
                          "algorithmic_bytes_per_launch": nbytes / launches if launches else None},
         }

@@ -132,7 +132,8 @@ int sift_hip_vertex_parabola(sift_hip_ctx* ctx, const uint16_t* lnx, const float
 int sift_hip_sort_by_filter(sift_hip_ctx* ctx, const uint8_t* flags, int n, int32_t* perm);
 /* The whole cleanup (sift.cpp:37-42: sort, find first filtered, u16_t size, resize): original
  * indices of the surviving points in their post-sort order.  on_gpu = 1 runs the cleanup kernel
- * (kernels_cleanup.hip), 0 the host's std::sort glue; both must agree. */
+ * (kernels_cleanup.hip; 2 = its global-memory key variant used for very large n), 0 the host's
+ * std::sort glue; all must agree. */
 int sift_hip_cleanup_survivors(sift_hip_ctx* ctx, const uint8_t* flags, int n, int32_t* survivors,
                                int32_t* count, int on_gpu);
 

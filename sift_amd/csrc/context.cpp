@@ -1186,15 +1186,16 @@ int sift_hip_cleanup_survivors(sift_hip_ctx* c, const uint8_t* flags, int n, int
     return guarded(nullptr, 0, [&]() {
         SIFT_HIP_CHECK(hipSetDevice(c->device));
         Scratch s;
-        const size_t m = (size_t)std::max(n, 1);
-        uint8_t* d_fl = s.upload(flags, m);
+        const size_t m = (size_t)std::max(n, 1) + 64;
+        uint8_t* d_fl = s.dev<uint8_t>(m);
+        if (n) SIFT_HIP_CHECK(hipMemcpy(d_fl, flags, (size_t)n, hipMemcpyHostToDevice));
         uint8_t* wk = s.dev<uint8_t>(m);
         uint32_t* wi = s.dev<uint32_t>(m);
         uint32_t* wi2 = s.dev<uint32_t>(m);
         uint32_t* wp = s.dev<uint32_t>(m);
         uint32_t* out = s.dev<uint32_t>(m);
         int* info = s.dev<int>(2);
-        launch_cleanup_kat(c->stream, d_fl, n, wk, wi, wi2, wp, out, info);
+        launch_cleanup_kat(c->stream, d_fl, n, wk, wi, wi2, wp, out, info, on_gpu == 2 ? 1 : 0);
         SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
         int h_info[2];
         SIFT_HIP_CHECK(hipMemcpy(h_info, info, sizeof(h_info), hipMemcpyDeviceToHost));

@@ -41,6 +41,31 @@ struct CleanupShared {
 
 __device__ __forceinline__ int floor_log2(int n) { return 31 - __clz(n); }
 
+// Key storage.  The keys are read far more often than anything else and every access is on the
+// critical path of a one-workgroup-per-image kernel, so they live in LDS as a bit mask whenever
+// the image's candidate count fits (kBitCap); otherwise in a global byte array.
+struct GlobalKeys {
+    uint8_t* k;
+    __device__ __forceinline__ int get(int i) const { return k[i]; }
+    __device__ __forceinline__ void init(int i, int v) const { k[i] = (uint8_t)v; }
+    __device__ __forceinline__ void swap(int a, int b) const {
+        const uint8_t ka = k[a], kb = k[b];
+        k[a] = kb;
+        k[b] = ka;
+    }
+};
+struct LdsBitKeys {
+    uint32_t* w;
+    __device__ __forceinline__ int get(int i) const { return (int)((w[i >> 5] >> (i & 31)) & 1u); }
+    __device__ __forceinline__ void swap(int a, int b) const {  // disjoint pairs may share words: atomics
+        if (get(a) != get(b)) {
+            atomicXor(&w[a >> 5], 1u << (a & 31));
+            atomicXor(&w[b >> 5], 1u << (b & 31));
+        }
+    }
+};
+constexpr int kBitCap = 1 << 20;   // 128 KiB of LDS
+
 // Ranks of this thread's four elements (one in each of four consecutive 1024-element chunks, so the
 // four loads that produced `hit` are coalesced and in flight together) among the hits of the
 // current 4096-element tile, plus the tile's total.  Double-buffered per-wave counters sh.wc[par].
@@ -95,7 +120,8 @@ __device__ __forceinline__ int pure_final_pos(int pos, int f, int m, int d) {
 // Core: K[0..n) keys (0 kept, 1 filtered) and I[0..n) payload are permuted in global memory like
 // __introsort_loop would; I2 receives the arrangement after the all-kept ranges' evolution.
 // P is scratch for swap sources (n/2 + 1 entries).  Returns via sh.fallback.
-__device__ void introsort_binary(CleanupShared& sh, int n, uint8_t* __restrict__ K, uint32_t* __restrict__ I,
+template <class Keys>
+__device__ void introsort_binary(CleanupShared& sh, int n, const Keys K, uint32_t* __restrict__ I,
                                  uint32_t* __restrict__ I2, uint32_t* __restrict__ P) {
     const int tid = threadIdx.x;
     if (tid == 0) {
@@ -117,7 +143,7 @@ __device__ void introsort_binary(CleanupShared& sh, int n, uint8_t* __restrict__
                 sh.d -= 1;
                 // __move_median_to_first(f, f+1, mid, l-1)
                 const int a = f + 1, b = f + (l - f) / 2, c = l - 1;
-                const int ka = K[a], kb = K[b], kc = K[c];
+                const int ka = K.get(a), kb = K.get(b), kc = K.get(c);
                 auto comp = [](int x, int y) { return x == 0 && y == 1; };
                 int s;
                 if (comp(ka, kb)) {
@@ -127,9 +153,8 @@ __device__ void introsort_binary(CleanupShared& sh, int n, uint8_t* __restrict__
                 } else if (comp(ka, kc)) s = a;
                 else if (comp(kb, kc)) s = c;
                 else s = b;
-                const uint8_t kf = K[f], ks = K[s];
-                K[f] = ks;
-                K[s] = kf;
+                const int ks = K.get(s);
+                K.swap(f, s);
                 const uint32_t jf = I[f], js = I[s];
                 I[f] = js;
                 I[s] = jf;
@@ -152,7 +177,7 @@ __device__ void introsort_binary(CleanupShared& sh, int n, uint8_t* __restrict__
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     pos[u] = base + u * kCT + tid;
-                    hit[u] = pos[u] < L && K[pos[u]] == 1;
+                    hit[u] = pos[u] < L && K.get(pos[u]) == 1;
                 }
                 int tile_total;
                 tile_rank4(sh, par, hit, rk, tile_total);
@@ -181,7 +206,7 @@ __device__ void introsort_binary(CleanupShared& sh, int n, uint8_t* __restrict__
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     pos[u] = base - u * kCT - tid;
-                    hit[u] = pos[u] >= F && K[pos[u]] == 0;
+                    hit[u] = pos[u] >= F && K.get(pos[u]) == 0;
                 }
                 int tile_total;
                 tile_rank4(sh, par, hit, rk, tile_total);
@@ -206,9 +231,7 @@ __device__ void introsort_binary(CleanupShared& sh, int n, uint8_t* __restrict__
         for (int t = tid; t < T; t += kCT) {
             const int a = (int)P[t];
             const int b = p == 1 ? (L - 1 - t) : (F + t);
-            const uint8_t ka = K[a], kb = K[b];
-            K[a] = kb;
-            K[b] = ka;
+            K.swap(a, b);
             const uint32_t ia = I[a], ib = I[b];
             I[a] = ib;
             I[b] = ia;
@@ -237,7 +260,7 @@ __device__ void introsort_binary(CleanupShared& sh, int n, uint8_t* __restrict__
     // left them; inside, each one moves to its closed-form final position.
 #pragma unroll 4
     for (int i = tid; i < n; i += kCT)
-        if (K[i] == 0) I2[i] = I[i];
+        if (K.get(i) == 0) I2[i] = I[i];
     __syncthreads();
     const int npure = sh.npure;
     for (int r = 0; r < npure; ++r) {
@@ -254,14 +277,14 @@ __device__ void introsort_binary(CleanupShared& sh, int n, uint8_t* __restrict__
 
 // Stable partition: kept elements in position order -> out[0..size), size = count mod 65536.
 // `emit(rank, payload)` is called for rank < size.
-template <class Emit>
-__device__ int compact_kept(CleanupShared& sh, int n, const uint8_t* __restrict__ K,
-                            const uint32_t* __restrict__ I2, Emit emit, int* total_out = nullptr) {
+template <class Keys, class Emit>
+__device__ int compact_kept(CleanupShared& sh, int n, const Keys K, const uint32_t* __restrict__ I2, Emit emit,
+                            int* total_out = nullptr) {
     const int tid = threadIdx.x;
     // total first (needed for the u16 truncation)
     int cnt = 0;
 #pragma unroll 4
-    for (int i = tid; i < n; i += kCT) cnt += K[i] == 0;
+    for (int i = tid; i < n; i += kCT) cnt += K.get(i) == 0;
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
     if (tid == 0) sh.T = 0;
     __syncthreads();
@@ -278,7 +301,7 @@ __device__ int compact_kept(CleanupShared& sh, int n, const uint8_t* __restrict_
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             pos[u] = base + u * kCT + tid;
-            hit[u] = pos[u] < n && K[pos[u]] == 0;
+            hit[u] = pos[u] < n && K.get(pos[u]) == 0;
         }
         int tile_total;
         tile_rank4(sh, par, hit, rk, tile_total);
@@ -292,34 +315,33 @@ __device__ int compact_kept(CleanupShared& sh, int n, const uint8_t* __restrict_
     return size;
 }
 
-// ---- cleanup 1: flags of the extrema candidates -> ordered survivor list ---------------------
-__global__ __launch_bounds__(kCT) void cleanup1_kernel(const uint8_t* __restrict__ flags,
-                                                       const int* __restrict__ totals, long long cand_cap,
-                                                       uint8_t* __restrict__ wk, uint32_t* __restrict__ wi,
-                                                       uint32_t* __restrict__ wi2, uint32_t* __restrict__ wp,
-                                                       uint32_t* __restrict__ list,
-                                                       OrientIn* __restrict__ oin,
-                                                       const Candidate* __restrict__ cands, int list_cap,
-                                                       int* __restrict__ list_cnt, int* __restrict__ fallback) {
-    __shared__ CleanupShared sh;
-    const int img = blockIdx.x;
-    const int n = totals[img];
-    const size_t off = (size_t)img * (size_t)cand_cap;
-    uint8_t* K = wk + off;
-    uint32_t* I = wi + off;
-    uint32_t* I2 = wi2 + off;
-    uint32_t* P = wp + off;
-    const uint8_t* fl = flags + off;
-#pragma unroll 4
-    for (int i = threadIdx.x; i < n; i += kCT) {
-        K[i] = fl[i] ? 1 : 0;
-        I[i] = (uint32_t)i;
+extern __shared__ uint32_t s_dyn_bits[];   // kBitCap / 32 words when the launch provides them
+
+// flags -> key bits (one __ballot per 64 elements, no atomics) and identity payload
+__device__ void init_bits_from_flags(const LdsBitKeys K, const uint8_t* __restrict__ fl, int n,
+                                     uint32_t* __restrict__ I) {
+    const int lane = threadIdx.x & 63;
+    for (int base = 0; base < n; base += kCT) {
+        const int i = base + (int)threadIdx.x;
+        const bool f = i < n && fl[i] != 0;
+        const unsigned long long m = __ballot(f);
+        if (lane == 0 && i < n) {
+            const int wd = (base + ((int)threadIdx.x & ~63)) >> 5;
+            K.w[wd] = (uint32_t)m;
+            K.w[wd + 1] = (uint32_t)(m >> 32);
+        }
+        if (i < n) I[i] = (uint32_t)i;
     }
     __syncthreads();
+}
+
+template <class Keys>
+__device__ void cleanup1_body(CleanupShared& sh, int n, const Keys K, const uint8_t* __restrict__ fl,
+                              uint32_t* __restrict__ I, uint32_t* __restrict__ I2, uint32_t* __restrict__ P,
+                              uint32_t* __restrict__ out, OrientIn* __restrict__ ord,
+                              const Candidate* __restrict__ cd, int img, int* __restrict__ list_cnt,
+                              int* __restrict__ fallback) {
     introsort_binary(sh, n, K, I, I2, P);
-    uint32_t* out = list + (size_t)img * (size_t)list_cap;
-    OrientIn* ord = oin + (size_t)img * (size_t)list_cap;
-    const Candidate* cd = cands + off;
     auto make_in = [&](uint32_t cand, uint32_t kp) {
         const Candidate c = cd[cand];
         OrientIn o;
@@ -359,6 +381,42 @@ __global__ __launch_bounds__(kCT) void cleanup1_kernel(const uint8_t* __restrict
     }
 }
 
+// ---- cleanup 1: flags of the extrema candidates -> ordered survivor list ---------------------
+__global__ __launch_bounds__(kCT) void cleanup1_kernel(const uint8_t* __restrict__ flags,
+                                                       const int* __restrict__ totals, long long cand_cap,
+                                                       uint8_t* __restrict__ wk, uint32_t* __restrict__ wi,
+                                                       uint32_t* __restrict__ wi2, uint32_t* __restrict__ wp,
+                                                       uint32_t* __restrict__ list,
+                                                       OrientIn* __restrict__ oin,
+                                                       const Candidate* __restrict__ cands, int list_cap,
+                                                       int* __restrict__ list_cnt, int* __restrict__ fallback) {
+    __shared__ CleanupShared sh;
+    const int img = blockIdx.x;
+    const int n = totals[img];
+    const size_t off = (size_t)img * (size_t)cand_cap;
+    uint32_t* I = wi + off;
+    uint32_t* I2 = wi2 + off;
+    uint32_t* P = wp + off;
+    const uint8_t* fl = flags + off;
+    uint32_t* out = list + (size_t)img * (size_t)list_cap;
+    OrientIn* ord = oin + (size_t)img * (size_t)list_cap;
+    const Candidate* cd = cands + off;
+    if (n <= kBitCap) {
+        const LdsBitKeys K{s_dyn_bits};
+        init_bits_from_flags(K, fl, n, I);
+        cleanup1_body(sh, n, K, fl, I, I2, P, out, ord, cd, img, list_cnt, fallback);
+    } else {
+        const GlobalKeys K{wk + off};
+#pragma unroll 4
+        for (int i = threadIdx.x; i < n; i += kCT) {
+            K.k[i] = fl[i] ? 1 : 0;
+            I[i] = (uint32_t)i;
+        }
+        __syncthreads();
+        cleanup1_body(sh, n, K, fl, I, I2, P, out, ord, cd, img, list_cnt, fallback);
+    }
+}
+
 __global__ void build_orient_in_kernel(const Candidate* __restrict__ cands, long long cand_cap,
                                        const uint32_t* __restrict__ list, const int* __restrict__ list_cnt,
                                        int list_cap, OrientIn* __restrict__ oin) {
@@ -384,10 +442,12 @@ __global__ __launch_bounds__(kCT) void cleanup2_kernel(const Candidate* __restri
                                                        int* __restrict__ status) {
     __shared__ CleanupShared sh;
     __shared__ int s_multi, s_throw;
+    __shared__ uint32_t s_bits2[65536 / 32];   // n <= 65535 here (u16_t size of the first cleanup)
     const int img = blockIdx.x;
     const int n = list_cnt[img];
     const size_t off = (size_t)img * (size_t)list_cap;
-    uint8_t* K = wk + off;
+    const LdsBitKeys K{s_bits2};
+    (void)wk;
     uint32_t* I = wi + off;
     uint32_t* I2 = wi2 + off;
     uint32_t* P = wp + off;
@@ -397,12 +457,22 @@ __global__ __launch_bounds__(kCT) void cleanup2_kernel(const Candidate* __restri
         s_throw = 0x7fffffff;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += kCT) {
-        const OrientOut o = oo[i];
-        K[i] = o.filtered ? 1 : 0;
-        I[i] = (uint32_t)i;
-        if (!o.filtered && o.npeaks > 1) s_multi = 1;
-        if (!o.filtered && o.throws) atomicMin(&s_throw, i);
+    for (int base = 0; base < n; base += kCT) {
+        const int i = base + (int)threadIdx.x;
+        OrientOut o;
+        o.filtered = 0; o.npeaks = 0; o.throws = 0; o.orientation = 0.0f;
+        if (i < n) o = oo[i];
+        const unsigned long long m = __ballot(i < n && o.filtered != 0);
+        if ((threadIdx.x & 63) == 0 && i < n) {
+            const int wd = (base + ((int)threadIdx.x & ~63)) >> 5;
+            K.w[wd] = (uint32_t)m;
+            K.w[wd + 1] = (uint32_t)(m >> 32);
+        }
+        if (i < n) {
+            I[i] = (uint32_t)i;
+            if (!o.filtered && o.npeaks > 1) s_multi = 1;
+            if (!o.filtered && o.throws) atomicMin(&s_throw, i);
+        }
     }
     __syncthreads();
     introsort_binary(sh, n, K, I, I2, P);
@@ -433,17 +503,27 @@ __global__ __launch_bounds__(kCT) void cleanup2_kernel(const Candidate* __restri
 
 // KAT entry: flags -> survivor order (whole kept prefix, no u16 truncation applied by the caller)
 __global__ __launch_bounds__(kCT) void cleanup_kat_kernel(const uint8_t* __restrict__ flags, int n,
-                                                          uint8_t* __restrict__ K, uint32_t* __restrict__ I,
+                                                          uint8_t* __restrict__ Kg, uint32_t* __restrict__ I,
                                                           uint32_t* __restrict__ I2, uint32_t* __restrict__ P,
-                                                          uint32_t* __restrict__ out, int* __restrict__ info) {
+                                                          uint32_t* __restrict__ out, int* __restrict__ info,
+                                                          int force_global) {
     __shared__ CleanupShared sh;
-    for (int i = threadIdx.x; i < n; i += kCT) {
-        K[i] = flags[i] ? 1 : 0;
-        I[i] = (uint32_t)i;
+    int size;
+    if (n <= kBitCap && !force_global) {
+        const LdsBitKeys K{s_dyn_bits};
+        init_bits_from_flags(K, flags, n, I);
+        introsort_binary(sh, n, K, I, I2, P);
+        size = compact_kept(sh, n, K, I2, [&](int r, uint32_t id) { out[r] = id; });
+    } else {
+        const GlobalKeys K{Kg};
+        for (int i = threadIdx.x; i < n; i += kCT) {
+            K.k[i] = flags[i] ? 1 : 0;
+            I[i] = (uint32_t)i;
+        }
+        __syncthreads();
+        introsort_binary(sh, n, K, I, I2, P);
+        size = compact_kept(sh, n, K, I2, [&](int r, uint32_t id) { out[r] = id; });
     }
-    __syncthreads();
-    introsort_binary(sh, n, K, I, I2, P);
-    const int size = compact_kept(sh, n, K, I2, [&](int r, uint32_t id) { out[r] = id; });
     if (threadIdx.x == 0) {
         info[0] = size;
         info[1] = sh.fallback;
@@ -453,8 +533,13 @@ __global__ __launch_bounds__(kCT) void cleanup_kat_kernel(const uint8_t* __restr
 void launch_cleanup1(hipStream_t s, int n_images, const uint8_t* d_flags, const int* d_totals, long long cand_cap,
                      uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, uint32_t* d_list, OrientIn* d_oin,
                      const Candidate* d_cands, int list_cap, int* d_list_cnt, int* d_fallback) {
-    hipLaunchKernelGGL(cleanup1_kernel, dim3((unsigned)n_images), dim3(kCT), 0, s, d_flags, d_totals, cand_cap, wk,
-                       wi, wi2, wp, d_list, d_oin, d_cands, list_cap, d_list_cnt, d_fallback);
+    static const bool attr_ok = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(cleanup1_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kBitCap / 8) == hipSuccess;
+    }();
+    (void)attr_ok;
+    hipLaunchKernelGGL(cleanup1_kernel, dim3((unsigned)n_images), dim3(kCT), kBitCap / 8, s, d_flags, d_totals, cand_cap,
+                       wk, wi, wi2, wp, d_list, d_oin, d_cands, list_cap, d_list_cnt, d_fallback);
 }
 
 void launch_build_orient_in(hipStream_t s, const Candidate* d_cands, long long cand_cap, const uint32_t* d_list,
@@ -472,8 +557,14 @@ void launch_cleanup2(hipStream_t s, int n_images, const Candidate* d_cands, long
 }
 
 void launch_cleanup_kat(hipStream_t s, const uint8_t* d_flags, int n, uint8_t* wk, uint32_t* wi, uint32_t* wi2,
-                        uint32_t* wp, uint32_t* d_out, int* d_info) {
-    hipLaunchKernelGGL(cleanup_kat_kernel, dim3(1), dim3(kCT), 0, s, d_flags, n, wk, wi, wi2, wp, d_out, d_info);
+                        uint32_t* wp, uint32_t* d_out, int* d_info, int force_global) {
+    static const bool attr_ok = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(cleanup_kat_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kBitCap / 8) == hipSuccess;
+    }();
+    (void)attr_ok;
+    hipLaunchKernelGGL(cleanup_kat_kernel, dim3(1), dim3(kCT), kBitCap / 8, s, d_flags, n, wk, wi, wi2, wp, d_out, d_info,
+                       force_global);
 }
 
 }  // namespace sift_hip

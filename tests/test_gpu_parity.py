@@ -338,9 +338,10 @@ def test_cleanup_kernel_matches_std_sort(ctx):
         nz = int((flags == 0).sum())
         want = perm[:nz & 0xffff]                       # u16_t size (sift.cpp:41)
         host = _survivors(ctx, flags, 0)
-        gpu = _survivors(ctx, flags, 1)
         assert host.size == want.size and (host == want).all(), (flags.size, "host glue")
-        assert gpu.size == want.size and (gpu == want).all(), (flags.size, float(flags.mean()) if flags.size else 0, "gpu kernel")
+        for variant in (1, 2):   # keys in LDS bits / keys in global bytes
+            gpu = _survivors(ctx, flags, variant)
+            assert gpu.size == want.size and (gpu == want).all(), (flags.size, float(flags.mean()) if flags.size else 0, "gpu kernel", variant)
 
 
 def test_pipeline_parity_host_glue_path(ctx, report_dir):
