@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="contexts (streams + host threads) per GPU, each taking an equal share of the batch, so one\n"
+                         "lane's latency-bound stages overlap the other's bandwidth-bound ones")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -91,29 +94,43 @@ def main():
     d_frames = torch.from_numpy(frames).to(dev)
     torch.cuda.synchronize()
 
-    ctx = Context(local_rank)
+    lanes = max(1, min(args.lanes, nf))
+    share = [nf // lanes + (1 if i < nf % lanes else 0) for i in range(lanes)]
+    first = [sum(share[:i]) for i in range(lanes)]
+    ctxs = [Context(local_rank) for _ in range(lanes)]
+    ctx = ctxs[0]
     params = _lib.Params(DOGS, OCTAVES, SIGMA, K_SQRT2, 0)
     L = ctx._L
+    frame_bytes = W * H * 4
+    pool = ThreadPool(lanes) if lanes > 1 else None
 
     from sift_amd.gather import gather_keypoints
 
+    def run_lane(i):
+        ctxs[i].calculate_batch_device(d_frames.data_ptr() + first[i] * frame_bytes, share[i], W, H, params)
+        return ctxs[i].total()
+
     def step():
-        ctx.calculate_batch_device(d_frames.data_ptr(), nf, W, H, params)
-        total = ctx.total()
+        totals = pool.map(run_lane, range(lanes)) if pool else [run_lane(0)]   # ctypes calls release the GIL
+        total = sum(totals)
         if world > 1:
             # RCCL gather of the keypoint lists only (counts, then records + descriptors to rank 0)
             kp = torch.empty(max(total, 1) * 20, dtype=torch.uint8, device=dev)
             desc = torch.empty(max(total, 1) * 128, dtype=torch.float32, device=dev)
-            if total:
-                L.sift_hip_result_copy(ctx._h, C.c_void_p(kp.data_ptr()), C.c_void_p(desc.data_ptr()))
-            counts = torch.from_numpy(ctx.counts()).to(dev)
+            off = 0
+            for c, t in zip(ctxs, totals):   # lanes hold consecutive image ranges: concatenation keeps image order
+                if t:
+                    L.sift_hip_result_copy(c._h, C.c_void_p(kp.data_ptr() + off * 20), C.c_void_p(desc.data_ptr() + off * 512))
+                off += t
+            counts = torch.from_numpy(np.concatenate([c.counts() for c in ctxs])).to(dev)
             gather_keypoints(kp, desc, counts, dst=0)
         return total
 
     for _ in range(args.warmup):
         step()
-    ctx.set_option("profile", 1)
-    ctx.profile_reset()
+    for c in ctxs:
+        c.set_option("profile", 1)
+        c.profile_reset()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -125,7 +142,8 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    ctx.set_option("profile", 0)
+    for c in ctxs:
+        c.set_option("profile", 0)
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -136,7 +154,8 @@ def main():
         kps = int(k.item())
 
     if rank == 0:
-        ms, launches, nbytes = ctx.profile(0)
+        prof = [c.profile(0) for c in ctxs]
+        ms, launches, nbytes = (sum(p[i] for p in prof) for i in range(3))
         achieved = (nbytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0
         out = {
             "metric": "keypoints/sec, 1920x1080 4oct/3DoG",
@@ -153,7 +172,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"batch of {nf} synthetic 1920x1080 greyscale frames per GPU, sigma 1.6, k sqrt2, "
                                    f"4 octaves x 3 DoGs, subpixel off (BASELINE config 4 per-GPU share)",
-                       "frames_per_gpu": nf, "frames_total": nf * world, "keypoints_per_step": kps // max(args.steps, 1),
+                       "frames_per_gpu": nf, "frames_total": nf * world, "lanes_per_gpu": lanes, "keypoints_per_step": kps // max(args.steps, 1),
                        "frames_per_s": nf * world * args.steps / dt,
                        "gather": "RCCL p2p of keypoint records + descriptors to rank 0" if world > 1 else "none (1 GPU)"},
             "roofline": {"kernel": "blur_fused_kernel (separable Gaussian + DoG, all pyramid levels)",

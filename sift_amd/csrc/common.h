@@ -124,6 +124,7 @@ void launch_cleanup2(hipStream_t s, int n_images, const Candidate* d_cands, long
                      const uint32_t* d_list, const int* d_list_cnt, int list_cap, const OrientOut* d_orient,
                      uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, FinalKp* d_final, int* d_final_cnt,
                      int* d_status);
+void cleanup_set_stamp_buffer(unsigned long long* d);
 void launch_cleanup_kat(hipStream_t s, const uint8_t* d_flags, int n, uint8_t* wk, uint32_t* wi, uint32_t* wi2,
                         uint32_t* wp, uint32_t* d_out, int* d_info, int force_global);
 void launch_w16(hipStream_t s, const DevPlan& plan, int level, const float* d_taps16, int radius16);

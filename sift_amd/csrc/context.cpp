@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -1195,10 +1196,24 @@ int sift_hip_cleanup_survivors(sift_hip_ctx* c, const uint8_t* flags, int n, int
         uint32_t* wp = s.dev<uint32_t>(m);
         uint32_t* out = s.dev<uint32_t>(m);
         int* info = s.dev<int>(2);
+        unsigned long long* st = nullptr;
+        if (getenv("SIFT_CLEANUP_STAMPS")) {
+            st = s.dev<unsigned long long>(16);
+            SIFT_HIP_CHECK(hipMemset(st, 0, 16 * sizeof(unsigned long long)));
+            cleanup_set_stamp_buffer(st);
+        }
         launch_cleanup_kat(c->stream, d_fl, n, wk, wi, wi2, wp, out, info, on_gpu == 2 ? 1 : 0);
         SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
         int h_info[2];
         SIFT_HIP_CHECK(hipMemcpy(h_info, info, sizeof(h_info), hipMemcpyDeviceToHost));
+        if (st) {
+            unsigned long long hs[16];
+            SIFT_HIP_CHECK(hipMemcpy(hs, st, sizeof(hs), hipMemcpyDeviceToHost));
+            cleanup_set_stamp_buffer(nullptr);
+            std::fprintf(stderr, "cleanup stamps (us): init %.1f loop %.1f copy %.1f pure %.1f compact %.1f  npure %llu\n",
+                         (hs[1] - hs[0]) / 100.0, (hs[2] - hs[1]) / 100.0, (hs[3] - hs[2]) / 100.0, (hs[4] - hs[3]) / 100.0,
+                         (hs[5] - hs[4]) / 100.0, hs[6]);
+        }
         if (h_info[1]) {  // introsort depth limit: the host's std::sort decides
             std::vector<uint32_t> sv;
             cleanup_survivors(flags, n, sv);

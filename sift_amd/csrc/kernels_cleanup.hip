@@ -66,6 +66,12 @@ struct LdsBitKeys {
 };
 constexpr int kBitCap = 1 << 20;   // 128 KiB of LDS
 
+// optional phase stamps (diagnostic builds of the KAT entry only): 100 MHz wall clock
+__device__ unsigned long long* g_stamp = nullptr;
+__device__ __forceinline__ void stamp(int slot) {
+    if (g_stamp && threadIdx.x == 0 && blockIdx.x == 0) g_stamp[slot] = wall_clock64();
+}
+
 // Ranks of this thread's four elements (one in each of four consecutive 1024-element chunks, so the
 // four loads that produced `hit` are coalesced and in flight together) among the hits of the
 // current 4096-element tile, plus the tile's total.  Double-buffered per-wave counters sh.wc[par].
@@ -124,6 +130,7 @@ template <class Keys>
 __device__ void introsort_binary(CleanupShared& sh, int n, const Keys K, uint32_t* __restrict__ I,
                                  uint32_t* __restrict__ I2, uint32_t* __restrict__ P) {
     const int tid = threadIdx.x;
+    stamp(1);
     if (tid == 0) {
         sh.f = 0;
         sh.l = n;
@@ -256,12 +263,14 @@ __device__ void introsort_binary(CleanupShared& sh, int n, const Keys K, uint32_
         __syncthreads();
     }
     __syncthreads();
+    stamp(2);
     // Only kept elements are ever read back.  Outside the all-kept ranges they stay where the loop
     // left them; inside, each one moves to its closed-form final position.
 #pragma unroll 4
     for (int i = tid; i < n; i += kCT)
         if (K.get(i) == 0) I2[i] = I[i];
     __syncthreads();
+    stamp(3);
     const int npure = sh.npure;
     for (int r = 0; r < npure; ++r) {
         const PureRange pr = sh.pure[r];
@@ -509,11 +518,15 @@ __global__ __launch_bounds__(kCT) void cleanup_kat_kernel(const uint8_t* __restr
                                                           int force_global) {
     __shared__ CleanupShared sh;
     int size;
+    stamp(0);
     if (n <= kBitCap && !force_global) {
         const LdsBitKeys K{s_dyn_bits};
         init_bits_from_flags(K, flags, n, I);
         introsort_binary(sh, n, K, I, I2, P);
+        stamp(4);
         size = compact_kept(sh, n, K, I2, [&](int r, uint32_t id) { out[r] = id; });
+        stamp(5);
+        if (threadIdx.x == 0 && g_stamp) g_stamp[6] = (unsigned long long)sh.npure;
     } else {
         const GlobalKeys K{Kg};
         for (int i = threadIdx.x; i < n; i += kCT) {
@@ -555,6 +568,8 @@ void launch_cleanup2(hipStream_t s, int n_images, const Candidate* d_cands, long
     hipLaunchKernelGGL(cleanup2_kernel, dim3((unsigned)n_images), dim3(kCT), 0, s, d_cands, cand_cap, d_list,
                        d_list_cnt, list_cap, d_orient, wk, wi, wi2, wp, d_final, d_final_cnt, d_status);
 }
+
+void cleanup_set_stamp_buffer(unsigned long long* d) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), &d, sizeof(d)); }
 
 void launch_cleanup_kat(hipStream_t s, const uint8_t* d_flags, int n, uint8_t* wk, uint32_t* wi, uint32_t* wi2,
                         uint32_t* wp, uint32_t* d_out, int* d_info, int force_global) {

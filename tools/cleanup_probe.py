@@ -1,0 +1,13 @@
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+os.environ["SIFT_CLEANUP_STAMPS"] = "1"
+from sift_amd.sift import Context
+ctx = Context(0)
+rng = np.random.default_rng(0)
+for n, p in [(180000, 0.89), (180000, 0.89), (180000, 0.5), (20000, 0.02)]:
+    flags = (rng.random(n) < p).astype(np.uint8)
+    out = np.zeros(n, np.int32); cnt = C.c_int32()
+    for v in (1, 2):
+        print("n", n, "p", p, "variant", v, flush=True)
+        ctx._L.sift_hip_cleanup_survivors(ctx._h, flags, n, out, C.byref(cnt), v)
