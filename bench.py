@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lanes", type=int, default=2,
+    ap.add_argument("--lanes", type=int, default=1,
                     help="contexts (streams + host threads) per GPU, each taking an equal share of the batch, so one\n"
                          "lane's latency-bound stages overlap the other's bandwidth-bound ones")
     args = ap.parse_args()

@@ -376,3 +376,40 @@ def test_cpp_dropin_example(ctx, tmp_path):
         f.write(b"P5\n160 120\n255\n" + small.tobytes())
     out = subprocess.run([str(exe), "small.pgm", "4", "3", "0"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
     assert "kernel longer than line" in out.stderr
+
+
+def test_cli_result_file(ctx, tmp_path, monkeypatch):
+    """sift_amd.cli (main.cpp's options, result writer and overlay)."""
+    from sift_amd import cli
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.chdir(tmp_path)
+    import shutil
+    shutil.copy(os.path.join(root, "tests", "golden", "parrot_r.pgm"), tmp_path / "parrot_r.pgm")
+    assert cli.main(["-i", "parrot_r.pgm", "-o", "4", "-d", "3", "-r", "1"]) == 0
+    g = np.load(os.path.join(root, "tests", "golden", "case_parrot.npz"))
+    lines = open(tmp_path / "interstpoints.txt").read().splitlines()
+    assert len(lines) - 1 == int(g["counts"][-1])
+    loc, scale, ori, desc = lines[1].split("\t")
+    assert loc == f"[{int(g['kp_x'][0])}, {int(g['kp_y'][0])}]"
+    assert abs(float(ori) - float(g["kp_orientation"][0])) < 1e-3
+    assert len(desc.strip("[]").rstrip(", ").split(", ")) == 128
+    assert os.path.exists(tmp_path / "parrot_r.pgm_orientation.png")
+
+
+def test_config3_exception_and_nearest_runnable(ctx):
+    """BASELINE config 3: 1920x1080, subpixel, 4 oct x 5 DoG throws in the reference (App. B-13);
+    the nearest runnable setting (subpixel, 4 x 3) is compared in full."""
+    img = synth_frame(1920, 1080, 7)
+    run = O.OracleRun(np.zeros_like(img), 5, 4, subpixel=True)
+    assert run.status == 1 and "separableConvolveY(): kernel longer than line" in run.error
+    with pytest.raises(PreconditionViolation) as e:
+        ctx.calculate_batch(img[None], _lib.Params(5, 4, 1.6, O.K_SQRT2, 1))
+    assert str(e.value) == run.error
+    im = ctx.image(0)                              # the caller's image was already replaced (B-16)
+    assert im is not None and im.shape == (2160, 3840)
+    small = synth_frame(960, 540, 7)               # same pipeline at a quarter of the pixels (oracle time)
+    ctx.calculate_batch(small[None], _lib.Params(3, 4, 1.6, O.K_SQRT2, 1))
+    kp, desc = ctx.results()
+    want, wdesc = O.OracleRun(small, 3, 4, subpixel=True).points("final")
+    assert kp.size == want.size and (kp["x"] == want["x"]).all() and (kp["y"] == want["y"]).all()
+    assert desc.tobytes() == wdesc.tobytes()
