@@ -263,6 +263,164 @@ __global__ __launch_bounds__(256, (TH == 32 ? 4 : (R <= 8 ? 3 : (R <= 24 ? 2 : 1
 }
 
 // ---------------------------------------------------------------------------------------------
+// Streaming blur (small radii, rows that are 16-byte aligned).  Every WAVE is on its own: it owns a
+// strip of up to 256 columns (4 per lane) and a chunk of rows, and walks the chunk top to bottom:
+//   * the source row (plus RA reflected halo columns each side) is fetched PF rows ahead into
+//     registers, then dropped into a per-wave LDS row (a ring of R+1 rows when the DoG needs the
+//     source again R rows later);
+//   * row pass: ds_read_b128 window -> 4 consecutive outputs per lane, the reference's order;
+//   * column pass in REGISTERS: the 2R+1 partial sums of the lane's 4 columns slide by one each row,
+//         A[j] = A[j+1] + tap[j] * mid      (A[2R] = 0 + tap[2R] * mid)
+//     so output row y receives its terms for source rows y-R .. y+R in ascending order from 0.0f,
+//     exactly the reference's sequence; A[0] is complete after the step and is stored.
+// No workgroup barrier, no intermediate tile in LDS, no vertical halo inside a chunk: HBM sees each
+// source row once per chunk (+2R rows of run-in) and LDS traffic is the row windows only.
+// ---------------------------------------------------------------------------------------------
+// Prefetch depth: a divisor-friendly number of rows so that the 2R run-in rows are whole unrolled bodies.
+constexpr int stream_pf(int r) { return r <= 4 ? 2 * r : (r == 9 || r == 12) ? 6 : r == 10 ? 5 : r; }
+// waves per SIMD the register budget is cut for (512 VGPRs per lane per SIMD)
+constexpr int stream_occ(int r) { return r <= 5 ? 3 : 2; }
+
+template <int R, bool DOG>
+__global__ __launch_bounds__(256, stream_occ(R)) void blur_stream_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          float* __restrict__ dog, int w, int h, int strips,
+                                                          int strip_w, int chunks, int chunk_h, int total_units,
+                                                          const float* __restrict__ taps) {
+    constexpr int PF = stream_pf(R);
+    static_assert((2 * R) % PF == 0, "run-in must be whole bodies");
+    constexpr int RA = (R + 3) & ~3;
+    constexpr int PAD = RA - R;
+    constexpr int NT = 2 * R + 1;
+    constexpr int ROWF = 256 + 2 * RA;   // floats per LDS row
+    constexpr int DP = DOG ? R + 1 : 1;  // ring depth
+    constexpr int NV = PAD + 4 + 2 * R;
+    constexpr int NV4 = (NV + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float s_ring[4][DP * ROWF + 64];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int unit = (int)blockIdx.x * 4 + wave;
+    if (unit >= total_units) return;
+    const int per_img = strips * chunks;
+    const int img = unit / per_img;
+    const int rem = unit - img * per_img;
+    const int chunk = rem / strips;
+    const int strip = rem - chunk * strips;
+    const int xs = strip * strip_w;
+    const int sw = min(strip_w, w - xs);
+    // every chunk is chunk_h rows (a multiple of PF); the last one is pulled up to end at the image's
+    // last row and rewrites a few rows of its neighbour with the same values
+    const int y0 = min(chunk * chunk_h, h - chunk_h);
+    const int nsteps = chunk_h + 2 * R;
+
+    const float* __restrict__ src = in + (size_t)img * (size_t)w * (size_t)h;
+    const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
+    float* ring = s_ring[wave];
+
+    // Lanes beyond the strip shadow its last lane (same addresses, same values): every lane runs the
+    // same instruction stream with no predication, which keeps the compiler's vmcnt bookkeeping exact
+    // and the prefetched rows really in flight.
+    const int el = min(lane, sw / 4 - 1);
+    const int mcol = xs + 4 * el;
+    // halo: lanes < 2*RA fetch one reflected column each; the others repeat lane 0 into a dump slot
+    const bool has_halo = lane < 2 * RA;
+    const int hl = has_halo ? lane : 0;
+    const int hcol = reflect_clamp(hl < RA ? xs - RA + hl : xs + sw + (hl - RA), w);
+    const int hslot = hl < RA ? hl : RA + sw + (hl - RA);
+    const int hdump = DP * ROWF + lane;
+    // uniform row base (SGPR pair) + 32-bit per-lane byte offset: no 64-bit per-lane addresses to keep
+    const unsigned moff = 4u * (unsigned)mcol, hoff = 4u * (unsigned)hcol;
+
+    float tp[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) tp[k] = taps[k];
+
+    float4 A[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) A[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v pm[PF];
+    float ph[PF];
+    // rows past the end of the stream are clamped to a legal row and never used
+#define SIFT_STREAM_FETCH(S, U)                                                        \
+    {                                                                                  \
+        const char* rowp_ = reinterpret_cast<const char*>(src + (size_t)reflect_clamp(y0 - R + (S), h) * (size_t)w); \
+        pm[U] = *reinterpret_cast<const f4v*>(rowp_ + moff);                           \
+        ph[U] = *reinterpret_cast<const float*>(rowp_ + hoff);                         \
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) SIFT_STREAM_FETCH(u, u)
+
+    int slot = 0;                       // ring slot of step s
+    int pslot = DP > 1 ? DP - R : 0;    // ring slot of step s - R (DP = R + 1)
+
+#define SIFT_STREAM_STEP(S, U, STORE)                                                                      \
+    {                                                                                                      \
+        float* row = ring + slot * ROWF;                                                                   \
+        *reinterpret_cast<f4v*>(row + RA + 4 * el) = pm[U];                                                \
+        (has_halo ? row : ring)[has_halo ? hslot : hdump] = ph[U];                                         \
+        __builtin_amdgcn_wave_barrier();                                                                   \
+        SIFT_STREAM_FETCH((S) + PF, U)                                                                     \
+        float4 f4[NV4];                                                                                    \
+        const float4* p4 = reinterpret_cast<const float4*>(row) + el;                                      \
+        _Pragma("unroll") for (int c = 0; c < NV4; ++c) f4[c] = p4[c];                                     \
+        float v[NV4 * 4];                                                                                  \
+        _Pragma("unroll") for (int c = 0; c < NV4; ++c) {                                                  \
+            v[4 * c + 0] = f4[c].x;                                                                        \
+            v[4 * c + 1] = f4[c].y;                                                                        \
+            v[4 * c + 2] = f4[c].z;                                                                        \
+            v[4 * c + 3] = f4[c].w;                                                                        \
+        }                                                                                                  \
+        float4 m = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                                                    \
+        _Pragma("unroll") for (int k = 0; k < NT; ++k) {                                                   \
+            const float tap = tp[NT - 1 - k];                                                              \
+            m.x += tap * v[PAD + k];                                                                       \
+            m.y += tap * v[PAD + k + 1];                                                                   \
+            m.z += tap * v[PAD + k + 2];                                                                   \
+            m.w += tap * v[PAD + k + 3];                                                                   \
+        }                                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                   \
+            const float tap = tp[j];                                                                       \
+            const float4 nx = j + 1 < NT ? A[j + 1] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);                 \
+            A[j].x = nx.x + tap * m.x;                                                                     \
+            A[j].y = nx.y + tap * m.y;                                                                     \
+            A[j].z = nx.z + tap * m.z;                                                                     \
+            A[j].w = nx.w + tap * m.w;                                                                     \
+        }                                                                                                  \
+        if (STORE) {                                                                                       \
+            const int y = y0 + (S) - 2 * R;                                                                \
+            const size_t o = img_off + (size_t)y * (size_t)w;                                              \
+            if (DOG) {                                                                                     \
+                const float4 prev = *reinterpret_cast<const float4*>(ring + pslot * ROWF + RA + 4 * el);   \
+                const float dx = A[0].x - prev.x, dy = A[0].y - prev.y;                                    \
+                const float dz = A[0].z - prev.z, dw = A[0].w - prev.w;                                    \
+                *reinterpret_cast<float4*>(reinterpret_cast<char*>(dog + o) + moff) =                      \
+                    make_float4(128.0f + dx, 128.0f + dy, 128.0f + dz, 128.0f + dw);                       \
+            }                                                                                              \
+            *reinterpret_cast<float4*>(reinterpret_cast<char*>(out + o) + moff) = A[0];                    \
+        }                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        slot = slot + 1 == DP ? 0 : slot + 1;                                                              \
+        pslot = pslot + 1 == DP ? 0 : pslot + 1;                                                           \
+    }
+
+    // run-in: 2R rows that only feed the partial sums
+    int s0 = 0;
+    for (; s0 < 2 * R; s0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) SIFT_STREAM_STEP(s0 + u, u, false)
+    }
+    // steady state: whole bodies, every step stores a row (chunk_h is a multiple of PF: no tail)
+    for (; s0 < nsteps; s0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) SIFT_STREAM_STEP(s0 + u, u, true)
+    }
+#undef SIFT_STREAM_STEP
+#undef SIFT_STREAM_FETCH
+}
+
+// ---------------------------------------------------------------------------------------------
 // Two-pass fallback for any radius (r = 0 and r > kMaxRadiusFused included): the reference's own
 // structure, X pass into tmp then Y pass.  Taps in LDS.
 // ---------------------------------------------------------------------------------------------
@@ -364,8 +522,49 @@ static void launch_fused_r(hipStream_t s, const float* in, float* out, float* do
     launch_fused_rt<R, 64>(s, in, out, dog, w, h, n, d_taps);
 }
 
+static int stream_waves() {
+    static int v = [] { const char* e = getenv("SIFT_STREAM_WAVES"); return e ? atoi(e) : 2048; }();
+    return v;
+}
+
+constexpr int kMaxRadiusStream = 12;
+
+template <int R>
+static bool launch_stream_r(hipStream_t s, const float* in, float* out, float* dog, int w, int h, int n,
+                            const float* d_taps) {
+    if constexpr (R > kMaxRadiusStream) {
+        return false;
+    } else {
+        const int target = stream_waves();
+        if (target <= 0) return false;
+        const bool aligned = (((uintptr_t)in | (uintptr_t)out | (uintptr_t)dog) & 15u) == 0;
+        if (!(w % 4 == 0 && aligned) || w < 4 || h < R + 1 || w < R + 1) return false;
+        const int strips = (w + 255) / 256;
+        const int strip_w = (((w + strips - 1) / strips) + 3) & ~3;
+        int chunks = target / (n * strips);
+        if (chunks < 1) chunks = 1;
+        int chunk_h = (h + chunks - 1) / chunks;
+        if (chunk_h < 4 * R) chunk_h = 4 * R;   // keep the 2R run-in rows a minor share
+        constexpr int PF = stream_pf(R);
+        chunk_h = (chunk_h + PF - 1) / PF * PF;  // whole unrolled bodies
+        if (chunk_h > h) chunk_h = h / PF * PF;
+        if (chunk_h < PF) return false;
+        chunks = (h + chunk_h - 1) / chunk_h;
+        const int total = n * strips * chunks;
+        const int grid = (total + 3) / 4;
+        if (dog)
+            hipLaunchKernelGGL((blur_stream_kernel<R, true>), dim3((unsigned)grid), dim3(256), 0, s, in, out, dog, w, h,
+                               strips, strip_w, chunks, chunk_h, total, d_taps);
+        else
+            hipLaunchKernelGGL((blur_stream_kernel<R, false>), dim3((unsigned)grid), dim3(256), 0, s, in, out, dog, w,
+                               h, strips, strip_w, chunks, chunk_h, total, d_taps);
+        return true;
+    }
+}
+
 #define SIFT_FUSED_CASE(R) \
     case R:                \
+        if (launch_stream_r<R>(s, in, out, dog, w, h, n, d_taps)) return; \
         launch_fused_r<R>(s, in, out, dog, w, h, n, d_taps); \
         return;
 
