@@ -276,26 +276,30 @@ __global__ __launch_bounds__(256, (TH == 32 ? 4 : (R <= 8 ? 3 : (R <= 24 ? 2 : 1
 // No workgroup barrier, no intermediate tile in LDS, no vertical halo inside a chunk: HBM sees each
 // source row once per chunk (+2R rows of run-in) and LDS traffic is the row windows only.
 // ---------------------------------------------------------------------------------------------
-// Prefetch depth: a divisor-friendly number of rows so that the 2R run-in rows are whole unrolled bodies.
-constexpr int stream_pf(int r) { return r <= 4 ? 2 * r : (r == 9 || r == 12) ? 6 : r == 10 ? 5 : r; }
+constexpr int kStreamPF = 4;  // source rows in flight per wave (registers)
+// run-in rows before the first output: 2R rounded up to whole unrolled bodies (the extra leading rows
+// only feed partial sums that are never stored)
+constexpr int stream_runin(int r) { return (2 * r + kStreamPF - 1) / kStreamPF * kStreamPF; }
 // waves per SIMD the register budget is cut for (512 VGPRs per lane per SIMD)
-constexpr int stream_occ(int r) { return r <= 5 ? 3 : 2; }
+constexpr int stream_occ(int r, int cpl) { return cpl == 4 ? (r <= 8 ? 3 : 2) : (r <= 8 ? 4 : r <= 12 ? 3 : 2); }
 
-template <int R, bool DOG>
-__global__ __launch_bounds__(256, stream_occ(R)) void blur_stream_kernel(const float* __restrict__ in, float* __restrict__ out,
+template <int R, bool DOG, int CPL>
+__global__ __launch_bounds__(256, stream_occ(R, CPL)) void blur_stream_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                           float* __restrict__ dog, int w, int h, int strips,
                                                           int strip_w, int chunks, int chunk_h, int total_units,
                                                           const float* __restrict__ taps) {
-    constexpr int PF = stream_pf(R);
-    static_assert((2 * R) % PF == 0, "run-in must be whole bodies");
-    constexpr int RA = (R + 3) & ~3;
+    constexpr int PF = kStreamPF;
+    constexpr int RI = stream_runin(R);
+    constexpr int E = RI - 2 * R;
+    constexpr int RA = (R + CPL - 1) / CPL * CPL;  // halo columns each side, a whole number of lane vectors
     constexpr int PAD = RA - R;
     constexpr int NT = 2 * R + 1;
-    constexpr int ROWF = 256 + 2 * RA;   // floats per LDS row
-    constexpr int DP = DOG ? R + 1 : 1;  // ring depth
-    constexpr int NV = PAD + 4 + 2 * R;
-    constexpr int NV4 = (NV + 3) / 4;
-    __shared__ __attribute__((aligned(16))) float s_ring[4][DP * ROWF + 64];
+    constexpr int ROWF = 64 * CPL + 2 * RA;  // floats per LDS row
+    constexpr int DP = DOG ? R + 2 : 1;  // ring depth: rows s-R .. s+1 are live when the DoG reads its source
+    constexpr int NV = PAD + CPL + 2 * R;
+    constexpr int NV4 = (NV + CPL - 1) / CPL;  // lane vectors per window
+    __shared__ __attribute__((aligned(16))) float s_ring[4][DP * ROWF];
+    typedef float f4v __attribute__((ext_vector_type(CPL)));  // CPL consecutive columns of one row
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -311,23 +315,23 @@ __global__ __launch_bounds__(256, stream_occ(R)) void blur_stream_kernel(const f
     // every chunk is chunk_h rows (a multiple of PF); the last one is pulled up to end at the image's
     // last row and rewrites a few rows of its neighbour with the same values
     const int y0 = min(chunk * chunk_h, h - chunk_h);
-    const int nsteps = chunk_h + 2 * R;
+    const int nsteps = chunk_h + RI;
+    const int p0 = y0 - R - E;  // source row of stream index 0 (reflected)
 
     const float* __restrict__ src = in + (size_t)img * (size_t)w * (size_t)h;
     const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
     float* ring = s_ring[wave];
 
     // Lanes beyond the strip shadow its last lane (same addresses, same values): every lane runs the
-    // same instruction stream with no predication, which keeps the compiler's vmcnt bookkeeping exact
-    // and the prefetched rows really in flight.
-    const int el = min(lane, sw / 4 - 1);
-    const int mcol = xs + 4 * el;
-    // halo: lanes < 2*RA fetch one reflected column each; the others repeat lane 0 into a dump slot
+    // same instruction stream and no global access sits under a branch, which keeps the compiler's
+    // vmcnt bookkeeping exact and the prefetched rows really in flight.
+    const int el = min(lane, sw / CPL - 1);
+    const int mcol = xs + CPL * el;
+    // halo: lanes < 2*RA fetch one reflected column each (the others repeat lane 0's and drop it)
     const bool has_halo = lane < 2 * RA;
     const int hl = has_halo ? lane : 0;
     const int hcol = reflect_clamp(hl < RA ? xs - RA + hl : xs + sw + (hl - RA), w);
     const int hslot = hl < RA ? hl : RA + sw + (hl - RA);
-    const int hdump = DP * ROWF + lane;
     // uniform row base (SGPR pair) + 32-bit per-lane byte offset: no 64-bit per-lane addresses to keep
     const unsigned moff = 4u * (unsigned)mcol, hoff = 4u * (unsigned)hcol;
 
@@ -335,88 +339,90 @@ __global__ __launch_bounds__(256, stream_occ(R)) void blur_stream_kernel(const f
 #pragma unroll
     for (int k = 0; k < NT; ++k) tp[k] = taps[k];
 
-    float4 A[NT];
+    f4v A[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) A[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int j = 0; j < NT; ++j) A[j] = (f4v)(0.0f);
 
-    typedef float f4v __attribute__((ext_vector_type(4)));
     f4v pm[PF];
     float ph[PF];
+    f4v W[NV4];
     // rows past the end of the stream are clamped to a legal row and never used
-#define SIFT_STREAM_FETCH(S, U)                                                        \
-    {                                                                                  \
-        const char* rowp_ = reinterpret_cast<const char*>(src + (size_t)reflect_clamp(y0 - R + (S), h) * (size_t)w); \
-        pm[U] = *reinterpret_cast<const f4v*>(rowp_ + moff);                           \
-        ph[U] = *reinterpret_cast<const float*>(rowp_ + hoff);                         \
+#define SIFT_STREAM_FETCH(T, U)                                                                                       \
+    {                                                                                                                 \
+        const char* rowp_ = reinterpret_cast<const char*>(src + (size_t)reflect_clamp(p0 + (T), h) * (size_t)w);      \
+        pm[U] = *reinterpret_cast<const f4v*>(rowp_ + moff);                                                          \
+        ph[U] = *reinterpret_cast<const float*>(rowp_ + hoff);                                                        \
+    }
+    // LDS stage of stream row T (held in pm[U]): into the ring, refill pm[U] from HBM, read the window
+#define SIFT_STREAM_LDS(T, U)                                                                                         \
+    {                                                                                                                 \
+        float* row_ = ring + wslot * ROWF;                                                                            \
+        *reinterpret_cast<f4v*>(row_ + RA + CPL * el) = pm[U];                                                          \
+        if (has_halo) row_[hslot] = ph[U];                                                                            \
+        __builtin_amdgcn_wave_barrier();                                                                              \
+        SIFT_STREAM_FETCH((T) + PF, U)                                                                                \
+        const f4v* p4_ = reinterpret_cast<const f4v*>(row_) + el;                                                     \
+        _Pragma("unroll") for (int c = 0; c < NV4; ++c) W[c] = p4_[c];                                                \
+        wslot = wslot + 1 == DP ? 0 : wslot + 1;                                                                      \
     }
 #pragma unroll
     for (int u = 0; u < PF; ++u) SIFT_STREAM_FETCH(u, u)
 
-    int slot = 0;                       // ring slot of step s
-    int pslot = DP > 1 ? DP - R : 0;    // ring slot of step s - R (DP = R + 1)
+    int wslot = 0;                 // ring slot the next LDS stage writes
+    int pslot = DP > 1 ? 2 : 0;    // ring slot of stream row s - R   (-R mod (R + 2))
+    SIFT_STREAM_LDS(0, 0)
 
-#define SIFT_STREAM_STEP(S, U, STORE)                                                                      \
-    {                                                                                                      \
-        float* row = ring + slot * ROWF;                                                                   \
-        *reinterpret_cast<f4v*>(row + RA + 4 * el) = pm[U];                                                \
-        (has_halo ? row : ring)[has_halo ? hslot : hdump] = ph[U];                                         \
-        __builtin_amdgcn_wave_barrier();                                                                   \
-        SIFT_STREAM_FETCH((S) + PF, U)                                                                     \
-        float4 f4[NV4];                                                                                    \
-        const float4* p4 = reinterpret_cast<const float4*>(row) + el;                                      \
-        _Pragma("unroll") for (int c = 0; c < NV4; ++c) f4[c] = p4[c];                                     \
-        float v[NV4 * 4];                                                                                  \
-        _Pragma("unroll") for (int c = 0; c < NV4; ++c) {                                                  \
-            v[4 * c + 0] = f4[c].x;                                                                        \
-            v[4 * c + 1] = f4[c].y;                                                                        \
-            v[4 * c + 2] = f4[c].z;                                                                        \
-            v[4 * c + 3] = f4[c].w;                                                                        \
-        }                                                                                                  \
-        float4 m = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                                                    \
-        _Pragma("unroll") for (int k = 0; k < NT; ++k) {                                                   \
-            const float tap = tp[NT - 1 - k];                                                              \
-            m.x += tap * v[PAD + k];                                                                       \
-            m.y += tap * v[PAD + k + 1];                                                                   \
-            m.z += tap * v[PAD + k + 2];                                                                   \
-            m.w += tap * v[PAD + k + 3];                                                                   \
-        }                                                                                                  \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                   \
-            const float tap = tp[j];                                                                       \
-            const float4 nx = j + 1 < NT ? A[j + 1] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);                 \
-            A[j].x = nx.x + tap * m.x;                                                                     \
-            A[j].y = nx.y + tap * m.y;                                                                     \
-            A[j].z = nx.z + tap * m.z;                                                                     \
-            A[j].w = nx.w + tap * m.w;                                                                     \
-        }                                                                                                  \
-        if (STORE) {                                                                                       \
-            const int y = y0 + (S) - 2 * R;                                                                \
-            const size_t o = img_off + (size_t)y * (size_t)w;                                              \
-            if (DOG) {                                                                                     \
-                const float4 prev = *reinterpret_cast<const float4*>(ring + pslot * ROWF + RA + 4 * el);   \
-                const float dx = A[0].x - prev.x, dy = A[0].y - prev.y;                                    \
-                const float dz = A[0].z - prev.z, dw = A[0].w - prev.w;                                    \
-                *reinterpret_cast<float4*>(reinterpret_cast<char*>(dog + o) + moff) =                      \
-                    make_float4(128.0f + dx, 128.0f + dy, 128.0f + dz, 128.0f + dw);                       \
-            }                                                                                              \
-            *reinterpret_cast<float4*>(reinterpret_cast<char*>(out + o) + moff) = A[0];                    \
-        }                                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                 \
-        slot = slot + 1 == DP ? 0 : slot + 1;                                                              \
-        pslot = pslot + 1 == DP ? 0 : pslot + 1;                                                           \
+    // one step: row pass of stream row S from the window read a step earlier; the next row's LDS stage
+    // is issued before the column pass so that its latency hides under it
+#define SIFT_STREAM_STEP(S, U, STORE)                                                                                 \
+    {                                                                                                                 \
+        f4v m = (f4v)(0.0f);                                                                                          \
+        {                                                                                                             \
+            float v[NV4 * CPL];                                                                                       \
+            _Pragma("unroll") for (int c = 0; c < NV4; ++c)                                                           \
+                _Pragma("unroll") for (int e = 0; e < CPL; ++e) v[CPL * c + e] = W[c][e];                             \
+            _Pragma("unroll") for (int k = 0; k < NT; ++k) {                                                          \
+                const float tap = tp[NT - 1 - k];                                                                     \
+                _Pragma("unroll") for (int e = 0; e < CPL; ++e) m[e] += tap * v[PAD + k + e];                         \
+            }                                                                                                         \
+        }                                                                                                             \
+        f4v prev = (f4v)(0.0f);                                                                                       \
+        if (DOG && (STORE)) prev = *reinterpret_cast<const f4v*>(ring + pslot * ROWF + RA + CPL * el);                  \
+        __builtin_amdgcn_wave_barrier();                                                                              \
+        SIFT_STREAM_LDS((S) + 1, ((U) + 1) % PF)                                                                      \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                              \
+            const float tap = tp[j];                                                                                  \
+            const f4v nx = j + 1 < NT ? A[j + 1] : (f4v)(0.0f);                                                       \
+            A[j] = nx + tap * m;                                                                                      \
+        }                                                                                                             \
+        if (STORE) {                                                                                                  \
+            const int y = y0 + (S) - RI;                                                                              \
+            const size_t o = img_off + (size_t)y * (size_t)w;                                                         \
+            if (DOG) {                                                                                                \
+                const f4v dif = A[0] - prev;                                                                          \
+                *reinterpret_cast<f4v*>(reinterpret_cast<char*>(dog + o) + moff) = 128.0f + dif;                      \
+            }                                                                                                         \
+            *reinterpret_cast<f4v*>(reinterpret_cast<char*>(out + o) + moff) = A[0];                                  \
+        }                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        pslot = pslot + 1 == DP ? 0 : pslot + 1;                                                                      \
     }
 
-    // run-in: 2R rows that only feed the partial sums
+    // run-in: RI rows that only feed the partial sums
     int s0 = 0;
-    for (; s0 < 2 * R; s0 += PF) {
+#pragma unroll 1
+    for (; s0 < RI; s0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) SIFT_STREAM_STEP(s0 + u, u, false)
     }
-    // steady state: whole bodies, every step stores a row (chunk_h is a multiple of PF: no tail)
+    // steady state: every step completes one output row (chunk_h is a multiple of PF: no tail)
+#pragma unroll 1
     for (; s0 < nsteps; s0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) SIFT_STREAM_STEP(s0 + u, u, true)
     }
 #undef SIFT_STREAM_STEP
+#undef SIFT_STREAM_LDS
 #undef SIFT_STREAM_FETCH
 }
 
@@ -527,38 +533,52 @@ static int stream_waves() {
     return v;
 }
 
-constexpr int kMaxRadiusStream = 12;
+constexpr int kMaxRadiusStream = 14;   // beyond: the 2R+1 partial sums per column no longer fit the register file
+constexpr int kMinStreamWaves = 1024;  // below one wave per SIMD the tile kernel's finer work units win
 
+template <int R, int CPL>
+static bool launch_stream_rc(hipStream_t s, const float* in, float* out, float* dog, int w, int h, int n,
+                             const float* d_taps) {
+    const int target = stream_waves();
+    if (target <= 0) return false;
+    const bool aligned = (((uintptr_t)in | (uintptr_t)out | (uintptr_t)dog) & (4u * CPL - 1u)) == 0;
+    if (!(w % CPL == 0 && aligned) || w < CPL || h < R + 1 || w < R + 1) return false;
+    constexpr int SW = 64 * CPL;
+    const int strips = (w + SW - 1) / SW;
+    const int strip_w = (((w + strips - 1) / strips) + CPL - 1) / CPL * CPL;
+    constexpr int PF = kStreamPF;
+    constexpr int RI = stream_runin(R);
+    int chunks = target / (n * strips);
+    if (chunks < 1) chunks = 1;
+    int chunk_h = (h + chunks - 1) / chunks;
+    if (chunk_h < 3 * RI) chunk_h = 3 * RI;  // keep the run-in rows a minor share
+    chunk_h = (chunk_h + PF - 1) / PF * PF;  // whole unrolled bodies
+    if (chunk_h > h) return false;
+    chunks = (h + chunk_h - 1) / chunk_h;
+    const int total = n * strips * chunks;
+    if (total < kMinStreamWaves) return false;
+    const int grid = (total + 3) / 4;
+    if (dog)
+        hipLaunchKernelGGL((blur_stream_kernel<R, true, CPL>), dim3((unsigned)grid), dim3(256), 0, s, in, out, dog, w, h,
+                           strips, strip_w, chunks, chunk_h, total, d_taps);
+    else
+        hipLaunchKernelGGL((blur_stream_kernel<R, false, CPL>), dim3((unsigned)grid), dim3(256), 0, s, in, out, dog, w,
+                           h, strips, strip_w, chunks, chunk_h, total, d_taps);
+    return true;
+}
+
+// 4 columns per lane while the kernel is HBM-bound (r <= 5); 2 columns per lane beyond, where the
+// arithmetic per row grows and the halved register footprint buys the waves to overlap it with HBM.
 template <int R>
 static bool launch_stream_r(hipStream_t s, const float* in, float* out, float* dog, int w, int h, int n,
                             const float* d_taps) {
     if constexpr (R > kMaxRadiusStream) {
         return false;
+    } else if constexpr (R <= 5) {
+        if (launch_stream_rc<R, 4>(s, in, out, dog, w, h, n, d_taps)) return true;
+        return false;
     } else {
-        const int target = stream_waves();
-        if (target <= 0) return false;
-        const bool aligned = (((uintptr_t)in | (uintptr_t)out | (uintptr_t)dog) & 15u) == 0;
-        if (!(w % 4 == 0 && aligned) || w < 4 || h < R + 1 || w < R + 1) return false;
-        const int strips = (w + 255) / 256;
-        const int strip_w = (((w + strips - 1) / strips) + 3) & ~3;
-        int chunks = target / (n * strips);
-        if (chunks < 1) chunks = 1;
-        int chunk_h = (h + chunks - 1) / chunks;
-        if (chunk_h < 4 * R) chunk_h = 4 * R;   // keep the 2R run-in rows a minor share
-        constexpr int PF = stream_pf(R);
-        chunk_h = (chunk_h + PF - 1) / PF * PF;  // whole unrolled bodies
-        if (chunk_h > h) chunk_h = h / PF * PF;
-        if (chunk_h < PF) return false;
-        chunks = (h + chunk_h - 1) / chunk_h;
-        const int total = n * strips * chunks;
-        const int grid = (total + 3) / 4;
-        if (dog)
-            hipLaunchKernelGGL((blur_stream_kernel<R, true>), dim3((unsigned)grid), dim3(256), 0, s, in, out, dog, w, h,
-                               strips, strip_w, chunks, chunk_h, total, d_taps);
-        else
-            hipLaunchKernelGGL((blur_stream_kernel<R, false>), dim3((unsigned)grid), dim3(256), 0, s, in, out, dog, w,
-                               h, strips, strip_w, chunks, chunk_h, total, d_taps);
-        return true;
+        return launch_stream_rc<R, 2>(s, in, out, dog, w, h, n, d_taps);
     }
 }
 
