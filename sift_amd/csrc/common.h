@@ -119,11 +119,15 @@ void launch_build_orient_in(hipStream_t s, const Candidate* d_cands, long long c
                             const int* d_list_cnt, int list_cap, int n_images, OrientIn* d_oin);
 void launch_cleanup1(hipStream_t s, int n_images, const uint8_t* d_flags, const int* d_totals, long long cand_cap,
                      uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, uint32_t* d_list, OrientIn* d_oin,
-                     const Candidate* d_cands, int list_cap, int* d_list_cnt, int* d_fallback);
+                     uint32_t* d_lrank, const Candidate* d_cands, int list_cap, int* d_list_cnt, int* d_late_cnt,
+                     int* d_fallback);
+void launch_orient_prepare(hipStream_t s, int n_images, const uint8_t* d_flags, const int* d_totals, long long cand_cap,
+                           int* d_chunk_cnt, const Candidate* d_cands, int list_cap, OrientIn* d_oin, int* d_early_cnt);
+size_t orient_prepare_chunks(long long cand_cap);
 void launch_cleanup2(hipStream_t s, int n_images, const Candidate* d_cands, long long cand_cap,
                      const uint32_t* d_list, const int* d_list_cnt, int list_cap, const OrientOut* d_orient,
-                     uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, FinalKp* d_final, int* d_final_cnt,
-                     int* d_status);
+                     const uint32_t* d_lrank, uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, FinalKp* d_final,
+                     int* d_final_cnt, int* d_status);
 void cleanup_set_stamp_buffer(unsigned long long* d);
 void launch_cleanup_kat(hipStream_t s, const uint8_t* d_flags, int n, uint8_t* wk, uint32_t* wi, uint32_t* wi2,
                         uint32_t* wp, uint32_t* d_out, int* d_info, int force_global);

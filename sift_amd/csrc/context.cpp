@@ -103,7 +103,7 @@ struct sift_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;          // side stream: work that can overlap the 1-block-per-image cleanup
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork0 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     bool fused = true;
     bool gpu_cleanup = true;
     bool profile = false;
@@ -115,6 +115,7 @@ struct sift_hip_ctx {
     DevBuf d_wk, d_wi, d_wi2, d_wp, d_status, d_tile, d_pool;
     DevBuf d_order;
     DevBuf d_list, d_list_cnt, d_orient, d_peaks, d_final, d_final_cnt, d_out_base, d_kp, d_desc;
+    DevBuf d_lrank, d_ochunk, d_ocnt;   // list position -> orientation result; kept counts per 1024 candidates; early/late counts
     HostBuf h_flags, h_orient, h_peaks;
     // results of the last batch
     std::vector<int32_t> status, counts;
@@ -394,6 +395,9 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
     c->d_list.ensure((size_t)kListCap * (size_t)n * sizeof(uint32_t));
     c->d_list_cnt.ensure((size_t)n * sizeof(int));
     c->d_order.ensure((size_t)kListCap * (size_t)n * sizeof(OrientIn));
+    c->d_lrank.ensure((size_t)kListCap * (size_t)n * sizeof(uint32_t));
+    c->d_ochunk.ensure(orient_prepare_chunks(dv.cand_capacity) * (size_t)n * sizeof(int));
+    c->d_ocnt.ensure((size_t)n * 2 * sizeof(int));
     c->d_orient.ensure((size_t)kListCap * (size_t)n * sizeof(OrientOut));
     c->d_peaks.ensure((size_t)kListCap * (size_t)n * 36 * sizeof(float));
     c->d_final.ensure((size_t)kListCap * (size_t)n * sizeof(FinalKp));
@@ -595,16 +599,20 @@ bool mid_gpu(sift_hip_ctx* c) {
     c->d_wp.ensure(per * (size_t)n * sizeof(uint32_t));
     c->d_status.ensure((size_t)n * 5 * sizeof(int));
     int* d_fb1 = c->d_status.as<int>() + (size_t)n * 4;
+    int* d_late = c->d_ocnt.as<int>() + n;
     launch_cleanup1(s, n, c->d_flags.as<uint8_t>(), c->d_totals.as<int>(), dv.cand_capacity, c->d_wk.as<uint8_t>(),
                     c->d_wi.as<uint32_t>(), c->d_wi2.as<uint32_t>(), c->d_wp.as<uint32_t>(), c->d_list.as<uint32_t>(),
-                    c->d_order.as<OrientIn>(), c->d_cands.as<Candidate>(), kListCap, c->d_list_cnt.as<int>(), d_fb1);
+                    c->d_order.as<OrientIn>(), c->d_lrank.as<uint32_t>(), c->d_cands.as<Candidate>(), kListCap,
+                    c->d_list_cnt.as<int>(), d_late, d_fb1);
+    // the side stream has meanwhile run the orientation stage for every image without u16 truncation
     SIFT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
-    launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_order.as<OrientIn>(), c->d_list_cnt.as<int>(), kListCap,
+    // late launch: only the images whose survivor list was truncated (counts are 0 for the others)
+    launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_order.as<OrientIn>(), d_late, kListCap,
                        c->d_orient.as<OrientOut>(), c->d_peaks.as<float>());
     launch_cleanup2(s, n, c->d_cands.as<Candidate>(), dv.cand_capacity, c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
-                    kListCap, c->d_orient.as<OrientOut>(), c->d_wk.as<uint8_t>(), c->d_wi.as<uint32_t>(),
-                    c->d_wi2.as<uint32_t>(), c->d_wp.as<uint32_t>(), c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(),
-                    c->d_status.as<int>());
+                    kListCap, c->d_orient.as<OrientOut>(), c->d_lrank.as<uint32_t>(), c->d_wk.as<uint8_t>(),
+                    c->d_wi.as<uint32_t>(), c->d_wi2.as<uint32_t>(), c->d_wp.as<uint32_t>(), c->d_final.as<FinalKp>(),
+                    c->d_final_cnt.as<int>(), c->d_status.as<int>());
     std::vector<int> st((size_t)n * 5);
     SIFT_HIP_CHECK(hipMemcpyAsync(st.data(), c->d_status.p, st.size() * sizeof(int), hipMemcpyDeviceToHost, s));
     SIFT_HIP_CHECK(hipStreamSynchronize(s));
@@ -638,7 +646,8 @@ void ensure_host_stages(sift_hip_ctx* c) {
     std::vector<int> cnt1((size_t)n), cnt2((size_t)n);
     SIFT_HIP_CHECK(hipMemcpy(cnt1.data(), c->d_list_cnt.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
     SIFT_HIP_CHECK(hipMemcpy(cnt2.data(), c->d_final_cnt.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
-    std::vector<OrientOut> oo;
+    std::vector<OrientOut> oo((size_t)kListCap);
+    std::vector<uint32_t> lr;
     std::vector<FinalKp> fk;
     for (int i = 0; i < n; ++i) {
         if (c->totals[(size_t)i])
@@ -647,9 +656,10 @@ void ensure_host_stages(sift_hip_ctx* c) {
                                      (size_t)c->totals[(size_t)i], hipMemcpyDeviceToHost));
         auto& l1 = c->list1[(size_t)i];
         l1.resize((size_t)cnt1[(size_t)i]);
-        oo.resize(l1.size());
+        lr.resize(l1.size());
         if (!l1.empty()) {
             SIFT_HIP_CHECK(hipMemcpy(l1.data(), c->d_list.as<uint32_t>() + (size_t)i * kListCap, l1.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            SIFT_HIP_CHECK(hipMemcpy(lr.data(), c->d_lrank.as<uint32_t>() + (size_t)i * kListCap, lr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
             SIFT_HIP_CHECK(hipMemcpy(oo.data(), c->d_orient.as<OrientOut>() + (size_t)i * kListCap, oo.size() * sizeof(OrientOut), hipMemcpyDeviceToHost));
         }
         auto& ao = c->after_orient[(size_t)i];
@@ -657,7 +667,7 @@ void ensure_host_stages(sift_hip_ctx* c) {
         ao.clear();
         fin.clear();
         if (c->status[(size_t)i]) continue;  // the reference threw inside _orientationAssignment
-        for (size_t k = 0; k < l1.size(); ++k) ao.push_back(PointRec{l1[k], oo[k].orientation, oo[k].filtered});
+        for (size_t k = 0; k < l1.size(); ++k) ao.push_back(PointRec{l1[k], oo[lr[k]].orientation, oo[lr[k]].filtered});
         fk.resize((size_t)cnt2[(size_t)i]);
         if (!fk.empty())
             SIFT_HIP_CHECK(hipMemcpy(fk.data(), c->d_final.as<FinalKp>() + (size_t)i * kListCap, fk.size() * sizeof(FinalKp), hipMemcpyDeviceToHost));
@@ -696,20 +706,31 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
         return P.fail_status;
     }
 
-    // extrema + edge responses (sift.cpp:33-34); gradient maps of the selected levels and W16
+    // Gradient maps and W16 only need the pyramid: side stream, from here on
     const DevPlan* dpl = c->d_plan.as<DevPlan>();
-    launch_extrema_mask(s, dpl, dv, c->d_masks.as<unsigned long long>(), c->d_counts.as<int>());
-    launch_extrema_scan(s, dv, c->d_counts.as<int>(), c->d_totals.as<int>());
-    launch_extrema_expand(s, dpl, dv, c->d_masks.as<unsigned long long>(), c->d_counts.as<int>(), c->d_cands.as<Candidate>());
-    launch_edge_filter(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_totals.as<int>(), c->d_flags.as<uint8_t>());
-    // Gradient maps and W16 only need the pyramid: they run on the side stream so that they fill the
-    // CUs the one-workgroup-per-image cleanup kernel leaves idle.
-    SIFT_HIP_CHECK(hipEventRecord(c->ev_fork, s));
-    SIFT_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    SIFT_HIP_CHECK(hipEventRecord(c->ev_fork0, s));
+    SIFT_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork0, 0));
     for (int lvl : P.grad_levels) {
         const int o = lvl / (D + 1);
         launch_gradient(c->stream2, dv.gauss[lvl], dv.mag[lvl], dv.ori[lvl], dv.prod[lvl], dv.obin[lvl], dv.w[o], dv.h[o], n);
         launch_w16(c->stream2, dv, lvl, c->d_taps16.as<float>(), P.radius16);
+    }
+    // extrema + edge responses (sift.cpp:33-34)
+    launch_extrema_mask(s, dpl, dv, c->d_masks.as<unsigned long long>(), c->d_counts.as<int>());
+    launch_extrema_scan(s, dv, c->d_counts.as<int>(), c->d_totals.as<int>());
+    launch_extrema_expand(s, dpl, dv, c->d_masks.as<unsigned long long>(), c->d_counts.as<int>(), c->d_cands.as<Candidate>());
+    launch_edge_filter(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_totals.as<int>(), c->d_flags.as<uint8_t>());
+    // The orientation stage is order-independent: it follows the gradient maps on the side stream, over
+    // the kept candidates in scan order, while the one-workgroup-per-image cleanup kernel emulates the
+    // reference's sort on the main stream (sift.cpp:37-47).
+    SIFT_HIP_CHECK(hipEventRecord(c->ev_fork, s));
+    SIFT_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    if (c->gpu_cleanup) {
+        launch_orient_prepare(c->stream2, n, c->d_flags.as<uint8_t>(), c->d_totals.as<int>(), dv.cand_capacity,
+                              c->d_ochunk.as<int>(), c->d_cands.as<Candidate>(), kListCap, c->d_order.as<OrientIn>(),
+                              c->d_ocnt.as<int>());
+        launch_orientation(c->stream2, dpl, dv, c->d_cands.as<Candidate>(), c->d_order.as<OrientIn>(), c->d_ocnt.as<int>(),
+                           kListCap, c->d_orient.as<OrientOut>(), c->d_peaks.as<float>());
     }
     SIFT_HIP_CHECK(hipEventRecord(c->ev_join, c->stream2));
     // cleanup, orientation assignment, cleanup (sift.cpp:37-54)
@@ -790,6 +811,7 @@ int sift_hip_create(int device, sift_hip_ctx** out, char* err, int errlen) {
         c->device = device;
         SIFT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         SIFT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork0, hipEventDisableTiming));
         SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
         *out = c;
@@ -803,11 +825,12 @@ void sift_hip_destroy(sift_hip_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->arena, &c->d_plan, &c->d_taps, &c->d_luts, &c->d_taps16, &c->d_input, &c->d_base, &c->d_tmp, &c->d_tmp2,
                       &c->d_wk, &c->d_wi, &c->d_wi2, &c->d_wp, &c->d_status, &c->d_tile, &c->d_pool, &c->d_order, &c->d_masks, &c->d_counts, &c->d_totals, &c->d_cands, &c->d_flags, &c->d_list, &c->d_list_cnt, &c->d_orient,
-                      &c->d_peaks, &c->d_final, &c->d_final_cnt, &c->d_out_base, &c->d_kp, &c->d_desc})
+                      &c->d_peaks, &c->d_final, &c->d_final_cnt, &c->d_out_base, &c->d_kp, &c->d_desc, &c->d_lrank, &c->d_ochunk, &c->d_ocnt})
         b->release();
     for (HostBuf* b : {&c->h_flags, &c->h_orient, &c->h_peaks}) b->release();
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(c->ev_fork0);
     (void)hipEventDestroy(c->ev_fork);
     (void)hipEventDestroy(c->ev_join);
     (void)hipStreamDestroy(c->stream2);

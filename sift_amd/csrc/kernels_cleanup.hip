@@ -348,8 +348,8 @@ template <class Keys>
 __device__ void cleanup1_body(CleanupShared& sh, int n, const Keys K, const uint8_t* __restrict__ fl,
                               uint32_t* __restrict__ I, uint32_t* __restrict__ I2, uint32_t* __restrict__ P,
                               uint32_t* __restrict__ out, OrientIn* __restrict__ ord,
-                              const Candidate* __restrict__ cd, int img, int* __restrict__ list_cnt,
-                              int* __restrict__ fallback) {
+                              uint32_t* __restrict__ lrank, const Candidate* __restrict__ cd, int img,
+                              int* __restrict__ list_cnt, int* __restrict__ late_cnt, int* __restrict__ fallback) {
     introsort_binary(sh, n, K, I, I2, P);
     auto make_in = [&](uint32_t cand, uint32_t kp) {
         const Candidate c = cd[cand];
@@ -361,8 +361,9 @@ __device__ void cleanup1_body(CleanupShared& sh, int n, const Keys K, const uint
     // I is free from here on: it records each survivor's list position by candidate index
     const int size = compact_kept(sh, n, K, I2, [&](int r, uint32_t id) { out[r] = id; I[id] = (uint32_t)r; }, &total);
     __syncthreads();
-    // Processing order for the (order-independent) orientation stage: ascending candidate index,
-    // i.e. the scan's spatial order, so that consecutive keypoints share most of their window.
+    // The (order-independent) orientation stage has run, or is running, on the side stream over ALL
+    // kept candidates in ascending candidate index (orient_emit_kernel); its results are addressed
+    // by that spatial rank.  lrank[r] = spatial rank of the survivor at list position r.
     if (total == size) {
         int running = 0, par = 0;
         for (int base = 0; base < n; base += 4 * kCT) {
@@ -377,15 +378,19 @@ __device__ void cleanup1_body(CleanupShared& sh, int n, const Keys K, const uint
             tile_rank4(sh, par, hit, rk, tile_total);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (hit[u]) ord[running + rk[u]] = make_in((uint32_t)pos[u], I[pos[u]]);
+                if (hit[u]) lrank[I[pos[u]]] = (uint32_t)(running + rk[u]);
             running += tile_total;
             par ^= 1;
         }
-    } else {  // u16 truncation dropped survivors: keep list order
-        for (int r = threadIdx.x; r < size; r += kCT) ord[r] = make_in(out[r], (uint32_t)r);
+    } else {  // u16 truncation dropped survivors: the orientation stage runs late, in list order
+        for (int r = threadIdx.x; r < size; r += kCT) {
+            ord[r] = make_in(out[r], (uint32_t)r);
+            lrank[r] = (uint32_t)r;
+        }
     }
     if (threadIdx.x == 0) {
         list_cnt[img] = size;
+        late_cnt[img] = total == size ? 0 : size;
         fallback[img] = sh.fallback;
     }
 }
@@ -396,9 +401,10 @@ __global__ __launch_bounds__(kCT) void cleanup1_kernel(const uint8_t* __restrict
                                                        uint8_t* __restrict__ wk, uint32_t* __restrict__ wi,
                                                        uint32_t* __restrict__ wi2, uint32_t* __restrict__ wp,
                                                        uint32_t* __restrict__ list,
-                                                       OrientIn* __restrict__ oin,
+                                                       OrientIn* __restrict__ oin, uint32_t* __restrict__ lranks,
                                                        const Candidate* __restrict__ cands, int list_cap,
-                                                       int* __restrict__ list_cnt, int* __restrict__ fallback) {
+                                                       int* __restrict__ list_cnt, int* __restrict__ late_cnt,
+                                                       int* __restrict__ fallback) {
     __shared__ CleanupShared sh;
     const int img = blockIdx.x;
     const int n = totals[img];
@@ -409,11 +415,12 @@ __global__ __launch_bounds__(kCT) void cleanup1_kernel(const uint8_t* __restrict
     const uint8_t* fl = flags + off;
     uint32_t* out = list + (size_t)img * (size_t)list_cap;
     OrientIn* ord = oin + (size_t)img * (size_t)list_cap;
+    uint32_t* lrank = lranks + (size_t)img * (size_t)list_cap;
     const Candidate* cd = cands + off;
     if (n <= kBitCap) {
         const LdsBitKeys K{s_dyn_bits};
         init_bits_from_flags(K, fl, n, I);
-        cleanup1_body(sh, n, K, fl, I, I2, P, out, ord, cd, img, list_cnt, fallback);
+        cleanup1_body(sh, n, K, fl, I, I2, P, out, ord, lrank, cd, img, list_cnt, late_cnt, fallback);
     } else {
         const GlobalKeys K{wk + off};
 #pragma unroll 4
@@ -422,7 +429,7 @@ __global__ __launch_bounds__(kCT) void cleanup1_kernel(const uint8_t* __restrict
             I[i] = (uint32_t)i;
         }
         __syncthreads();
-        cleanup1_body(sh, n, K, fl, I, I2, P, out, ord, cd, img, list_cnt, fallback);
+        cleanup1_body(sh, n, K, fl, I, I2, P, out, ord, lrank, cd, img, list_cnt, late_cnt, fallback);
     }
 }
 
@@ -438,6 +445,120 @@ __global__ void build_orient_in_kernel(const Candidate* __restrict__ cands, long
     oin[(size_t)img * (size_t)list_cap + r] = o;
 }
 
+// ---- orientation stage input, straight from the edge-filter flags ------------------------------
+// _orientationAssignment (sift.cpp:163-203) treats every point on its own, so it does not have to wait
+// for the first cleanup's ordering: the kept candidates are compacted in ascending candidate index
+// (scan order: neighbours share most of their 16x16 window) and processed on the side stream while
+// cleanup 1 emulates the sort.  Images whose kept count does not fit the u16_t size of sift.cpp:41
+// are left to the late launch that follows cleanup 1 (late_cnt).
+constexpr int kOprepChunk = 1024;   // candidates per chunk
+constexpr int kOprepGridX = 512;    // chunks are strided over this many workgroups per image
+
+__global__ __launch_bounds__(256) void orient_count_kernel(const uint8_t* __restrict__ flags,
+                                                           const int* __restrict__ totals, long long cand_cap,
+                                                           int chunks_cap, int* __restrict__ chunk_cnt) {
+    __shared__ int s_w[4];
+    const int img = blockIdx.y;
+    const int n = totals[img];
+    const uint8_t* fl = flags + (size_t)img * (size_t)cand_cap;
+    for (int chunk = blockIdx.x; chunk * kOprepChunk < n; chunk += gridDim.x) {
+        bool hit[4];
+        int c = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = chunk * kOprepChunk + u * 256 + (int)threadIdx.x;
+            hit[u] = i < n && fl[i] == 0;
+            c += __popcll(__ballot(hit[u]));
+        }
+        if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) chunk_cnt[(size_t)img * (size_t)chunks_cap + chunk] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void orient_emit_kernel(const uint8_t* __restrict__ flags,
+                                                          const int* __restrict__ totals, long long cand_cap,
+                                                          int chunks_cap, const int* __restrict__ chunk_cnt,
+                                                          const Candidate* __restrict__ cands, int list_cap,
+                                                          OrientIn* __restrict__ oin, int* __restrict__ early_cnt) {
+    __shared__ int s_red[2][4];
+    __shared__ int s_wc[4][4];
+    const int img = blockIdx.y;
+    const int n = totals[img];
+    const int nchunks = (n + kOprepChunk - 1) / kOprepChunk;
+    const uint8_t* fl = flags + (size_t)img * (size_t)cand_cap;
+    const Candidate* cd = cands + (size_t)img * (size_t)cand_cap;
+    const int* cc = chunk_cnt + (size_t)img * (size_t)chunks_cap;
+    OrientIn* ord = oin + (size_t)img * (size_t)list_cap;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (nchunks == 0 && blockIdx.x == 0 && threadIdx.x == 0) early_cnt[img] = 0;
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        // kept candidates before this chunk, and in the whole image
+        int before = 0, all = 0;
+        for (int q = threadIdx.x; q < nchunks; q += 256) {
+            const int v = cc[q];
+            all += v;
+            before += q < chunk ? v : 0;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            before += __shfl_xor(before, d);
+            all += __shfl_xor(all, d);
+        }
+        if (lane == 0) { s_red[0][wv] = before; s_red[1][wv] = all; }
+        __syncthreads();
+        before = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+        all = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+        const bool early = all <= 0xFFFF;   // u16_t size = kept count: nothing is truncated
+        if (chunk == 0 && threadIdx.x == 0) early_cnt[img] = early ? all : 0;
+        if (early) {
+            bool hit[4];
+            unsigned long long m[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = chunk * kOprepChunk + u * 256 + (int)threadIdx.x;
+                hit[u] = i < n && fl[i] == 0;
+                m[u] = __ballot(hit[u]);
+                if (lane == 0) s_wc[u][wv] = __popcll(m[u]);
+            }
+            __syncthreads();
+            int run = before;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int bw = 0, tot = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int v = s_wc[u][q];
+                    bw += q < wv ? v : 0;
+                    tot += v;
+                }
+                if (hit[u]) {
+                    const int r = run + bw + __popcll(m[u] & ((1ull << lane) - 1ull));
+                    const int i = chunk * kOprepChunk + u * 256 + (int)threadIdx.x;
+                    const Candidate c = cd[i];
+                    OrientIn o;
+                    o.x = c.x; o.y = c.y; o.octave = c.octave; o.index = c.index; o.kp = (uint32_t)r; o.pad = 0;
+                    ord[r] = o;
+                }
+                run += tot;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_orient_prepare(hipStream_t s, int n_images, const uint8_t* d_flags, const int* d_totals, long long cand_cap,
+                           int* d_chunk_cnt, const Candidate* d_cands, int list_cap, OrientIn* d_oin, int* d_early_cnt) {
+    const int chunks_cap = (int)((cand_cap + kOprepChunk - 1) / kOprepChunk);
+    const dim3 grid((unsigned)(chunks_cap < kOprepGridX ? chunks_cap : kOprepGridX), (unsigned)n_images);
+    hipLaunchKernelGGL(orient_count_kernel, grid, dim3(256), 0, s, d_flags, d_totals, cand_cap, chunks_cap, d_chunk_cnt);
+    hipLaunchKernelGGL(orient_emit_kernel, grid, dim3(256), 0, s, d_flags, d_totals, cand_cap, chunks_cap,
+                       (const int*)d_chunk_cnt, d_cands, list_cap, d_oin, d_early_cnt);
+}
+
+size_t orient_prepare_chunks(long long cand_cap) { return (size_t)((cand_cap + kOprepChunk - 1) / kOprepChunk); }
+
 // ---- cleanup 2: after orientation assignment -> FinalKp list ---------------------------------------
 // status[img*4 + {0: count, 1: fallback (depth limit or a point with several orientation peaks),
 //                 2: index of the first point whose dead blur throws (or INT_MAX), 3: its code}]
@@ -445,6 +566,7 @@ __global__ __launch_bounds__(kCT) void cleanup2_kernel(const Candidate* __restri
                                                        const uint32_t* __restrict__ list,
                                                        const int* __restrict__ list_cnt, int list_cap,
                                                        const OrientOut* __restrict__ orient,
+                                                       const uint32_t* __restrict__ lranks,
                                                        uint8_t* __restrict__ wk, uint32_t* __restrict__ wi,
                                                        uint32_t* __restrict__ wi2, uint32_t* __restrict__ wp,
                                                        FinalKp* __restrict__ finals, int* __restrict__ final_cnt,
@@ -461,6 +583,7 @@ __global__ __launch_bounds__(kCT) void cleanup2_kernel(const Candidate* __restri
     uint32_t* I2 = wi2 + off;
     uint32_t* P = wp + off;
     const OrientOut* oo = orient + off;
+    const uint32_t* lr = lranks + off;   // list position -> index of its orientation result
     if (threadIdx.x == 0) {
         s_multi = 0;
         s_throw = 0x7fffffff;
@@ -470,7 +593,7 @@ __global__ __launch_bounds__(kCT) void cleanup2_kernel(const Candidate* __restri
         const int i = base + (int)threadIdx.x;
         OrientOut o;
         o.filtered = 0; o.npeaks = 0; o.throws = 0; o.orientation = 0.0f;
-        if (i < n) o = oo[i];
+        if (i < n) o = oo[lr[i]];
         const unsigned long long m = __ballot(i < n && o.filtered != 0);
         if ((threadIdx.x & 63) == 0 && i < n) {
             const int wd = (base + ((int)threadIdx.x & ~63)) >> 5;
@@ -493,7 +616,7 @@ __global__ __launch_bounds__(kCT) void cleanup2_kernel(const Candidate* __restri
         const Candidate k = cd[c];
         FinalKp f;
         f.cand = c;
-        f.orientation = oo[id].orientation;
+        f.orientation = oo[lr[id]].orientation;
         f.x = k.x;
         f.y = k.y;
         f.octave = k.octave;
@@ -506,7 +629,7 @@ __global__ __launch_bounds__(kCT) void cleanup2_kernel(const Candidate* __restri
         status[img * 4 + 0] = thr ? 0 : size;
         status[img * 4 + 1] = (sh.fallback || s_multi) ? 1 : 0;
         status[img * 4 + 2] = s_throw;
-        status[img * 4 + 3] = thr ? oo[s_throw].throws : 0;
+        status[img * 4 + 3] = thr ? oo[lr[s_throw]].throws : 0;
     }
 }
 
@@ -545,14 +668,15 @@ __global__ __launch_bounds__(kCT) void cleanup_kat_kernel(const uint8_t* __restr
 
 void launch_cleanup1(hipStream_t s, int n_images, const uint8_t* d_flags, const int* d_totals, long long cand_cap,
                      uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, uint32_t* d_list, OrientIn* d_oin,
-                     const Candidate* d_cands, int list_cap, int* d_list_cnt, int* d_fallback) {
+                     uint32_t* d_lrank, const Candidate* d_cands, int list_cap, int* d_list_cnt, int* d_late_cnt,
+                     int* d_fallback) {
     static const bool attr_ok = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(cleanup1_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kBitCap / 8) == hipSuccess;
     }();
     (void)attr_ok;
     hipLaunchKernelGGL(cleanup1_kernel, dim3((unsigned)n_images), dim3(kCT), kBitCap / 8, s, d_flags, d_totals, cand_cap,
-                       wk, wi, wi2, wp, d_list, d_oin, d_cands, list_cap, d_list_cnt, d_fallback);
+                       wk, wi, wi2, wp, d_list, d_oin, d_lrank, d_cands, list_cap, d_list_cnt, d_late_cnt, d_fallback);
 }
 
 void launch_build_orient_in(hipStream_t s, const Candidate* d_cands, long long cand_cap, const uint32_t* d_list,
@@ -563,10 +687,10 @@ void launch_build_orient_in(hipStream_t s, const Candidate* d_cands, long long c
 
 void launch_cleanup2(hipStream_t s, int n_images, const Candidate* d_cands, long long cand_cap,
                      const uint32_t* d_list, const int* d_list_cnt, int list_cap, const OrientOut* d_orient,
-                     uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, FinalKp* d_final, int* d_final_cnt,
-                     int* d_status) {
+                     const uint32_t* d_lrank, uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, FinalKp* d_final,
+                     int* d_final_cnt, int* d_status) {
     hipLaunchKernelGGL(cleanup2_kernel, dim3((unsigned)n_images), dim3(kCT), 0, s, d_cands, cand_cap, d_list,
-                       d_list_cnt, list_cap, d_orient, wk, wi, wi2, wp, d_final, d_final_cnt, d_status);
+                       d_list_cnt, list_cap, d_orient, d_lrank, wk, wi, wi2, wp, d_final, d_final_cnt, d_status);
 }
 
 void cleanup_set_stamp_buffer(unsigned long long* d) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), &d, sizeof(d)); }
