@@ -152,7 +152,12 @@ constexpr int kDescBatch = 8;
 constexpr int kStageRow = 20;                       // staged window row: 16 samples + pad
 constexpr int kStageStride = 16 * kStageRow + 1;    // per keypoint: odd, so batch neighbours shift banks by one
 
-__global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restrict__ plan, int level,
+struct TileKp {   // what the per-pixel chains need of a keypoint
+    unsigned short x, y;
+    float orientation;
+};
+
+__global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __restrict__ plan, int level,
                                                          const FinalKp* __restrict__ finals,
                                                          const int* __restrict__ final_cnt, int final_cap,
                                                          const int* __restrict__ tile_cnt,
@@ -163,10 +168,10 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
                                                          float* __restrict__ desc_out, int dbg) {
     __shared__ __attribute__((aligned(16))) float s_ori[kExt * kExt];
     __shared__ __attribute__((aligned(16))) float s_mag[kExt * kExt];
-    __shared__ __attribute__((aligned(16))) float s_gau[kExt * kExt];
     __shared__ float s_w16[256];
     __shared__ unsigned short s_list[kTileListCap];   // vector index k of each list entry, ascending
-    __shared__ FinalKp s_fin[kTileListCap];
+    __shared__ TileKp s_fin[kTileListCap];
+    __shared__ unsigned char s_flag[kTileListCap];    // bit 0 = fails the bounds test, bit 1 = emitted by this tile
     // histogram inputs of a batch, laid out [sample-in-cell q][cell][keypoint m]: the phase-B reader
     // (thread = (m, cell), q marching) then touches 128 consecutive words per read
     __shared__ __attribute__((aligned(16))) float s_val[kStageStride * kDescBatch];
@@ -199,13 +204,13 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
     // initial gradient / Gaussian values of the extended tile: 16-byte loads (all issued before the
     // LDS stores) when rows are 16-byte aligned, scalar otherwise
     if (!(dbg & 4)) {
-        const bool vec = (w & 3) == 0 && ((((uintptr_t)gm | (uintptr_t)go | (uintptr_t)gg) & 15u) == 0);
+        const bool vec = (w & 3) == 0 && ((((uintptr_t)gm | (uintptr_t)go) & 15u) == 0);
         if (vec) {
             constexpr int R4 = kExt / 4;                 // float4 per tile row
             static_assert(kExt * R4 == 4 * 256, "tile init assumes 4 float4 per thread and array");
             const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            float4 o0 = z, o1 = z, o2 = z, o3 = z, m0 = z, m1 = z, m2 = z, m3 = z, g0 = z, g1 = z, g2 = z, g3 = z;
-#define SIFT_TILE_LOAD(i, vo, vm, vg)                                                             \
+            float4 o0 = z, o1 = z, o2 = z, o3 = z, m0 = z, m1 = z, m2 = z, m3 = z;
+#define SIFT_TILE_LOAD(i, vo, vm)                                                                 \
             {                                                                                     \
                 const int e = tid + 256 * (i);                                                    \
                 const int ly = e / R4, c4 = e - ly * R4;                                          \
@@ -214,21 +219,18 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
                     const size_t o = (size_t)Y * (size_t)w + (size_t)X;                           \
                     vo = *reinterpret_cast<const float4*>(go + o);                                \
                     vm = *reinterpret_cast<const float4*>(gm + o);                                \
-                    vg = *reinterpret_cast<const float4*>(gg + o);                                \
                 }                                                                                 \
             }
-            SIFT_TILE_LOAD(0, o0, m0, g0)
-            SIFT_TILE_LOAD(1, o1, m1, g1)
-            SIFT_TILE_LOAD(2, o2, m2, g2)
-            SIFT_TILE_LOAD(3, o3, m3, g3)
+            SIFT_TILE_LOAD(0, o0, m0)
+            SIFT_TILE_LOAD(1, o1, m1)
+            SIFT_TILE_LOAD(2, o2, m2)
+            SIFT_TILE_LOAD(3, o3, m3)
 #undef SIFT_TILE_LOAD
             float4* po = reinterpret_cast<float4*>(s_ori);
             float4* pm = reinterpret_cast<float4*>(s_mag);
-            float4* pg = reinterpret_cast<float4*>(s_gau);
             auto sw4 = [](int e) { const int ly = e / R4; return e ^ ((ly & 1) << 2); };  // same swizzle, float4 units
             po[sw4(tid)] = o0; po[sw4(tid + 256)] = o1; po[sw4(tid + 512)] = o2; po[sw4(tid + 768)] = o3;
             pm[sw4(tid)] = m0; pm[sw4(tid + 256)] = m1; pm[sw4(tid + 512)] = m2; pm[sw4(tid + 768)] = m3;
-            pg[sw4(tid)] = g0; pg[sw4(tid + 256)] = g1; pg[sw4(tid + 512)] = g2; pg[sw4(tid + 768)] = g3;
         } else {
             for (int idx = tid; idx < kExt * kExt; idx += 256) {
                 const int ly = idx / kExt, lx = idx - ly * kExt;
@@ -237,7 +239,6 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
                 const size_t o = (size_t)(ok ? Y : 0) * (size_t)w + (size_t)(ok ? X : 0);
                 s_ori[tile_idx(lx, ly)] = ok ? go[o] : 0.0f;
                 s_mag[tile_idx(lx, ly)] = ok ? gm[o] : 0.0f;
-                s_gau[tile_idx(lx, ly)] = ok ? gg[o] : 0.0f;
             }
         }
     }
@@ -249,21 +250,25 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
         bool kfilt, owned, inside;
         int lx, ly, X, Y;
     };
-    // The LDS copy of a record reuses `cand` for two per-tile flags: bit 0 = the descriptor stage's
-    // own bounds test fails (sift.cpp:65-70; never newly true after the orientation stage's
-    // stricter test), bit 1 = the keypoint's location lies in this tile's core (it is emitted here).
-    auto with_flags = [&](FinalKp f) {
+    // Two per-tile flags of a record: bit 0 = the descriptor stage's own bounds test fails
+    // (sift.cpp:65-70; never newly true after the orientation stage's stricter test), bit 1 = the
+    // keypoint's location lies in this tile's core (it is emitted here).
+    auto flags_of = [&](const FinalKp& f) {
         const int kx = f.x, ky = f.y;
         const bool kfilt = kx < kRegion || kx > w - kRegion || ky < kRegion || ky > h - kRegion;
         const bool owned = kx >= cx0 && kx < cx0 + kCore && ky >= cy0 && ky < cy0 + kCore;
-        f.cand = (kfilt ? 1u : 0u) | (owned ? 2u : 0u);
-        return f;
+        return (unsigned char)((kfilt ? 1u : 0u) | (owned ? 2u : 0u));
     };
-    auto geometry = [&](const FinalKp& f) {
+    auto compact = [](const FinalKp& f) {
+        TileKp t;
+        t.x = f.x; t.y = f.y; t.orientation = f.orientation;
+        return t;
+    };
+    auto geometry = [&](const TileKp& f, unsigned fl) {
         Geo g;
         const int kx = f.x, ky = f.y;
-        g.kfilt = (f.cand & 1u) != 0;
-        g.owned = (f.cand & 2u) != 0;
+        g.kfilt = (fl & 1u) != 0;
+        g.owned = (fl & 2u) != 0;
         g.lx = (rx - (kx - kRegion)) & 15;   // window-local x of the pixel with X = rx (mod 16)
         g.ly = (ry - (ky - kRegion)) & 15;
         g.X = kx - kRegion + g.lx;
@@ -278,14 +283,29 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
     auto lds_only_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     auto run_segment = [&](int n_seg) {
         for (int e0 = 0; e0 < n_seg; e0 += kDescBatch) {
+            // the Gaussian-level pixels of the keypoints this tile emits come straight from HBM/L2 (read
+            // once each, no reuse): issued for the whole batch before the chains start
+            float pg[kDescBatch];
+#pragma unroll
+            for (int m = 0; m < kDescBatch; ++m) {
+                pg[m] = 0.0f;
+                if (e0 + m < n_seg) {
+                    const unsigned fl = s_flag[e0 + m];
+                    if (fl == 2u) {   // emitted here and inside the bounds: the whole window lies in the image
+                        const Geo g = geometry(s_fin[e0 + m], fl);
+                        pg[m] = gg[(size_t)g.Y * (size_t)w + (size_t)g.X];
+                    }
+                }
+            }
             if (!(dbg & 1))
             // ---- phase A: per-pixel chains, no barrier -------------------------------------------------
 #pragma unroll
             for (int m = 0; m < kDescBatch; ++m) {
                 if (e0 + m < n_seg) {
-                    const FinalKp f = s_fin[e0 + m];
-                    const Geo g = geometry(f);
-                    if (!g.kfilt) {
+                    const TileKp f = s_fin[e0 + m];
+                    const Geo g = geometry(f, s_flag[e0 + m]);
+                    // a wave none of whose pixels falls into the tile has nothing to do for this keypoint
+                    if (!g.kfilt && __builtin_amdgcn_ballot_w64(g.inside) != 0ull) {
                         float o = 0.0f, mg = 0.0f;
                         if (g.inside) {
                             const int idx = tile_idx(g.X - ex0, g.Y - ey0);
@@ -297,7 +317,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
                         if (g.owned) {
                             // alg::orientationHistogram8 inputs in descriptor order: cell = (x/4)*4 + y/4
                             // (x outer, sift.cpp:95-96), inside a cell x outer, y inner
-                            const float sum = mg * s_gau[tile_idx(g.X - ex0, g.Y - ey0)];
+                            const float sum = mg * pg[m];
                             unsigned i = f32_to_u16_x86_d(__builtin_floorf(o / 45.0f));
                             i = i % 7u;
                             const int slot = m * kStageStride + g.ly * kStageRow + g.lx;  // window layout, padded rows
@@ -314,9 +334,9 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
                 const int sbase = m * kStageStride + (cell & 3) * 4 * kStageRow + (cell >> 2) * 4;
                 const int e = e0 + m;
                 if (e < n_seg) {
-                    const FinalKp f = s_fin[e];
-                    const bool kfilt = (f.cand & 1u) != 0;
-                    const bool owned = (f.cand & 2u) != 0;
+                    const unsigned fl = s_flag[e];
+                    const bool kfilt = (fl & 1u) != 0;
+                    const bool owned = (fl & 2u) != 0;
                     if (owned) {
                         const long long ok = obase + (long long)s_list[e];
                         float h0 = 0.0f, h1 = 0.0f, h2 = 0.0f, h3 = 0.0f, h4 = 0.0f, h5 = 0.0f, h6 = 0.0f;
@@ -349,6 +369,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
                         dst[0] = make_float4(h0, h1, h2, h3);
                         dst[1] = make_float4(h4, h5, h6, h7);
                         if (cell == 0) {
+                            const FinalKp f = fin[s_list[e]];
                             sift_hip_keypoint r;
                             r.scale = plan->dog_scale[f.octave * D + f.index];
                             r.orientation = f.orientation;
@@ -382,7 +403,8 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
             int r = 0;
             for (int j = 0; j < n_tile; ++j) r += s_raw[j].cand < v;
             s_list[r] = (unsigned short)v;
-            s_fin[r] = with_flags(rec);
+            s_fin[r] = compact(rec);
+            s_flag[r] = flags_of(rec);
         }
         __syncthreads();
         if (!(dbg & 8)) run_segment(n_tile);
@@ -417,7 +439,8 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const DevPlan* __restri
             if (hit) {
                 const int p = off + __popcll(m & ((1ull << lane) - 1ull));
                 s_list[p] = (unsigned short)k;
-                s_fin[p] = with_flags(f);
+                s_fin[p] = compact(f);
+                s_flag[p] = flags_of(f);
             }
             __syncthreads();
             if (tid == 0) s_n = n_before + s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
