@@ -185,12 +185,12 @@ void run_blur(sift_hip_ctx* c, const float* in, float* out, float* dog, int w, i
     if (c->profile) {
         a = get_event(c);
         b = get_event(c);
-        SIFT_HIP_CHECK(hipEventRecord(a, c->stream));
     }
+    // the events ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL): start/stop are the
+    // kernel's begin/end timestamps and back-to-back launches stay back-to-back
     launch_blur(c->stream, c->fused, in, c->d_tmp.as<float>(), out, dog, w, h, n, c->d_taps.as<float>() + tap_off,
-                radius);
+                radius, a, b);
     if (c->profile) {
-        SIFT_HIP_CHECK(hipEventRecord(b, c->stream));
         const double px = (double)w * (double)h * (double)n;
         c->pending.push_back({a, b, is_fused ? 0 : 1, px * (dog ? 12.0 : 8.0)});
     }

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(1024) void desc_tile_scan_kernel(const int* __restr
 // values: they are staged per keypoint in LDS, kDescBatch keypoints at a time (two barriers per
 // batch), and built by all 256 threads, two keypoints at once.
 constexpr int kDescBatch = 8;
+constexpr int kDescHalf = 4;                       // keypoints whose pixel reads are issued together
 constexpr int kStageRow = 20;                       // staged window row: 16 samples + pad
 constexpr int kStageStride = 16 * kStageRow + 1;    // per keypoint: odd, so batch neighbours shift banks by one
 
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __res
     __shared__ __attribute__((aligned(16))) float s_mag[kExt * kExt];
     __shared__ float s_w16[256];
     __shared__ unsigned short s_list[kTileListCap];   // vector index k of each list entry, ascending
-    __shared__ TileKp s_fin[kTileListCap];
+    __shared__ __attribute__((aligned(8))) TileKp s_fin[kTileListCap];
     __shared__ unsigned char s_flag[kTileListCap];    // bit 0 = fails the bounds test, bit 1 = emitted by this tile
     // histogram inputs of a batch, laid out [sample-in-cell q][cell][keypoint m]: the phase-B reader
     // (thread = (m, cell), q marching) then touches 128 consecutive words per read
@@ -246,10 +247,6 @@ __global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __res
 
     const int rx = tid & 15, ry = tid >> 4;  // residues of the pixels this thread owns
 
-    struct Geo {   // this thread's pixel inside keypoint f's window
-        bool kfilt, owned, inside;
-        int lx, ly, X, Y;
-    };
     // Two per-tile flags of a record: bit 0 = the descriptor stage's own bounds test fails
     // (sift.cpp:65-70; never newly true after the orientation stage's stricter test), bit 1 = the
     // keypoint's location lies in this tile's core (it is emitted here).
@@ -264,111 +261,149 @@ __global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __res
         t.x = f.x; t.y = f.y; t.orientation = f.orientation;
         return t;
     };
-    auto geometry = [&](const TileKp& f, unsigned fl) {
-        Geo g;
-        const int kx = f.x, ky = f.y;
-        g.kfilt = (fl & 1u) != 0;
-        g.owned = (fl & 2u) != 0;
-        g.lx = (rx - (kx - kRegion)) & 15;   // window-local x of the pixel with X = rx (mod 16)
-        g.ly = (ry - (ky - kRegion)) & 15;
-        g.X = kx - kRegion + g.lx;
-        g.Y = ky - kRegion + g.ly;
-        const int ex = g.X - ex0, ey = g.Y - ey0;
-        g.inside = ex >= 0 && ex < kExt && ey >= 0 && ey < kExt;
-        return g;
-    };
-
     // Processes the ordered entries s_fin[0..n_seg) / s_list[0..n_seg).
     // cross-thread data only moves through LDS here: do not drain the output stores at barriers
     auto lds_only_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     auto run_segment = [&](int n_seg) {
+        // whole batches: the tail is padded with records that fail the bounds test (no access, no output)
+        for (int i = n_seg + tid; i < ((n_seg + kDescBatch - 1) & ~(kDescBatch - 1)); i += 256) {
+            TileKp z;
+            z.x = z.y = 0; z.orientation = 0.0f;
+            s_fin[i] = z;
+            s_flag[i] = 1;
+        }
+        lds_only_barrier();
         for (int e0 = 0; e0 < n_seg; e0 += kDescBatch) {
+            // Record fields are the same for every lane of a wave: they are moved to scalar registers, so
+            // the per-keypoint window arithmetic is mostly SALU and the kept / emitted tests are scalar
+            // branches.  The list is padded to whole batches with records that fail the bounds test.
+#define SIFT_DESC_RECORD(E, WX, WY, FL, ORI)                                                                     \
+            const uint2 rec_ = *reinterpret_cast<const uint2*>(&s_fin[E]);                                       \
+            const unsigned xy_ = __builtin_amdgcn_readfirstlane(rec_.x);                                         \
+            const float ORI = __uint_as_float(__builtin_amdgcn_readfirstlane(rec_.y));                           \
+            const unsigned FL = __builtin_amdgcn_readfirstlane((unsigned)s_flag[E]);                             \
+            const int WX = (int)(xy_ & 0xffffu) - kRegion, WY = (int)(xy_ >> 16) - kRegion;
             // the Gaussian-level pixels of the keypoints this tile emits come straight from HBM/L2 (read
             // once each, no reuse): issued for the whole batch before the chains start
             float pg[kDescBatch];
 #pragma unroll
             for (int m = 0; m < kDescBatch; ++m) {
                 pg[m] = 0.0f;
-                if (e0 + m < n_seg) {
-                    const unsigned fl = s_flag[e0 + m];
-                    if (fl == 2u) {   // emitted here and inside the bounds: the whole window lies in the image
-                        const Geo g = geometry(s_fin[e0 + m], fl);
-                        pg[m] = gg[(size_t)g.Y * (size_t)w + (size_t)g.X];
-                    }
+                SIFT_DESC_RECORD(e0 + m, wx, wy, fl, ori_unused)
+                (void)ori_unused;
+                if (fl == 2u) {   // emitted here and inside the bounds: the whole window lies in the image
+                    const int X = wx + ((rx - wx) & 15), Y = wy + ((ry - wy) & 15);
+                    pg[m] = gg[(size_t)Y * (size_t)w + (size_t)X];
                 }
             }
-            if (!(dbg & 1))
             // ---- phase A: per-pixel chains, no barrier -------------------------------------------------
+            // A thread owns one pixel of every window, and two keypoints of a batch rarely share it.  So
+            // the LDS reads of kDescHalf keypoints are issued together and the (rare) read-after-write
+            // between them is resolved in registers: keypoint j takes its input from the latest earlier
+            // keypoint of the group with the same LDS index, else from LDS.  Writes go out in keypoint
+            // order (LDS executes a wave's accesses in order), so the last one wins, as in the
+            // reference's sequential in-place updates (sift.cpp:80-92).
+            if (!(dbg & 1))
 #pragma unroll
-            for (int m = 0; m < kDescBatch; ++m) {
-                if (e0 + m < n_seg) {
-                    const TileKp f = s_fin[e0 + m];
-                    const Geo g = geometry(f, s_flag[e0 + m]);
-                    // a wave none of whose pixels falls into the tile has nothing to do for this keypoint
-                    if (!g.kfilt && __builtin_amdgcn_ballot_w64(g.inside) != 0ull) {
-                        float o = 0.0f, mg = 0.0f;
-                        if (g.inside) {
-                            const int idx = tile_idx(g.X - ex0, g.Y - ey0);
-                            o = s_ori[idx] + f.orientation;            // sift.cpp:82
-                            s_ori[idx] = o;
-                            mg = s_mag[idx] + s_w16[g.lx + 16 * g.ly];  // sift.cpp:90, weighting(x, y) window-local
-                            s_mag[idx] = mg;
-                        }
-                        if (g.owned) {
-                            // alg::orientationHistogram8 inputs in descriptor order: cell = (x/4)*4 + y/4
-                            // (x outer, sift.cpp:95-96), inside a cell x outer, y inner
-                            const float sum = mg * pg[m];
-                            unsigned i = f32_to_u16_x86_d(__builtin_floorf(o / 45.0f));
-                            i = i % 7u;
-                            const int slot = m * kStageStride + g.ly * kStageRow + g.lx;  // window layout, padded rows
-                            s_val[slot] = sum;
-                            s_bin[slot] = (unsigned char)i;
-                        }
-                    }
+            for (int hb = 0; hb < kDescBatch; hb += kDescHalf) {
+                int idx[kDescHalf], stg[kDescHalf];
+                bool own[kDescHalf];
+                float ro[kDescHalf], rm[kDescHalf], wt[kDescHalf], orient[kDescHalf];
+#pragma unroll
+                for (int j = 0; j < kDescHalf; ++j) {
+                    SIFT_DESC_RECORD(e0 + hb + j, wx, wy, fl, ori)
+                    const int lx = (rx - wx) & 15, ly = (ry - wy) & 15;   // window-local position of this thread's pixel
+                    const int ex = lx + (wx - ex0), ey = ly + (wy - ey0);
+                    const bool in = (unsigned)(ex | ey) < (unsigned)kExt && (fl & 1u) == 0u;
+                    idx[j] = in ? tile_idx(ex, ey) : -1 - j;   // no access: unique, matches nothing
+                    own[j] = fl == 2u;
+                    orient[j] = ori;
+                    wt[j] = s_w16[lx + 16 * ly];   // weighting(x, y), window-local (sift.cpp:90)
+                    stg[j] = (hb + j) * kStageStride + ly * kStageRow + lx;  // window layout, padded rows
                 }
+#pragma unroll
+                for (int j = 0; j < kDescHalf; ++j) {
+                    const int ri = idx[j] < 0 ? 0 : idx[j];   // idle lanes read a harmless word
+                    ro[j] = s_ori[ri];
+                    rm[j] = s_mag[ri];
+                }
+                float no[kDescHalf], nm[kDescHalf];
+#pragma unroll
+                for (int j = 0; j < kDescHalf; ++j) {
+                    float o = ro[j], mg = rm[j];
+#pragma unroll
+                    for (int i = 0; i < j; ++i)
+                        if (idx[i] == idx[j]) {
+                            o = no[i];
+                            mg = nm[i];
+                        }
+                    no[j] = o + orient[j];   // sift.cpp:82
+                    nm[j] = mg + wt[j];      // sift.cpp:90
+                }
+#pragma unroll
+                for (int j = 0; j < kDescHalf; ++j)
+                    if (idx[j] >= 0) {
+                        s_ori[idx[j]] = no[j];
+                        s_mag[idx[j]] = nm[j];
+                    }
+#pragma unroll
+                for (int j = 0; j < kDescHalf; ++j)
+                    if (own[j]) {   // scalar; every pixel of an emitted keypoint's window is inside the tile
+                        // alg::orientationHistogram8 inputs in descriptor order: cell = (x/4)*4 + y/4
+                        // (x outer, sift.cpp:95-96), inside a cell x outer, y inner
+                        const float sum = nm[j] * pg[hb + j];
+                        unsigned i = f32_to_u16_x86_d(__builtin_floorf(no[j] / 45.0f));
+                        i = i % 7u;
+                        s_val[stg[j]] = sum;
+                        s_bin[stg[j]] = (unsigned char)i;
+                    }
             }
+#undef SIFT_DESC_RECORD
             lds_only_barrier();
-            // ---- phase B: one thread per (keypoint of the batch, cell): 8 bins in registers --------------
-            if (!(dbg & 2) && tid < 16 * kDescBatch) {
-                const int m = tid >> 4, cell = tid & 15;   // cell = (x/4)*4 + y/4, sift.cpp:95-96
+            // ---- phase B: two threads per (keypoint of the batch, cell): bins 0-3 and 4-7 in registers ------
+            if (!(dbg & 2)) {
+                const int m = tid >> 5, cell = (tid >> 1) & 15, half = tid & 1;   // cell = (x/4)*4 + y/4, sift.cpp:95-96
                 const int sbase = m * kStageStride + (cell & 3) * 4 * kStageRow + (cell >> 2) * 4;
                 const int e = e0 + m;
                 if (e < n_seg) {
                     const unsigned fl = s_flag[e];
                     const bool kfilt = (fl & 1u) != 0;
                     const bool owned = (fl & 2u) != 0;
-                    if (owned) {
+                    if (owned) {   // uniform over the 32 threads of a keypoint (partners included)
                         const long long ok = obase + (long long)s_list[e];
-                        float h0 = 0.0f, h1 = 0.0f, h2 = 0.0f, h3 = 0.0f, h4 = 0.0f, h5 = 0.0f, h6 = 0.0f;
-                        float h7 = 0.0f;  // bin 7 is never written (the index is taken % 7) but is normalised
+                        // bin 7 is never written (the index is taken % 7) but is normalised: a = bins 0|4, ... d = 3|7
+                        float ha = 0.0f, hb2 = 0.0f, hc = 0.0f, hd = 0.0f;
                         if (!kfilt) {
                             // alg::orientationHistogram8: samples of the cell in x-outer / y-inner order
+                            const unsigned b0 = half ? 4u : 0u;
 #pragma unroll
                             for (int q = 0; q < 16; ++q) {
                                 const int at = sbase + (q & 3) * kStageRow + (q >> 2);   // x outer, y inner
                                 const float v = s_val[at];
-                                const unsigned b = s_bin[at];
-                                h0 = (b == 0u) ? h0 + v : h0;
-                                h1 = (b == 1u) ? h1 + v : h1;
-                                h2 = (b == 2u) ? h2 + v : h2;
-                                h3 = (b == 3u) ? h3 + v : h3;
-                                h4 = (b == 4u) ? h4 + v : h4;
-                                h5 = (b == 5u) ? h5 + v : h5;
-                                h6 = (b == 6u) ? h6 + v : h6;
+                                const unsigned b = (unsigned)s_bin[at] - b0;
+                                ha = (b == 0u) ? ha + v : ha;
+                                hb2 = (b == 1u) ? hb2 + v : hb2;
+                                hc = (b == 2u) ? hc + v : hc;
+                                hd = (b == 3u) ? hd + v : hd;     // b == 3 with half: bin 7, never produced
                             }
                             // alg::normalizeVector: length = b0 + ... + b7 sequentially; skip if 0
-                            float length = 0.0f;
-                            length += h0; length += h1; length += h2; length += h3;
-                            length += h4; length += h5; length += h6; length += h7;
+                            float lo = 0.0f;
+                            lo += ha; lo += hb2; lo += hc; lo += hd;               // bins 0..3 (used by half 0)
+                            const float lo_partner = __shfl_xor(lo, 1);            // half 1 receives bins 0..3's sum
+                            float length = lo;
+                            if (half) {
+                                length = lo_partner;
+                                length += ha; length += hb2; length += hc; length += hd;   // + bins 4..7
+                            }
+                            const float len_partner = __shfl_xor(length, 1);       // half 0 receives the full length
+                            if (!half) length = len_partner;
                             if (!(length == 0.0f)) {
-                                h0 = h0 / length; h1 = h1 / length; h2 = h2 / length; h3 = h3 / length;
-                                h4 = h4 / length; h5 = h5 / length; h6 = h6 / length; h7 = h7 / length;
+                                ha = ha / length; hb2 = hb2 / length; hc = hc / length; hd = hd / length;
                             }
                         }
                         float4* dst = reinterpret_cast<float4*>(desc_out + (size_t)ok * 128 + (size_t)cell * 8);
-                        dst[0] = make_float4(h0, h1, h2, h3);
-                        dst[1] = make_float4(h4, h5, h6, h7);
-                        if (cell == 0) {
+                        dst[half] = make_float4(ha, hb2, hc, hd);
+                        if (cell == 0 && half == 0) {
                             const FinalKp f = fin[s_list[e]];
                             sift_hip_keypoint r;
                             r.scale = plan->dog_scale[f.octave * D + f.index];
@@ -391,6 +426,7 @@ __global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __res
 
     // the unsorted records are staged in the (not yet used) histogram staging area
     static_assert(sizeof(FinalKp) * kTileListCap <= sizeof(float) * kStageStride * kDescBatch, "s_raw overlay");
+    static_assert(kTileListCap % kDescBatch == 0 && sizeof(TileKp) == 8, "list padding / record layout");
     FinalKp* s_raw = reinterpret_cast<FinalKp*>(s_val);
     if (n_tile <= kTileListCap) {
         // fetch the tile's list and rank-sort it by vector index (indices are unique)

@@ -13,6 +13,8 @@
 // reflect(p) = -p for p < 0, 2(w-1)-p for p >= w.
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "common.h"
 
 #pragma clang fp contract(off)
@@ -493,6 +495,10 @@ __global__ void dog_kernel(const float* __restrict__ lower, const float* __restr
     out[i] = 128.0f + dif;
 }
 
+// Optional timing events of the launch in progress: handed to hipExtLaunchKernelGGL, which stamps them
+// from the dispatch packet itself (no extra barrier packets between back-to-back launches).
+static thread_local hipEvent_t t_ev_start = nullptr, t_ev_stop = nullptr;
+
 static int blur_th() {
     static int th = [] { const char* e = getenv("SIFT_BLUR_TH"); return e ? atoi(e) : 64; }();
     return th;
@@ -509,10 +515,10 @@ static void launch_fused_rt(hipStream_t s, const float* in, float* out, float* d
     const bool aligned = (((uintptr_t)in | (uintptr_t)out | (uintptr_t)dog) & 15u) == 0;
     const int vec_ok = (w % 4 == 0 && aligned) ? 1 : 0;
     if (dog)
-        hipLaunchKernelGGL((blur_fused_kernel<R, true, TH>), dim3((unsigned)grid), dim3(256), 0, s, in, out, dog, w, h,
+        hipExtLaunchKernelGGL((blur_fused_kernel<R, true, TH>), dim3((unsigned)grid), dim3(256), 0, s, t_ev_start, t_ev_stop, 0, in, out, dog, w, h,
                            tiles_x, tiles_y, total, vec_ok, d_taps);
     else
-        hipLaunchKernelGGL((blur_fused_kernel<R, false, TH>), dim3((unsigned)grid), dim3(256), 0, s, in, out, dog, w, h,
+        hipExtLaunchKernelGGL((blur_fused_kernel<R, false, TH>), dim3((unsigned)grid), dim3(256), 0, s, t_ev_start, t_ev_stop, 0, in, out, dog, w, h,
                            tiles_x, tiles_y, total, vec_ok, d_taps);
 }
 
@@ -559,10 +565,10 @@ static bool launch_stream_rc(hipStream_t s, const float* in, float* out, float* 
     if (total < kMinStreamWaves) return false;
     const int grid = (total + 3) / 4;
     if (dog)
-        hipLaunchKernelGGL((blur_stream_kernel<R, true, CPL>), dim3((unsigned)grid), dim3(256), 0, s, in, out, dog, w, h,
+        hipExtLaunchKernelGGL((blur_stream_kernel<R, true, CPL>), dim3((unsigned)grid), dim3(256), 0, s, t_ev_start, t_ev_stop, 0, in, out, dog, w, h,
                            strips, strip_w, chunks, chunk_h, total, d_taps);
     else
-        hipLaunchKernelGGL((blur_stream_kernel<R, false, CPL>), dim3((unsigned)grid), dim3(256), 0, s, in, out, dog, w,
+        hipExtLaunchKernelGGL((blur_stream_kernel<R, false, CPL>), dim3((unsigned)grid), dim3(256), 0, s, t_ev_start, t_ev_stop, 0, in, out, dog, w,
                            h, strips, strip_w, chunks, chunk_h, total, d_taps);
     return true;
 }
@@ -589,7 +595,11 @@ static bool launch_stream_r(hipStream_t s, const float* in, float* out, float* d
         return;
 
 void launch_blur(hipStream_t s, bool fused, const float* in, float* tmp, float* out, float* dog, int w,
-                 int h, int n, const float* d_taps, int radius) {
+                 int h, int n, const float* d_taps, int radius, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    struct Scope {
+        Scope(hipEvent_t a, hipEvent_t b) { t_ev_start = a; t_ev_stop = b; }
+        ~Scope() { t_ev_start = t_ev_stop = nullptr; }
+    } scope(ev_start, ev_stop);
     if (fused && radius >= 1 && radius <= kMaxRadiusFused) {
         switch (radius) {
             SIFT_FUSED_CASE(1) SIFT_FUSED_CASE(2) SIFT_FUSED_CASE(3) SIFT_FUSED_CASE(4)
@@ -602,6 +612,8 @@ void launch_blur(hipStream_t s, bool fused, const float* in, float* tmp, float* 
             SIFT_FUSED_CASE(29) SIFT_FUSED_CASE(30) SIFT_FUSED_CASE(31) SIFT_FUSED_CASE(32)
         }
     }
+    // two-pass fallback: two kernels, bracketed by ordinary event records
+    if (ev_start) (void)hipEventRecord(ev_start, s);
     const dim3 grid((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)n);
     const size_t shm = sizeof(float) * (size_t)(2 * radius + 1);
     hipLaunchKernelGGL(gauss_row_generic, grid, dim3(256), shm, s, in, tmp, w, h, d_taps, radius);
@@ -611,6 +623,7 @@ void launch_blur(hipStream_t s, bool fused, const float* in, float* tmp, float* 
     else
         hipLaunchKernelGGL(gauss_col_generic<false>, grid, dim3(256), shm, s, (const float*)tmp, in, out, dog,
                            w, h, d_taps, radius);
+    if (ev_stop) (void)hipEventRecord(ev_stop, s);
 }
 
 void launch_resample(hipStream_t s, const float* src, float* dst, int ws, int hs, int wd, int hd, int n,

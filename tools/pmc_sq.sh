@@ -16,7 +16,7 @@ for d in ("gpurun_out/pmc_sq", "gpurun_out/pmc_sq2"):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("sift_hip::", "")
             acc[name][r["Counter_Name"]] += float(r["Counter_Value"])
-    for name in ("descriptor_kernel", "cleanup1_kernel", "orientation_kernel", "edge_filter_kernel", "gradient_kernel", "blur_fused_kernel<5, true>", "blur_fused_kernel<10, true>"):
+    for name in ("descriptor_kernel", "cleanup1_kernel", "orientation_kernel", "edge_filter_kernel", "gradient_kernel", "blur_stream_kernel<5, true, 4>", "blur_stream_kernel<10, true, 2>", "blur_stream_kernel<7, true, 2>", "extrema_mask_kernel"):
         if name in acc:
             print(name, {k: f"{v:.3g}" for k, v in sorted(acc[name].items())})
 PY
