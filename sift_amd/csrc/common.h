@@ -124,7 +124,9 @@ void launch_cleanup1(hipStream_t s, int n_images, const uint8_t* d_flags, const 
 void launch_orient_prepare(hipStream_t s, int n_images, const uint8_t* d_flags, const int* d_totals, long long cand_cap,
                            int* d_chunk_cnt, const Candidate* d_cands, int list_cap, OrientIn* d_oin, int* d_early_cnt);
 size_t orient_prepare_chunks(long long cand_cap);
-void launch_cleanup2(hipStream_t s, int n_images, const Candidate* d_cands, long long cand_cap,
+bool cleanup2_can_bin(int tiles_per_image);
+void launch_cleanup2(hipStream_t s, int n_images, const DevPlan* d_plan, int bin_tiles, int* d_tile_cnt, int* d_tile_off,
+                     FinalKp* d_pool, int pool_cap, const Candidate* d_cands, long long cand_cap,
                      const uint32_t* d_list, const int* d_list_cnt, int list_cap, const OrientOut* d_orient,
                      const uint32_t* d_lrank, uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, FinalKp* d_final,
                      int* d_final_cnt, int* d_status);

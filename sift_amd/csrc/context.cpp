@@ -107,6 +107,7 @@ struct sift_hip_ctx {
     bool fused = true;
     bool gpu_cleanup = true;
     bool profile = false;
+    bool binned = false;   // this batch's keypoints are already binned to descriptor tiles
     int host_threads = 0;
     int desc_dbg = 0;
     Plan plan;
@@ -586,6 +587,18 @@ void mid_host(sift_hip_ctx* c) {
 
 // GPU path: both cleanups as kernels (kernels_cleanup.hip); the host only reads 4 ints per image.
 // Returns false when some image needs the host path.
+// keypoints -> descriptor tiles (device-side counts only)
+void bin_keypoints(sift_hip_ctx* c) {
+    Plan& P = c->plan;
+    const DevPlan& dv = P.dev;
+    const size_t nt = (size_t)dv.desc_tiles_per_image * (size_t)P.n;
+    int* t_cnt = c->d_tile.as<int>();
+    int* t_off = t_cnt + nt;
+    int* t_cur = t_off + nt;
+    launch_desc_binning(c->stream, c->d_plan.as<DevPlan>(), dv, c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(), kListCap, t_cnt,
+                        t_off, t_cur, c->d_pool.as<FinalKp>(), kPoolCap);
+}
+
 bool mid_gpu(sift_hip_ctx* c) {
     Plan& P = c->plan;
     const DevPlan& dv = P.dev;
@@ -609,15 +622,24 @@ bool mid_gpu(sift_hip_ctx* c) {
     // late launch: only the images whose survivor list was truncated (counts are 0 for the others)
     launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_order.as<OrientIn>(), d_late, kListCap,
                        c->d_orient.as<OrientOut>(), c->d_peaks.as<float>());
-    launch_cleanup2(s, n, c->d_cands.as<Candidate>(), dv.cand_capacity, c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
+    const bool fused_bin = cleanup2_can_bin(dv.desc_tiles_per_image);
+    const size_t nt = (size_t)dv.desc_tiles_per_image * (size_t)n;
+    launch_cleanup2(s, n, dpl, fused_bin ? 1 : 0, c->d_tile.as<int>(), c->d_tile.as<int>() + nt, c->d_pool.as<FinalKp>(), kPoolCap,
+                    c->d_cands.as<Candidate>(), dv.cand_capacity, c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
                     kListCap, c->d_orient.as<OrientOut>(), c->d_lrank.as<uint32_t>(), c->d_wk.as<uint8_t>(),
                     c->d_wi.as<uint32_t>(), c->d_wi2.as<uint32_t>(), c->d_wp.as<uint32_t>(), c->d_final.as<FinalKp>(),
                     c->d_final_cnt.as<int>(), c->d_status.as<int>());
+    // the tile binning only needs the device-side lists: it keeps the GPU busy while the host waits for the counts
+    if (!fused_bin) bin_keypoints(c);
+    c->binned = true;
     std::vector<int> st((size_t)n * 5);
     SIFT_HIP_CHECK(hipMemcpyAsync(st.data(), c->d_status.p, st.size() * sizeof(int), hipMemcpyDeviceToHost, s));
     SIFT_HIP_CHECK(hipStreamSynchronize(s));
     for (int i = 0; i < n; ++i)
-        if (st[(size_t)i * 4 + 1] || st[(size_t)n * 4 + (size_t)i]) return false;
+        if (st[(size_t)i * 4 + 1] || st[(size_t)n * 4 + (size_t)i]) {
+            c->binned = false;   // the host path rebuilds the lists
+            return false;
+        }
     for (int i = 0; i < n; ++i) {
         c->counts[(size_t)i] = st[(size_t)i * 4 + 0];
         if (st[(size_t)i * 4 + 2] != 0x7fffffff) {  // sift.cpp:184 would throw for this image
@@ -679,7 +701,7 @@ void ensure_host_stages(sift_hip_ctx* c) {
 int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     Plan& P = c->plan;
     const DevPlan& dv = P.dev;
-    const int n = P.n, D = P.D;
+    const int n = P.n;
     hipStream_t s = c->stream;
     c->status.assign((size_t)n, 0);
     c->counts.assign((size_t)n, 0);
@@ -693,6 +715,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     c->have_result = false;
     c->have_pyramid = false;
     c->stages_on_host = false;
+    c->binned = false;
 
     run_pyramid(c, d_in);
     c->have_pyramid = true;
@@ -706,12 +729,13 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
         return P.fail_status;
     }
 
-    // Gradient maps and W16 only need the pyramid: side stream, from here on
+    // Gradient maps and W16 only need the pyramid: side stream, from here on.  (Not earlier: sharing the
+    // CUs with the HBM-bound blur kernels slows those by more than the overlap wins.)
     const DevPlan* dpl = c->d_plan.as<DevPlan>();
     SIFT_HIP_CHECK(hipEventRecord(c->ev_fork0, s));
     SIFT_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork0, 0));
     for (int lvl : P.grad_levels) {
-        const int o = lvl / (D + 1);
+        const int o = lvl / (P.D + 1);
         launch_gradient(c->stream2, dv.gauss[lvl], dv.mag[lvl], dv.ori[lvl], dv.prod[lvl], dv.obin[lvl], dv.w[o], dv.h[o], n);
         launch_w16(c->stream2, dv, lvl, c->d_taps16.as<float>(), P.radius16);
     }
@@ -754,9 +778,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
         const size_t nt = (size_t)dv.desc_tiles_per_image * (size_t)n;
         int* t_cnt = c->d_tile.as<int>();
         int* t_off = t_cnt + nt;
-        int* t_cur = t_off + nt;
-        launch_desc_binning(s, dpl, dv, c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(), kListCap, t_cnt, t_off, t_cur,
-                            c->d_pool.as<FinalKp>(), kPoolCap);
+        if (!c->binned) bin_keypoints(c);
         for (int lvl : P.grad_levels)
             launch_descriptors(s, dpl, dv, lvl, c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(), kListCap, t_cnt, t_off,
                                c->d_pool.as<FinalKp>(), kPoolCap, c->d_out_base.as<long long>(),
