@@ -101,8 +101,12 @@ void launch_dog(hipStream_t s, const float* lower, const float* higher, float* o
 void launch_extrema_mask(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan,
                          unsigned long long* d_masks, int* d_counts);
 void launch_extrema_scan(hipStream_t s, const DevPlan& plan, int* d_counts, int* d_totals);
+bool extrema_edge_supported(const DevPlan& plan);
+void launch_extrema_edge(hipStream_t s, const DevPlan& plan, unsigned long long* d_masks, unsigned long long* d_fmasks,
+                         int* d_counts);
 void launch_extrema_expand(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan,
-                           const unsigned long long* d_masks, const int* d_offsets, Candidate* d_cands);
+                           const unsigned long long* d_masks, const int* d_offsets, Candidate* d_cands,
+                           const unsigned long long* d_fmasks = nullptr, uint8_t* d_flags = nullptr);
 void launch_edge_filter(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const Candidate* d_cands,
                         const int* d_totals, uint8_t* d_flags);
 void launch_edge_filter_points(hipStream_t s, const float* d0, const float* d1, const float* d2, int w, int h,

@@ -105,6 +105,7 @@ struct sift_hip_ctx {
     hipStream_t stream2 = nullptr;          // side stream: work that can overlap the 1-block-per-image cleanup
     hipEvent_t ev_fork0 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     bool fused = true;
+    bool fused_edge = true;   // extremum scan and edge filter in one LDS-tiled pass
     bool gpu_cleanup = true;
     bool profile = false;
     bool binned = false;   // this batch's keypoints are already binned to descriptor tiles
@@ -112,7 +113,7 @@ struct sift_hip_ctx {
     int desc_dbg = 0;
     Plan plan;
     DevBuf arena, d_plan, d_taps, d_luts, d_taps16, d_input, d_base, d_tmp, d_tmp2;
-    DevBuf d_masks, d_counts, d_totals, d_cands, d_flags;
+    DevBuf d_masks, d_fmasks, d_counts, d_totals, d_cands, d_flags;
     DevBuf d_wk, d_wi, d_wi2, d_wp, d_status, d_tile, d_pool;
     DevBuf d_order;
     DevBuf d_list, d_list_cnt, d_orient, d_peaks, d_final, d_final_cnt, d_out_base, d_kp, d_desc;
@@ -389,6 +390,7 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
     SIFT_HIP_CHECK(hipMemcpyAsync(c->d_taps16.p, P.taps16.data(), P.taps16.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     const size_t nw = (size_t)dv.words_per_image * (size_t)n;
     c->d_masks.ensure(nw * sizeof(unsigned long long));
+    c->d_fmasks.ensure(nw * sizeof(unsigned long long));
     c->d_counts.ensure(nw * sizeof(int));
     c->d_totals.ensure((size_t)n * sizeof(int));
     c->d_cands.ensure((size_t)dv.cand_capacity * (size_t)n * sizeof(Candidate));
@@ -732,18 +734,28 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     // Gradient maps and W16 only need the pyramid: side stream, from here on.  (Not earlier: sharing the
     // CUs with the HBM-bound blur kernels slows those by more than the overlap wins.)
     const DevPlan* dpl = c->d_plan.as<DevPlan>();
+    static const bool serial_gradient = getenv("SIFT_SERIAL_GRADIENT") != nullptr;   // diagnostics: no overlap
+    hipStream_t gs = serial_gradient ? s : c->stream2;
     SIFT_HIP_CHECK(hipEventRecord(c->ev_fork0, s));
     SIFT_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork0, 0));
     for (int lvl : P.grad_levels) {
         const int o = lvl / (P.D + 1);
-        launch_gradient(c->stream2, dv.gauss[lvl], dv.mag[lvl], dv.ori[lvl], dv.prod[lvl], dv.obin[lvl], dv.w[o], dv.h[o], n);
-        launch_w16(c->stream2, dv, lvl, c->d_taps16.as<float>(), P.radius16);
+        launch_gradient(gs, dv.gauss[lvl], dv.mag[lvl], dv.ori[lvl], dv.prod[lvl], dv.obin[lvl], dv.w[o], dv.h[o], n);
+        launch_w16(gs, dv, lvl, c->d_taps16.as<float>(), P.radius16);
     }
     // extrema + edge responses (sift.cpp:33-34)
-    launch_extrema_mask(s, dpl, dv, c->d_masks.as<unsigned long long>(), c->d_counts.as<int>());
-    launch_extrema_scan(s, dv, c->d_counts.as<int>(), c->d_totals.as<int>());
-    launch_extrema_expand(s, dpl, dv, c->d_masks.as<unsigned long long>(), c->d_counts.as<int>(), c->d_cands.as<Candidate>());
-    launch_edge_filter(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_totals.as<int>(), c->d_flags.as<uint8_t>());
+    if (c->fused_edge && extrema_edge_supported(dv)) {
+        // one pass over the DoG levels: extremum test and edge-response filter from LDS tiles
+        launch_extrema_edge(s, dv, c->d_masks.as<unsigned long long>(), c->d_fmasks.as<unsigned long long>(), c->d_counts.as<int>());
+        launch_extrema_scan(s, dv, c->d_counts.as<int>(), c->d_totals.as<int>());
+        launch_extrema_expand(s, dpl, dv, c->d_masks.as<unsigned long long>(), c->d_counts.as<int>(), c->d_cands.as<Candidate>(),
+                              c->d_fmasks.as<unsigned long long>(), c->d_flags.as<uint8_t>());
+    } else {
+        launch_extrema_mask(s, dpl, dv, c->d_masks.as<unsigned long long>(), c->d_counts.as<int>());
+        launch_extrema_scan(s, dv, c->d_counts.as<int>(), c->d_totals.as<int>());
+        launch_extrema_expand(s, dpl, dv, c->d_masks.as<unsigned long long>(), c->d_counts.as<int>(), c->d_cands.as<Candidate>());
+        launch_edge_filter(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_totals.as<int>(), c->d_flags.as<uint8_t>());
+    }
     // The orientation stage is order-independent: it follows the gradient maps on the side stream, over
     // the kept candidates in scan order, while the one-workgroup-per-image cleanup kernel emulates the
     // reference's sort on the main stream (sift.cpp:37-47).
@@ -846,7 +858,7 @@ void sift_hip_destroy(sift_hip_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->arena, &c->d_plan, &c->d_taps, &c->d_luts, &c->d_taps16, &c->d_input, &c->d_base, &c->d_tmp, &c->d_tmp2,
-                      &c->d_wk, &c->d_wi, &c->d_wi2, &c->d_wp, &c->d_status, &c->d_tile, &c->d_pool, &c->d_order, &c->d_masks, &c->d_counts, &c->d_totals, &c->d_cands, &c->d_flags, &c->d_list, &c->d_list_cnt, &c->d_orient,
+                      &c->d_wk, &c->d_wi, &c->d_wi2, &c->d_wp, &c->d_status, &c->d_tile, &c->d_pool, &c->d_order, &c->d_masks, &c->d_fmasks, &c->d_counts, &c->d_totals, &c->d_cands, &c->d_flags, &c->d_list, &c->d_list_cnt, &c->d_orient,
                       &c->d_peaks, &c->d_final, &c->d_final_cnt, &c->d_out_base, &c->d_kp, &c->d_desc, &c->d_lrank, &c->d_ochunk, &c->d_ocnt})
         b->release();
     for (HostBuf* b : {&c->h_flags, &c->h_orient, &c->h_peaks}) b->release();
@@ -863,6 +875,7 @@ void sift_hip_destroy(sift_hip_ctx* c) {
 int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     if (!c || !name) return SIFT_HIP_EINVAL;
     if (!std::strcmp(name, "fused_blur")) { c->fused = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "fused_edge")) { c->fused_edge = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "desc_dbg")) { c->desc_dbg = value; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "gpu_cleanup")) { c->gpu_cleanup = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "profile")) { c->profile = value != 0; return SIFT_HIP_OK; }

@@ -101,4 +101,48 @@ SIFT_HD float fdlibm_atan2f(float y, float x) {
     }
 }
 
+// Branch-free evaluation of the same algorithm for the common case, for the GPU: the four argument
+// reductions of atanf differ only in the numerator and denominator of their single division, so they are
+// selected first and divided once; the polynomial and the quadrant fix-up are the same operations in the
+// same order as above.  Everything else (NaN, infinities, zeros, x == 1, |y/x| outside [2^-29, 2^25),
+// exponent gap > 60) is left to fdlibm_atan2f.
+SIFT_HD bool fdlibm_atan2f_common(float y, float x, float& out) {
+    const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const int32_t hx = f2i(x), hy = f2i(y);
+    const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    const int32_t k = (iy - ix) >> 23;
+    const float t = fabs_bits(y / x);
+    const int32_t it = f2i(t);
+    const bool common = ix < 0x7f800000 && iy < 0x7f800000 && ix != 0 && iy != 0 && hx != 0x3f800000 && k <= 60 &&
+                        k >= -60 && it < 0x4c000000 && it >= 0x31000000;
+    // argument reduction: x' = num / den
+    const bool c_small = it < 0x3ee00000, c0 = it < 0x3f300000, c1 = it < 0x3f980000, c2 = it < 0x401c0000;
+    const float num = c_small ? t : c0 ? 2.0f * t - 1.0f : c1 ? t - 1.0f : c2 ? t - 1.5f : -1.0f;
+    const float den = c_small ? 1.0f : c0 ? 2.0f + t : c1 ? t + 1.0f : c2 ? 1.0f + 1.5f * t : t;
+    const float hi = c0 ? 4.6364760399e-01f : c1 ? 7.8539812565e-01f : c2 ? 9.8279368877e-01f : 1.5707962513e+00f;
+    const float lo = c0 ? 5.0121582440e-09f : c1 ? 3.7748947079e-08f : c2 ? 3.4473217170e-08f : 7.5497894159e-08f;
+    const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f,
+                aT3 = -1.1111110449e-01f, aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f,
+                aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f, aT8 = 4.9768779427e-02f,
+                aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+    const float xr = num / den;
+    const float z = xr * xr;
+    const float w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    const float p = xr * (s1 + s2);
+    const float at = c_small ? xr - p : hi - ((p - lo) - xr);   // atanf(|y/x|) >= 0
+    const float zz = at - pi_lo;
+    const float r = hx >= 0 ? at : pi - zz;                       // m = 0 / 2 (y >= 0)
+    const float rn = hx >= 0 ? i2f(f2i(at) ^ (int32_t)0x80000000) : zz - pi;   // m = 1 / 3 (y < 0)
+    out = hy >= 0 ? r : rn;
+    return common;
+}
+
+SIFT_HD float fdlibm_atan2f_sel(float y, float x) {
+    float r;
+    if (fdlibm_atan2f_common(y, x, r)) return r;
+    return fdlibm_atan2f(y, x);
+}
+
 }  // namespace sift_hip

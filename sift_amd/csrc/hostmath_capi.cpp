@@ -11,6 +11,16 @@ float hostmath_atan2f(float y, float x) { return sift_hip::fdlibm_atan2f(y, x); 
 void hostmath_atan2f_array(const float* y, const float* x, int n, float* out) {
     for (int i = 0; i < n; ++i) out[i] = sift_hip::fdlibm_atan2f(y[i], x[i]);
 }
+// the GPU's branch-free common path + fallback; also reports how many inputs took the common path
+int hostmath_atan2f_sel_array(const float* y, const float* x, int n, float* out) {
+    int common = 0;
+    for (int i = 0; i < n; ++i) {
+        float r;
+        common += sift_hip::fdlibm_atan2f_common(y[i], x[i], r) ? 1 : 0;
+        out[i] = sift_hip::fdlibm_atan2f_sel(y[i], x[i]);
+    }
+    return common;
+}
 // matrices row-fastest like vigra::Matrix: a[i + 3*j] = A(i, j)
 int hostmath_inverse3(const float* a, float* res) {
     float A[3][3], R[3][3] = {};

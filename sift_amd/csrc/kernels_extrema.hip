@@ -130,7 +130,9 @@ __global__ __launch_bounds__(1024) void extrema_scan_kernel(int* __restrict__ co
 __global__ __launch_bounds__(256) void extrema_expand_kernel(const DevPlan* __restrict__ plan,
                                                              const unsigned long long* __restrict__ masks,
                                                              const int* __restrict__ offsets,
-                                                             Candidate* __restrict__ cands) {
+                                                             Candidate* __restrict__ cands,
+                                                             const unsigned long long* __restrict__ fmasks,
+                                                             uint8_t* __restrict__ flags) {
     const int words = plan->words_per_image;
     const long long total_words = (long long)words * plan->n_images;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -151,10 +153,14 @@ __global__ __launch_bounds__(256) void extrema_expand_kernel(const DevPlan* __re
         c.octave = (uint16_t)plan->scan_octave[sl];
         c.index = (uint16_t)plan->scan_dog[sl];
         Candidate* out = cands + (size_t)img * (size_t)plan->cand_capacity + (size_t)offsets[wi];
+        // with the fused scan the edge filter's verdicts arrive as a second bit word
+        const unsigned long long fm = fmasks ? fmasks[wi] : 0ull;
+        uint8_t* fout = flags ? flags + (size_t)img * (size_t)plan->cand_capacity + (size_t)offsets[wi] : nullptr;
         while (m) {
             const int bit = __ffsll((long long)m) - 1;
             c.y = (uint16_t)(yb * 64 + bit);
             *out++ = c;
+            if (fout) *fout++ = (uint8_t)((fm >> bit) & 1ull);
             m &= m - 1ull;
         }
     }
@@ -164,15 +170,17 @@ __global__ __launch_bounds__(256) void extrema_expand_kernel(const DevPlan* __re
 // Body of the per-point loop of _eliminateEdgeResponses (sift.cpp:295-345).  true => filtered.
 // d0/d1/d2 = dogs(octave, index-1 / index / index+1) of one image, row pitch w.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool edge_response_filtered(const float* __restrict__ d0,
-                                                       const float* __restrict__ d1,
-                                                       const float* __restrict__ d2, int w, int x, int y) {
-    const size_t c = (size_t)y * (size_t)w + (size_t)x;
-    const size_t up = c - (size_t)w, dn = c + (size_t)w;
-    const float i1c = d1[c], i1l = d1[c - 1], i1r = d1[c + 1], i1u = d1[up], i1d = d1[dn];
-    const float i1ul = d1[up - 1], i1ur = d1[up + 1], i1dl = d1[dn - 1], i1dr = d1[dn + 1];
-    const float i0c = d0[c], i0l = d0[c - 1], i0r = d0[c + 1], i0u = d0[up], i0d = d0[dn];
-    const float i2c = d2[c], i2l = d2[c - 1], i2r = d2[c + 1], i2d = d2[dn];
+struct EdgeTaps {   // the 18 DoG samples the per-point body reads
+    float i1c, i1l, i1r, i1u, i1d, i1ul, i1ur, i1dl, i1dr;
+    float i0c, i0l, i0r, i0u, i0d;
+    float i2c, i2l, i2r, i2d;
+};
+
+__device__ __forceinline__ bool edge_response_core(const EdgeTaps& tp) {
+    const float i1c = tp.i1c, i1l = tp.i1l, i1r = tp.i1r, i1u = tp.i1u, i1d = tp.i1d;
+    const float i1ul = tp.i1ul, i1ur = tp.i1ur, i1dl = tp.i1dl, i1dr = tp.i1dr;
+    const float i0c = tp.i0c, i0l = tp.i0l, i0r = tp.i0r, i0u = tp.i0u, i0d = tp.i0d;
+    const float i2c = tp.i2c, i2l = tp.i2l, i2r = tp.i2r, i2d = tp.i2d;
     // alg::foDerivative (algorithms.cpp:69-71)
     float D[3];
     D[0] = (i1l - i1r) / 2.0f;
@@ -207,6 +215,128 @@ __device__ __forceinline__ bool edge_response_filtered(const float* __restrict__
     const float t = 12.1f;                            // (f32)(std::pow(10 + 1, 2) / 10), :294
     if ((double)tr * (double)tr / (double)det > (double)t) return true;   // :343
     return false;
+}
+
+__device__ __forceinline__ bool edge_response_filtered(const float* __restrict__ d0,
+                                                       const float* __restrict__ d1,
+                                                       const float* __restrict__ d2, int w, int x, int y) {
+    const size_t c = (size_t)y * (size_t)w + (size_t)x;
+    const size_t up = c - (size_t)w, dn = c + (size_t)w;
+    EdgeTaps t;
+    t.i1c = d1[c]; t.i1l = d1[c - 1]; t.i1r = d1[c + 1]; t.i1u = d1[up]; t.i1d = d1[dn];
+    t.i1ul = d1[up - 1]; t.i1ur = d1[up + 1]; t.i1dl = d1[dn - 1]; t.i1dr = d1[dn + 1];
+    t.i0c = d0[c]; t.i0l = d0[c - 1]; t.i0r = d0[c + 1]; t.i0u = d0[up]; t.i0d = d0[dn];
+    t.i2c = d2[c]; t.i2l = d2[c - 1]; t.i2r = d2[c + 1]; t.i2d = d2[dn];
+    return edge_response_core(t);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused scan + edge filter.  A workgroup stages a 32-column x 64-row tile (+1 halo) of the three DoG
+// levels in LDS with row-coalesced loads, so neither the 12-sample extremum test nor the 18-sample
+// edge-response body issues a scattered global load (a thread-per-candidate gather touches one cache
+// line per lane and row: the standalone filter is bound by the address path, not by arithmetic).
+//   * wave v scans rows 16v..16v+15, two rows x 32 columns per step; candidates are ballot-compacted
+//     into the wave's LDS queue, then processed 64 at a time (dense lanes for the 3x3 QR body);
+//   * results are the same per-(column, 64-row block) words as the mask kernel writes, plus a second
+//     word of `filtered` bits; the expansion turns both into the candidate records and flag bytes in
+//     the reference's octave / dog / x / y order.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFxCols = 32;
+constexpr int kFxLead = 4;                      // columns staged left of the tile (16-byte aligned loads)
+constexpr int kFxPitch = kFxCols + 2 * kFxLead; // 40 floats per staged row: x0-4 .. x0+35
+constexpr int kFxRows = 64 + 2;
+constexpr int kFxRow4 = kFxPitch / 4;
+
+__global__ __launch_bounds__(256) void extrema_edge_kernel(const float* __restrict__ d0, const float* __restrict__ d1,
+                                                           const float* __restrict__ d2, int w, int h, int nyb,
+                                                           int word_base, int words_per_image,
+                                                           unsigned long long* __restrict__ masks,
+                                                           unsigned long long* __restrict__ fmasks,
+                                                           int* __restrict__ counts) {
+    __shared__ __attribute__((aligned(16))) float s_t[3][kFxRows * kFxPitch];
+    __shared__ unsigned short s_q[4][16 * kFxCols];
+    __shared__ unsigned long long s_cm[4][kFxCols];
+    __shared__ unsigned long long s_fm[kFxCols];
+    __shared__ int s_qn[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int x0 = blockIdx.x * kFxCols, yb = blockIdx.y, img = blockIdx.z;
+    const int ya = yb * 64;
+    const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
+    const float* __restrict__ src[3] = {d0 + img_off, d1 + img_off, d2 + img_off};
+    // tile: rows ya-1 .. ya+64, columns x0-4 .. x0+35 as 16-byte groups (w is a multiple of 4 here).  Rows
+    // and groups outside the image are clamped; clamped samples are only read by non-candidates.
+    for (int e = tid; e < kFxRows * kFxRow4; e += 256) {
+        const int r = e / kFxRow4, c4 = e - r * kFxRow4;
+        int gy = ya - 1 + r, gx = x0 - kFxLead + 4 * c4;
+        gy = gy < 0 ? 0 : (gy >= h ? h - 1 : gy);
+        gx = gx < 0 ? 0 : (gx > w - 4 ? w - 4 : gx);
+        const size_t o = (size_t)gy * (size_t)w + (size_t)gx;
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+            *reinterpret_cast<float4*>(&s_t[l][r * kFxPitch + 4 * c4]) = *reinterpret_cast<const float4*>(src[l] + o);
+    }
+    if (tid < kFxCols) s_fm[tid] = 0ull;
+    __syncthreads();
+
+    const int col = lane & 31, sub = lane >> 5;
+    const int x = x0 + col;
+    const bool x_ok = x >= 1 && x <= w - 2;
+    unsigned long long mask = 0ull;
+    int qn = 0;   // wave-uniform
+    unsigned short* q = s_q[wv];
+#pragma unroll 2
+    for (int st = 0; st < 8; ++st) {
+        const int row = 16 * wv + 2 * st + sub;   // tile-local output row; LDS row index = row + 1
+        const int y = ya + row;
+        const int at = (row + 1) * kFxPitch + (col + kFxLead);
+        const float c = s_t[1][at];
+        bool any_gt = false, any_lt = false;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const float a = s_t[l][at - kFxPitch - 1], b = s_t[l][at - kFxPitch], d = s_t[l][at - 1];
+            any_gt |= (a > c) | (b > c) | (d > c);
+            any_lt |= (a < c) | (b < c) | (d < c);
+            if (l != 1) {
+                const float e = s_t[l][at];
+                any_gt |= e > c;
+                any_lt |= e < c;
+            }
+        }
+        const bool cand = x_ok && y >= 1 && y <= h - 2 && (!any_gt || !any_lt);
+        mask |= (unsigned long long)(cand ? 1u : 0u) << row;
+        const unsigned long long bal = __ballot(cand);
+        if (cand) q[qn + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(col | (row << 5));
+        qn += __popcll(bal);
+    }
+    mask |= __shfl_xor(mask, 32);   // the two half-waves hold alternate rows of the same column
+    if (lane < kFxCols) s_cm[wv][lane] = mask;
+    if (lane == 0) s_qn[wv] = qn;
+    __syncthreads();
+    // the four queues are walked as one list so that the 3x3 QR body runs on (nearly) full waves
+    const int n0 = s_qn[0], n1 = n0 + s_qn[1], n2 = n1 + s_qn[2], n3 = n2 + s_qn[3];
+    for (int g = tid; g < n3; g += 256) {
+        const int qi = g < n0 ? 0 : g < n1 ? 1 : g < n2 ? 2 : 3;
+        const int off = qi == 0 ? 0 : qi == 1 ? n0 : qi == 2 ? n1 : n2;
+        const unsigned e = s_q[qi][g - off];
+        const int qc = (int)(e & 31u), qr = (int)(e >> 5);
+        const int at = (qr + 1) * kFxPitch + (qc + kFxLead);
+        const int up = at - kFxPitch, dn = at + kFxPitch;
+        EdgeTaps t;
+        t.i1c = s_t[1][at]; t.i1l = s_t[1][at - 1]; t.i1r = s_t[1][at + 1]; t.i1u = s_t[1][up]; t.i1d = s_t[1][dn];
+        t.i1ul = s_t[1][up - 1]; t.i1ur = s_t[1][up + 1]; t.i1dl = s_t[1][dn - 1]; t.i1dr = s_t[1][dn + 1];
+        t.i0c = s_t[0][at]; t.i0l = s_t[0][at - 1]; t.i0r = s_t[0][at + 1]; t.i0u = s_t[0][up]; t.i0d = s_t[0][dn];
+        t.i2c = s_t[2][at]; t.i2l = s_t[2][at - 1]; t.i2r = s_t[2][at + 1]; t.i2d = s_t[2][dn];
+        if (edge_response_core(t)) atomicOr(&s_fm[qc], 1ull << qr);
+    }
+    __syncthreads();
+    if (tid < kFxCols && x0 + tid < w) {
+        const unsigned long long m = s_cm[0][tid] | s_cm[1][tid] | s_cm[2][tid] | s_cm[3][tid];
+        const size_t wi = (size_t)img * (size_t)words_per_image + (size_t)word_base + (size_t)(x0 + tid) * (size_t)nyb +
+                          (size_t)yb;
+        masks[wi] = m;
+        fmasks[wi] = s_fm[tid];
+        counts[wi] = __popcll(m);
+    }
 }
 
 __global__ __launch_bounds__(256) void edge_filter_kernel(const DevPlan* __restrict__ plan,
@@ -260,19 +390,45 @@ void launch_extrema_mask(hipStream_t s, const DevPlan* d_plan, const DevPlan& pl
     }
 }
 
+// the fused kernel stages 16-byte groups: every scanned octave's rows must be 16-byte aligned and at least one group wide
+bool extrema_edge_supported(const DevPlan& plan) {
+    for (int k = 0; k < plan.n_scan; ++k) {
+        const int o = plan.scan_octave[k];
+        if (plan.w[o] % 4 != 0 || plan.w[o] < 4) return false;
+        const int l = o * plan.dogs + plan.scan_dog[k];
+        for (int j = -1; j <= 1; ++j)
+            if ((uintptr_t)plan.dog[l + j] & 15u) return false;
+    }
+    return true;
+}
+
+void launch_extrema_edge(hipStream_t s, const DevPlan& plan, unsigned long long* d_masks, unsigned long long* d_fmasks,
+                         int* d_counts) {
+    for (int k = 0; k < plan.n_scan; ++k) {
+        const int o = plan.scan_octave[k], i = plan.scan_dog[k];
+        const int w = plan.w[o], h = plan.h[o];
+        const int l = o * plan.dogs + i;
+        const dim3 grid((unsigned)((w + kFxCols - 1) / kFxCols), (unsigned)plan.scan_nyb[k], (unsigned)plan.n_images);
+        hipLaunchKernelGGL(extrema_edge_kernel, grid, dim3(256), 0, s, (const float*)plan.dog[l - 1],
+                           (const float*)plan.dog[l], (const float*)plan.dog[l + 1], w, h, plan.scan_nyb[k],
+                           plan.scan_word_base[k], plan.words_per_image, d_masks, d_fmasks, d_counts);
+    }
+}
+
 void launch_extrema_scan(hipStream_t s, const DevPlan& plan, int* d_counts, int* d_totals) {
     hipLaunchKernelGGL(extrema_scan_kernel, dim3((unsigned)plan.n_images), dim3(1024), 0, s, d_counts,
                        plan.words_per_image, d_totals);
 }
 
 void launch_extrema_expand(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan,
-                           const unsigned long long* d_masks, const int* d_offsets, Candidate* d_cands) {
+                           const unsigned long long* d_masks, const int* d_offsets, Candidate* d_cands,
+                           const unsigned long long* d_fmasks, uint8_t* d_flags) {
     const long long total_words = (long long)plan.words_per_image * plan.n_images;
     long long blocks = (total_words + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(extrema_expand_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d_plan, d_masks,
-                       d_offsets, d_cands);
+                       d_offsets, d_cands, d_fmasks, d_flags);
 }
 
 void launch_edge_filter(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const Candidate* d_cands,

@@ -45,7 +45,9 @@ __global__ __launch_bounds__(256) void gradient_kernel(const float* __restrict__
         m = (float)__builtin_sqrt((double)dx * (double)dx + (double)dy * (double)dy);
         // std::fmod(atan2f(dy, dx) + 360.f, 360.) (algorithms.cpp:114-115); atan2f in [-pi, pi] so the
         // double fmod reduces to one conditional subtraction, which is exact.
-        const float r = fdlibm_atan2f(dy, dx);
+        // branch-free common path (one division for every argument range); rare inputs take the full routine
+        float r;
+        if (!fdlibm_atan2f_common(dy, dx, r)) r = fdlibm_atan2f(dy, dx);
         const double s = (double)(r + 360.0f);
         a = (float)(s >= 360.0 ? s - 360.0 : s);
     }

@@ -211,6 +211,15 @@ def test_pipeline_parity_two_pass_blur(ctx, report_dir):
         ctx.set_option("fused_blur", 1)
 
 
+def test_pipeline_parity_separate_scan_and_edge_filter(ctx, report_dir):
+    """The unfused path (mask kernel + thread-per-candidate edge filter) stays a checked alternative."""
+    ctx.set_option("fused_edge", 0)
+    try:
+        compare_run(ctx, synth_frame(320, 250, 4), 3, 3, False, "separate scan / edge filter 320x250", report_dir)
+    finally:
+        ctx.set_option("fused_edge", 1)
+
+
 def test_batch_images_independent(ctx, report_dir):
     """Every frame of a batch gets the single-frame result (frames differ)."""
     params = _lib.Params(3, 3, 1.6, O.K_SQRT2, 0)

@@ -20,6 +20,8 @@ def hm():
     H = C.CDLL(path)
     fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
     H.hostmath_atan2f_array.argtypes = [fp, fp, C.c_int, fp]
+    H.hostmath_atan2f_sel_array.argtypes = [fp, fp, C.c_int, fp]
+    H.hostmath_atan2f_sel_array.restype = C.c_int
     H.hostmath_inverse3.argtypes = [fp, fp]
     H.hostmath_solve3.argtypes = [fp, fp, fp]
     H.hostmath_vertex_parabola.restype = C.c_float
@@ -51,6 +53,12 @@ def test_atan2f_matches_libm(hm):
     want = np.array([O.lib().oracle_atan2f(float(a), float(b)) for a, b in zip(y[idx], x[idx])], np.float32)
     g = got[idx]
     same = (g.view(np.uint32) == want.view(np.uint32)) | (np.isnan(g) & np.isnan(want))
+    assert same.all()
+    # the branch-free common path the gradient kernel takes (+ fallback) is the same function, bit for bit
+    got2 = np.empty_like(y)
+    ncommon = hm.hostmath_atan2f_sel_array(y, x, y.size, got2)
+    assert ncommon > y.size // 3
+    same = (got2.view(np.uint32) == got.view(np.uint32)) | (np.isnan(got2) & np.isnan(got))
     assert same.all()
 
 
