@@ -175,10 +175,11 @@ def main():
                        "frames_per_gpu": nf, "frames_total": nf * world, "lanes_per_gpu": lanes, "keypoints_per_step": kps // max(args.steps, 1),
                        "frames_per_s": nf * world * args.steps / dt,
                        "gather": "RCCL p2p of keypoint records + descriptors to rank 0" if world > 1 else "none (1 GPU)"},
-            "roofline": {"kernel": "blur_fused_kernel (separable Gaussian + DoG, all pyramid levels)",
+            "roofline": {"kernel": "blur_stream_kernel / blur_fused_kernel (separable Gaussian + DoG; every launch of the pyramid)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
                          "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench)",
+                         "timing": "hipEventElapsedTime over start/stop events attached to each blur dispatch (hipExtLaunchKernelGGL) on the library's stream, inside the timed region",
                          "launches": launches, "avg_launch_ms": ms / launches if launches else None,
                          "algorithmic_bytes_per_launch": nbytes / launches if launches else None},
         }
