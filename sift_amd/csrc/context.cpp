@@ -400,7 +400,7 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
     c->d_order.ensure((size_t)kListCap * (size_t)n * sizeof(OrientIn));
     c->d_lrank.ensure((size_t)kListCap * (size_t)n * sizeof(uint32_t));
     c->d_ochunk.ensure(orient_prepare_chunks(dv.cand_capacity) * (size_t)n * sizeof(int));
-    c->d_ocnt.ensure((size_t)n * 2 * sizeof(int));
+    c->d_ocnt.ensure((size_t)n * 4 * sizeof(int));   // early counts, late counts, group counters of the two launches
     c->d_orient.ensure((size_t)kListCap * (size_t)n * sizeof(OrientOut));
     c->d_peaks.ensure((size_t)kListCap * (size_t)n * 36 * sizeof(float));
     c->d_final.ensure((size_t)kListCap * (size_t)n * sizeof(FinalKp));
@@ -534,7 +534,7 @@ void mid_host(sift_hip_ctx* c) {
     launch_build_orient_in(s, c->d_cands.as<Candidate>(), dv.cand_capacity, c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
                            kListCap, n, c->d_order.as<OrientIn>());
     launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_order.as<OrientIn>(), c->d_list_cnt.as<int>(), kListCap,
-                       c->d_orient.as<OrientOut>(), c->d_peaks.as<float>());
+                       c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 3 * n);
     c->h_orient.ensure((size_t)n * kListCap * sizeof(OrientOut));
     for (int i = 0; i < n; ++i)
         if (cnt1[(size_t)i])
@@ -623,7 +623,7 @@ bool mid_gpu(sift_hip_ctx* c) {
     SIFT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
     // late launch: only the images whose survivor list was truncated (counts are 0 for the others)
     launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_order.as<OrientIn>(), d_late, kListCap,
-                       c->d_orient.as<OrientOut>(), c->d_peaks.as<float>());
+                       c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 3 * n);
     const bool fused_bin = cleanup2_can_bin(dv.desc_tiles_per_image);
     const size_t nt = (size_t)dv.desc_tiles_per_image * (size_t)n;
     launch_cleanup2(s, n, dpl, fused_bin ? 1 : 0, c->d_tile.as<int>(), c->d_tile.as<int>() + nt, c->d_pool.as<FinalKp>(), kPoolCap,
@@ -766,7 +766,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
                               c->d_ochunk.as<int>(), c->d_cands.as<Candidate>(), kListCap, c->d_order.as<OrientIn>(),
                               c->d_ocnt.as<int>());
         launch_orientation(c->stream2, dpl, dv, c->d_cands.as<Candidate>(), c->d_order.as<OrientIn>(), c->d_ocnt.as<int>(),
-                           kListCap, c->d_orient.as<OrientOut>(), c->d_peaks.as<float>());
+                           kListCap, c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 2 * n);
     }
     SIFT_HIP_CHECK(hipEventRecord(c->ev_join, c->stream2));
     // cleanup, orientation assignment, cleanup (sift.cpp:37-54)
@@ -1256,8 +1256,8 @@ int sift_hip_cleanup_survivors(sift_hip_ctx* c, const uint8_t* flags, int n, int
         int* info = s.dev<int>(2);
         unsigned long long* st = nullptr;
         if (getenv("SIFT_CLEANUP_STAMPS")) {
-            st = s.dev<unsigned long long>(16);
-            SIFT_HIP_CHECK(hipMemset(st, 0, 16 * sizeof(unsigned long long)));
+            st = s.dev<unsigned long long>(512);
+            SIFT_HIP_CHECK(hipMemset(st, 0, 512 * sizeof(unsigned long long)));
             cleanup_set_stamp_buffer(st);
         }
         launch_cleanup_kat(c->stream, d_fl, n, wk, wi, wi2, wp, out, info, on_gpu == 2 ? 1 : 0);
@@ -1265,8 +1265,17 @@ int sift_hip_cleanup_survivors(sift_hip_ctx* c, const uint8_t* flags, int n, int
         int h_info[2];
         SIFT_HIP_CHECK(hipMemcpy(h_info, info, sizeof(h_info), hipMemcpyDeviceToHost));
         if (st) {
-            unsigned long long hs[16];
+            unsigned long long hs[512];
             SIFT_HIP_CHECK(hipMemcpy(hs, st, sizeof(hs), hipMemcpyDeviceToHost));
+            if (hs[7]) {   // per-round stamps of the word-parallel rounds: start, after pivot step, after scan, after swaps
+                std::fprintf(stderr, "rounds %llu:", hs[7]);
+                for (unsigned long long r = 0; r < hs[7] && r < 120; ++r)
+                    std::fprintf(stderr, " [p%llu n%llu %.1f %.1f %.1f %.1f]", hs[16 + 4 * r + 3] >> 60, (hs[16 + 4 * r + 3] >> 32) & 0xfffffff,
+                                 (hs[16 + 4 * r + 1] - hs[16 + 4 * r]) / 100.0, (hs[16 + 4 * r + 2] - hs[16 + 4 * r + 1]) / 100.0,
+                                 ((hs[16 + 4 * r + 3] & 0xffffffffull) - (hs[16 + 4 * r + 2] & 0xffffffffull)) / 100.0,
+                                 r + 1 < hs[7] ? (hs[16 + 4 * (r + 1)] - hs[16 + 4 * r]) / 100.0 : 0.0);
+                std::fprintf(stderr, "\n");
+            }
             cleanup_set_stamp_buffer(nullptr);
             std::fprintf(stderr, "cleanup stamps (us): init %.1f loop %.1f copy %.1f pure %.1f compact %.1f  npure %llu\n",
                          (hs[1] - hs[0]) / 100.0, (hs[2] - hs[1]) / 100.0, (hs[3] - hs[2]) / 100.0, (hs[4] - hs[3]) / 100.0,

@@ -18,6 +18,8 @@
 // One 1024-thread workgroup per image; ranks come from wavefront __ballot + popcount prefix sums.
 // tests/test_abi.py checks the host twin of this scheme, tests/test_gpu_parity.py this kernel,
 // against std::sort itself.
+#include <type_traits>
+
 #include "common.h"
 
 namespace sift_hip {
@@ -284,6 +286,322 @@ __device__ void introsort_binary(CleanupShared& sh, int n, const Keys K, uint32_
     __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same rounds for LDS bit keys, word-parallel.  With ~94 % of the candidates filtered almost
+// every swap of a round exchanges two filtered elements and changes nothing; only the swaps that
+// involve a kept element move a payload (and only kept payloads are ever read again).  So a round
+//   1. snapshots the range's 64-bit key words in registers (a contiguous run of words per thread)
+//      and counts the hits (filtered keys from the left for a filtered pivot, kept keys from the
+//      right for a kept pivot); one workgroup scan gives every thread the rank of its first hit;
+//   2. decides per hit whether its swap takes part (pos + t < L-1, resp. F + t < pos: monotone, so
+//      the participants are the same prefix the sequential loop stops at) and fetches the swap
+//      partners' keys as a bit field (they are a contiguous run of positions: L-1-t, resp. F+t);
+//   3. applies only the swaps that matter with atomic bit updates and payload moves.
+// Partner positions of different threads never overlap, partner and hit zones are disjoint, and the
+// hits come from the snapshot, so no other synchronisation is needed inside a round.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxChunk = kBitCap / 64 / kCT;   // key words per thread when the whole array is one range
+
+__device__ __forceinline__ unsigned long long load_word64(const uint32_t* w, int q) {
+    return (unsigned long long)w[2 * q] | ((unsigned long long)w[2 * q + 1] << 32);
+}
+// keys of positions [lo, lo + len), 1 <= len <= 64: bit j <-> position lo + j
+__device__ __forceinline__ unsigned long long load_field(const uint32_t* w, int lo, int len) {
+    const int q = lo >> 6, sft = lo & 63;
+    unsigned long long v = load_word64(w, q) >> sft;
+    if (sft + len > 64) v |= load_word64(w, q + 1) << (64 - sft);
+    return len == 64 ? v : (v & ((1ull << len) - 1ull));
+}
+// position of the i-th (0-based) set bit of h, i < popcount(h)
+__device__ __forceinline__ int select64(unsigned long long h, int i) {
+    int pos = 0;
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+        const int c = __popcll((h >> pos) & ((1ull << sft) - 1ull));
+        if (i >= c) {
+            i -= c;
+            pos += sft;
+        }
+    }
+    return pos;
+}
+// exclusive prefix of v over the workgroup in thread order (+ total); two barriers
+__device__ __forceinline__ int block_exclusive_scan(CleanupShared& sh, int v, int& total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+    }
+    __syncthreads();
+    if (lane == 63) sh.wc[0][0][wv] = inc;
+    __syncthreads();
+    int before = 0, tot = 0;
+#pragma unroll
+    for (int q = 0; q < kCT / 64; ++q) {
+        const int c = sh.wc[0][0][q];
+        before += q < wv ? c : 0;
+        tot += c;
+    }
+    total = tot;
+    return before + inc - v;
+}
+__device__ __forceinline__ void key_clear(const LdsBitKeys K, int pos) { atomicAnd(&K.w[pos >> 5], ~(1u << (pos & 31))); }
+__device__ __forceinline__ void key_set(const LdsBitKeys K, int pos) { atomicOr(&K.w[pos >> 5], 1u << (pos & 31)); }
+
+__device__ void introsort_bits(CleanupShared& sh, int n, const LdsBitKeys K, uint32_t* __restrict__ I,
+                               uint32_t* __restrict__ I2) {
+    const int tid = threadIdx.x;
+    stamp(1);
+    if (tid == 0) {
+        sh.f = 0;
+        sh.l = n;
+        sh.d = n > 0 ? 2 * floor_log2(n) : 0;
+        sh.npure = 0;
+        sh.fallback = 0;
+    }
+    __syncthreads();
+    int round = 0;
+    while (true) {
+        const int f = sh.f, l = sh.l;
+        if (l - f <= 16 || sh.fallback) break;
+        __syncthreads();
+        if (round < 120) stamp(16 + 4 * round);
+        if (tid == 0) {
+            if (sh.d == 0) {
+                sh.fallback = 1;
+            } else {
+                sh.d -= 1;
+                // __move_median_to_first(f, f+1, mid, l-1)
+                const int a = f + 1, b = f + (l - f) / 2, c = l - 1;
+                const int ka = K.get(a), kb = K.get(b), kc = K.get(c);
+                auto comp = [](int x, int y) { return x == 0 && y == 1; };
+                int s;
+                if (comp(ka, kb)) {
+                    if (comp(kb, kc)) s = b;
+                    else if (comp(ka, kc)) s = c;
+                    else s = a;
+                } else if (comp(ka, kc)) s = a;
+                else if (comp(kb, kc)) s = c;
+                else s = b;
+                const int ks = K.get(s), kf = K.get(f);
+                K.swap(f, s);
+                if (ks == 0 || kf == 0) {   // a filtered element's payload is never read again
+                    const uint32_t jf = I[f], js = I[s];
+                    I[f] = js;
+                    I[s] = jf;
+                }
+                sh.p = ks;
+                sh.flag = 0x7fffffff;
+                sh.T = 0x7fffffff;
+            }
+        }
+        __syncthreads();
+        if (sh.fallback) break;
+        if (round < 120) stamp(16 + 4 * round + 1);
+        const int p = sh.p;
+        const int F = f + 1, L = l;
+        const int q0 = F >> 6, q1 = (L - 1) >> 6;
+        const int chunk = (q1 - q0 + 1 + kCT - 1) / kCT;   // <= kMaxChunk
+        // 1. snapshot + count.  Thread order = hit order: words ascend from the left for p == 1, descend from the right for p == 0
+        unsigned long long H[kMaxChunk];
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < kMaxChunk; ++j) {
+            H[j] = 0ull;
+            if (j < chunk) {
+                const int q = p == 1 ? q0 + tid * chunk + j : q1 - tid * chunk - j;
+                if (q >= q0 && q <= q1) {
+                    const int base = q << 6;
+                    const int lo = F > base ? F - base : 0;              // first position of the range inside the word
+                    const int hi = L - base < 64 ? L - base : 64;        // one past the last
+                    unsigned long long m = hi == 64 ? ~0ull : ((1ull << hi) - 1ull);
+                    m &= ~0ull << lo;
+                    const unsigned long long bits = load_word64(K.w, q);
+                    H[j] = (p == 1 ? bits : ~bits) & m;
+                    cnt += __popcll(H[j]);
+                }
+            }
+        }
+        int total;
+        int t = block_exclusive_scan(sh, cnt, total);
+        if (round < 120) stamp(16 + 4 * round + 2);
+        // 2 + 3. participation, partner keys, the swaps that matter
+#pragma unroll
+        for (int j = 0; j < kMaxChunk; ++j) {
+            const unsigned long long h = H[j];
+            if (j < chunk && h != 0ull) {
+                const int q = p == 1 ? q0 + tid * chunk + j : q1 - tid * chunk - j;
+                const int base = q << 6;
+                const int k = __popcll(h);
+                int kp;   // participating hits of this word (a prefix in hit order)
+                if (p == 1) {
+                    // hit i (ascending position): partner L-1-(t+i); takes part iff pos + t + i < L - 1
+                    const int pos_last = base + 63 - __clzll((long long)h);
+                    if (pos_last + t + k - 1 < L - 1) {
+                        kp = k;
+                    } else {
+                        kp = 0;
+                        unsigned long long r = h;
+                        int fpos = 0;
+                        while (r) {
+                            fpos = base + __ffsll((long long)r) - 1;
+                            if (fpos + t + kp >= L - 1) break;
+                            ++kp;
+                            r &= r - 1ull;
+                        }
+                        if (t + kp < sh.T) {   // (rank, position) of the first failing hit: both minimal together
+                            atomicMin(&sh.T, t + kp);
+                            atomicMin(&sh.flag, fpos);
+                        }
+                    }
+                    if (kp > 0) {
+                        const int bhi = L - 1 - t, blo = bhi - kp + 1;
+                        const unsigned long long field = load_field(K.w, blo, kp);   // bit (kp-1-i) <-> partner of hit i
+                        const unsigned long long rev = __brevll(field) >> (64 - kp);
+                        unsigned long long M = ~rev & (kp == 64 ? ~0ull : ((1ull << kp) - 1ull));   // partner kept: it moves
+                        while (M) {
+                            int na = 0;
+                            int pa[4], pb[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                pa[u] = pb[u] = 0;
+                                if (M) {
+                                    const int i = __ffsll((long long)M) - 1;
+                                    M &= M - 1ull;
+                                    pa[u] = base + select64(h, i);
+                                    pb[u] = bhi - i;
+                                    na = u + 1;
+                                }
+                            }
+                            uint32_t v[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (u < na) v[u] = I[pb[u]];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (u < na) {
+                                    I[pa[u]] = v[u];
+                                    key_clear(K, pa[u]);   // the kept element now sits at the hit's position
+                                    key_set(K, pb[u]);
+                                }
+                        }
+                    }
+                } else {
+                    // hit i (descending position): partner F+(t+i); takes part iff F + t + i < pos
+                    const int pos_min = base + __ffsll((long long)h) - 1;
+                    if (F + t + k - 1 < pos_min) {
+                        kp = k;
+                    } else {
+                        kp = 0;
+                        unsigned long long r = h;
+                        while (r) {
+                            const int pos = base + 63 - __clzll((long long)r);
+                            if (!(F + t + kp < pos)) break;
+                            ++kp;
+                            r &= ~(1ull << (pos - base));
+                        }
+                        if (t + kp < sh.T) atomicMin(&sh.T, t + kp);
+                    }
+                    if (kp > 0) {
+                        const int blo = F + t;
+                        const unsigned long long field = load_field(K.w, blo, kp);   // bit i <-> partner of hit i
+                        unsigned long long r = h;
+                        for (int i0 = 0; i0 < kp; i0 += 4) {
+                            int pa[4], pb[4];
+                            uint32_t va[4], vb[4];
+                            const int nb = kp - i0 < 4 ? kp - i0 : 4;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                pa[u] = pb[u] = 0;
+                                if (u < nb) {
+                                    const int pos = 63 - __clzll((long long)r);
+                                    r &= ~(1ull << pos);
+                                    pa[u] = base + pos;
+                                    pb[u] = blo + i0 + u;
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (u < nb) {
+                                    va[u] = I[pa[u]];
+                                    vb[u] = I[pb[u]];
+                                }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (u < nb) {
+                                    I[pb[u]] = va[u];
+                                    if ((field >> (i0 + u)) & 1ull) {   // partner filtered: the kept element moves there
+                                        key_clear(K, pb[u]);
+                                        key_set(K, pa[u]);
+                                    } else {
+                                        I[pa[u]] = vb[u];               // two kept elements trade places
+                                    }
+                                }
+                        }
+                    }
+                }
+                t += k;
+            }
+        }
+        __syncthreads();
+        if (round < 120 && g_stamp && tid == 0 && blockIdx.x == 0)
+            g_stamp[16 + 4 * round + 3] = (wall_clock64() & 0xffffffffull) | ((unsigned long long)(L - F) << 32) | ((unsigned long long)p << 60);
+        ++round;
+        const int T = (sh.T == 0x7fffffff) ? total : sh.T;
+        __syncthreads();
+        if (tid == 0) {
+            if (p == 1) {
+                const int fail = sh.flag;
+                const int cut = (fail != 0x7fffffff && fail == L - 1 - T) ? L - 1 - T : L - T;
+                sh.l = cut;  // right part [cut, l) is all filtered: dead
+            } else {
+                const int cut = F + T;
+                if (sh.npure < kMaxPure) {
+                    sh.pure[sh.npure] = PureRange{f, cut - f, sh.d};
+                    sh.npure += 1;
+                } else {
+                    sh.fallback = 1;
+                }
+                sh.f = cut;  // left part [f, cut) is all kept
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (g_stamp && tid == 0 && blockIdx.x == 0) g_stamp[7] = (unsigned long long)round;
+    stamp(2);
+    // Only kept elements are ever read back.  Outside the all-kept ranges they stay where the loop
+    // left them; inside, each one moves to its closed-form final position.
+    {
+        const int nq = (n + 63) >> 6;
+        for (int q = tid; q < nq; q += kCT) {
+            const int base = q << 6;
+            unsigned long long kept = ~load_word64(K.w, q);
+            if (n - base < 64) kept &= (1ull << (n - base)) - 1ull;
+            while (kept) {
+                const int pos = base + __ffsll((long long)kept) - 1;
+                kept &= kept - 1ull;
+                I2[pos] = I[pos];
+            }
+        }
+    }
+    __syncthreads();
+    stamp(3);
+    const int npure = sh.npure;
+    for (int r = 0; r < npure; ++r) {
+        const PureRange pr = sh.pure[r];
+        if (pr.m <= 16) continue;  // already final
+        for (int j = tid; j < pr.m; j += kCT) {
+            const int dest = pure_final_pos(pr.f + j, pr.f, pr.m, pr.d);
+            if (dest < 0) sh.fallback = 1;
+            else I2[dest] = I[pr.f + j];
+        }
+    }
+    __syncthreads();
+}
+
 // Stable partition: kept elements in position order -> out[0..size), size = count mod 65536.
 // `emit(rank, payload)` is called for rank < size.
 template <class Keys, class Emit>
@@ -330,16 +648,26 @@ extern __shared__ uint32_t s_dyn_bits[];   // kBitCap / 32 words when the launch
 __device__ void init_bits_from_flags(const LdsBitKeys K, const uint8_t* __restrict__ fl, int n,
                                      uint32_t* __restrict__ I) {
     const int lane = threadIdx.x & 63;
-    for (int base = 0; base < n; base += kCT) {
-        const int i = base + (int)threadIdx.x;
-        const bool f = i < n && fl[i] != 0;
-        const unsigned long long m = __ballot(f);
-        if (lane == 0 && i < n) {
-            const int wd = (base + ((int)threadIdx.x & ~63)) >> 5;
-            K.w[wd] = (uint32_t)m;
-            K.w[wd + 1] = (uint32_t)(m >> 32);
+    constexpr int UN = 8;   // flag loads in flight per thread
+    for (int base0 = 0; base0 < n; base0 += UN * kCT) {
+        uint8_t v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int i = base0 + u * kCT + (int)threadIdx.x;
+            v[u] = i < n ? fl[i] : (uint8_t)0;
         }
-        if (i < n) I[i] = (uint32_t)i;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int base = base0 + u * kCT;
+            const int i = base + (int)threadIdx.x;
+            const unsigned long long m = __ballot(i < n && v[u] != 0);
+            if (lane == 0 && i < n) {
+                const int wd = (base + ((int)threadIdx.x & ~63)) >> 5;
+                K.w[wd] = (uint32_t)m;
+                K.w[wd + 1] = (uint32_t)(m >> 32);
+            }
+            if (i < n) I[i] = (uint32_t)i;
+        }
     }
     __syncthreads();
 }
@@ -350,7 +678,8 @@ __device__ void cleanup1_body(CleanupShared& sh, int n, const Keys K, const uint
                               uint32_t* __restrict__ out, OrientIn* __restrict__ ord,
                               uint32_t* __restrict__ lrank, const Candidate* __restrict__ cd, int img,
                               int* __restrict__ list_cnt, int* __restrict__ late_cnt, int* __restrict__ fallback) {
-    introsort_binary(sh, n, K, I, I2, P);
+    if constexpr (std::is_same<Keys, LdsBitKeys>::value) introsort_bits(sh, n, K, I, I2);
+    else introsort_binary(sh, n, K, I, I2, P);
     auto make_in = [&](uint32_t cand, uint32_t kp) {
         const Candidate c = cd[cand];
         OrientIn o;
@@ -395,6 +724,113 @@ __device__ void cleanup1_body(CleanupShared& sh, int n, const Keys K, const uint
     }
 }
 
+// LDS-key variant of the first cleanup.  The payload that travels through the sort is the kept
+// candidate's SPATIAL RANK (its rank among the kept candidates in candidate order), which is what
+// the orientation results are addressed by; rank -> candidate index goes through a table.  Only the
+// ~6 % kept candidates get a payload at all, and every pass below walks 64-bit key words.
+__device__ void cleanup1_bits_body(CleanupShared& sh, int n, const LdsBitKeys K, const uint8_t* __restrict__ fl,
+                                   uint32_t* __restrict__ I, uint32_t* __restrict__ I2, uint32_t* __restrict__ crank,
+                                   uint32_t* __restrict__ out, OrientIn* __restrict__ ord,
+                                   uint32_t* __restrict__ lrank, const Candidate* __restrict__ cd, int img,
+                                   int* __restrict__ list_cnt, int* __restrict__ late_cnt, int* __restrict__ fallback) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    // flags -> key bits (one __ballot per 64 elements); loads only, several in flight
+    {
+        constexpr int UN = 8;
+        for (int base0 = 0; base0 < n; base0 += UN * kCT) {
+            uint8_t v[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int i = base0 + u * kCT + tid;
+                v[u] = i < n ? fl[i] : (uint8_t)0;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int base = base0 + u * kCT;
+                const int i = base + tid;
+                const unsigned long long m = __ballot(i < n && v[u] != 0);
+                if (lane == 0 && i < n) {
+                    const int wd = (base + (tid & ~63)) >> 5;
+                    K.w[wd] = (uint32_t)m;
+                    K.w[wd + 1] = (uint32_t)(m >> 32);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int nq = (n + 63) >> 6;
+    const int chunk = (nq + kCT - 1) / kCT;   // <= kMaxChunk
+    auto kept_word = [&](int q) {
+        unsigned long long kept = ~load_word64(K.w, q);
+        const int base = q << 6;
+        if (n - base < 64) kept &= (1ull << (n - base)) - 1ull;
+        return kept;
+    };
+    // spatial ranks: payload of every kept candidate + the rank -> candidate table
+    int total;
+    {
+        int cnt = 0;
+        for (int j = 0; j < chunk; ++j) {
+            const int q = tid * chunk + j;
+            if (q < nq) cnt += __popcll(kept_word(q));
+        }
+        int r = block_exclusive_scan(sh, cnt, total);
+        for (int j = 0; j < chunk; ++j) {
+            const int q = tid * chunk + j;
+            if (q >= nq) break;
+            unsigned long long kept = kept_word(q);
+            while (kept) {
+                const int pos = (q << 6) + __ffsll((long long)kept) - 1;
+                kept &= kept - 1ull;
+                I[pos] = (uint32_t)r;
+                crank[r] = (uint32_t)pos;
+                ++r;
+            }
+        }
+        __syncthreads();
+    }
+    const int size = total & 0xffff;   // u16_t size (sift.cpp:41)
+    introsort_bits(sh, n, K, I, I2);
+    // stable partition: kept elements in final position order -> list positions
+    {
+        int cnt = 0;
+        for (int j = 0; j < chunk; ++j) {
+            const int q = tid * chunk + j;
+            if (q < nq) cnt += __popcll(kept_word(q));
+        }
+        int dummy;
+        int r = block_exclusive_scan(sh, cnt, dummy);
+        for (int j = 0; j < chunk; ++j) {
+            const int q = tid * chunk + j;
+            if (q >= nq || r >= size) break;
+            unsigned long long kept = kept_word(q);
+            while (kept && r < size) {
+                const int pos = (q << 6) + __ffsll((long long)kept) - 1;
+                kept &= kept - 1ull;
+                const uint32_t sr = I2[pos];
+                out[r] = crank[sr];
+                lrank[r] = sr;   // the orientation stage's results are addressed by spatial rank
+                ++r;
+            }
+        }
+        __syncthreads();
+    }
+    if (total != size) {  // u16 truncation dropped survivors: the orientation stage runs late, in list order
+        for (int r = tid; r < size; r += kCT) {
+            const Candidate c = cd[out[r]];
+            OrientIn o;
+            o.x = c.x; o.y = c.y; o.octave = c.octave; o.index = c.index; o.kp = (uint32_t)r; o.pad = 0;
+            ord[r] = o;
+            lrank[r] = (uint32_t)r;
+        }
+    }
+    if (tid == 0) {
+        list_cnt[img] = size;
+        late_cnt[img] = total == size ? 0 : size;
+        fallback[img] = sh.fallback;
+    }
+}
+
 // ---- cleanup 1: flags of the extrema candidates -> ordered survivor list ---------------------
 __global__ __launch_bounds__(kCT) void cleanup1_kernel(const uint8_t* __restrict__ flags,
                                                        const int* __restrict__ totals, long long cand_cap,
@@ -419,8 +855,7 @@ __global__ __launch_bounds__(kCT) void cleanup1_kernel(const uint8_t* __restrict
     const Candidate* cd = cands + off;
     if (n <= kBitCap) {
         const LdsBitKeys K{s_dyn_bits};
-        init_bits_from_flags(K, fl, n, I);
-        cleanup1_body(sh, n, K, fl, I, I2, P, out, ord, lrank, cd, img, list_cnt, late_cnt, fallback);
+        cleanup1_bits_body(sh, n, K, fl, I, I2, P, out, ord, lrank, cd, img, list_cnt, late_cnt, fallback);
     } else {
         const GlobalKeys K{wk + off};
 #pragma unroll 4
@@ -588,7 +1023,7 @@ __global__ __launch_bounds__(kCT) void cleanup2_kernel(const DevPlan* __restrict
                                                        int* __restrict__ status) {
     __shared__ CleanupShared sh;
     __shared__ int s_multi, s_throw;
-    __shared__ uint32_t s_bits2[65536 / 32];   // n <= 65535 here (u16_t size of the first cleanup)
+    __shared__ __attribute__((aligned(8))) uint32_t s_bits2[65536 / 32 + 2];   // n <= 65535 here (u16_t size of the first cleanup)
     const int img = blockIdx.x;
     const int n = list_cnt[img];
     const size_t off = (size_t)img * (size_t)list_cap;
@@ -622,6 +1057,8 @@ __global__ __launch_bounds__(kCT) void cleanup2_kernel(const DevPlan* __restrict
         }
     }
     __syncthreads();
+    // kept keys dominate here (few points fail the border test): every hit moves a payload, which the
+    // tile-based rounds spread over all threads
     introsort_binary(sh, n, K, I, I2, P);
     const uint32_t* l1 = list + off;
     const Candidate* cd = cands + (size_t)img * (size_t)cand_cap;
@@ -723,7 +1160,7 @@ __global__ __launch_bounds__(kCT) void cleanup_kat_kernel(const uint8_t* __restr
     if (n <= kBitCap && !force_global) {
         const LdsBitKeys K{s_dyn_bits};
         init_bits_from_flags(K, flags, n, I);
-        introsort_binary(sh, n, K, I, I2, P);
+        introsort_bits(sh, n, K, I, I2);
         stamp(4);
         size = compact_kept(sh, n, K, I2, [&](int r, uint32_t id) { out[r] = id; });
         stamp(5);

@@ -10,6 +10,8 @@
 // (so every sample lands in histogram bin 0), the bin index is (u16)floor(ori/10) % 35, the
 // histogram sum is sequential in (x outer, y inner) order, the peak set has std::set<float>
 // semantics and `orientation = *peaks.begin()`.
+#include <cstdlib>
+
 #include "common.h"
 #include "linalg3.h"
 
@@ -78,13 +80,24 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
                                                           const OrientIn* __restrict__ oin,
                                                           const int* __restrict__ list_cnt, int list_cap,
                                                           OrientOut* __restrict__ out,
-                                                          float* __restrict__ peaks_out) {
+                                                          float* __restrict__ peaks_out, int* __restrict__ next_group,
+                                                          int dbg) {
     // staging (phase 1) and the peak sets (phase 2) are never live together: they share storage
     __shared__ __attribute__((aligned(16))) float s_stage[4 * kOrientSub * kOrientStride];
     __shared__ __attribute__((aligned(16))) unsigned char s_sbin[4 * kOrientSub * kOrientStride];
     __shared__ float s_hist[36][kOrientGroup];
     __shared__ unsigned short s_kp[kOrientGroup];    // survivor-list position of each slot
     __shared__ unsigned char s_state[kOrientGroup];  // bit0 border-filtered, bits 1-2 throw code, bit7 run
+    // what phase 1 needs to know about a keypoint's (octave, dog): looked up once per workgroup instead of a
+    // chain of dependent scalar loads from the plan per keypoint
+    struct LevelInfo {
+        int wh;        // w | h << 16 of the nearest Gaussian level's octave
+        int dead;      // dead_blur_radius code
+        const float* prod;
+        const uint8_t* obin;
+    };
+    __shared__ LevelInfo s_lvl[kMaxLevels];
+    __shared__ int s_grp;
     static_assert(sizeof(float) * 4 * kOrientSub * kOrientStride >= sizeof(float) * 36 * kOrientGroup, "s_set overlay");
     float (*s_set)[kOrientGroup] = reinterpret_cast<float (*)[kOrientGroup]>(s_stage);
 
@@ -97,8 +110,24 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
     const size_t lbase = (size_t)img * (size_t)list_cap;
     float* __restrict__ wprod = s_stage + wv * kOrientSub * kOrientStride;
     unsigned char* __restrict__ wbin = s_sbin + wv * kOrientSub * kOrientStride;
-    // the survivor count lives on the device: a fixed grid strides over the groups of keypoints
-    for (int grp = blockIdx.x; grp * kOrientGroup < cnt; grp += gridDim.x) {
+    if (cnt <= 0) return;
+    for (int l = tid; l < plan->octaves * D; l += 256) {
+        const int lvl = plan->nearest_level[l];
+        const int no = lvl / (D + 1);
+        LevelInfo li;
+        li.wh = plan->w[no] | (plan->h[no] << 16);
+        li.dead = plan->dead_blur_radius[l];
+        li.prod = plan->prod[lvl];
+        li.obin = plan->obin[lvl];
+        s_lvl[l] = li;
+    }
+    // the survivor count lives on the device: workgroups draw groups of keypoints from a per-image counter
+    while (true) {
+        __syncthreads();
+        if (tid == 0) s_grp = atomicAdd(&next_group[img], 1);
+        __syncthreads();
+        const int grp = s_grp;
+        if (grp * kOrientGroup >= cnt) break;
         // ---- phase 1 --------------------------------------------------------------------------
         for (int sb = 0; sb < kOrientGroup / 4 / kOrientSub; ++sb) {
             const int slot0 = wv * (kOrientGroup / 4) + sb * kOrientSub;
@@ -129,18 +158,23 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
                     if (lane == 0) s_kp[slot] = (unsigned short)kp;
                     const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
                     const int l = (int)(oi & 0xffffu) * D + (int)(oi >> 16);
-                    const int lvl = plan->nearest_level[l];
-                    const int no = lvl / (D + 1);
-                    const int w = plan->w[no], h = plan->h[no];
+                    const LevelInfo li = s_lvl[l];
+                    const int wh = __builtin_amdgcn_readfirstlane(li.wh);
+                    const int w = wh & 0xffff, h = (int)((unsigned)wh >> 16);
                     const bool border = (x < kRegion || x >= w - kRegion) || (y < kRegion || y >= h - kRegion);  // sift.cpp:173-174
-                    const int throws = border ? 0 : plan->dead_blur_radius[l];  // sift.cpp:184 (0 ok, else error code)
+                    const int throws = border ? 0 : __builtin_amdgcn_readfirstlane(li.dead);  // sift.cpp:184 (0 ok, else error code)
                     const bool run = !border && throws == 0;
                     if (lane == 0) s_state[slot] = (unsigned char)((border ? 1 : 0) | (throws << 1) | (run ? 0x80 : 0));
-                    if (run) {
+                    if (run && !(dbg & 4)) {
                         runmask |= 1u << k;
                         const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
-                        const float* __restrict__ gp = plan->prod[lvl] + img_off;
-                        const uint8_t* __restrict__ gb = plan->obin[lvl] + img_off;
+                        const unsigned long long pp64 = (unsigned long long)(uintptr_t)li.prod, pb64 = (unsigned long long)(uintptr_t)li.obin;
+                        const float* __restrict__ gp = reinterpret_cast<const float*>((uintptr_t)(
+                            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)pp64) |
+                            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(pp64 >> 32)) << 32))) + img_off;
+                        const uint8_t* __restrict__ gb = reinterpret_cast<const uint8_t*>((uintptr_t)(
+                            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)pb64) |
+                            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(pb64 >> 32)) << 32))) + img_off;
                         const int x0 = x - kRegion, y0 = y - kRegion;
 #pragma unroll
                         for (int it = 0; it < 4; ++it) {
@@ -177,7 +211,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
             // lane k: ordered sum of keypoint k (x outer, y inner == staging order)
             float acc = 0.0f;
             unsigned b0 = 0;
-            if (lane < kOrientSub && ((runmask & unimask) >> lane) & 1u) {
+            if (!(dbg & 2) && lane < kOrientSub && ((runmask & unimask) >> lane) & 1u) {
                 const float4* __restrict__ pv = reinterpret_cast<const float4*>(wprod + lane * kOrientStride);
                 b0 = wbin[lane * kOrientStride];
 #pragma unroll 4
@@ -229,19 +263,20 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
             r.npeaks = 0;
             r.filtered = (unsigned char)(st & 1u);
             r.throws = (unsigned char)((st >> 1) & 3u);
-            if (st & 0x80u) {
-                // Sift::_findPeaks (sift.cpp:220-286) on histogram column `tid`
+            if ((st & 0x80u) && !(dbg & 1)) {
+                // Sift::_findPeaks (sift.cpp:220-286) on histogram column `tid`: the 36 bins are pulled into
+                // registers first (independent LDS reads in flight), the serial logic then runs on registers
+                float hv[36];
+#pragma unroll
+                for (int i = 0; i < 36; ++i) hv[i] = s_hist[i][tid];
                 int max_index = 0;
-                float hmax = s_hist[0][tid];
+                float hmax = hv[0];
+#pragma unroll
                 for (int i = 1; i < 36; ++i) {
-                    const float v = s_hist[i][tid];
+                    const float v = hv[i];
                     if (hmax < v) { hmax = v; max_index = i; }  // std::max_element: first largest
                 }
                 const float range = (float)((double)hmax * 0.8);
-                auto thresholded = [&](int i) {
-                    const float v = s_hist[i][tid];
-                    return (v < range) ? -1.0f : v;
-                };
                 auto vertex_at = [&](int i) {
                     unsigned short lnx, rnx;
                     float lny, rny;
@@ -253,6 +288,25 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
                     else         { rnx = (unsigned short)((i + 1) * 10 + 5); rny = s_hist[i + 1][tid]; }
                     return vertex_parabola(lnx, lny, px, py, rnx, rny);
                 };
+                // peaks_only after the 80% threshold and the in-place local-maximum sweep (i = 1..34 uses the
+                // already updated left neighbour and the not yet updated right): which bins survive, as a bit set
+                unsigned long long peak_bits = 0ull;
+                {
+                    auto thresholded = [&](float v) { return (v < range) ? -1.0f : v; };
+                    float left = thresholded(hv[0]);      // peaks_only[0], never touched by the sweep
+                    float cur = thresholded(hv[1]);
+                    if (left > -1.0f) peak_bits |= 1ull;
+#pragma unroll
+                    for (int i = 1; i < 36; ++i) {
+                        const float right = (i < 35) ? thresholded(hv[i < 35 ? i + 1 : 35]) : 0.0f;
+                        float only_i = cur;
+                        if (i < 35 && (cur < left || cur < right)) only_i = -1.0f;
+                        left = only_i;
+                        cur = right;
+                        if (only_i > -1.0f) peak_bits |= 1ull << i;
+                    }
+                    peak_bits &= ~(1ull << max_index);
+                }
                 // std::set<float>::emplace: a NaN first element blocks every later insert (no key
                 // compares less than it and it compares less than none); a later NaN is never
                 // inserted; numbers insert sorted and unique.
@@ -260,22 +314,9 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
                 s_set[0][tid] = v0;
                 int n = 1;
                 const bool nan_first = (v0 != v0);
-                // peaks_only after the 80% threshold and the in-place local-maximum sweep
-                // (i = 1..34 uses the already updated left neighbour and the not yet updated right)
-                float left = thresholded(0);      // peaks_only[0], never touched by the sweep
-                float cur = thresholded(1);
-                for (int i = 0; i < 36; ++i) {
-                    float only_i;
-                    if (i == 0) {
-                        only_i = left;
-                    } else {
-                        const float right = (i < 35) ? thresholded(i + 1) : 0.0f;
-                        only_i = cur;
-                        if (i < 35 && (cur < left || cur < right)) only_i = -1.0f;
-                        left = only_i;
-                        cur = right;
-                    }
-                    if (!(only_i > -1.0f) || i == max_index) continue;
+                while (peak_bits) {   // ascending bin order, as the reference's loop
+                    const int i = __ffsll((long long)peak_bits) - 1;
+                    peak_bits &= peak_bits - 1ull;
                     const float v = vertex_at(i);
                     if (!nan_first && v == v) {
                         int pos = 0;
@@ -308,11 +349,13 @@ void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, floa
 
 void launch_orientation(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const Candidate* d_cands,
                         const OrientIn* d_oin, const int* d_list_cnt, int list_cap, OrientOut* d_out,
-                        float* d_peaks) {
+                        float* d_peaks, int* d_next_group) {
     (void)d_cands;
     const dim3 grid(128, (unsigned)plan.n_images);
+    static const int dbg = [] { const char* e = getenv("SIFT_ORIENT_DBG"); return e ? atoi(e) : 0; }();   // timing ablations only
+    (void)hipMemsetAsync(d_next_group, 0, sizeof(int) * (size_t)plan.n_images, s);
     hipLaunchKernelGGL(orientation_kernel, grid, dim3(256), 0, s, d_plan, d_oin, d_list_cnt, list_cap, d_out,
-                       d_peaks);
+                       d_peaks, d_next_group, dbg);
 }
 
 }  // namespace sift_hip
