@@ -6,9 +6,10 @@ greyscale frames, 4 octaves x 3 DoGs (BASELINE.json metric / config 4's per-GPU 
 
 One process per GPU (launched by torch.distributed.run for N > 1).  A "step" is one pass of the
 whole hot path (pyramid, DoG, extrema, edge filter, orientation, descriptors) over one batch of
-FRAMES_PER_GPU device-resident frames per GPU; for N > 1 the step ends with the RCCL gather of the
-keypoint lists (records + descriptors, never images) on rank 0.  Weak scaling: per-GPU work is
-fixed.  Rank 0 prints ONE JSON line.
+FRAMES_PER_GPU device-resident frames per GPU; for N > 1 every step's keypoint lists (records +
+descriptors, never images) are gathered on rank 0 over RCCL, the transfer of step k overlapping the
+kernels of step k+1, all inside the timed region.  Weak scaling: per-GPU work is fixed.  Rank 0
+prints ONE JSON line.
 """
 import argparse
 import ctypes as C
@@ -64,6 +65,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
+                    "exercise the N > 1 flow where ranks have to share one GPU: results are staged through host memory)")
+    ap.add_argument("--share-device", action="store_true", help="testing: every rank uses GPU 0")
     ap.add_argument("--lanes", type=int, default=1,
                     help="contexts (streams + host threads) per GPU, each taking an equal share of the batch, so one\n"
                          "lane's latency-bound stages overlap the other's bandwidth-bound ones")
@@ -81,11 +85,17 @@ def main():
     from sift_amd.sift import Context, K_SQRT2
     from sift_amd.synthetic import synth_frame
 
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     nf = args.frames
     seeds = [rank * nf + i + 1 for i in range(nf)]  # config 4: seeds 1..256 block-sharded
@@ -104,30 +114,50 @@ def main():
     frame_bytes = W * H * 4
     pool = ThreadPool(lanes) if lanes > 1 else None
 
-    from sift_amd.gather import gather_keypoints
+    from sift_amd.gather import gather_finish, gather_start
 
     def run_lane(i):
         ctxs[i].calculate_batch_device(d_frames.data_ptr() + first[i] * frame_bytes, share[i], W, H, params)
         return ctxs[i].total()
 
+    # N > 1: the RCCL gather of step k (keypoint records + descriptors to rank 0, never images) is only
+    # STARTED at the end of step k and overlaps the kernels of step k+1, which run on the library's own
+    # streams; two result buffers alternate, and every gather is finished inside the timed region.
+    in_flight = []          # (GatherHandle, buffers kept alive)
+    bufs = [None, None]
+    step_no = [0]
+
     def step():
         totals = pool.map(run_lane, range(lanes)) if pool else [run_lane(0)]   # ctypes calls release the GIL
         total = sum(totals)
         if world > 1:
-            # RCCL gather of the keypoint lists only (counts, then records + descriptors to rank 0)
-            kp = torch.empty(max(total, 1) * 20, dtype=torch.uint8, device=dev)
-            desc = torch.empty(max(total, 1) * 128, dtype=torch.float32, device=dev)
+            b = step_no[0] & 1
+            step_no[0] += 1
+            while len(in_flight) > 1:      # the buffer pair about to be reused must have left
+                gather_finish(in_flight.pop(0)[0])
+            need = max(total, 1)
+            if bufs[b] is None or bufs[b][0].numel() < need * 20:
+                bufs[b] = (torch.empty(need * 20 * 5 // 4, dtype=torch.uint8, device=dev),
+                           torch.empty(need * 128 * 5 // 4, dtype=torch.float32, device=dev))
+            kp, desc = bufs[b]
             off = 0
             for c, t in zip(ctxs, totals):   # lanes hold consecutive image ranges: concatenation keeps image order
                 if t:
                     L.sift_hip_result_copy(c._h, C.c_void_p(kp.data_ptr() + off * 20), C.c_void_p(desc.data_ptr() + off * 512))
                 off += t
-            counts = torch.from_numpy(np.concatenate([c.counts() for c in ctxs])).to(dev)
-            gather_keypoints(kp, desc, counts, dst=0)
+            counts = torch.from_numpy(np.concatenate([c.counts() for c in ctxs])).to(comm_dev)
+            if comm_dev.type == "cpu":     # test backend: stage through host memory
+                kp, desc = kp[:need * 20].cpu(), desc[:need * 128].cpu()
+            in_flight.append((gather_start(kp, desc, counts, dst=0), (kp, desc)))
         return total
+
+    def drain():
+        while in_flight:
+            gather_finish(in_flight.pop(0)[0])
 
     for _ in range(args.warmup):
         step()
+    drain()
     for c in ctxs:
         c.set_option("profile", 1)
         c.profile_reset()
@@ -138,6 +168,7 @@ def main():
     kps = 0
     for _ in range(args.steps):
         kps += step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -146,10 +177,10 @@ def main():
         c.set_option("profile", 0)
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        k = torch.tensor([kps], dtype=torch.int64, device=dev)
+        k = torch.tensor([kps], dtype=torch.int64, device=comm_dev)
         dist.all_reduce(k, op=dist.ReduceOp.SUM)
         kps = int(k.item())
 
@@ -174,7 +205,7 @@ def main():
                                    f"4 octaves x 3 DoGs, subpixel off (BASELINE config 4 per-GPU share)",
                        "frames_per_gpu": nf, "frames_total": nf * world, "lanes_per_gpu": lanes, "keypoints_per_step": kps // max(args.steps, 1),
                        "frames_per_s": nf * world * args.steps / dt,
-                       "gather": "RCCL p2p of keypoint records + descriptors to rank 0" if world > 1 else "none (1 GPU)"},
+                       "gather": "RCCL p2p of keypoint records + descriptors to rank 0, started per step and overlapped with the next step" if world > 1 else "none (1 GPU)"},
             "roofline": {"kernel": "blur_stream_kernel / blur_fused_kernel (separable Gaussian + DoG; every launch of the pyramid)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),

@@ -165,6 +165,13 @@ hipEvent_t get_event(sift_hip_ctx* c) {
 }
 
 void resolve_events(sift_hip_ctx* c) {
+    if (c->pending.size() >= 2 && getenv("SIFT_PYRAMID_SPAN")) {   // diagnostics: wall time of the blur chain vs the sum of its kernels
+        float span = 0, sum = 0;
+        (void)hipEventSynchronize(c->pending.back().b);
+        (void)hipEventElapsedTime(&span, c->pending.front().a, c->pending.back().b);
+        for (auto& p : c->pending) { float ms = 0; (void)hipEventElapsedTime(&ms, p.a, p.b); sum += ms; }
+        std::fprintf(stderr, "pyramid span %.3f ms, sum of blur kernels %.3f ms, launches %zu\n", span, sum, c->pending.size());
+    }
     for (auto& p : c->pending) {
         float ms = 0;
         SIFT_HIP_CHECK(hipEventSynchronize(p.b));

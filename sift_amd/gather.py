@@ -46,3 +46,67 @@ def gather_keypoints(kp_bytes: torch.Tensor, desc: torch.Tensor, counts: torch.T
                                          dist.P2POp(dist.isend, desc[:total * 128].contiguous(), dst)]):
             w.wait()
     return None
+
+
+class GatherHandle:
+    """One gather in flight: the point-to-point works plus what `finish` needs to assemble the result."""
+
+    def __init__(self, works, parts, sizes, allc, keep):
+        self.works, self.parts, self.sizes, self.allc, self.keep = works, parts, sizes, allc, keep
+
+
+def gather_start(kp_bytes: torch.Tensor, desc: torch.Tensor, counts: torch.Tensor, dst: int = 0) -> GatherHandle:
+    """Non-blocking form of `gather_keypoints`: the (tiny) count exchange is done here, the record and
+    descriptor transfers are only STARTED, so they overlap whatever the caller does next (the next
+    batch's kernels run on the library's own streams).  The caller must not touch `kp_bytes` / `desc`
+    until `gather_finish` returned."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = kp_bytes.device
+    total = int(counts.sum().item())
+    n_img = torch.tensor([counts.numel(), total], dtype=torch.int64, device=dev)
+    sizes = [torch.empty_like(n_img) for _ in range(world)]
+    dist.all_gather(sizes, n_img)
+    sizes = [tuple(int(v) for v in s.tolist()) for s in sizes]
+    m = max(s[0] for s in sizes)
+    padded = torch.zeros(m, dtype=torch.int32, device=dev)
+    padded[:counts.numel()] = counts.to(torch.int32)
+    allc = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(allc, padded)
+    works, parts = [], None
+    if rank == dst:
+        # one contiguous destination in rank order (= global image order): every rank's part is received
+        # straight into its slice, the local part is copied there
+        total_all = sum(sz[1] for sz in sizes)
+        kp_all = torch.empty(total_all * 20, dtype=torch.uint8, device=dev)
+        desc_all = torch.empty(total_all * 128, dtype=torch.float32, device=dev)
+        ops, off = [], 0
+        for r in range(world):
+            t = sizes[r][1]
+            if r == rank:
+                kp_all[off * 20:(off + t) * 20].copy_(kp_bytes[:t * 20])
+                desc_all[off * 128:(off + t) * 128].copy_(desc[:t * 128])
+            elif t:
+                ops += [dist.P2POp(dist.irecv, kp_all[off * 20:(off + t) * 20], r),
+                        dist.P2POp(dist.irecv, desc_all[off * 128:(off + t) * 128], r)]
+            off += t
+        if ops:
+            works = dist.batch_isend_irecv(ops)
+        parts = (kp_all, desc_all)
+        keep = (kp_bytes, desc)
+    else:
+        keep = (kp_bytes[:total * 20].contiguous(), desc[:total * 128].contiguous())
+        if total:
+            works = dist.batch_isend_irecv([dist.P2POp(dist.isend, keep[0], dst), dist.P2POp(dist.isend, keep[1], dst)])
+    return GatherHandle(works, parts, sizes, allc, keep)
+
+
+def gather_finish(h: GatherHandle):
+    """Wait for the transfers of `h`.  On the destination rank returns (kp_bytes_all, desc_all, counts_all)
+    in rank order; None on the other ranks."""
+    for w in h.works:
+        w.wait()
+    if h.parts is None:
+        return None
+    world = len(h.sizes)
+    counts_all = torch.cat([h.allc[r][:h.sizes[r][0]] for r in range(world)])
+    return h.parts[0], h.parts[1], counts_all

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from sift_amd.gather import gather_keypoints
+from sift_amd.gather import gather_finish, gather_keypoints, gather_start
 
 
 def _fake_rank_data(rank):
@@ -29,6 +29,20 @@ def _worker(rank, world, port, q):
         q.put((out[0].numpy().copy(), out[1].numpy().copy(), out[2].numpy().copy()))
     else:
         assert out is None
+    # pipelined form (bench.py, N > 1): two gathers in flight, finished in order
+    hs = []
+    for step in range(3):
+        c2, k2, d2 = _fake_rank_data(rank + 10 * (step + 1))
+        hs.append((step, gather_start(torch.from_numpy(k2), torch.from_numpy(d2), torch.from_numpy(c2), dst=0)))
+        if len(hs) > 2:
+            st, h = hs.pop(0)
+            res = gather_finish(h)
+            if rank == 0:
+                q.put((st, res[0].numpy().copy(), res[1].numpy().copy(), res[2].numpy().copy()))
+    for st, h in hs:
+        res = gather_finish(h)
+        if rank == 0:
+            q.put((st, res[0].numpy().copy(), res[1].numpy().copy(), res[2].numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -44,6 +58,7 @@ def test_gather_two_ranks():
     for p in procs:
         p.start()
     kp, desc, counts = q.get(timeout=120)
+    piped = [q.get(timeout=120) for _ in range(3)]
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -52,3 +67,9 @@ def test_gather_two_ranks():
     assert (counts == np.concatenate([c0, c1])).all()
     assert (kp == np.concatenate([k0, k1])).all()
     assert (desc == np.concatenate([d0, d1])).all()
+    for st, kp2, desc2, counts2 in piped:
+        a0, b0, e0 = _fake_rank_data(0 + 10 * (st + 1))
+        a1, b1, e1 = _fake_rank_data(1 + 10 * (st + 1))
+        assert (counts2 == np.concatenate([a0, a1])).all()
+        assert (kp2 == np.concatenate([b0, b1])).all()
+        assert (desc2 == np.concatenate([e0, e1])).all()
