@@ -142,9 +142,11 @@ void launch_w16(hipStream_t s, const DevPlan& plan, int level, const float* d_ta
 void launch_desc_binning(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const FinalKp* d_final,
                          const int* d_final_cnt, int final_cap, int* d_tile_cnt, int* d_tile_off,
                          int* d_tile_cur, FinalKp* d_pool, int pool_cap);
+void launch_out_base(hipStream_t s, const int* d_final_cnt, int n, long long* d_out_base);
 void launch_descriptors(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level,
                         const FinalKp* d_final, const int* d_final_cnt, int final_cap,
                         const int* d_tile_cnt, const int* d_tile_off, const FinalKp* d_pool, int pool_cap,
-                        const long long* d_out_base, sift_hip_keypoint* d_kp_out, float* d_desc_out, int dbg = 0);
+                        const long long* d_out_base, sift_hip_keypoint* d_kp_out, float* d_desc_out, long long out_cap,
+                        int dbg = 0);
 
 }  // namespace sift_hip

@@ -109,6 +109,8 @@ struct sift_hip_ctx {
     bool gpu_cleanup = true;
     bool profile = false;
     bool binned = false;   // this batch's keypoints are already binned to descriptor tiles
+    bool described = false;   // ... and their descriptors are already computed
+    long long out_cap = 0;    // keypoints d_kp / d_desc hold
     int host_threads = 0;
     int desc_dbg = 0;
     Plan plan;
@@ -608,6 +610,25 @@ void bin_keypoints(sift_hip_ctx* c) {
                         t_off, t_cur, c->d_pool.as<FinalKp>(), kPoolCap);
 }
 
+void ensure_outputs(sift_hip_ctx* c, long long keypoints) {
+    if (keypoints <= c->out_cap) return;
+    c->out_cap = keypoints;
+    c->d_kp.ensure((size_t)keypoints * sizeof(sift_hip_keypoint));
+    c->d_desc.ensure((size_t)keypoints * 128 * sizeof(float));
+}
+
+void launch_descriptor_stage(sift_hip_ctx* c) {
+    Plan& P = c->plan;
+    const DevPlan& dv = P.dev;
+    const size_t nt = (size_t)dv.desc_tiles_per_image * (size_t)P.n;
+    int* t_cnt = c->d_tile.as<int>();
+    int* t_off = t_cnt + nt;
+    for (int lvl : P.grad_levels)
+        launch_descriptors(c->stream, c->d_plan.as<DevPlan>(), dv, lvl, c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(), kListCap,
+                           t_cnt, t_off, c->d_pool.as<FinalKp>(), kPoolCap, c->d_out_base.as<long long>(),
+                           c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->out_cap, c->desc_dbg);
+}
+
 bool mid_gpu(sift_hip_ctx* c) {
     Plan& P = c->plan;
     const DevPlan& dv = P.dev;
@@ -641,12 +662,20 @@ bool mid_gpu(sift_hip_ctx* c) {
     // the tile binning only needs the device-side lists: it keeps the GPU busy while the host waits for the counts
     if (!fused_bin) bin_keypoints(c);
     c->binned = true;
+    // The descriptor stage does not wait for the counts to reach the host: output slots come from a device-side
+    // scan and the output arrays keep a generous capacity; should a batch ever exceed it, the (idempotent: the
+    // mutated maps only live in LDS) stage is simply run again after growing them.
+    launch_out_base(s, c->d_final_cnt.as<int>(), n, c->d_out_base.as<long long>());
+    ensure_outputs(c, std::max<long long>(c->out_cap, (long long)n * 32768));
+    launch_descriptor_stage(c);
+    c->described = true;
     std::vector<int> st((size_t)n * 5);
     SIFT_HIP_CHECK(hipMemcpyAsync(st.data(), c->d_status.p, st.size() * sizeof(int), hipMemcpyDeviceToHost, s));
     SIFT_HIP_CHECK(hipStreamSynchronize(s));
     for (int i = 0; i < n; ++i)
         if (st[(size_t)i * 4 + 1] || st[(size_t)n * 4 + (size_t)i]) {
             c->binned = false;   // the host path rebuilds the lists
+            c->described = false;
             return false;
         }
     for (int i = 0; i < n; ++i) {
@@ -725,6 +754,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     c->have_pyramid = false;
     c->stages_on_host = false;
     c->binned = false;
+    c->described = false;
 
     run_pyramid(c, d_in);
     c->have_pyramid = true;
@@ -790,18 +820,14 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
         total += c->counts[(size_t)i];
     }
     c->total = total;
-    c->d_kp.ensure(std::max<size_t>((size_t)total, 1) * sizeof(sift_hip_keypoint));
-    c->d_desc.ensure(std::max<size_t>((size_t)total, 1) * 128 * sizeof(float));
-    SIFT_HIP_CHECK(hipMemcpyAsync(c->d_out_base.p, c->out_base.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice, s));
-    if (total > 0) {
-        const size_t nt = (size_t)dv.desc_tiles_per_image * (size_t)n;
-        int* t_cnt = c->d_tile.as<int>();
-        int* t_off = t_cnt + nt;
-        if (!c->binned) bin_keypoints(c);
-        for (int lvl : P.grad_levels)
-            launch_descriptors(s, dpl, dv, lvl, c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(), kListCap, t_cnt, t_off,
-                               c->d_pool.as<FinalKp>(), kPoolCap, c->d_out_base.as<long long>(),
-                               c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->desc_dbg);
+    if (c->described && total > c->out_cap) c->described = false;   // outputs were too small: grow and redo
+    if (!c->described) {
+        ensure_outputs(c, std::max<long long>(total, 1));
+        SIFT_HIP_CHECK(hipMemcpyAsync(c->d_out_base.p, c->out_base.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice, s));
+        if (total > 0) {
+            if (!c->binned) bin_keypoints(c);
+            launch_descriptor_stage(c);
+        }
     }
     SIFT_HIP_CHECK(hipStreamSynchronize(s));
     c->have_result = true;

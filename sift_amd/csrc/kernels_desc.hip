@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __res
                                                          const FinalKp* __restrict__ pool, int pool_cap,
                                                          const long long* __restrict__ out_base,
                                                          sift_hip_keypoint* __restrict__ kp_out,
-                                                         float* __restrict__ desc_out, int dbg) {
+                                                         float* __restrict__ desc_out, long long out_cap, int dbg) {
     __shared__ __attribute__((aligned(16))) float s_ori[kExt * kExt];
     __shared__ __attribute__((aligned(16))) float s_mag[kExt * kExt];
     __shared__ float s_w16[256];
@@ -369,8 +369,9 @@ __global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __res
                     const unsigned fl = s_flag[e];
                     const bool kfilt = (fl & 1u) != 0;
                     const bool owned = (fl & 2u) != 0;
-                    if (owned) {   // uniform over the 32 threads of a keypoint (partners included)
-                        const long long ok = obase + (long long)s_list[e];
+                    const long long ok = obase + (long long)s_list[e];
+                    // (the output arrays are sized before the final counts reach the host: see run_batch)
+                    if (owned && ok < out_cap) {   // uniform over the 32 threads of a keypoint (partners included)
                         // bin 7 is never written (the index is taken % 7) but is normalised: a = bins 0|4, ... d = 3|7
                         float ha = 0.0f, hb2 = 0.0f, hc = 0.0f, hd = 0.0f;
                         if (!kfilt) {
@@ -510,13 +511,42 @@ void launch_desc_binning(hipStream_t s, const DevPlan* d_plan, const DevPlan& pl
                        d_tile_cnt, (const int*)d_tile_off, d_tile_cur, d_pool, pool_cap);
 }
 
+// exclusive scan of the per-image final counts -> first output slot of every image
+__global__ __launch_bounds__(1024) void out_base_kernel(const int* __restrict__ final_cnt, int n,
+                                                        long long* __restrict__ out_base) {
+    __shared__ long long s_part[1024];
+    const int tid = threadIdx.x;
+    const int chunk = (n + 1023) / 1024;
+    const int lo = tid * chunk, hi = min(lo + chunk, n);
+    long long sum = 0;
+    for (int i = lo; i < hi; ++i) sum += final_cnt[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const long long v = tid >= off ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    long long run = s_part[tid] - sum;
+    for (int i = lo; i < hi; ++i) {
+        out_base[i] = run;
+        run += final_cnt[i];
+    }
+}
+
+void launch_out_base(hipStream_t s, const int* d_final_cnt, int n, long long* d_out_base) {
+    hipLaunchKernelGGL(out_base_kernel, dim3(1), dim3(1024), 0, s, d_final_cnt, n, d_out_base);
+}
+
 void launch_descriptors(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level,
                         const FinalKp* d_final, const int* d_final_cnt, int final_cap,
                         const int* d_tile_cnt, const int* d_tile_off, const FinalKp* d_pool, int pool_cap,
-                        const long long* d_out_base, sift_hip_keypoint* d_kp_out, float* d_desc_out, int dbg) {
+                        const long long* d_out_base, sift_hip_keypoint* d_kp_out, float* d_desc_out, long long out_cap,
+                        int dbg) {
     const dim3 grid((unsigned)plan.desc_ntx[level], (unsigned)plan.desc_nty[level], (unsigned)plan.n_images);
     hipLaunchKernelGGL(descriptor_kernel, grid, dim3(256), 0, s, d_plan, level, d_final, d_final_cnt, final_cap,
-                       d_tile_cnt, d_tile_off, d_pool, pool_cap, d_out_base, d_kp_out, d_desc_out, dbg);
+                       d_tile_cnt, d_tile_off, d_pool, pool_cap, d_out_base, d_kp_out, d_desc_out, out_cap, dbg);
 }
 
 }  // namespace sift_hip
