@@ -68,7 +68,33 @@ def make_case(name, img, dogs, octaves, subpixel=False, meta=None):
     print(name, "final", fin.size)
 
 
+def make_digest_case(name, img, dogs, octaves, subpixel, meta, throwing_octaves=None):
+    """Large cases (BASELINE config 5): only digests are committed, the arrays would be tens of MB."""
+    out = {}
+    if throwing_octaves is not None:   # the reference throws for this many octaves (App. B-14): keep its message
+        run = O.OracleRun(img, dogs, throwing_octaves, subpixel=subpixel)
+        assert run.status == 1
+        out["throw_octaves"] = np.int64(throwing_octaves)
+        out["throw_message"] = np.array(run.error)
+        run.close()
+    run = O.OracleRun(img, dogs, octaves, subpixel=subpixel)
+    assert run.status == 0, run.error
+    fin, desc = run.points("final")
+    counts = np.array([run.points(s)[0].size for s in ("candidates", "after_sort1", "after_orient", "after_sort2", "final")], np.int64)
+    np.savez_compressed(os.path.join(HERE, f"digest_{name}.npz"),
+                        meta=np.array([dogs, octaves, int(subpixel)] + list(meta), np.int64), counts=counts,
+                        kp_sha=np.array(sha(np.stack([fin["x"], fin["y"], fin["octave"], fin["index"]], 1).astype(np.uint16))),
+                        orientation_sha=np.array(sha(fin["orientation"])), scale_sha=np.array(sha(fin["scale"])),
+                        descriptors_sha=np.array(sha(desc)), first_kp=np.array([fin["x"][0], fin["y"][0], fin["octave"][0]], np.int64),
+                        **out)
+    print(name, "final", fin.size, "oracle seconds", run.seconds)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "config5":
+        # BASELINE config 5: 3840x2160, subpixel, 6 octaves throws in the reference; 5 octaves runs
+        make_digest_case("config5_4k", synth_frame(3840, 2160, 3), 3, 5, True, [3840, 2160, 3], throwing_octaves=6)
+        return
     pgm = os.path.join(HERE, "parrot_r.pgm")
     if os.path.exists("/root/reference/example/parrot.jpg"):
         from PIL import Image

@@ -318,6 +318,29 @@ def test_hip_matches_golden(ctx, name):
     assert desc.tobytes() == g["descriptors"].tobytes()
 
 
+def test_config5_4k_subpixel_digest(ctx):
+    """BASELINE config 5: 3840x2160, subpixel, 3 DoGs.  6 octaves makes the reference throw in the dead 16x16
+    blur of an octave-5 keypoint (App. B-14): same message here; 5 octaves runs: counts of every stage and
+    SHA-256 of keypoints, orientations, scales and descriptors equal the oracle's (tests/golden/digest_*.npz,
+    make_golden.py config5 — the oracle needs minutes for this frame).  Also covers the paths only big
+    frames take: > 2^20 candidates per image (global-memory sort keys) and > 4096 descriptor tiles."""
+    from golden_util import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "digest_config5_4k.npz"))
+    dogs, octaves, subpixel, w, h, seed = (int(v) for v in g["meta"])
+    img = synth_frame(w, h, seed)
+    with pytest.raises(PreconditionViolation) as e:
+        ctx.calculate_batch(img[None], _lib.Params(dogs, int(g["throw_octaves"]), 1.6, O.K_SQRT2, subpixel))
+    assert str(e.value) == str(g["throw_message"])
+    ctx.calculate_batch(img[None], _lib.Params(dogs, octaves, 1.6, O.K_SQRT2, subpixel))
+    got = [ctx.stage(s).size for s in ("candidates", "after_sort1", "after_orient", "after_sort2", "final")]
+    assert got == g["counts"].tolist()
+    kp, desc = ctx.results()
+    assert sha(np.stack([kp["x"], kp["y"], kp["octave"], kp["index"]], 1).astype(np.uint16)) == str(g["kp_sha"])
+    assert sha(kp["orientation"]) == str(g["orientation_sha"])
+    assert sha(kp["scale"]) == str(g["scale_sha"])
+    assert sha(desc) == str(g["descriptors_sha"])
+
+
 # ------------------------------------------------------------------------------------------------
 # cleanup (std::sort + u16 truncation) as a GPU kernel vs libstdc++ itself
 # ------------------------------------------------------------------------------------------------
