@@ -114,10 +114,10 @@ void launch_edge_filter_points(hipStream_t s, const float* d0, const float* d1, 
 void launch_vertex_parabola(hipStream_t s, const uint16_t* lnx, const float* lny, const uint16_t* px,
                             const float* py, const uint16_t* rnx, const float* rny, int m, float* out);
 void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, float* prod, uint8_t* obin, int w, int h,
-                     int n);
+                     int n, int* d_any_bin = nullptr);
 void launch_orientation(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const Candidate* d_cands,
                         const OrientIn* d_oin, const int* d_list_cnt, int list_cap, OrientOut* d_out,
-                        float* d_peaks, int* d_next_group);
+                        float* d_peaks, int* d_next_group, const int* d_any_bin = nullptr);
 // host-glue path: orientation inputs in list order from an uploaded survivor list
 void launch_build_orient_in(hipStream_t s, const Candidate* d_cands, long long cand_cap, const uint32_t* d_list,
                             const int* d_list_cnt, int list_cap, int n_images, OrientIn* d_oin);
@@ -136,7 +136,8 @@ void launch_cleanup2(hipStream_t s, int n_images, const DevPlan* d_plan, int bin
                      int* d_final_cnt, int* d_status);
 void cleanup_set_stamp_buffer(unsigned long long* d);
 void launch_cleanup_kat(hipStream_t s, const uint8_t* d_flags, int n, uint8_t* wk, uint32_t* wi, uint32_t* wi2,
-                        uint32_t* wp, uint32_t* d_out, int* d_info, int force_global);
+                        uint32_t* wp, uint32_t* d_out, int* d_info, int force_global, OrientIn* d_ord,
+                        uint32_t* d_lrank, const Candidate* d_cd);
 void launch_w16(hipStream_t s, const DevPlan& plan, int level, const float* d_taps16, int radius16);
 // bins the final keypoints into per-tile lists (counts -> offsets -> fill), then one workgroup per tile
 void launch_desc_binning(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const FinalKp* d_final,

@@ -350,7 +350,7 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
         dv.desc_tiles_per_image = std::max(tb, 1);
     }
     dv.words_per_image = std::max(words, 1);
-    dv.cand_capacity = std::max(cap, 1LL);
+    dv.cand_capacity = (std::max(cap, 1LL) + 15) / 16 * 16;   // every image's flag bytes start 16-byte aligned
     gauss_taps(1.6f, P.taps16, P.radius16);
 
     // ---- device memory ----------------------------------------------------------------------------
@@ -409,7 +409,7 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
     c->d_order.ensure((size_t)kListCap * (size_t)n * sizeof(OrientIn));
     c->d_lrank.ensure((size_t)kListCap * (size_t)n * sizeof(uint32_t));
     c->d_ochunk.ensure(orient_prepare_chunks(dv.cand_capacity) * (size_t)n * sizeof(int));
-    c->d_ocnt.ensure((size_t)n * 4 * sizeof(int));   // early counts, late counts, group counters of the two launches
+    c->d_ocnt.ensure((size_t)n * 5 * sizeof(int));   // early counts, late counts, group counters of the two launches, bin flags
     c->d_orient.ensure((size_t)kListCap * (size_t)n * sizeof(OrientOut));
     c->d_peaks.ensure((size_t)kListCap * (size_t)n * 36 * sizeof(float));
     c->d_final.ensure((size_t)kListCap * (size_t)n * sizeof(FinalKp));
@@ -543,7 +543,7 @@ void mid_host(sift_hip_ctx* c) {
     launch_build_orient_in(s, c->d_cands.as<Candidate>(), dv.cand_capacity, c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
                            kListCap, n, c->d_order.as<OrientIn>());
     launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_order.as<OrientIn>(), c->d_list_cnt.as<int>(), kListCap,
-                       c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 3 * n);
+                       c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 3 * n, c->d_ocnt.as<int>() + 4 * n);
     c->h_orient.ensure((size_t)n * kListCap * sizeof(OrientOut));
     for (int i = 0; i < n; ++i)
         if (cnt1[(size_t)i])
@@ -651,7 +651,7 @@ bool mid_gpu(sift_hip_ctx* c) {
     SIFT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
     // late launch: only the images whose survivor list was truncated (counts are 0 for the others)
     launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_order.as<OrientIn>(), d_late, kListCap,
-                       c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 3 * n);
+                       c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 3 * n, c->d_ocnt.as<int>() + 4 * n);
     const bool fused_bin = cleanup2_can_bin(dv.desc_tiles_per_image);
     const size_t nt = (size_t)dv.desc_tiles_per_image * (size_t)n;
     launch_cleanup2(s, n, dpl, fused_bin ? 1 : 0, c->d_tile.as<int>(), c->d_tile.as<int>() + nt, c->d_pool.as<FinalKp>(), kPoolCap,
@@ -775,9 +775,11 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     hipStream_t gs = serial_gradient ? s : c->stream2;
     SIFT_HIP_CHECK(hipEventRecord(c->ev_fork0, s));
     SIFT_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork0, 0));
+    SIFT_HIP_CHECK(hipMemsetAsync(c->d_ocnt.as<int>() + 4 * n, 0, (size_t)n * sizeof(int), gs));   // "some sample has a bin != 0" per image
     for (int lvl : P.grad_levels) {
         const int o = lvl / (P.D + 1);
-        launch_gradient(gs, dv.gauss[lvl], dv.mag[lvl], dv.ori[lvl], dv.prod[lvl], dv.obin[lvl], dv.w[o], dv.h[o], n);
+        launch_gradient(gs, dv.gauss[lvl], dv.mag[lvl], dv.ori[lvl], dv.prod[lvl], dv.obin[lvl], dv.w[o], dv.h[o], n,
+                        c->d_ocnt.as<int>() + 4 * n);
         launch_w16(gs, dv, lvl, c->d_taps16.as<float>(), P.radius16);
     }
     // extrema + edge responses (sift.cpp:33-34)
@@ -803,7 +805,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
                               c->d_ochunk.as<int>(), c->d_cands.as<Candidate>(), kListCap, c->d_order.as<OrientIn>(),
                               c->d_ocnt.as<int>());
         launch_orientation(c->stream2, dpl, dv, c->d_cands.as<Candidate>(), c->d_order.as<OrientIn>(), c->d_ocnt.as<int>(),
-                           kListCap, c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 2 * n);
+                           kListCap, c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 2 * n, c->d_ocnt.as<int>() + 4 * n);
     }
     SIFT_HIP_CHECK(hipEventRecord(c->ev_join, c->stream2));
     // cleanup, orientation assignment, cleanup (sift.cpp:37-54)
@@ -1293,7 +1295,11 @@ int sift_hip_cleanup_survivors(sift_hip_ctx* c, const uint8_t* flags, int n, int
             SIFT_HIP_CHECK(hipMemset(st, 0, 512 * sizeof(unsigned long long)));
             cleanup_set_stamp_buffer(st);
         }
-        launch_cleanup_kat(c->stream, d_fl, n, wk, wi, wi2, wp, out, info, on_gpu == 2 ? 1 : 0);
+        OrientIn* kord = s.dev<OrientIn>(65536);
+        uint32_t* klr = s.dev<uint32_t>(65536);
+        Candidate* kcd = s.dev<Candidate>(m);
+        SIFT_HIP_CHECK(hipMemset(kcd, 0, m * sizeof(Candidate)));
+        launch_cleanup_kat(c->stream, d_fl, n, wk, wi, wi2, wp, out, info, on_gpu == 2 ? 1 : 0, kord, klr, kcd);
         SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
         int h_info[2];
         SIFT_HIP_CHECK(hipMemcpy(h_info, info, sizeof(h_info), hipMemcpyDeviceToHost));
@@ -1310,9 +1316,14 @@ int sift_hip_cleanup_survivors(sift_hip_ctx* c, const uint8_t* flags, int n, int
                 std::fprintf(stderr, "\n");
             }
             cleanup_set_stamp_buffer(nullptr);
-            std::fprintf(stderr, "cleanup stamps (us): init %.1f loop %.1f copy %.1f pure %.1f compact %.1f  npure %llu\n",
-                         (hs[1] - hs[0]) / 100.0, (hs[2] - hs[1]) / 100.0, (hs[3] - hs[2]) / 100.0, (hs[4] - hs[3]) / 100.0,
-                         (hs[5] - hs[4]) / 100.0, hs[6]);
+            if (hs[8])
+                std::fprintf(stderr, "cleanup1 stamps (us): bits %.1f ranks %.1f loop %.1f copy %.1f pure %.1f compact %.1f  npure %llu\n",
+                             (hs[8] - hs[0]) / 100.0, (hs[9] - hs[8]) / 100.0, (hs[2] - hs[1]) / 100.0, (hs[3] - hs[2]) / 100.0,
+                             (hs[4] - hs[3]) / 100.0, (hs[5] - hs[4]) / 100.0, hs[6]);
+            else
+                std::fprintf(stderr, "cleanup stamps (us): init %.1f loop %.1f copy %.1f pure %.1f compact %.1f  npure %llu\n",
+                             (hs[1] - hs[0]) / 100.0, (hs[2] - hs[1]) / 100.0, (hs[3] - hs[2]) / 100.0, (hs[4] - hs[3]) / 100.0,
+                             (hs[5] - hs[4]) / 100.0, hs[6]);
         }
         if (h_info[1]) {  // introsort depth limit: the host's std::sort decides
             std::vector<uint32_t> sv;

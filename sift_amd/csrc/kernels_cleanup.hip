@@ -66,7 +66,9 @@ struct LdsBitKeys {
         }
     }
 };
-constexpr int kBitCap = 1 << 20;   // 128 KiB of LDS
+constexpr int kBitCap = 1 << 19;   // 64 KiB of LDS for the key bits
+constexpr int kMoveSlots = 10;     // pending payload moves per thread (LDS, behind the key bits)
+constexpr int kDynLds = kBitCap / 8 + 1024 * kMoveSlots * 8;
 
 // optional phase stamps (diagnostic builds of the KAT entry only): 100 MHz wall clock
 __device__ unsigned long long* g_stamp = nullptr;
@@ -427,22 +429,40 @@ __device__ void introsort_bits(CleanupShared& sh, int n, const LdsBitKeys K, uin
         int total;
         int t = block_exclusive_scan(sh, cnt, total);
         if (round < 120) stamp(16 + 4 * round + 2);
-        // 2 + 3. participation, partner keys, the swaps that matter
+        // pending payload moves of this thread: (destination, source) pairs parked in LDS, so that all their loads
+        // are in flight together and all stores follow (the moves of a round touch disjoint positions)
+        uint2* myq = reinterpret_cast<uint2*>(K.w + kBitCap / 32) + tid * kMoveSlots;
+        int nmv = 0;
+        auto flush_moves = [&]() {
+            uint32_t v[kMoveSlots];
+#pragma unroll
+            for (int u = 0; u < kMoveSlots; ++u)
+                if (u < nmv) v[u] = I[myq[u].y];
+#pragma unroll
+            for (int u = 0; u < kMoveSlots; ++u)
+                if (u < nmv) I[myq[u].x] = v[u];
+            nmv = 0;
+        };
+        // 2 + 3. participation, partner keys, the swaps that matter.  Lanes find different numbers of moves; the
+        // queue is drained at wave-uniform points only (when any lane's is full), so a wave pays one load and one
+        // store round trip per ~kMoveSlots moves of its busiest lane instead of one per lane and batch.
 #pragma unroll
         for (int j = 0; j < kMaxChunk; ++j) {
             const unsigned long long h = H[j];
+            const int q = p == 1 ? q0 + tid * chunk + j : q1 - tid * chunk - j;
+            const int base = q << 6;
+            const int k = __popcll(h);
+            int kp = 0;                  // participating hits of this word (a prefix in hit order)
+            unsigned long long M = 0ull; // p == 1: hits whose partner is kept (they receive it)
+            unsigned long long field = 0ull;
+            int bref = 0;                // p == 1: partner of hit 0 (bhi); p == 0: partner of hit 0 (blo)
             if (j < chunk && h != 0ull) {
-                const int q = p == 1 ? q0 + tid * chunk + j : q1 - tid * chunk - j;
-                const int base = q << 6;
-                const int k = __popcll(h);
-                int kp;   // participating hits of this word (a prefix in hit order)
                 if (p == 1) {
                     // hit i (ascending position): partner L-1-(t+i); takes part iff pos + t + i < L - 1
                     const int pos_last = base + 63 - __clzll((long long)h);
                     if (pos_last + t + k - 1 < L - 1) {
                         kp = k;
                     } else {
-                        kp = 0;
                         unsigned long long r = h;
                         int fpos = 0;
                         while (r) {
@@ -457,36 +477,10 @@ __device__ void introsort_bits(CleanupShared& sh, int n, const LdsBitKeys K, uin
                         }
                     }
                     if (kp > 0) {
-                        const int bhi = L - 1 - t, blo = bhi - kp + 1;
-                        const unsigned long long field = load_field(K.w, blo, kp);   // bit (kp-1-i) <-> partner of hit i
+                        bref = L - 1 - t;
+                        field = load_field(K.w, bref - kp + 1, kp);   // bit (kp-1-i) <-> partner of hit i
                         const unsigned long long rev = __brevll(field) >> (64 - kp);
-                        unsigned long long M = ~rev & (kp == 64 ? ~0ull : ((1ull << kp) - 1ull));   // partner kept: it moves
-                        while (M) {
-                            int na = 0;
-                            int pa[4], pb[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                pa[u] = pb[u] = 0;
-                                if (M) {
-                                    const int i = __ffsll((long long)M) - 1;
-                                    M &= M - 1ull;
-                                    pa[u] = base + select64(h, i);
-                                    pb[u] = bhi - i;
-                                    na = u + 1;
-                                }
-                            }
-                            uint32_t v[4];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                if (u < na) v[u] = I[pb[u]];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                if (u < na) {
-                                    I[pa[u]] = v[u];
-                                    key_clear(K, pa[u]);   // the kept element now sits at the hit's position
-                                    key_set(K, pb[u]);
-                                }
-                        }
+                        M = ~rev & (kp == 64 ? ~0ull : ((1ull << kp) - 1ull));
                     }
                 } else {
                     // hit i (descending position): partner F+(t+i); takes part iff F + t + i < pos
@@ -494,7 +488,6 @@ __device__ void introsort_bits(CleanupShared& sh, int n, const LdsBitKeys K, uin
                     if (F + t + k - 1 < pos_min) {
                         kp = k;
                     } else {
-                        kp = 0;
                         unsigned long long r = h;
                         while (r) {
                             const int pos = base + 63 - __clzll((long long)r);
@@ -505,46 +498,46 @@ __device__ void introsort_bits(CleanupShared& sh, int n, const LdsBitKeys K, uin
                         if (t + kp < sh.T) atomicMin(&sh.T, t + kp);
                     }
                     if (kp > 0) {
-                        const int blo = F + t;
-                        const unsigned long long field = load_field(K.w, blo, kp);   // bit i <-> partner of hit i
-                        unsigned long long r = h;
-                        for (int i0 = 0; i0 < kp; i0 += 4) {
-                            int pa[4], pb[4];
-                            uint32_t va[4], vb[4];
-                            const int nb = kp - i0 < 4 ? kp - i0 : 4;
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                pa[u] = pb[u] = 0;
-                                if (u < nb) {
-                                    const int pos = 63 - __clzll((long long)r);
-                                    r &= ~(1ull << pos);
-                                    pa[u] = base + pos;
-                                    pb[u] = blo + i0 + u;
-                                }
-                            }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                if (u < nb) {
-                                    va[u] = I[pa[u]];
-                                    vb[u] = I[pb[u]];
-                                }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                if (u < nb) {
-                                    I[pb[u]] = va[u];
-                                    if ((field >> (i0 + u)) & 1ull) {   // partner filtered: the kept element moves there
-                                        key_clear(K, pb[u]);
-                                        key_set(K, pa[u]);
-                                    } else {
-                                        I[pa[u]] = vb[u];               // two kept elements trade places
-                                    }
-                                }
-                        }
+                        bref = F + t;
+                        field = load_field(K.w, bref, kp);   // bit i <-> partner of hit i
                     }
                 }
                 t += k;
             }
+            if (p == 1) {
+                while (__any(M != 0ull)) {
+                    if (M) {
+                        const int i = __ffsll((long long)M) - 1;
+                        M &= M - 1ull;
+                        const int a = base + select64(h, i), b = bref - i;
+                        key_clear(K, a);   // the kept element will sit at the hit's position
+                        key_set(K, b);
+                        myq[nmv++] = make_uint2((unsigned)a, (unsigned)b);   // I[a] = I[b]
+                    }
+                    if (__any(nmv == kMoveSlots)) flush_moves();
+                }
+            } else {
+                unsigned long long r = h;
+                int i = 0;
+                while (__any(i < kp)) {
+                    if (i < kp) {
+                        const int pos = 63 - __clzll((long long)r);
+                        r &= ~(1ull << pos);
+                        const int a = base + pos, b = bref + i;
+                        myq[nmv++] = make_uint2((unsigned)b, (unsigned)a);       // I[b] = I[a]
+                        if ((field >> i) & 1ull) {   // partner filtered: the kept element moves there
+                            key_clear(K, b);
+                            key_set(K, a);
+                        } else {
+                            myq[nmv++] = make_uint2((unsigned)a, (unsigned)b);   // two kept elements trade places
+                        }
+                        ++i;
+                    }
+                    if (__any(nmv + 2 > kMoveSlots)) flush_moves();   // the two halves of a trade stay in one batch
+                }
+            }
         }
+        flush_moves();
         __syncthreads();
         if (round < 120 && g_stamp && tid == 0 && blockIdx.x == 0)
             g_stamp[16 + 4 * round + 3] = (wall_clock64() & 0xffffffffull) | ((unsigned long long)(L - F) << 32) | ((unsigned long long)p << 60);
@@ -642,7 +635,7 @@ __device__ int compact_kept(CleanupShared& sh, int n, const Keys K, const uint32
     return size;
 }
 
-extern __shared__ uint32_t s_dyn_bits[];   // kBitCap / 32 words when the launch provides them
+extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn_bits[];   // kBitCap / 32 words when the launch provides them
 
 // flags -> key bits (one __ballot per 64 elements, no atomics) and identity payload
 __device__ void init_bits_from_flags(const LdsBitKeys K, const uint8_t* __restrict__ fl, int n,
@@ -734,30 +727,52 @@ __device__ void cleanup1_bits_body(CleanupShared& sh, int n, const LdsBitKeys K,
                                    uint32_t* __restrict__ lrank, const Candidate* __restrict__ cd, int img,
                                    int* __restrict__ list_cnt, int* __restrict__ late_cnt, int* __restrict__ fallback) {
     const int tid = threadIdx.x, lane = tid & 63;
-    // flags -> key bits (one __ballot per 64 elements); loads only, several in flight
+    // flags (bytes 0 / 1) -> key bits.  16 flags per 16-byte load, four loads in flight per thread; the 16
+    // key bits of a load are one 16-bit store into the LDS word array.
     {
-        constexpr int UN = 8;
-        for (int base0 = 0; base0 < n; base0 += UN * kCT) {
-            uint8_t v[UN];
+        unsigned short* kw16 = reinterpret_cast<unsigned short*>(K.w);
+        const int n16 = n >> 4;                       // whole 16-flag groups
+        const bool vec = (reinterpret_cast<uintptr_t>(fl) & 15u) == 0;
+        auto pack4 = [](uint32_t x) {                 // "byte != 0" of each of the 4 bytes -> 4 bits
+            const uint32_t m = ((x | ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu)) >> 7) & 0x01010101u;
+            return (m | (m >> 7) | (m >> 14) | (m >> 21)) & 0xFu;
+        };
+        int done = 0;
+        if (vec) {
+            constexpr int UN = 4;
+            for (int g0 = 0; g0 < n16; g0 += UN * kCT) {
+                uint4 v[UN];
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int i = base0 + u * kCT + tid;
-                v[u] = i < n ? fl[i] : (uint8_t)0;
-            }
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int base = base0 + u * kCT;
-                const int i = base + tid;
-                const unsigned long long m = __ballot(i < n && v[u] != 0);
-                if (lane == 0 && i < n) {
-                    const int wd = (base + (tid & ~63)) >> 5;
-                    K.w[wd] = (uint32_t)m;
-                    K.w[wd + 1] = (uint32_t)(m >> 32);
+                for (int u = 0; u < UN; ++u) {
+                    const int g = g0 + u * kCT + tid;
+                    v[u] = g < n16 ? reinterpret_cast<const uint4*>(fl)[g] : make_uint4(0, 0, 0, 0);
                 }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int g = g0 + u * kCT + tid;
+                    if (g < n16)
+                        kw16[g] = (unsigned short)(pack4(v[u].x) | (pack4(v[u].y) << 4) | (pack4(v[u].z) << 8) | (pack4(v[u].w) << 12));
+                }
+            }
+            done = n16 << 4;
+        }
+        // tail (and everything when the flags are not 16-byte aligned): one flag per thread, ballots.  `done` is
+        // a multiple of 16; the ballot path wants 64-aligned word pairs, so it restarts at the enclosing multiple
+        // of 64 and rewrites those (identical) bits.
+        __syncthreads();
+        for (int base = done & ~63; base < n; base += kCT) {
+            const int i = base + tid;
+            const bool f = i < n && fl[i] != 0;
+            const unsigned long long m = __ballot(f);
+            if (lane == 0 && i < n) {
+                const int wd = (base + (tid & ~63)) >> 5;
+                K.w[wd] = (uint32_t)m;
+                K.w[wd + 1] = (uint32_t)(m >> 32);
             }
         }
         __syncthreads();
     }
+    stamp(8);
     const int nq = (n + 63) >> 6;
     const int chunk = (nq + kCT - 1) / kCT;   // <= kMaxChunk
     auto kept_word = [&](int q) {
@@ -790,27 +805,47 @@ __device__ void cleanup1_bits_body(CleanupShared& sh, int n, const LdsBitKeys K,
         __syncthreads();
     }
     const int size = total & 0xffff;   // u16_t size (sift.cpp:41)
+    stamp(9);
     introsort_bits(sh, n, K, I, I2);
-    // stable partition: kept elements in final position order -> list positions
+    stamp(4);
+    // stable partition: kept elements in final position order -> list positions.  The kept elements now sit in
+    // the first few hundred words, so the words are dealt round-robin (one per thread and pass) and the
+    // positions are first listed by rank (in I, which is dead by now); the dependent gathers
+    // position -> spatial rank -> candidate then run evenly over all threads.
     {
-        int cnt = 0;
-        for (int j = 0; j < chunk; ++j) {
-            const int q = tid * chunk + j;
-            if (q < nq) cnt += __popcll(kept_word(q));
-        }
-        int dummy;
-        int r = block_exclusive_scan(sh, cnt, dummy);
-        for (int j = 0; j < chunk; ++j) {
-            const int q = tid * chunk + j;
-            if (q >= nq || r >= size) break;
-            unsigned long long kept = kept_word(q);
+        int run = 0;   // kept elements in earlier passes
+        for (int q0 = 0; q0 < nq && run < size; q0 += kCT) {
+            const int q = q0 + tid;
+            unsigned long long kept = q < nq ? kept_word(q) : 0ull;
+            int pass_total;
+            int r = run + block_exclusive_scan(sh, __popcll(kept), pass_total);
             while (kept && r < size) {
-                const int pos = (q << 6) + __ffsll((long long)kept) - 1;
+                I[r] = (uint32_t)((q << 6) + __ffsll((long long)kept) - 1);
                 kept &= kept - 1ull;
-                const uint32_t sr = I2[pos];
-                out[r] = crank[sr];
-                lrank[r] = sr;   // the orientation stage's results are addressed by spatial rank
                 ++r;
+            }
+            run += pass_total;
+        }
+        __syncthreads();
+        constexpr int UN = 4;
+        for (int r0 = 0; r0 < size; r0 += UN * kCT) {
+            uint32_t pos[UN], sr[UN], cand[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int r = r0 + u * kCT + tid;
+                pos[u] = r < size ? I[r] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) sr[u] = r0 + u * kCT + tid < size ? I2[pos[u]] : 0u;
+#pragma unroll
+            for (int u = 0; u < UN; ++u) cand[u] = crank[sr[u]];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int r = r0 + u * kCT + tid;
+                if (r < size) {
+                    out[r] = cand[u];
+                    lrank[r] = sr[u];   // the orientation stage's results are addressed by spatial rank
+                }
             }
         }
         __syncthreads();
@@ -1153,16 +1188,19 @@ __global__ __launch_bounds__(kCT) void cleanup_kat_kernel(const uint8_t* __restr
                                                           uint8_t* __restrict__ Kg, uint32_t* __restrict__ I,
                                                           uint32_t* __restrict__ I2, uint32_t* __restrict__ P,
                                                           uint32_t* __restrict__ out, int* __restrict__ info,
-                                                          int force_global) {
+                                                          int force_global, OrientIn* __restrict__ ord,
+                                                          uint32_t* __restrict__ lrank,
+                                                          const Candidate* __restrict__ cd) {
     __shared__ CleanupShared sh;
+    __shared__ int s_cnt[3];
     int size;
     stamp(0);
     if (n <= kBitCap && !force_global) {
+        // the production body of the first cleanup (its list is the survivor order this entry returns)
         const LdsBitKeys K{s_dyn_bits};
-        init_bits_from_flags(K, flags, n, I);
-        introsort_bits(sh, n, K, I, I2);
-        stamp(4);
-        size = compact_kept(sh, n, K, I2, [&](int r, uint32_t id) { out[r] = id; });
+        cleanup1_bits_body(sh, n, K, flags, I, I2, P, out, ord, lrank, cd, 0, &s_cnt[0], &s_cnt[1], &s_cnt[2]);
+        __syncthreads();
+        size = s_cnt[0];
         stamp(5);
         if (threadIdx.x == 0 && g_stamp) g_stamp[6] = (unsigned long long)sh.npure;
     } else {
@@ -1187,10 +1225,10 @@ void launch_cleanup1(hipStream_t s, int n_images, const uint8_t* d_flags, const 
                      int* d_fallback) {
     static const bool attr_ok = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(cleanup1_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kBitCap / 8) == hipSuccess;
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kDynLds) == hipSuccess;
     }();
     (void)attr_ok;
-    hipLaunchKernelGGL(cleanup1_kernel, dim3((unsigned)n_images), dim3(kCT), kBitCap / 8, s, d_flags, d_totals, cand_cap,
+    hipLaunchKernelGGL(cleanup1_kernel, dim3((unsigned)n_images), dim3(kCT), kDynLds, s, d_flags, d_totals, cand_cap,
                        wk, wi, wi2, wp, d_list, d_oin, d_lrank, d_cands, list_cap, d_list_cnt, d_late_cnt, d_fallback);
 }
 
@@ -1215,14 +1253,15 @@ void launch_cleanup2(hipStream_t s, int n_images, const DevPlan* d_plan, int bin
 void cleanup_set_stamp_buffer(unsigned long long* d) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), &d, sizeof(d)); }
 
 void launch_cleanup_kat(hipStream_t s, const uint8_t* d_flags, int n, uint8_t* wk, uint32_t* wi, uint32_t* wi2,
-                        uint32_t* wp, uint32_t* d_out, int* d_info, int force_global) {
+                        uint32_t* wp, uint32_t* d_out, int* d_info, int force_global, OrientIn* d_ord, uint32_t* d_lrank,
+                        const Candidate* d_cd) {
     static const bool attr_ok = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(cleanup_kat_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kBitCap / 8) == hipSuccess;
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kDynLds) == hipSuccess;
     }();
     (void)attr_ok;
-    hipLaunchKernelGGL(cleanup_kat_kernel, dim3(1), dim3(kCT), kBitCap / 8, s, d_flags, n, wk, wi, wi2, wp, d_out, d_info,
-                       force_global);
+    hipLaunchKernelGGL(cleanup_kat_kernel, dim3(1), dim3(kCT), kDynLds, s, d_flags, n, wk, wi, wi2, wp, d_out, d_info,
+                       force_global, d_ord, d_lrank, d_cd);
 }
 
 }  // namespace sift_hip

@@ -33,7 +33,8 @@ __device__ __forceinline__ unsigned f32_to_u16_x86(float v) {
 // sift.cpp:130-160: interior pixels only, border stays 0.
 __global__ __launch_bounds__(256) void gradient_kernel(const float* __restrict__ g, float* __restrict__ mag,
                                                        float* __restrict__ ori, float* __restrict__ prod,
-                                                       uint8_t* __restrict__ obin, int w, int h) {
+                                                       uint8_t* __restrict__ obin, int w, int h,
+                                                       int* __restrict__ any_bin) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= w) return;
@@ -58,7 +59,11 @@ __global__ __launch_bounds__(256) void gradient_kernel(const float* __restrict__
     // per-pixel inputs of alg::orientationHistogram36 (algorithms.cpp:126-128), which reads the
     // INITIAL maps: weight = magnitude * gaussian, bin = (u16)floor(orientation / 10) % 35
     prod[o] = m * g[o];
-    obin[o] = (uint8_t)(f32_to_u16_x86(__builtin_floorf(a / 10.0f)) % 35u);
+    const unsigned bin = f32_to_u16_x86(__builtin_floorf(a / 10.0f)) % 35u;
+    obin[o] = (uint8_t)bin;
+    // The reference feeds radians where degrees were meant (App. B-9): every sample lands in bin 0.  The
+    // orientation stage skips the bin map of an image as long as this flag stays clear.
+    if (bin != 0u && any_bin) any_bin[blockIdx.z] = 1;
 }
 
 // Two phases per workgroup of 128 keypoints:
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
                                                           const int* __restrict__ list_cnt, int list_cap,
                                                           OrientOut* __restrict__ out,
                                                           float* __restrict__ peaks_out, int* __restrict__ next_group,
-                                                          int dbg) {
+                                                          const int* __restrict__ any_bin, int dbg) {
     // staging (phase 1) and the peak sets (phase 2) are never live together: they share storage
     __shared__ __attribute__((aligned(16))) float s_stage[4 * kOrientSub * kOrientStride];
     __shared__ __attribute__((aligned(16))) unsigned char s_sbin[4 * kOrientSub * kOrientStride];
@@ -111,6 +116,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
     float* __restrict__ wprod = s_stage + wv * kOrientSub * kOrientStride;
     unsigned char* __restrict__ wbin = s_sbin + wv * kOrientSub * kOrientStride;
     if (cnt <= 0) return;
+    const bool bins_zero = any_bin != nullptr && any_bin[img] == 0;   // block-uniform: every sample of this image has bin 0
     for (int l = tid; l < plan->octaves * D; l += 256) {
         const int lvl = plan->nearest_level[l];
         const int no = lvl / (D + 1);
@@ -176,13 +182,21 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
                             (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)pb64) |
                             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(pb64 >> 32)) << 32))) + img_off;
                         const int x0 = x - kRegion, y0 = y - kRegion;
+                        if (bins_zero) {
+                            // one 16-byte load per lane covers the whole window: lane = (row, 4-column group)
+                            const size_t o = (size_t)(y0 + (lane >> 2)) * (size_t)w + (size_t)(x0 + 4 * (lane & 3));
+                            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                            const f4u v4 = *reinterpret_cast<const f4u*>(gp + o);
+                            pp[k][0] = v4.x; pp[k][1] = v4.y; pp[k][2] = v4.z; pp[k][3] = v4.w;
+                        } else {
 #pragma unroll
-                        for (int it = 0; it < 4; ++it) {
-                            const int ly = it * 4 + (lane >> 4);
-                            const int lx = lane & 15;
-                            const size_t o = (size_t)(y0 + ly) * (size_t)w + (size_t)(x0 + lx);
-                            pp[k][it] = gp[o];
-                            pb[k][it] = gb[o];
+                            for (int it = 0; it < 4; ++it) {
+                                const int ly = it * 4 + (lane >> 4);
+                                const int lx = lane & 15;
+                                const size_t o = (size_t)(y0 + ly) * (size_t)w + (size_t)(x0 + lx);
+                                pp[k][it] = gp[o];
+                                pb[k][it] = gb[o];
+                            }
                         }
                     }
                 }
@@ -190,6 +204,16 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
 #pragma unroll
             for (int k = 0; k < kOrientSub; ++k) {
                 if (!((runmask >> k) & 1u)) continue;  // wave-uniform
+                if (bins_zero) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int lx = 4 * (lane & 3) + it, ly = lane >> 2;
+                        wprod[k * kOrientStride + lx * kOrientCol + ly] = pp[k][it];
+                    }
+                    if (lane == 0) wbin[k * kOrientStride] = 0;
+                    unimask |= 1u << k;
+                    continue;
+                }
                 unsigned first_bin = 0;
                 bool same = true;
 #pragma unroll
@@ -342,20 +366,20 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
 }
 
 void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, float* prod, uint8_t* obin, int w, int h,
-                     int n) {
+                     int n, int* d_any_bin) {
     const dim3 grid((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)n);
-    hipLaunchKernelGGL(gradient_kernel, grid, dim3(256), 0, s, g, mag, ori, prod, obin, w, h);
+    hipLaunchKernelGGL(gradient_kernel, grid, dim3(256), 0, s, g, mag, ori, prod, obin, w, h, d_any_bin);
 }
 
 void launch_orientation(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const Candidate* d_cands,
                         const OrientIn* d_oin, const int* d_list_cnt, int list_cap, OrientOut* d_out,
-                        float* d_peaks, int* d_next_group) {
+                        float* d_peaks, int* d_next_group, const int* d_any_bin) {
     (void)d_cands;
     const dim3 grid(128, (unsigned)plan.n_images);
     static const int dbg = [] { const char* e = getenv("SIFT_ORIENT_DBG"); return e ? atoi(e) : 0; }();   // timing ablations only
     (void)hipMemsetAsync(d_next_group, 0, sizeof(int) * (size_t)plan.n_images, s);
     hipLaunchKernelGGL(orientation_kernel, grid, dim3(256), 0, s, d_plan, d_oin, d_list_cnt, list_cap, d_out,
-                       d_peaks, d_next_group, dbg);
+                       d_peaks, d_next_group, d_any_bin, dbg);
 }
 
 }  // namespace sift_hip
