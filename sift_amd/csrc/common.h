@@ -133,7 +133,7 @@ void launch_cleanup2(hipStream_t s, int n_images, const DevPlan* d_plan, int bin
                      FinalKp* d_pool, int pool_cap, const Candidate* d_cands, long long cand_cap,
                      const uint32_t* d_list, const int* d_list_cnt, int list_cap, const OrientOut* d_orient,
                      const uint32_t* d_lrank, uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, FinalKp* d_final,
-                     int* d_final_cnt, int* d_status);
+                     int* d_final_cnt, int* d_status, FinalKp* d_recs);
 void cleanup_set_stamp_buffer(unsigned long long* d);
 void launch_cleanup_kat(hipStream_t s, const uint8_t* d_flags, int n, uint8_t* wk, uint32_t* wi, uint32_t* wi2,
                         uint32_t* wp, uint32_t* d_out, int* d_info, int force_global, OrientIn* d_ord,

@@ -119,7 +119,7 @@ struct sift_hip_ctx {
     DevBuf d_wk, d_wi, d_wi2, d_wp, d_status, d_tile, d_pool;
     DevBuf d_order;
     DevBuf d_list, d_list_cnt, d_orient, d_peaks, d_final, d_final_cnt, d_out_base, d_kp, d_desc;
-    DevBuf d_lrank, d_ochunk, d_ocnt;   // list position -> orientation result; kept counts per 1024 candidates; early/late counts
+    DevBuf d_lrank, d_ochunk, d_ocnt, d_recs;   // list position -> orientation result; kept counts per 1024 candidates; early/late counts
     HostBuf h_flags, h_orient, h_peaks;
     // results of the last batch
     std::vector<int32_t> status, counts;
@@ -408,6 +408,7 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
     c->d_list_cnt.ensure((size_t)n * sizeof(int));
     c->d_order.ensure((size_t)kListCap * (size_t)n * sizeof(OrientIn));
     c->d_lrank.ensure((size_t)kListCap * (size_t)n * sizeof(uint32_t));
+    c->d_recs.ensure((size_t)kListCap * (size_t)n * sizeof(FinalKp));
     c->d_ochunk.ensure(orient_prepare_chunks(dv.cand_capacity) * (size_t)n * sizeof(int));
     c->d_ocnt.ensure((size_t)n * 5 * sizeof(int));   // early counts, late counts, group counters of the two launches, bin flags
     c->d_orient.ensure((size_t)kListCap * (size_t)n * sizeof(OrientOut));
@@ -658,7 +659,7 @@ bool mid_gpu(sift_hip_ctx* c) {
                     c->d_cands.as<Candidate>(), dv.cand_capacity, c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
                     kListCap, c->d_orient.as<OrientOut>(), c->d_lrank.as<uint32_t>(), c->d_wk.as<uint8_t>(),
                     c->d_wi.as<uint32_t>(), c->d_wi2.as<uint32_t>(), c->d_wp.as<uint32_t>(), c->d_final.as<FinalKp>(),
-                    c->d_final_cnt.as<int>(), c->d_status.as<int>());
+                    c->d_final_cnt.as<int>(), c->d_status.as<int>(), c->d_recs.as<FinalKp>());
     // the tile binning only needs the device-side lists: it keeps the GPU busy while the host waits for the counts
     if (!fused_bin) bin_keypoints(c);
     c->binned = true;
@@ -672,6 +673,16 @@ bool mid_gpu(sift_hip_ctx* c) {
     std::vector<int> st((size_t)n * 5);
     SIFT_HIP_CHECK(hipMemcpyAsync(st.data(), c->d_status.p, st.size() * sizeof(int), hipMemcpyDeviceToHost, s));
     SIFT_HIP_CHECK(hipStreamSynchronize(s));
+    if (getenv("SIFT_CLEANUP2_STAMPS")) {   // diagnostics: phases of the second cleanup (image 0)
+        static unsigned long long* dst = nullptr;
+        if (!dst) { (void)hipMalloc(&dst, 512 * sizeof(unsigned long long)); (void)hipMemset(dst, 0, 512 * sizeof(unsigned long long)); cleanup_set_stamp_buffer(dst); }
+        else {
+            unsigned long long hs[512];
+            (void)hipMemcpy(hs, dst, sizeof(hs), hipMemcpyDeviceToHost);
+            std::fprintf(stderr, "cleanup2 (us): init %.1f sort %.1f compact+emit %.1f binning %.1f | rounds-internal: loop %.1f copy %.1f\n", (hs[101] - hs[100]) / 100.0,
+                         (hs[102] - hs[101]) / 100.0, (hs[103] - hs[102]) / 100.0, (hs[104] - hs[103]) / 100.0, (hs[2] - hs[1]) / 100.0, (hs[3] - hs[2]) / 100.0);
+        }
+    }
     for (int i = 0; i < n; ++i)
         if (st[(size_t)i * 4 + 1] || st[(size_t)n * 4 + (size_t)i]) {
             c->binned = false;   // the host path rebuilds the lists
@@ -894,7 +905,7 @@ void sift_hip_destroy(sift_hip_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->arena, &c->d_plan, &c->d_taps, &c->d_luts, &c->d_taps16, &c->d_input, &c->d_base, &c->d_tmp, &c->d_tmp2,
                       &c->d_wk, &c->d_wi, &c->d_wi2, &c->d_wp, &c->d_status, &c->d_tile, &c->d_pool, &c->d_order, &c->d_masks, &c->d_fmasks, &c->d_counts, &c->d_totals, &c->d_cands, &c->d_flags, &c->d_list, &c->d_list_cnt, &c->d_orient,
-                      &c->d_peaks, &c->d_final, &c->d_final_cnt, &c->d_out_base, &c->d_kp, &c->d_desc, &c->d_lrank, &c->d_ochunk, &c->d_ocnt})
+                      &c->d_peaks, &c->d_final, &c->d_final_cnt, &c->d_out_base, &c->d_kp, &c->d_desc, &c->d_lrank, &c->d_ochunk, &c->d_ocnt, &c->d_recs})
         b->release();
     for (HostBuf* b : {&c->h_flags, &c->h_orient, &c->h_peaks}) b->release();
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }

@@ -279,10 +279,28 @@ __device__ void introsort_binary(CleanupShared& sh, int n, const Keys K, uint32_
     for (int r = 0; r < npure; ++r) {
         const PureRange pr = sh.pure[r];
         if (pr.m <= 16) continue;  // already final
-        for (int j = tid; j < pr.m; j += kCT) {
-            const int dest = pure_final_pos(pr.f + j, pr.f, pr.m, pr.d);
-            if (dest < 0) sh.fallback = 1;
-            else I2[dest] = I[pr.f + j];
+        // four elements per thread: their loads are issued together, the closed forms run meanwhile
+        for (int j0 = tid; j0 < pr.m; j0 += 4 * kCT) {
+            uint32_t v[4];
+            int dest[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * kCT;
+                v[u] = j < pr.m ? I[pr.f + j] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * kCT;
+                dest[u] = j < pr.m ? pure_final_pos(pr.f + j, pr.f, pr.m, pr.d) : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * kCT;
+                if (j < pr.m) {
+                    if (dest[u] < 0) sh.fallback = 1;
+                    else I2[dest[u]] = v[u];
+                }
+            }
         }
     }
     __syncthreads();
@@ -586,10 +604,28 @@ __device__ void introsort_bits(CleanupShared& sh, int n, const LdsBitKeys K, uin
     for (int r = 0; r < npure; ++r) {
         const PureRange pr = sh.pure[r];
         if (pr.m <= 16) continue;  // already final
-        for (int j = tid; j < pr.m; j += kCT) {
-            const int dest = pure_final_pos(pr.f + j, pr.f, pr.m, pr.d);
-            if (dest < 0) sh.fallback = 1;
-            else I2[dest] = I[pr.f + j];
+        // four elements per thread: their loads are issued together, the closed forms run meanwhile
+        for (int j0 = tid; j0 < pr.m; j0 += 4 * kCT) {
+            uint32_t v[4];
+            int dest[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * kCT;
+                v[u] = j < pr.m ? I[pr.f + j] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * kCT;
+                dest[u] = j < pr.m ? pure_final_pos(pr.f + j, pr.f, pr.m, pr.d) : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * kCT;
+                if (j < pr.m) {
+                    if (dest[u] < 0) sh.fallback = 1;
+                    else I2[dest[u]] = v[u];
+                }
+            }
         }
     }
     __syncthreads();
@@ -1055,75 +1091,101 @@ __global__ __launch_bounds__(kCT) void cleanup2_kernel(const DevPlan* __restrict
                                                        uint8_t* __restrict__ wk, uint32_t* __restrict__ wi,
                                                        uint32_t* __restrict__ wi2, uint32_t* __restrict__ wp,
                                                        FinalKp* __restrict__ finals, int* __restrict__ final_cnt,
-                                                       int* __restrict__ status) {
+                                                       int* __restrict__ status, FinalKp* __restrict__ recs) {
     __shared__ CleanupShared sh;
     __shared__ int s_multi, s_throw;
-    __shared__ __attribute__((aligned(8))) uint32_t s_bits2[65536 / 32 + 2];   // n <= 65535 here (u16_t size of the first cleanup)
     const int img = blockIdx.x;
     const int n = list_cnt[img];
     const size_t off = (size_t)img * (size_t)list_cap;
-    const LdsBitKeys K{s_bits2};
-    (void)wk;
+    // keys as bytes in global memory: for these short, mostly-kept arrays the per-element rounds run ~3x
+    // faster on byte keys than on an LDS bit mask (every swap of the mask is two atomics)
+    const GlobalKeys K{wk + off};
     uint32_t* I = wi + off;
     uint32_t* I2 = wi2 + off;
     uint32_t* P = wp + off;
     const OrientOut* oo = orient + off;
+    const uint32_t* l1 = list + off;
+    const Candidate* cd = cands + (size_t)img * (size_t)cand_cap;
+    FinalKp* rec = recs + off;   // the record of list position i, gathered once, before the sort
     const uint32_t* lr = lranks + off;   // list position -> index of its orientation result
     if (threadIdx.x == 0) {
         s_multi = 0;
         s_throw = 0x7fffffff;
     }
     __syncthreads();
-    for (int base = 0; base < n; base += kCT) {
-        const int i = base + (int)threadIdx.x;
-        OrientOut o;
-        o.filtered = 0; o.npeaks = 0; o.throws = 0; o.orientation = 0.0f;
-        if (i < n) o = oo[lr[i]];
-        const unsigned long long m = __ballot(i < n && o.filtered != 0);
-        if ((threadIdx.x & 63) == 0 && i < n) {
-            const int wd = (base + ((int)threadIdx.x & ~63)) >> 5;
-            K.w[wd] = (uint32_t)m;
-            K.w[wd + 1] = (uint32_t)(m >> 32);
+    stamp(100);
+    {
+        // two dependent gathers per element (list position -> orientation slot -> result): four elements per
+        // thread in flight, and no store inside the loop (on gfx9 a load's wait also waits for older stores)
+        constexpr int UN = 4;
+        for (int base0 = 0; base0 < n; base0 += UN * kCT) {
+            uint32_t slot[UN], cnd[UN];
+            OrientOut o[UN];
+            Candidate kc[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int i = base0 + u * kCT + (int)threadIdx.x;
+                slot[u] = i < n ? lr[i] : 0u;
+                cnd[u] = i < n ? l1[i] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int i = base0 + u * kCT + (int)threadIdx.x;
+                o[u].filtered = 0; o[u].npeaks = 0; o[u].throws = 0; o[u].orientation = 0.0f;
+                kc[u].x = kc[u].y = kc[u].octave = kc[u].index = 0;
+                if (i < n) {
+                    o[u] = oo[slot[u]];
+                    kc[u] = cd[cnd[u]];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int base = base0 + u * kCT;
+                const int i = base + (int)threadIdx.x;
+                if (i < n) {
+                    FinalKp f;
+                    f.cand = cnd[u];
+                    f.orientation = o[u].orientation;
+                    f.x = kc[u].x; f.y = kc[u].y; f.octave = kc[u].octave; f.index = kc[u].index;
+                    rec[i] = f;
+                    K.k[i] = o[u].filtered != 0 ? 1 : 0;
+                    if (!o[u].filtered && o[u].npeaks > 1) s_multi = 1;
+                    if (!o[u].filtered && o[u].throws) atomicMin(&s_throw, i);
+                }
+            }
         }
-        if (i < n) {
-            I[i] = (uint32_t)i;
-            if (!o.filtered && o.npeaks > 1) s_multi = 1;
-            if (!o.filtered && o.throws) atomicMin(&s_throw, i);
-        }
+        for (int i = threadIdx.x; i < n; i += kCT) I[i] = (uint32_t)i;
     }
     __syncthreads();
     // kept keys dominate here (few points fail the border test): every hit moves a payload, which the
     // tile-based rounds spread over all threads
+    stamp(101);
     introsort_binary(sh, n, K, I, I2, P);
-    const uint32_t* l1 = list + off;
-    const Candidate* cd = cands + (size_t)img * (size_t)cand_cap;
+    stamp(102);
     FinalKp* out = finals + off;
-    const int size = compact_kept(sh, n, K, I2, [&](int r, uint32_t id) {
-        const uint32_t c = l1[id];
-        const Candidate k = cd[c];
-        FinalKp f;
-        f.cand = c;
-        f.orientation = oo[lr[id]].orientation;
-        f.x = k.x;
-        f.y = k.y;
-        f.octave = k.octave;
-        f.index = k.index;
-        out[r] = f;
-    });
+    const int size = compact_kept(sh, n, K, I2, [&](int r, uint32_t id) { out[r] = rec[id]; });
+    stamp(103);
     if (bin_tiles) {
         __shared__ int s_tcnt[kTileLdsCap];
         __shared__ int s_toff[kTileLdsCap];
         __shared__ int s_scan[kCT];
+        __shared__ int s_lv[kMaxLevels][3];   // per (octave, dog): tiles across, tiles down, first tile of its level
         const int tid = threadIdx.x;
         const int tpi = plan->desc_tiles_per_image;
         const int D = plan->dogs;
+        for (int l = tid; l < plan->octaves * D; l += kCT) {
+            const int level = plan->nearest_level[l];
+            s_lv[l][0] = plan->desc_ntx[level];
+            s_lv[l][1] = plan->desc_nty[level];
+            s_lv[l][2] = plan->desc_tile_base[level];
+        }
         const int nk = s_throw != 0x7fffffff ? 0 : size;   // a throwing image emits nothing
         for (int t = tid; t < tpi; t += kCT) s_tcnt[t] = 0;
         __syncthreads();   // also orders this workgroup's out[] writes before the reads below
         for (int r = tid; r < nk; r += kCT) {
             const FinalKp f = out[r];
-            const int level = plan->nearest_level[f.octave * D + f.index];
-            const int ntx = plan->desc_ntx[level], nty = plan->desc_nty[level], tb = plan->desc_tile_base[level];
+            const int lq = f.octave * D + f.index;
+            const int ntx = s_lv[lq][0], nty = s_lv[lq][1], tb = s_lv[lq][2];
             int x0, x1, y0, y1;
             desc_tile_span(f.x, ntx, x0, x1);
             desc_tile_span(f.y, nty, y0, y1);
@@ -1159,8 +1221,8 @@ __global__ __launch_bounds__(kCT) void cleanup2_kernel(const DevPlan* __restrict
         FinalKp* pl = pool + (size_t)img * (size_t)pool_cap;
         for (int r = tid; r < nk; r += kCT) {
             FinalKp f = out[r];
-            const int level = plan->nearest_level[f.octave * D + f.index];
-            const int ntx = plan->desc_ntx[level], nty = plan->desc_nty[level], tb = plan->desc_tile_base[level];
+            const int lq = f.octave * D + f.index;
+            const int ntx = s_lv[lq][0], nty = s_lv[lq][1], tb = s_lv[lq][2];
             int x0, x1, y0, y1;
             desc_tile_span(f.x, ntx, x0, x1);
             desc_tile_span(f.y, nty, y0, y1);
@@ -1173,6 +1235,7 @@ __global__ __launch_bounds__(kCT) void cleanup2_kernel(const DevPlan* __restrict
                 }
         }
     }
+    stamp(104);
     if (threadIdx.x == 0) {
         const bool thr = s_throw != 0x7fffffff;
         final_cnt[img] = thr ? 0 : size;
@@ -1244,10 +1307,10 @@ void launch_cleanup2(hipStream_t s, int n_images, const DevPlan* d_plan, int bin
                      FinalKp* d_pool, int pool_cap, const Candidate* d_cands, long long cand_cap,
                      const uint32_t* d_list, const int* d_list_cnt, int list_cap, const OrientOut* d_orient,
                      const uint32_t* d_lrank, uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, FinalKp* d_final,
-                     int* d_final_cnt, int* d_status) {
+                     int* d_final_cnt, int* d_status, FinalKp* d_recs) {
     hipLaunchKernelGGL(cleanup2_kernel, dim3((unsigned)n_images), dim3(kCT), 0, s, d_plan, bin_tiles, d_tile_cnt, d_tile_off,
                        d_pool, pool_cap, d_cands, cand_cap, d_list,
-                       d_list_cnt, list_cap, d_orient, d_lrank, wk, wi, wi2, wp, d_final, d_final_cnt, d_status);
+                       d_list_cnt, list_cap, d_orient, d_lrank, wk, wi, wi2, wp, d_final, d_final_cnt, d_status, d_recs);
 }
 
 void cleanup_set_stamp_buffer(unsigned long long* d) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), &d, sizeof(d)); }

@@ -102,11 +102,23 @@ __global__ __launch_bounds__(1024) void extrema_scan_kernel(int* __restrict__ co
     const int img = blockIdx.x;
     int* __restrict__ c = counts + (size_t)img * (size_t)words_per_image;
     const int tid = threadIdx.x;
-    const int chunk = (words_per_image + 1023) / 1024;
-    const int lo = tid * chunk;
+    // chunks are multiples of 4 words so that a thread streams its chunk with 16-byte loads / stores
+    // (several in flight), when the image's slice of the array is 16-byte aligned
+    const bool vec = (words_per_image & 3) == 0 && (reinterpret_cast<uintptr_t>(c) & 15u) == 0;
+    const int chunk = ((words_per_image + 1023) / 1024 + 3) & ~3;
+    const int lo = min(tid * chunk, words_per_image);
     const int hi = min(lo + chunk, words_per_image);
     int sum = 0;
-    for (int i = lo; i < hi; ++i) sum += c[i];
+    if (vec) {
+        const int4* c4 = reinterpret_cast<const int4*>(c);
+#pragma unroll 8
+        for (int i = lo >> 2; i < hi >> 2; ++i) {
+            const int4 v = c4[i];
+            sum += v.x + v.y + v.z + v.w;
+        }
+    } else {
+        for (int i = lo; i < hi; ++i) sum += c[i];
+    }
     s_part[tid] = sum;
     __syncthreads();
     // Hillis-Steele inclusive scan over the 1024 partial sums
@@ -117,10 +129,25 @@ __global__ __launch_bounds__(1024) void extrema_scan_kernel(int* __restrict__ co
         __syncthreads();
     }
     int run = s_part[tid] - sum;  // exclusive prefix of this chunk
-    for (int i = lo; i < hi; ++i) {
-        const int v = c[i];
-        c[i] = run;
-        run += v;
+    if (vec) {
+        int4* c4 = reinterpret_cast<int4*>(c);
+#pragma unroll 8
+        for (int i = lo >> 2; i < hi >> 2; ++i) {
+            const int4 v = c4[i];
+            int4 o;
+            o.x = run;
+            o.y = run + v.x;
+            o.z = o.y + v.y;
+            o.w = o.z + v.z;
+            run = o.w + v.w;
+            c4[i] = o;
+        }
+    } else {
+        for (int i = lo; i < hi; ++i) {
+            const int v = c[i];
+            c[i] = run;
+            run += v;
+        }
     }
     if (tid == 1023) totals[img] = s_part[1023];
 }
