@@ -68,7 +68,8 @@ int sift_hip_create(int device, sift_hip_ctx** out, char* err, int errlen);
 void sift_hip_destroy(sift_hip_ctx* ctx);
 /* Option knobs: "fused_blur" (1 default: single-kernel blur + DoG, streaming or LDS-tiled; 0: two-pass
  * row/col kernels), "fused_edge" (1 default: extremum scan and edge-response filter in one LDS-tiled pass;
- * 0: mask kernel + thread-per-candidate filter), "gpu_cleanup" (1 default: cleanup steps as GPU kernels;
+ * 0: mask kernel + thread-per-candidate filter), "fused_reduce" (1 default: reduceToNextLevel's blur stores only the
+ * pixels the decimation keeps; 0: blur into a temporary, then the resampling kernel), "gpu_cleanup" (1 default: cleanup steps as GPU kernels;
  * 0: std::sort on the host), "host_threads", "profile" (1: time every blur launch with events attached to
  * its dispatch), "desc_dbg" (diagnostics only). */
 int sift_hip_set_option(sift_hip_ctx* ctx, const char* name, int value);

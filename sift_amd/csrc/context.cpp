@@ -88,6 +88,7 @@ struct Plan {
     std::vector<float> taps;          // all tap tables back to back
     std::vector<int> luts;            // all index maps back to back
     std::vector<size_t> lut_x_off, lut_y_off;  // per octave transition (index o -> o+1); [O] = subpixel
+    std::vector<size_t> inv_x_off, inv_y_off;  // inverse maps (source -> destination or -1) of the decimations
     int fail_status = 0;              // plan-time precondition failure (depends only on sizes/params)
     size_t fail_op = (size_t)-1;      // first op that cannot run
     std::string fail_msg;
@@ -106,6 +107,7 @@ struct sift_hip_ctx {
     hipEvent_t ev_fork0 = nullptr, ev_fork = nullptr, ev_join = nullptr;
     bool fused = true;
     bool fused_edge = true;   // extremum scan and edge filter in one LDS-tiled pass
+    bool fused_reduce = true; // reduceToNextLevel: blur and decimation in one pass
     bool gpu_cleanup = true;
     bool profile = false;
     bool binned = false;   // this batch's keypoints are already binned to descriptor tiles
@@ -267,9 +269,24 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
         P.luts.insert(P.luts.end(), ly.begin(), ly.end());
         return true;
     };
+    // source index -> destination index (or -1) of a strictly increasing map, for the decimating blur
+    auto add_inverse = [&](size_t map_off, int nd, int ns, size_t& inv_off) {
+        std::vector<int> inv((size_t)ns, -1);
+        bool ok_inv = true;
+        for (int i = 0; i < nd; ++i) {
+            const int sidx = P.luts[map_off + (size_t)i];
+            if (sidx < 0 || sidx >= ns || inv[(size_t)sidx] != -1) { ok_inv = false; break; }
+            inv[(size_t)sidx] = i;
+        }
+        if (!ok_inv) { inv_off = (size_t)-1; return; }
+        inv_off = P.luts.size();
+        P.luts.insert(P.luts.end(), inv.begin(), inv.end());
+    };
 
     P.lut_x_off.assign((size_t)O + 1, 0);
     P.lut_y_off.assign((size_t)O + 1, 0);
+    P.inv_x_off.assign((size_t)O + 1, (size_t)-1);
+    P.inv_y_off.assign((size_t)O + 1, (size_t)-1);
     P.bw = w; P.bh = h;
     bool ok = true;
     if (prm.subpixel) {  // sift.cpp:20-21: increaseToNextLevel(img, 1.0)
@@ -303,6 +320,10 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
         if (ok && o < O - 1) {
             ok = add_blur(3, o, D - 1, dv.gauss_scale[o * (D + 1) + D - 1], dv.w[o], dv.h[o]) &&
                  add_lut(dv.w[o], dv.h[o], dv.w[o + 1], dv.h[o + 1], P.lut_x_off[(size_t)o], P.lut_y_off[(size_t)o]);
+            if (ok) {
+                add_inverse(P.lut_x_off[(size_t)o], dv.w[o + 1], dv.w[o], P.inv_x_off[(size_t)o]);
+                add_inverse(P.lut_y_off[(size_t)o], dv.h[o + 1], dv.h[o], P.inv_y_off[(size_t)o]);
+            }
         }
     }
     // _findNearestGaussian for every DoG scale (sift.cpp:205-218); dead 16x16 blur (sift.cpp:184)
@@ -450,9 +471,31 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
             }
             case 3: {  // reduceToNextLevel(g(o, D-1), g(o, D-1).scale)
                 const int o = op.octave;
-                run_blur(c, dv.gauss[o * (D + 1) + D - 1], c->d_tmp2.as<float>(), nullptr, op.w, op.h, n, op.tap_off, op.radius);
-                launch_resample(c->stream, c->d_tmp2.as<float>(), dv.gauss[(o + 1) * (D + 1)], dv.w[o], dv.h[o], dv.w[o + 1],
-                                dv.h[o + 1], n, c->d_luts.as<int>() + P.lut_x_off[(size_t)o], c->d_luts.as<int>() + P.lut_y_off[(size_t)o]);
+                const float* src = dv.gauss[o * (D + 1) + D - 1];
+                float* dst = dv.gauss[(o + 1) * (D + 1)];
+                bool done = false;
+                if (c->fused && c->fused_reduce && P.inv_x_off[(size_t)o] != (size_t)-1 && P.inv_y_off[(size_t)o] != (size_t)-1) {
+                    // blur and decimation in one pass: the full-resolution blurred image is never written
+                    hipEvent_t a = nullptr, b = nullptr;
+                    if (c->profile) { a = get_event(c); b = get_event(c); }
+                    done = launch_blur_reduce(c->stream, src, dst, op.w, op.h, dv.w[o + 1], dv.h[o + 1], n,
+                                              c->d_taps.as<float>() + op.tap_off, op.radius, c->d_luts.as<int>() + P.inv_x_off[(size_t)o],
+                                              c->d_luts.as<int>() + P.inv_y_off[(size_t)o], c->d_tmp.as<float>(), a, b);
+                    if (c->profile) {
+                        if (done) {
+                            const double px = (double)op.w * (double)op.h * (double)n, pd = (double)dv.w[o + 1] * (double)dv.h[o + 1] * (double)n;
+                            c->pending.push_back({a, b, 0, px * 4.0 + pd * 4.0});   // algorithmic bytes: source read + kept pixels written
+                        } else {
+                            c->event_pool.push_back(a);
+                            c->event_pool.push_back(b);
+                        }
+                    }
+                }
+                if (!done) {
+                    run_blur(c, src, c->d_tmp2.as<float>(), nullptr, op.w, op.h, n, op.tap_off, op.radius);
+                    launch_resample(c->stream, c->d_tmp2.as<float>(), dst, dv.w[o], dv.h[o], dv.w[o + 1],
+                                    dv.h[o + 1], n, c->d_luts.as<int>() + P.lut_x_off[(size_t)o], c->d_luts.as<int>() + P.lut_y_off[(size_t)o]);
+                }
                 break;
             }
         }
@@ -922,6 +965,7 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     if (!c || !name) return SIFT_HIP_EINVAL;
     if (!std::strcmp(name, "fused_blur")) { c->fused = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "fused_edge")) { c->fused_edge = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "fused_reduce")) { c->fused_reduce = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "desc_dbg")) { c->desc_dbg = value; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "gpu_cleanup")) { c->gpu_cleanup = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "profile")) { c->profile = value != 0; return SIFT_HIP_OK; }

@@ -285,11 +285,21 @@ constexpr int stream_runin(int r) { return (2 * r + kStreamPF - 1) / kStreamPF *
 // waves per SIMD the register budget is cut for (512 VGPRs per lane per SIMD)
 constexpr int stream_occ(int r, int cpl) { return cpl == 4 ? (r <= 8 ? 3 : 2) : (r <= 8 ? 4 : r <= 12 ? 3 : 2); }
 
-template <int R, bool DOG, int CPL>
+// decimation of the blurred image on the way out (alg::reduceToNextLevel, algorithms.cpp:24-36): only the pixels the
+// nearest-neighbour resampling keeps are stored, straight into the next octave's first level
+struct StreamDecimate {
+    const int* inv_x;   // source column -> destination column, or -1
+    const int* inv_y;   // source row -> destination row, or -1
+    int wd, hd;         // destination size
+    float* dump;        // >= 64 * CPL floats nobody reads: where the unselected pixels go (no branch around a store)
+};
+
+template <int R, bool DOG, int CPL, bool DEC = false>
 __global__ __launch_bounds__(256, stream_occ(R, CPL)) void blur_stream_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                           float* __restrict__ dog, int w, int h, int strips,
                                                           int strip_w, int chunks, int chunk_h, int total_units,
-                                                          const float* __restrict__ taps) {
+                                                          const float* __restrict__ taps, StreamDecimate dec) {
+    static_assert(!(DEC && DOG), "the decimating variant has no DoG output");
     constexpr int PF = kStreamPF;
     constexpr int RI = stream_runin(R);
     constexpr int E = RI - 2 * R;
@@ -336,6 +346,9 @@ __global__ __launch_bounds__(256, stream_occ(R, CPL)) void blur_stream_kernel(co
     const int hslot = hl < RA ? hl : RA + sw + (hl - RA);
     // uniform row base (SGPR pair) + 32-bit per-lane byte offset: no 64-bit per-lane addresses to keep
     const unsigned moff = 4u * (unsigned)mcol, hoff = 4u * (unsigned)hcol;
+    int dcol[CPL];   // DEC: destination column of each of this lane's source columns (-1: dropped)
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) dcol[e] = DEC ? dec.inv_x[mcol + e] : 0;
 
     float tp[NT];
 #pragma unroll
@@ -404,7 +417,16 @@ __global__ __launch_bounds__(256, stream_occ(R, CPL)) void blur_stream_kernel(co
                 const f4v dif = A[0] - prev;                                                                          \
                 *reinterpret_cast<f4v*>(reinterpret_cast<char*>(dog + o) + moff) = 128.0f + dif;                      \
             }                                                                                                         \
-            *reinterpret_cast<f4v*>(reinterpret_cast<char*>(out + o) + moff) = A[0];                                  \
+            if (DEC) {                                                                                                \
+                const int jd = dec.inv_y[y];   /* wave-uniform: half of the rows are dropped */                       \
+                if (jd >= 0) {                                                                                        \
+                    float* drow = out + ((size_t)img * (size_t)dec.hd + (size_t)jd) * (size_t)dec.wd;                 \
+                    _Pragma("unroll") for (int e = 0; e < CPL; ++e)                                                   \
+                        if (dcol[e] >= 0) drow[dcol[e]] = A[0][e];   /* consecutive lanes, consecutive columns */     \
+                }                                                                                                     \
+            } else {                                                                                                  \
+                *reinterpret_cast<f4v*>(reinterpret_cast<char*>(out + o) + moff) = A[0];                              \
+            }                                                                                                         \
         }                                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
         pslot = pslot + 1 == DP ? 0 : pslot + 1;                                                                      \
@@ -544,10 +566,10 @@ constexpr int kMinStreamWaves = 1024;  // below one wave per SIMD the tile kerne
 
 template <int R, int CPL>
 static bool launch_stream_rc(hipStream_t s, const float* in, float* out, float* dog, int w, int h, int n,
-                             const float* d_taps) {
+                             const float* d_taps, const StreamDecimate* dec = nullptr) {
     const int target = stream_waves();
     if (target <= 0) return false;
-    const bool aligned = (((uintptr_t)in | (uintptr_t)out | (uintptr_t)dog) & (4u * CPL - 1u)) == 0;
+    const bool aligned = (((uintptr_t)in | (dec ? 0 : (uintptr_t)out) | (uintptr_t)dog) & (4u * CPL - 1u)) == 0;
     if (!(w % CPL == 0 && aligned) || w < CPL || h < R + 1 || w < R + 1) return false;
     constexpr int SW = 64 * CPL;
     const int strips = (w + SW - 1) / SW;
@@ -564,12 +586,16 @@ static bool launch_stream_rc(hipStream_t s, const float* in, float* out, float* 
     const int total = n * strips * chunks;
     if (total < kMinStreamWaves) return false;
     const int grid = (total + 3) / 4;
-    if (dog)
+    const StreamDecimate none{nullptr, nullptr, 0, 0, nullptr};
+    if (dec)
+        hipExtLaunchKernelGGL((blur_stream_kernel<R, false, CPL, true>), dim3((unsigned)grid), dim3(256), 0, s, t_ev_start, t_ev_stop, 0, in,
+                              out, (float*)nullptr, w, h, strips, strip_w, chunks, chunk_h, total, d_taps, *dec);
+    else if (dog)
         hipExtLaunchKernelGGL((blur_stream_kernel<R, true, CPL>), dim3((unsigned)grid), dim3(256), 0, s, t_ev_start, t_ev_stop, 0, in, out, dog, w, h,
-                           strips, strip_w, chunks, chunk_h, total, d_taps);
+                           strips, strip_w, chunks, chunk_h, total, d_taps, none);
     else
         hipExtLaunchKernelGGL((blur_stream_kernel<R, false, CPL>), dim3((unsigned)grid), dim3(256), 0, s, t_ev_start, t_ev_stop, 0, in, out, dog, w,
-                           h, strips, strip_w, chunks, chunk_h, total, d_taps);
+                           h, strips, strip_w, chunks, chunk_h, total, d_taps, none);
     return true;
 }
 
@@ -577,14 +603,14 @@ static bool launch_stream_rc(hipStream_t s, const float* in, float* out, float* 
 // arithmetic per row grows and the halved register footprint buys the waves to overlap it with HBM.
 template <int R>
 static bool launch_stream_r(hipStream_t s, const float* in, float* out, float* dog, int w, int h, int n,
-                            const float* d_taps) {
+                            const float* d_taps, const StreamDecimate* dec = nullptr) {
     if constexpr (R > kMaxRadiusStream) {
         return false;
     } else if constexpr (R <= 5) {
-        if (launch_stream_rc<R, 4>(s, in, out, dog, w, h, n, d_taps)) return true;
+        if (launch_stream_rc<R, 4>(s, in, out, dog, w, h, n, d_taps, dec)) return true;
         return false;
     } else {
-        return launch_stream_rc<R, 2>(s, in, out, dog, w, h, n, d_taps);
+        return launch_stream_rc<R, 2>(s, in, out, dog, w, h, n, d_taps, dec);
     }
 }
 
@@ -624,6 +650,28 @@ void launch_blur(hipStream_t s, bool fused, const float* in, float* tmp, float* 
         hipLaunchKernelGGL(gauss_col_generic<false>, grid, dim3(256), shm, s, (const float*)tmp, in, out, dog,
                            w, h, d_taps, radius);
     if (ev_stop) (void)hipEventRecord(ev_stop, s);
+}
+
+#define SIFT_REDUCE_CASE(R) \
+    case R:                 \
+        return launch_stream_r<R>(s, in, dst, nullptr, w, h, n, d_taps, &dec);
+
+// Blur + nearest-neighbour decimation in one pass (streaming kernel only).  false: the caller runs the blur into a
+// temporary and the resampling kernel after it.
+bool launch_blur_reduce(hipStream_t s, const float* in, float* dst, int w, int h, int wd, int hd, int n, const float* d_taps,
+                        int radius, const int* d_inv_x, const int* d_inv_y, float* d_dump, hipEvent_t ev_start,
+                        hipEvent_t ev_stop) {
+    struct Scope {
+        Scope(hipEvent_t a, hipEvent_t b) { t_ev_start = a; t_ev_stop = b; }
+        ~Scope() { t_ev_start = t_ev_stop = nullptr; }
+    } scope(ev_start, ev_stop);
+    const StreamDecimate dec{d_inv_x, d_inv_y, wd, hd, d_dump};
+    switch (radius) {
+        SIFT_REDUCE_CASE(1) SIFT_REDUCE_CASE(2) SIFT_REDUCE_CASE(3) SIFT_REDUCE_CASE(4) SIFT_REDUCE_CASE(5)
+        SIFT_REDUCE_CASE(6) SIFT_REDUCE_CASE(7) SIFT_REDUCE_CASE(8) SIFT_REDUCE_CASE(9) SIFT_REDUCE_CASE(10)
+        SIFT_REDUCE_CASE(11) SIFT_REDUCE_CASE(12) SIFT_REDUCE_CASE(13) SIFT_REDUCE_CASE(14)
+    }
+    return false;
 }
 
 void launch_resample(hipStream_t s, const float* src, float* dst, int ws, int hs, int wd, int hd, int n,

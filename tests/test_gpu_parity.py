@@ -220,6 +220,15 @@ def test_pipeline_parity_separate_scan_and_edge_filter(ctx, report_dir):
         ctx.set_option("fused_edge", 1)
 
 
+def test_pipeline_parity_separate_blur_and_decimation(ctx, report_dir):
+    """reduceToNextLevel as blur -> temporary -> resampling kernel stays a checked alternative."""
+    ctx.set_option("fused_reduce", 0)
+    try:
+        compare_run(ctx, synth_frame(1024, 512, 8), 3, 3, False, "separate blur / decimation 1024x512", report_dir, batch_of=4)
+    finally:
+        ctx.set_option("fused_reduce", 1)
+
+
 def test_batch_images_independent(ctx, report_dir):
     """Every frame of a batch gets the single-frame result (frames differ)."""
     params = _lib.Params(3, 3, 1.6, O.K_SQRT2, 0)
