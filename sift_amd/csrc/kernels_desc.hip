@@ -150,8 +150,8 @@ __global__ __launch_bounds__(1024) void desc_tile_scan_kernel(const int* __restr
 // batch), and built by all 256 threads, two keypoints at once.
 constexpr int kDescBatch = 8;
 constexpr int kDescHalf = 4;                       // keypoints whose pixel reads are issued together
-constexpr int kStageRow = 20;                       // staged window row: 16 samples + pad
-constexpr int kStageStride = 16 * kStageRow + 1;    // per keypoint: odd, so batch neighbours shift banks by one
+constexpr int kStageRow = 20;                       // staged window COLUMN: 16 samples (y) + pad; multiple of 4
+constexpr int kStageStride = 16 * kStageRow + 4;    // per keypoint; multiple of 4: a cell's 4 y-samples are one 16-byte read
 
 struct TileKp {   // what the per-pixel chains need of a keypoint
     unsigned short x, y;
@@ -172,11 +172,11 @@ __global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __res
     __shared__ float s_w16[256];
     __shared__ unsigned short s_list[kTileListCap];   // vector index k of each list entry, ascending
     __shared__ __attribute__((aligned(8))) TileKp s_fin[kTileListCap];
-    __shared__ unsigned char s_flag[kTileListCap];    // bit 0 = fails the bounds test, bit 1 = emitted by this tile
+    __shared__ unsigned short s_flag[kTileListCap];   // bit 0 = fails the bounds test, bit 1 = emitted by this tile; bits 8-15 = octave*D + index
     // histogram inputs of a batch, laid out [sample-in-cell q][cell][keypoint m]: the phase-B reader
     // (thread = (m, cell), q marching) then touches 128 consecutive words per read
     __shared__ __attribute__((aligned(16))) float s_val[kStageStride * kDescBatch];
-    __shared__ unsigned char s_bin[kStageStride * kDescBatch];
+    __shared__ __attribute__((aligned(16))) unsigned char s_bin[kStageStride * kDescBatch];
     __shared__ int s_wcnt[4];
     __shared__ int s_n;
 
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __res
         const int kx = f.x, ky = f.y;
         const bool kfilt = kx < kRegion || kx > w - kRegion || ky < kRegion || ky > h - kRegion;
         const bool owned = kx >= cx0 && kx < cx0 + kCore && ky >= cy0 && ky < cy0 + kCore;
-        return (unsigned char)((kfilt ? 1u : 0u) | (owned ? 2u : 0u));
+        return (unsigned short)((kfilt ? 1u : 0u) | (owned ? 2u : 0u) | ((unsigned)(f.octave * D + f.index) << 8));
     };
     auto compact = [](const FinalKp& f) {
         TileKp t;
@@ -281,11 +281,14 @@ __global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __res
             const uint2 rec_ = *reinterpret_cast<const uint2*>(&s_fin[E]);                                       \
             const unsigned xy_ = __builtin_amdgcn_readfirstlane(rec_.x);                                         \
             const float ORI = __uint_as_float(__builtin_amdgcn_readfirstlane(rec_.y));                           \
-            const unsigned FL = __builtin_amdgcn_readfirstlane((unsigned)s_flag[E]);                             \
+            const unsigned FL = __builtin_amdgcn_readfirstlane((unsigned)s_flag[E]) & 3u;                        \
             const int WX = (int)(xy_ & 0xffffu) - kRegion, WY = (int)(xy_ >> 16) - kRegion;
             // the Gaussian-level pixels of the keypoints this tile emits come straight from HBM/L2 (read
             // once each, no reuse): issued for the whole batch before the chains start
             float pg[kDescBatch];
+            // the thread that writes keypoint (tid >> 5)'s record in phase B fetches its DoG scale now
+            float my_scale = 0.0f;
+            if ((tid & 31) == 0) my_scale = plan->dog_scale[s_flag[e0 + (tid >> 5)] >> 8];
 #pragma unroll
             for (int m = 0; m < kDescBatch; ++m) {
                 pg[m] = 0.0f;
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __res
                     own[j] = fl == 2u;
                     orient[j] = ori;
                     wt[j] = s_w16[lx + 16 * ly];   // weighting(x, y), window-local (sift.cpp:90)
-                    stg[j] = (hb + j) * kStageStride + ly * kStageRow + lx;  // window layout, padded rows
+                    stg[j] = (hb + j) * kStageStride + lx * kStageRow + ly;  // x-major (the histogram's sample order), padded columns
                 }
 #pragma unroll
                 for (int j = 0; j < kDescHalf; ++j) {
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __res
             // ---- phase B: two threads per (keypoint of the batch, cell): bins 0-3 and 4-7 in registers ------
             if (!(dbg & 2)) {
                 const int m = tid >> 5, cell = (tid >> 1) & 15, half = tid & 1;   // cell = (x/4)*4 + y/4, sift.cpp:95-96
-                const int sbase = m * kStageStride + (cell & 3) * 4 * kStageRow + (cell >> 2) * 4;
+                const int sbase = m * kStageStride + (cell >> 2) * 4 * kStageRow + (cell & 3) * 4;   // column 4*(x/4), row 4*(y/4)
                 const int e = e0 + m;
                 if (e < n_seg) {
                     const unsigned fl = s_flag[e];
@@ -378,14 +381,19 @@ __global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __res
                             // alg::orientationHistogram8: samples of the cell in x-outer / y-inner order
                             const unsigned b0 = half ? 4u : 0u;
 #pragma unroll
-                            for (int q = 0; q < 16; ++q) {
-                                const int at = sbase + (q & 3) * kStageRow + (q >> 2);   // x outer, y inner
-                                const float v = s_val[at];
-                                const unsigned b = (unsigned)s_bin[at] - b0;
-                                ha = (b == 0u) ? ha + v : ha;
-                                hb2 = (b == 1u) ? hb2 + v : hb2;
-                                hc = (b == 2u) ? hc + v : hc;
-                                hd = (b == 3u) ? hd + v : hd;     // b == 3 with half: bin 7, never produced
+                            for (int qx = 0; qx < 4; ++qx) {   // x outer: one staged column segment = 4 y-samples
+                                const float4 v4 = *reinterpret_cast<const float4*>(&s_val[sbase + qx * kStageRow]);
+                                const unsigned b4 = *reinterpret_cast<const unsigned*>(&s_bin[sbase + qx * kStageRow]);
+                                const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                                for (int qy = 0; qy < 4; ++qy) {   // y inner
+                                    const float v = vv[qy];
+                                    const unsigned b = ((b4 >> (8 * qy)) & 0xffu) - b0;
+                                    ha = (b == 0u) ? ha + v : ha;
+                                    hb2 = (b == 1u) ? hb2 + v : hb2;
+                                    hc = (b == 2u) ? hc + v : hc;
+                                    hd = (b == 3u) ? hd + v : hd;     // b == 3 with half: bin 7, never produced
+                                }
                             }
                             // alg::normalizeVector: length = b0 + ... + b7 sequentially; skip if 0
                             float lo = 0.0f;
@@ -405,14 +413,15 @@ __global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __res
                         float4* dst = reinterpret_cast<float4*>(desc_out + (size_t)ok * 128 + (size_t)cell * 8);
                         dst[half] = make_float4(ha, hb2, hc, hd);
                         if (cell == 0 && half == 0) {
-                            const FinalKp f = fin[s_list[e]];
+                            const TileKp f = s_fin[e];
+                            const unsigned oi = fl >> 8;   // octave * D + index
                             sift_hip_keypoint r;
-                            r.scale = plan->dog_scale[f.octave * D + f.index];
+                            r.scale = my_scale;
                             r.orientation = f.orientation;
                             r.x = f.x;
                             r.y = f.y;
-                            r.octave = f.octave;
-                            r.index = f.index;
+                            r.octave = (uint16_t)(oi / (unsigned)D);
+                            r.index = (uint16_t)(oi % (unsigned)D);
                             r.filtered = kfilt ? 1 : 0;
                             r.has_descriptor = kfilt ? 0 : 1;
                             r.reserved = 0;
