@@ -153,6 +153,11 @@ constexpr int kDescHalf = 4;                       // keypoints whose pixel read
 constexpr int kStageRow = 20;                       // staged window COLUMN: 16 samples (y) + pad; multiple of 4
 constexpr int kStageStride = 16 * kStageRow + 4;    // per keypoint; multiple of 4: a cell's 4 y-samples are one 16-byte read
 
+// value of the neighbouring lane (lane ^ 1) through the DPP quad permute: one VALU instruction, no LDS round trip
+__device__ __forceinline__ float lane_xor1(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+}
+
 struct TileKp {   // what the per-pixel chains need of a keypoint
     unsigned short x, y;
     float orientation;
@@ -398,13 +403,13 @@ __global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __res
                             // alg::normalizeVector: length = b0 + ... + b7 sequentially; skip if 0
                             float lo = 0.0f;
                             lo += ha; lo += hb2; lo += hc; lo += hd;               // bins 0..3 (used by half 0)
-                            const float lo_partner = __shfl_xor(lo, 1);            // half 1 receives bins 0..3's sum
+                            const float lo_partner = lane_xor1(lo);                 // half 1 receives bins 0..3's sum
                             float length = lo;
                             if (half) {
                                 length = lo_partner;
                                 length += ha; length += hb2; length += hc; length += hd;   // + bins 4..7
                             }
-                            const float len_partner = __shfl_xor(length, 1);       // half 0 receives the full length
+                            const float len_partner = lane_xor1(length);            // half 0 receives the full length
                             if (!half) length = len_partner;
                             if (!(length == 0.0f)) {
                                 ha = ha / length; hb2 = hb2 / length; hc = hc / length; hd = hd / length;
