@@ -734,6 +734,7 @@ bool mid_gpu(sift_hip_ctx* c) {
     c->h_status.ensure((size_t)n * 5 * sizeof(int));
     const int* st = c->h_status.as<int>();   // pinned: the copy is a real asynchronous DMA
     SIFT_HIP_CHECK(hipMemcpyAsync(c->h_status.p, c->d_status.p, (size_t)n * 5 * sizeof(int), hipMemcpyDeviceToHost, s));
+    resolve_events(c);   // the pyramid's timing events completed long ago: read them while the GPU is still busy
     wait_stream(c, s);
     if (getenv("SIFT_CLEANUP2_STAMPS")) {   // diagnostics: phases of the second cleanup (image 0)
         static unsigned long long* dst = nullptr;
