@@ -83,7 +83,7 @@ __device__ __forceinline__ void lds_read_window(const float4* p, float4 (&f)[N])
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int R, bool DOG, int TH = 64>
-__global__ __launch_bounds__(256, (TH == 32 ? 4 : (R <= 8 ? 3 : (R <= 24 ? 2 : 1)))) void blur_fused_kernel(const float* __restrict__ in,
+__global__ __launch_bounds__(256, (R <= 8 ? 3 : (R <= 24 ? 2 : 1))) void blur_fused_kernel(const float* __restrict__ in,
                                                          float* __restrict__ out,
                                                          float* __restrict__ dog, int w, int h,
                                                          int tiles_x, int tiles_y, int total_tiles,
@@ -521,17 +521,12 @@ __global__ void dog_kernel(const float* __restrict__ lower, const float* __restr
 // from the dispatch packet itself (no extra barrier packets between back-to-back launches).
 static thread_local hipEvent_t t_ev_start = nullptr, t_ev_stop = nullptr;
 
-static int blur_th() {
-    static int th = [] { const char* e = getenv("SIFT_BLUR_TH"); return e ? atoi(e) : 64; }();
-    return th;
-}
-
 template <int R, int TH>
 static void launch_fused_rt(hipStream_t s, const float* in, float* out, float* dog, int w, int h, int n,
                             const float* d_taps) {
     const int tiles_x = (w + 63) / 64, tiles_y = (h + TH - 1) / TH;
     const int total = tiles_x * tiles_y * n;
-    const int cap = TH == 32 ? 1536 : 1024;  // persistent workgroups offered per launch
+    const int cap = 1024;  // persistent workgroups offered per launch
     int grid = total < cap ? total : cap;
     if (grid >= 8) grid &= ~7;
     const bool aligned = (((uintptr_t)in | (uintptr_t)out | (uintptr_t)dog) & 15u) == 0;
@@ -547,12 +542,6 @@ static void launch_fused_rt(hipStream_t s, const float* in, float* out, float* d
 template <int R>
 static void launch_fused_r(hipStream_t s, const float* in, float* out, float* dog, int w, int h, int n,
                            const float* d_taps) {
-    if constexpr (R == 5 || R == 7 || R == 10) {
-        if (blur_th() == 32) {
-            launch_fused_rt<R, 32>(s, in, out, dog, w, h, n, d_taps);
-            return;
-        }
-    }
     launch_fused_rt<R, 64>(s, in, out, dog, w, h, n, d_taps);
 }
 
