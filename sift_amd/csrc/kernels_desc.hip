@@ -163,7 +163,17 @@ struct TileKp {   // what the per-pixel chains need of a keypoint
     float orientation;
 };
 
-__global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __restrict__ plan, int level,
+// what the kernel needs to know about its level, passed by value (kernel arguments are scalar registers: no
+// dependent loads from the plan before the first useful load can be issued)
+struct DescLevel {
+    int w, h, dogs, tiles_per_image, tile_base;
+    const float* mag;
+    const float* ori;
+    const float* gauss;
+    const float* w16;
+};
+
+__global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __restrict__ plan, DescLevel lv, int level,
                                                          const FinalKp* __restrict__ finals,
                                                          const int* __restrict__ final_cnt, int final_cap,
                                                          const int* __restrict__ tile_cnt,
@@ -188,18 +198,23 @@ __global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __res
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int img = blockIdx.z;
-    const int D = plan->dogs;
-    const int oct = level / (D + 1);
-    const int w = plan->w[oct], h = plan->h[oct];
+    const int D = lv.dogs;
+    const int w = lv.w, h = lv.h;
     const int cx0 = blockIdx.x * kCore, cy0 = blockIdx.y * kCore;
     const int ex0 = cx0 - kRegion, ey0 = cy0 - kRegion;
-    const int tile = img * plan->desc_tiles_per_image + plan->desc_tile_base[level] + blockIdx.y * gridDim.x + blockIdx.x;
+    const int tile = img * lv.tiles_per_image + lv.tile_base + blockIdx.y * gridDim.x + blockIdx.x;
     const int n_tile = tile_cnt[tile];
+    const int t_off = tile_off[tile];
     if (n_tile == 0) return;  // no window touches this tile: nothing to mutate, nothing to emit
     const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
-    const float* __restrict__ gm = plan->mag[level] + img_off;
-    const float* __restrict__ go = plan->ori[level] + img_off;
-    const float* __restrict__ gg = plan->gauss[level] + img_off;
+    const float* __restrict__ gm = lv.mag + img_off;
+    const float* __restrict__ go = lv.ori + img_off;
+    const float* __restrict__ gg = lv.gauss + img_off;
+    // the first 256 records of the tile's list travel together with the tile's pixels
+    const FinalKp* __restrict__ pool_src = pool + (size_t)img * (size_t)pool_cap + (size_t)t_off;
+    FinalKp first_rec;
+    first_rec.cand = 0; first_rec.orientation = 0.0f; first_rec.x = first_rec.y = first_rec.octave = first_rec.index = 0;
+    if (tid < n_tile && n_tile <= kTileListCap) first_rec = pool_src[tid];
     const FinalKp* __restrict__ fin = finals + (size_t)img * (size_t)final_cap;
     const int K = final_cnt[img];
     const long long obase = out_base[img];
@@ -248,7 +263,7 @@ __global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __res
             }
         }
     }
-    s_w16[tid] = plan->w16[level][(size_t)img * 256 + tid];
+    s_w16[tid] = lv.w16[(size_t)img * 256 + tid];
 
     const int rx = tid & 15, ry = tid >> 4;  // residues of the pixels this thread owns
 
@@ -445,8 +460,8 @@ __global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __res
     FinalKp* s_raw = reinterpret_cast<FinalKp*>(s_val);
     if (n_tile <= kTileListCap) {
         // fetch the tile's list and rank-sort it by vector index (indices are unique)
-        const FinalKp* __restrict__ src = pool + (size_t)img * (size_t)pool_cap + (size_t)tile_off[tile];
-        for (int i = tid; i < n_tile; i += 256) s_raw[i] = src[i];
+        if (tid < n_tile) s_raw[tid] = first_rec;
+        for (int i = tid + 256; i < n_tile; i += 256) s_raw[i] = pool_src[i];
         __syncthreads();
         for (int i = tid; i < n_tile; i += 256) {
             const FinalKp rec = s_raw[i];
@@ -559,7 +574,12 @@ void launch_descriptors(hipStream_t s, const DevPlan* d_plan, const DevPlan& pla
                         const long long* d_out_base, sift_hip_keypoint* d_kp_out, float* d_desc_out, long long out_cap,
                         int dbg) {
     const dim3 grid((unsigned)plan.desc_ntx[level], (unsigned)plan.desc_nty[level], (unsigned)plan.n_images);
-    hipLaunchKernelGGL(descriptor_kernel, grid, dim3(256), 0, s, d_plan, level, d_final, d_final_cnt, final_cap,
+    DescLevel lv;
+    const int oct = level / (plan.dogs + 1);
+    lv.w = plan.w[oct]; lv.h = plan.h[oct]; lv.dogs = plan.dogs;
+    lv.tiles_per_image = plan.desc_tiles_per_image; lv.tile_base = plan.desc_tile_base[level];
+    lv.mag = plan.mag[level]; lv.ori = plan.ori[level]; lv.gauss = plan.gauss[level]; lv.w16 = plan.w16[level];
+    hipLaunchKernelGGL(descriptor_kernel, grid, dim3(256), 0, s, d_plan, lv, level, d_final, d_final_cnt, final_cap,
                        d_tile_cnt, d_tile_off, d_pool, pool_cap, d_out_base, d_kp_out, d_desc_out, out_cap, dbg);
 }
 
