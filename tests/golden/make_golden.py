@@ -91,6 +91,10 @@ def make_digest_case(name, img, dogs, octaves, subpixel, meta, throwing_octaves=
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "truncation":
+        # App. B-7: more than 65535 points survive the edge filter, `u16_t size` keeps count mod 65536
+        make_digest_case("u16_truncation_4k", synth_frame(3840, 2160, 11), 3, 4, False, [3840, 2160, 11])
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "config5":
         # BASELINE config 5: 3840x2160, subpixel, 6 octaves throws in the reference; 5 octaves runs
         make_digest_case("config5_4k", synth_frame(3840, 2160, 3), 3, 5, True, [3840, 2160, 3], throwing_octaves=6)

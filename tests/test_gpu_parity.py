@@ -350,6 +350,23 @@ def test_config5_4k_subpixel_digest(ctx):
     assert sha(desc) == str(g["descriptors_sha"])
 
 
+def test_u16_size_truncation_in_the_pipeline(ctx):
+    """App. B-7 end to end: on this 3840x2160 frame 80523 points survive the edge filter, the reference's
+    `u16_t size` (sift.cpp:41) keeps 80523 mod 65536 = 14987 of them, and everything downstream (orientation
+    stage run late in list order, second cleanup, descriptors) follows from that list."""
+    from golden_util import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "digest_u16_truncation_4k.npz"))
+    dogs, octaves, subpixel, w, h, seed = (int(v) for v in g["meta"])
+    ctx.calculate_batch(synth_frame(w, h, seed)[None], _lib.Params(dogs, octaves, 1.6, O.K_SQRT2, subpixel))
+    got = [ctx.stage(s).size for s in ("candidates", "after_sort1", "after_orient", "after_sort2", "final")]
+    assert got == g["counts"].tolist()
+    assert got[1] == 14987
+    kp, desc = ctx.results()
+    assert sha(np.stack([kp["x"], kp["y"], kp["octave"], kp["index"]], 1).astype(np.uint16)) == str(g["kp_sha"])
+    assert sha(kp["orientation"]) == str(g["orientation_sha"])
+    assert sha(desc) == str(g["descriptors_sha"])
+
+
 # ------------------------------------------------------------------------------------------------
 # cleanup (std::sort + u16 truncation) as a GPU kernel vs libstdc++ itself
 # ------------------------------------------------------------------------------------------------
