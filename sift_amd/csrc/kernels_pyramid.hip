@@ -405,10 +405,16 @@ __global__ __launch_bounds__(256, stream_occ(R, CPL)) void blur_stream_kernel(co
         if (DOG && (STORE)) prev = *reinterpret_cast<const f4v*>(ring + pslot * ROWF + RA + CPL * el);                  \
         __builtin_amdgcn_wave_barrier();                                                                              \
         SIFT_STREAM_LDS((S) + 1, ((U) + 1) % PF)                                                                      \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                              \
-            const float tap = tp[j];                                                                                  \
-            const f4v nx = j + 1 < NT ? A[j + 1] : (f4v)(0.0f);                                                       \
-            A[j] = nx + tap * m;                                                                                      \
+        /* The taps are symmetric (tap[j] == tap[2R-j] bit for bit: initGaussian evaluates x*x), so the product  */   \
+        /* tap[j] * mid is the same float for slots j and 2R-j: one multiply serves both additions.             */   \
+        {                                                                                                             \
+            f4v An[NT];                                                                                               \
+            _Pragma("unroll") for (int i = 0; i <= R; ++i) {                                                          \
+                const f4v pr = tp[i] * m;                                                                             \
+                An[i] = A[i + 1] + pr;            /* i + 1 <= R + 1 <= 2R for R >= 1 */                               \
+                if (2 * R - i != i) An[2 * R - i] = (2 * R - i + 1 < NT ? A[2 * R - i + 1] : (f4v)(0.0f)) + pr;       \
+            }                                                                                                         \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j) A[j] = An[j];                                              \
         }                                                                                                             \
         if (STORE) {                                                                                                  \
             const int y = y0 + (S) - RI;                                                                              \

@@ -39,6 +39,11 @@ def test_host_glue_entry_points_without_gpu():
         r, t = gauss_taps(sigma)
         r2, t2 = O.gauss_taps(sigma)
         assert r == r2 and t.tobytes() == t2.tobytes()
+    # the streaming blur kernel shares the product tap[j] * x between the slots j and 2r - j of its column pass:
+    # the tables must be symmetric bit for bit (they are: initGaussian evaluates x * x)
+    for sigma in np.concatenate([np.linspace(0.2, 5.0, 97), [6.4, 9.050967, 12.8, 18.101934]]).astype(np.float32):
+        r, t = gauss_taps(float(sigma))
+        assert t.size == 2 * r + 1 and t.tobytes() == t[::-1].tobytes(), float(sigma)
     L = _lib.load()
     rng = np.random.default_rng(0)
     for n in (0, 1, 15, 16, 17, 33, 100, 1000, 4097, 70000):
