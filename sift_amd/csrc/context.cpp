@@ -742,8 +742,13 @@ bool mid_gpu(sift_hip_ctx* c) {
         else {
             unsigned long long hs[512];
             (void)hipMemcpy(hs, dst, sizeof(hs), hipMemcpyDeviceToHost);
-            std::fprintf(stderr, "cleanup2 (us): init %.1f sort %.1f compact+emit %.1f binning %.1f | rounds-internal: loop %.1f copy %.1f\n", (hs[101] - hs[100]) / 100.0,
-                         (hs[102] - hs[101]) / 100.0, (hs[103] - hs[102]) / 100.0, (hs[104] - hs[103]) / 100.0, (hs[2] - hs[1]) / 100.0, (hs[3] - hs[2]) / 100.0);
+            std::fprintf(stderr, "cleanup2 (us): init %.1f sort %.1f compact+emit %.1f binning %.1f\n", (hs[101] - hs[100]) / 100.0,
+                         (hs[102] - hs[101]) / 100.0, (hs[103] - hs[102]) / 100.0, (hs[104] - hs[103]) / 100.0);
+            std::fprintf(stderr, "cleanup1 (us): bits %.1f ranks %.1f | rounds %llu:", (hs[9] > hs[8] ? (hs[9] - hs[8]) / 100.0 : 0.0) * 0 + (hs[8] ? 0.0 : 0.0), (hs[9] - hs[8]) / 100.0, hs[7]);
+            for (unsigned long long r = 0; r < hs[7] && r < 40; ++r)
+                std::fprintf(stderr, " [p%llu n%llu %.1f]", hs[16 + 4 * r + 3] >> 60, (hs[16 + 4 * r + 3] >> 32) & 0xfffffff,
+                             r + 1 < hs[7] ? (hs[16 + 4 * (r + 1)] - hs[16 + 4 * r]) / 100.0 : 0.0);
+            std::fprintf(stderr, "\n");
         }
     }
     for (int i = 0; i < n; ++i)

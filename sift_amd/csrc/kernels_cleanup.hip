@@ -67,6 +67,7 @@ struct LdsBitKeys {
     }
 };
 constexpr int kBitCap = 1 << 19;   // 64 KiB of LDS for the key bits
+constexpr int kSmallRange = 8192;   // filtered-pivot rounds on ranges this short run element-parallel
 constexpr int kMoveSlots = 10;     // pending payload moves per thread (LDS, behind the key bits)
 constexpr int kDynLds = kBitCap / 8 + 1024 * kMoveSlots * 8;
 
@@ -370,8 +371,133 @@ __device__ __forceinline__ int block_exclusive_scan(CleanupShared& sh, int v, in
 __device__ __forceinline__ void key_clear(const LdsBitKeys K, int pos) { atomicAnd(&K.w[pos >> 5], ~(1u << (pos & 31))); }
 __device__ __forceinline__ void key_set(const LdsBitKeys K, int pos) { atomicOr(&K.w[pos >> 5], 1u << (pos & 31)); }
 
+// One kept-pivot round, element-parallel: the hits are the KEPT keys, every one of them moves a payload, and in the
+// ranges where such rounds happen (the left end fills up with kept elements) whole key words are hits - so the
+// swaps are listed by rank (P, global scratch) and applied by all threads, instead of word by word.
+// Returns T (block-uniform); sh.T must be 0x7fffffff on entry.
+__device__ int round_kept_pivot(CleanupShared& sh, const LdsBitKeys K, uint32_t* __restrict__ I,
+                                uint32_t* __restrict__ P, int F, int L) {
+    const int tid = threadIdx.x;
+    int running = 0, par = 0;
+    // t-th kept element from the right goes to F+t while it lies right of it
+    for (int base = L - 1; base >= F; base -= 4 * kCT) {
+        bool hit[4];
+        int pos[4], rk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            pos[u] = base - u * kCT - tid;
+            hit[u] = pos[u] >= F && K.get(pos[u]) == 0;
+        }
+        int tile_total;
+        tile_rank4(sh, par, hit, rk, tile_total);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (hit[u]) {
+                const int t = running + rk[u];
+                if (F + t < pos[u]) P[t] = (uint32_t)pos[u];
+                else atomicMin(&sh.T, t);
+            }
+        }
+        running += tile_total;
+        par ^= 1;
+        __syncthreads();
+        if (sh.T != 0x7fffffff) break;
+    }
+    __syncthreads();
+    const int T = (sh.T == 0x7fffffff) ? running : sh.T;
+    __syncthreads();
+    // apply the T disjoint swaps, four per thread in flight
+    for (int t0 = tid; t0 < T; t0 += 4 * kCT) {
+        int a[4], b[4];
+        uint32_t ia[4], ib[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * kCT;
+            a[u] = t < T ? (int)P[t] : -1;
+            b[u] = F + t;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (a[u] >= 0) {
+                ia[u] = I[a[u]];
+                ib[u] = I[b[u]];
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (a[u] >= 0) {
+                K.swap(a[u], b[u]);
+                I[a[u]] = ib[u];
+                I[b[u]] = ia[u];
+            }
+    }
+    return T;
+}
+
+// One filtered-pivot round, element-parallel (short ranges: the word-parallel form leaves most threads idle
+// there).  Only swaps whose partner is kept change anything.  Returns T; sh.T / sh.flag as in the other forms.
+__device__ int round_filtered_pivot_small(CleanupShared& sh, const LdsBitKeys K, uint32_t* __restrict__ I,
+                                          uint32_t* __restrict__ P, int F, int L) {
+    const int tid = threadIdx.x;
+    int running = 0, par = 0;
+    // t-th filtered element from the left goes to L-1-t while it lies left of it
+    for (int base = F; base < L; base += 4 * kCT) {
+        bool hit[4];
+        int pos[4], rk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            pos[u] = base + u * kCT + tid;
+            hit[u] = pos[u] < L && K.get(pos[u]) == 1;
+        }
+        int tile_total;
+        tile_rank4(sh, par, hit, rk, tile_total);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (hit[u]) {
+                const int t = running + rk[u];
+                if (pos[u] < L - 1 - t) {
+                    P[t] = (uint32_t)pos[u];
+                } else {  // participants are a prefix of the hits: the smallest failing rank is T
+                    atomicMin(&sh.T, t);
+                    atomicMin(&sh.flag, pos[u]);
+                }
+            }
+        }
+        running += tile_total;
+        par ^= 1;
+        __syncthreads();
+        if (sh.T != 0x7fffffff) break;
+    }
+    __syncthreads();
+    const int T = (sh.T == 0x7fffffff) ? running : sh.T;
+    __syncthreads();
+    for (int t0 = tid; t0 < T; t0 += 4 * kCT) {
+        int a[4], b[4];
+        uint32_t ib[4];
+        bool mv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * kCT;
+            b[u] = L - 1 - t;
+            mv[u] = t < T && K.get(b[u]) == 0;   // a filtered partner: nothing changes
+            a[u] = mv[u] ? (int)P[t] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (mv[u]) ib[u] = I[b[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (mv[u]) {
+                key_clear(K, a[u]);   // the kept partner now sits at the hit's position
+                key_set(K, b[u]);
+                I[a[u]] = ib[u];
+            }
+    }
+    return T;
+}
+
 __device__ void introsort_bits(CleanupShared& sh, int n, const LdsBitKeys K, uint32_t* __restrict__ I,
                                uint32_t* __restrict__ I2) {
+    uint32_t* __restrict__ P = I2;   // swap-source scratch of the kept-pivot rounds (I2 is only filled after the loop)
     const int tid = threadIdx.x;
     stamp(1);
     if (tid == 0) {
@@ -422,6 +548,39 @@ __device__ void introsort_bits(CleanupShared& sh, int n, const LdsBitKeys K, uin
         if (round < 120) stamp(16 + 4 * round + 1);
         const int p = sh.p;
         const int F = f + 1, L = l;
+        if (p == 0) {
+            const int T0 = round_kept_pivot(sh, K, I, P, F, L);
+            __syncthreads();
+            if (round < 120 && g_stamp && tid == 0 && blockIdx.x == 0)
+                g_stamp[16 + 4 * round + 3] = (wall_clock64() & 0xffffffffull) | ((unsigned long long)(L - F) << 32);
+            ++round;
+            if (tid == 0) {
+                const int cut = F + T0;
+                if (sh.npure < kMaxPure) {
+                    sh.pure[sh.npure] = PureRange{f, cut - f, sh.d};
+                    sh.npure += 1;
+                } else {
+                    sh.fallback = 1;
+                }
+                sh.f = cut;  // left part [f, cut) is all kept
+            }
+            __syncthreads();
+            continue;
+        }
+        if (L - F <= kSmallRange) {
+            const int T1 = round_filtered_pivot_small(sh, K, I, P, F, L);
+            __syncthreads();
+            if (round < 120 && g_stamp && tid == 0 && blockIdx.x == 0)
+                g_stamp[16 + 4 * round + 3] = (wall_clock64() & 0xffffffffull) | ((unsigned long long)(L - F) << 32) | (1ull << 60);
+            ++round;
+            if (tid == 0) {
+                const int fail = sh.flag;
+                const int cut = (fail != 0x7fffffff && fail == L - 1 - T1) ? L - 1 - T1 : L - T1;
+                sh.l = cut;  // right part [cut, l) is all filtered: dead
+            }
+            __syncthreads();
+            continue;
+        }
         const int q0 = F >> 6, q1 = (L - 1) >> 6;
         const int chunk = (q1 - q0 + 1 + kCT - 1) / kCT;   // <= kMaxChunk
         // 1. snapshot + count.  Thread order = hit order: words ascend from the left for p == 1, descend from the right for p == 0
