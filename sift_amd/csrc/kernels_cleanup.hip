@@ -239,14 +239,29 @@ __device__ void introsort_binary(CleanupShared& sh, int n, const Keys K, uint32_
         __syncthreads();
         const int T = (sh.T == 0x7fffffff) ? running : sh.T;
         __syncthreads();
-        // apply the T disjoint swaps
-        for (int t = tid; t < T; t += kCT) {
-            const int a = (int)P[t];
-            const int b = p == 1 ? (L - 1 - t) : (F + t);
-            K.swap(a, b);
-            const uint32_t ia = I[a], ib = I[b];
-            I[a] = ib;
-            I[b] = ia;
+        // apply the T disjoint swaps, four per thread in flight
+        for (int t0 = tid; t0 < T; t0 += 4 * kCT) {
+            int a[4], b[4];
+            uint32_t ia[4], ib[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + u * kCT;
+                a[u] = t < T ? (int)P[t] : -1;
+                b[u] = p == 1 ? (L - 1 - t) : (F + t);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (a[u] >= 0) {
+                    ia[u] = I[a[u]];
+                    ib[u] = I[b[u]];
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (a[u] >= 0) {
+                    K.swap(a[u], b[u]);
+                    I[a[u]] = ib[u];
+                    I[b[u]] = ia[u];
+                }
         }
         __syncthreads();
         if (tid == 0) {
