@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void gradient_kernel(const float* __restrict__
 }
 
 // Two phases per workgroup of 128 keypoints:
-//  1. histogram.  Each wave takes 32 keypoints, 8 at a time: the 16x16 windows of orientation /
+//  1. histogram.  Each wave takes 32 keypoints, 4 at a time (LDS for three workgroups per CU): the 16x16 windows of orientation /
 //     magnitude / Gaussian are fetched with row-coalesced loads and the 256 (bin, magnitude*gauss)
 //     pairs of each keypoint are staged in LDS in the reference's summation order (x outer, y inner);
 //     then LANE k runs keypoint k's ordered sum, so 8 dependent chains advance side by side.  All
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void gradient_kernel(const float* __restrict__
 //  2. peaks: one THREAD per keypoint runs the serial Sift::_findPeaks / vertexParabola logic on its
 //     histogram column in LDS, so 128 dependent chains run side by side instead of one per wave.
 constexpr int kOrientGroup = 128;
-constexpr int kOrientSub = 8;       // keypoints staged per wave at a time
+constexpr int kOrientSub = 4;       // keypoints staged per wave at a time
 constexpr int kOrientCol = 20;      // staged samples of one window column (16 + pad: 2-way instead of 8-way write conflicts)
 constexpr int kOrientStride = 324;  // floats (and bytes) between staged keypoints: lane k reads 16-byte words at bank 4k
 
