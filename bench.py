@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "exercise the N > 1 flow where ranks have to share one GPU: results are staged through host memory)")
     ap.add_argument("--share-device", action="store_true", help="testing: every rank uses GPU 0")
+    ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE", help="library option (sift_hip_set_option), e.g. fused_edge=0")
     ap.add_argument("--lanes", type=int, default=1,
                     help="contexts (streams + host threads) per GPU, each taking an equal share of the batch, so one\n"
                          "lane's latency-bound stages overlap the other's bandwidth-bound ones")
@@ -109,6 +110,10 @@ def main():
     first = [sum(share[:i]) for i in range(lanes)]
     ctxs = [Context(local_rank) for _ in range(lanes)]
     ctx = ctxs[0]
+    for kv in args.set:
+        name, value = kv.split("=")
+        for c in ctxs:
+            c.set_option(name, int(value))
     params = _lib.Params(DOGS, OCTAVES, SIGMA, K_SQRT2, 0)
     L = ctx._L
     frame_bytes = W * H * 4
