@@ -59,7 +59,11 @@ __global__ __launch_bounds__(256) void gradient_kernel(const float* __restrict__
     // per-pixel inputs of alg::orientationHistogram36 (algorithms.cpp:126-128), which reads the
     // INITIAL maps: weight = magnitude * gaussian, bin = (u16)floor(orientation / 10) % 35
     prod[o] = m * g[o];
-    const unsigned bin = f32_to_u16_x86(__builtin_floorf(a / 10.0f)) % 35u;
+    // a is in [0, 360).  RN(a / 10) is monotone, so a < 9.5 gives floor 0 and 350.5 <= a < 360 gives floor 35, i.e.
+    // bin 0 after % 35 either way — which is every pixel, the reference feeding radians (App. B-9); the division
+    // only runs for values in between.
+    unsigned bin = 0u;
+    if (!(a < 9.5f || (a >= 350.5f && a < 360.0f))) bin = f32_to_u16_x86(__builtin_floorf(a / 10.0f)) % 35u;
     obin[o] = (uint8_t)bin;
     // The reference feeds radians where degrees were meant (App. B-9): every sample lands in bin 0.  The
     // orientation stage skips the bin map of an image as long as this flag stays clear.
