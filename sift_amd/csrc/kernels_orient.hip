@@ -30,20 +30,16 @@ __device__ __forceinline__ unsigned f32_to_u16_x86(float v) {
     return (unsigned)i & 0xffffu;
 }
 
-// sift.cpp:130-160: interior pixels only, border stays 0.
-__global__ __launch_bounds__(256) void gradient_kernel(const float* __restrict__ g, float* __restrict__ mag,
-                                                       float* __restrict__ ori, float* __restrict__ prod,
-                                                       uint8_t* __restrict__ obin, int w, int h,
-                                                       int* __restrict__ any_bin) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= w) return;
-    const size_t base = (size_t)blockIdx.z * (size_t)w * (size_t)h;
-    const size_t o = base + (size_t)y * (size_t)w + (size_t)x;
-    float m = 0.0f, a = 0.0f;
-    if (x >= 1 && x <= w - 2 && y >= 1 && y <= h - 2) {
-        const float dx = g[o + 1] - g[o - 1];
-        const float dy = g[o + (size_t)w] - g[o - (size_t)w];
+// One pixel of the gradient maps (sift.cpp:130-160 with alg::gradientMagnitude / Orientation, algorithms.cpp:108-116):
+// magnitude, orientation, and the per-pixel inputs of alg::orientationHistogram36 (algorithms.cpp:126-128), which
+// reads the INITIAL maps: weight = magnitude * gaussian, bin = (u16)floor(orientation / 10) % 35.
+__device__ __forceinline__ void gradient_pixel(bool interior, float left, float right, float up, float down, float centre,
+                                               float& m, float& a, float& pr, unsigned& bin) {
+    m = 0.0f;
+    a = 0.0f;
+    if (interior) {   // border pixels stay 0
+        const float dx = right - left;
+        const float dy = down - up;
         // std::sqrt(std::pow(dx, 2) + std::pow(dy, 2)) evaluated in double (algorithms.cpp:109-110)
         m = (float)__builtin_sqrt((double)dx * (double)dx + (double)dy * (double)dy);
         // std::fmod(atan2f(dy, dx) + 360.f, 360.) (algorithms.cpp:114-115); atan2f in [-pi, pi] so the
@@ -54,20 +50,72 @@ __global__ __launch_bounds__(256) void gradient_kernel(const float* __restrict__
         const double s = (double)(r + 360.0f);
         a = (float)(s >= 360.0 ? s - 360.0 : s);
     }
-    mag[o] = m;
-    ori[o] = a;
-    // per-pixel inputs of alg::orientationHistogram36 (algorithms.cpp:126-128), which reads the
-    // INITIAL maps: weight = magnitude * gaussian, bin = (u16)floor(orientation / 10) % 35
-    prod[o] = m * g[o];
+    pr = m * centre;
     // a is in [0, 360).  RN(a / 10) is monotone, so a < 9.5 gives floor 0 and 350.5 <= a < 360 gives floor 35, i.e.
     // bin 0 after % 35 either way — which is every pixel, the reference feeding radians (App. B-9); the division
     // only runs for values in between.
-    unsigned bin = 0u;
+    bin = 0u;
     if (!(a < 9.5f || (a >= 350.5f && a < 360.0f))) bin = f32_to_u16_x86(__builtin_floorf(a / 10.0f)) % 35u;
+}
+
+__global__ __launch_bounds__(256) void gradient_kernel(const float* __restrict__ g, float* __restrict__ mag,
+                                                       float* __restrict__ ori, float* __restrict__ prod,
+                                                       uint8_t* __restrict__ obin, int w, int h,
+                                                       int* __restrict__ any_bin) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w) return;
+    const size_t base = (size_t)blockIdx.z * (size_t)w * (size_t)h;
+    const size_t o = base + (size_t)y * (size_t)w + (size_t)x;
+    const bool interior = x >= 1 && x <= w - 2 && y >= 1 && y <= h - 2;
+    float m, a, pr;
+    unsigned bin;
+    gradient_pixel(interior, interior ? g[o - 1] : 0.0f, interior ? g[o + 1] : 0.0f, interior ? g[o - (size_t)w] : 0.0f,
+                   interior ? g[o + (size_t)w] : 0.0f, g[o], m, a, pr, bin);
+    mag[o] = m;
+    ori[o] = a;
+    prod[o] = pr;
     obin[o] = (uint8_t)bin;
     // The reference feeds radians where degrees were meant (App. B-9): every sample lands in bin 0.  The
     // orientation stage skips the bin map of an image as long as this flag stays clear.
     if (bin != 0u && any_bin) any_bin[blockIdx.z] = 1;
+}
+
+// Four pixels of a row per thread (rows 16-byte aligned): 16-byte loads of the row and its two neighbours, all
+// issued before the arithmetic, 16-byte stores, a 4-byte store of the bins.
+__global__ __launch_bounds__(256) void gradient4_kernel(const float* __restrict__ g, float* __restrict__ mag,
+                                                        float* __restrict__ ori, float* __restrict__ prod,
+                                                        uint8_t* __restrict__ obin, int w, int h,
+                                                        int* __restrict__ any_bin) {
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y;
+    if (x >= w) return;
+    const size_t base = (size_t)blockIdx.z * (size_t)w * (size_t)h;
+    const size_t o = base + (size_t)y * (size_t)w + (size_t)x;
+    const bool row_in = y >= 1 && y <= h - 2;
+    const float4 c4 = *reinterpret_cast<const float4*>(g + o);
+    float4 u4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d4 = u4;
+    float lf = 0.0f, rt = 0.0f;
+    if (row_in) {
+        u4 = *reinterpret_cast<const float4*>(g + o - (size_t)w);
+        d4 = *reinterpret_cast<const float4*>(g + o + (size_t)w);
+        if (x >= 1) lf = g[o - 1];
+        if (x + 4 <= w - 1) rt = g[o + 4];
+    }
+    const float cv[6] = {lf, c4.x, c4.y, c4.z, c4.w, rt};
+    const float uv[4] = {u4.x, u4.y, u4.z, u4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+    float m[4], a[4], pr[4];
+    unsigned bin[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool interior = row_in && x + e >= 1 && x + e <= w - 2;
+        gradient_pixel(interior, cv[e], cv[e + 2], uv[e], dv[e], cv[e + 1], m[e], a[e], pr[e], bin[e]);
+    }
+    *reinterpret_cast<float4*>(mag + o) = make_float4(m[0], m[1], m[2], m[3]);
+    *reinterpret_cast<float4*>(ori + o) = make_float4(a[0], a[1], a[2], a[3]);
+    *reinterpret_cast<float4*>(prod + o) = make_float4(pr[0], pr[1], pr[2], pr[3]);
+    *reinterpret_cast<unsigned*>(obin + o) = bin[0] | (bin[1] << 8) | (bin[2] << 16) | (bin[3] << 24);
+    if ((bin[0] | bin[1] | bin[2] | bin[3]) != 0u && any_bin) any_bin[blockIdx.z] = 1;
 }
 
 // Two phases per workgroup of 128 keypoints:
@@ -371,6 +419,13 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
 
 void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, float* prod, uint8_t* obin, int w, int h,
                      int n, int* d_any_bin) {
+    const bool vec = (w & 3) == 0 && ((((uintptr_t)g | (uintptr_t)mag | (uintptr_t)ori | (uintptr_t)prod) & 15u) == 0) &&
+                     (((uintptr_t)obin & 3u) == 0);
+    if (vec) {
+        const dim3 grid4((unsigned)((w / 4 + 255) / 256), (unsigned)h, (unsigned)n);
+        hipLaunchKernelGGL(gradient4_kernel, grid4, dim3(256), 0, s, g, mag, ori, prod, obin, w, h, d_any_bin);
+        return;
+    }
     const dim3 grid((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)n);
     hipLaunchKernelGGL(gradient_kernel, grid, dim3(256), 0, s, g, mag, ori, prod, obin, w, h, d_any_bin);
 }
