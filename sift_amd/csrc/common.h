@@ -120,7 +120,7 @@ void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, floa
                      int n, int* d_any_bin = nullptr);
 void launch_orientation(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const Candidate* d_cands,
                         const OrientIn* d_oin, const int* d_list_cnt, int list_cap, OrientOut* d_out,
-                        float* d_peaks, int* d_next_group, const int* d_any_bin = nullptr);
+                        float* d_peaks, int* d_next_group, const int* d_any_bin = nullptr, int zero_counters = 1);
 // host-glue path: orientation inputs in list order from an uploaded survivor list
 void launch_build_orient_in(hipStream_t s, const Candidate* d_cands, long long cand_cap, const uint32_t* d_list,
                             const int* d_list_cnt, int list_cap, int n_images, OrientIn* d_oin);

@@ -713,7 +713,8 @@ bool mid_gpu(sift_hip_ctx* c) {
     SIFT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
     // late launch: only the images whose survivor list was truncated (counts are 0 for the others)
     launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_order.as<OrientIn>(), d_late, kListCap,
-                       c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 3 * n, c->d_ocnt.as<int>() + 4 * n);
+                       c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 3 * n, c->d_ocnt.as<int>() + 4 * n,
+                       0 /* its group counters were cleared together with the early launch's */);
     const bool fused_bin = cleanup2_can_bin(dv.desc_tiles_per_image);
     const size_t nt = (size_t)dv.desc_tiles_per_image * (size_t)n;
     launch_cleanup2(s, n, dpl, fused_bin ? 1 : 0, c->d_tile.as<int>(), c->d_tile.as<int>() + nt, c->d_pool.as<FinalKp>(), kPoolCap,
@@ -884,7 +885,8 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
                               c->d_ochunk.as<int>(), c->d_cands.as<Candidate>(), kListCap, c->d_order.as<OrientIn>(),
                               c->d_ocnt.as<int>());
         launch_orientation(c->stream2, dpl, dv, c->d_cands.as<Candidate>(), c->d_order.as<OrientIn>(), c->d_ocnt.as<int>(),
-                           kListCap, c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 2 * n, c->d_ocnt.as<int>() + 4 * n);
+                           kListCap, c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 2 * n, c->d_ocnt.as<int>() + 4 * n,
+                           2 /* also the late launch's counters, which follow */);
     }
     SIFT_HIP_CHECK(hipEventRecord(c->ev_join, c->stream2));
     // cleanup, orientation assignment, cleanup (sift.cpp:37-54)
