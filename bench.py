@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "exercise the N > 1 flow where ranks have to share one GPU: results are staged through host memory)")
     ap.add_argument("--share-device", action="store_true", help="testing: every rank uses GPU 0")
+    ap.add_argument("--full-descriptors", action="store_true", help="N > 1: send all 128 floats per keypoint instead of the 112 "
+                    "that carry information (bin 7 of every cell is structurally +0.0f)")
     ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE", help="library option (sift_hip_set_option), e.g. fused_edge=0")
     ap.add_argument("--lanes", type=int, default=1,
                     help="contexts (streams + host threads) per GPU, each taking an equal share of the batch, so one\n"
@@ -119,7 +121,7 @@ def main():
     frame_bytes = W * H * 4
     pool = ThreadPool(lanes) if lanes > 1 else None
 
-    from sift_amd.gather import gather_finish, gather_start
+    from sift_amd.gather import gather_finish, gather_start, pack_descriptors
 
     def run_lane(i):
         ctxs[i].calculate_batch_device(d_frames.data_ptr() + first[i] * frame_bytes, share[i], W, H, params)
@@ -151,9 +153,13 @@ def main():
                     L.sift_hip_result_copy(c._h, C.c_void_p(kp.data_ptr() + off * 20), C.c_void_p(desc.data_ptr() + off * 512))
                 off += t
             counts = torch.from_numpy(np.concatenate([c.counts() for c in ctxs])).to(comm_dev)
+            fpk = 128
+            if not args.full_descriptors:   # wire format: 112 floats per keypoint (lossless, see pack_descriptors)
+                desc = pack_descriptors(desc[:need * 128])
+                fpk = 112
             if comm_dev.type == "cpu":     # test backend: stage through host memory
-                kp, desc = kp[:need * 20].cpu(), desc[:need * 128].cpu()
-            in_flight.append((gather_start(kp, desc, counts, dst=0), (kp, desc)))
+                kp, desc = kp[:need * 20].cpu(), desc[:need * fpk].cpu()
+            in_flight.append((gather_start(kp, desc, counts, dst=0, floats_per_kp=fpk), (kp, desc)))
         return total
 
     def drain():
@@ -210,7 +216,8 @@ def main():
                                    f"4 octaves x 3 DoGs, subpixel off (BASELINE config 4 per-GPU share)",
                        "frames_per_gpu": nf, "frames_total": nf * world, "lanes_per_gpu": lanes, "keypoints_per_step": kps // max(args.steps, 1),
                        "frames_per_s": nf * world * args.steps / dt,
-                       "gather": "RCCL p2p of keypoint records + descriptors to rank 0, started per step and overlapped with the next step" if world > 1 else "none (1 GPU)"},
+                       "gather": ("RCCL p2p of keypoint records + descriptors to rank 0, started per step and overlapped with the next step; "
+                                  + ("128 floats per descriptor" if args.full_descriptors else "descriptors on the wire as 112 of 128 floats (bin 7 of each cell is structurally +0.0f; lossless)")) if world > 1 else "none (1 GPU)"},
             "roofline": {"kernel": "blur_stream_kernel / blur_fused_kernel (separable Gaussian + DoG; every launch of the pyramid)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),

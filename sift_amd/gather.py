@@ -48,6 +48,19 @@ def gather_keypoints(kp_bytes: torch.Tensor, desc: torch.Tensor, counts: torch.T
     return None
 
 
+def pack_descriptors(desc: torch.Tensor) -> torch.Tensor:
+    """128 -> 112 floats per keypoint for the wire: bin 7 of each of the 16 cells is never written by the
+    reference (`% 7`, algorithms.cpp:135-150) and normalises to +0.0f, so it carries no information.
+    Lossless: `unpack_descriptors(pack_descriptors(d))` is bit-identical to `d`."""
+    return desc.view(-1, 16, 8)[:, :, :7].contiguous().view(-1)
+
+
+def unpack_descriptors(packed: torch.Tensor) -> torch.Tensor:
+    out = torch.zeros(packed.numel() // 112, 16, 8, dtype=packed.dtype, device=packed.device)
+    out[:, :, :7] = packed.view(-1, 16, 7)
+    return out.view(-1)
+
+
 class GatherHandle:
     """One gather in flight: the point-to-point works plus what `finish` needs to assemble the result."""
 
@@ -55,7 +68,7 @@ class GatherHandle:
         self.works, self.parts, self.sizes, self.allc, self.keep = works, parts, sizes, allc, keep
 
 
-def gather_start(kp_bytes: torch.Tensor, desc: torch.Tensor, counts: torch.Tensor, dst: int = 0) -> GatherHandle:
+def gather_start(kp_bytes: torch.Tensor, desc: torch.Tensor, counts: torch.Tensor, dst: int = 0, floats_per_kp: int = 128) -> GatherHandle:
     """Non-blocking form of `gather_keypoints`: the (tiny) count exchange is done here, the record and
     descriptor transfers are only STARTED, so they overlap whatever the caller does next (the next
     batch's kernels run on the library's own streams).  The caller must not touch `kp_bytes` / `desc`
@@ -78,23 +91,23 @@ def gather_start(kp_bytes: torch.Tensor, desc: torch.Tensor, counts: torch.Tenso
         # straight into its slice, the local part is copied there
         total_all = sum(sz[1] for sz in sizes)
         kp_all = torch.empty(total_all * 20, dtype=torch.uint8, device=dev)
-        desc_all = torch.empty(total_all * 128, dtype=torch.float32, device=dev)
+        desc_all = torch.empty(total_all * floats_per_kp, dtype=torch.float32, device=dev)
         ops, off = [], 0
         for r in range(world):
             t = sizes[r][1]
             if r == rank:
                 kp_all[off * 20:(off + t) * 20].copy_(kp_bytes[:t * 20])
-                desc_all[off * 128:(off + t) * 128].copy_(desc[:t * 128])
+                desc_all[off * floats_per_kp:(off + t) * floats_per_kp].copy_(desc[:t * floats_per_kp])
             elif t:
                 ops += [dist.P2POp(dist.irecv, kp_all[off * 20:(off + t) * 20], r),
-                        dist.P2POp(dist.irecv, desc_all[off * 128:(off + t) * 128], r)]
+                        dist.P2POp(dist.irecv, desc_all[off * floats_per_kp:(off + t) * floats_per_kp], r)]
             off += t
         if ops:
             works = dist.batch_isend_irecv(ops)
         parts = (kp_all, desc_all)
         keep = (kp_bytes, desc)
     else:
-        keep = (kp_bytes[:total * 20].contiguous(), desc[:total * 128].contiguous())
+        keep = (kp_bytes[:total * 20].contiguous(), desc[:total * floats_per_kp].contiguous())
         if total:
             works = dist.batch_isend_irecv([dist.P2POp(dist.isend, keep[0], dst), dist.P2POp(dist.isend, keep[1], dst)])
     return GatherHandle(works, parts, sizes, allc, keep)

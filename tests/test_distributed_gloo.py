@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from sift_amd.gather import gather_finish, gather_keypoints, gather_start
+from sift_amd.gather import gather_finish, gather_keypoints, gather_start, pack_descriptors, unpack_descriptors
 
 
 def _fake_rank_data(rank):
@@ -33,6 +33,14 @@ def _worker(rank, world, port, q):
     hs = []
     for step in range(3):
         c2, k2, d2 = _fake_rank_data(rank + 10 * (step + 1))
+        if step == 1:   # packed wire format: 112 of 128 floats per keypoint
+            d2 = d2.reshape(-1, 16, 8).copy()
+            d2[:, :, 7] = 0.0
+            d2 = d2.reshape(-1)
+            packed = pack_descriptors(torch.from_numpy(d2))
+            assert unpack_descriptors(packed).numpy().tobytes() == d2.tobytes()
+            hs.append((step, gather_start(torch.from_numpy(k2), packed, torch.from_numpy(c2), dst=0, floats_per_kp=112)))
+            continue
         hs.append((step, gather_start(torch.from_numpy(k2), torch.from_numpy(d2), torch.from_numpy(c2), dst=0)))
         if len(hs) > 2:
             st, h = hs.pop(0)
@@ -72,4 +80,10 @@ def test_gather_two_ranks():
         a1, b1, e1 = _fake_rank_data(1 + 10 * (st + 1))
         assert (counts2 == np.concatenate([a0, a1])).all()
         assert (kp2 == np.concatenate([b0, b1])).all()
+        if st == 1:
+            full = np.concatenate([e0, e1]).reshape(-1, 16, 8).copy()
+            full[:, :, 7] = 0.0
+            desc2 = unpack_descriptors(torch.from_numpy(desc2)).numpy()
+            assert desc2.tobytes() == full.reshape(-1).tobytes()
+            continue
         assert (desc2 == np.concatenate([e0, e1])).all()
