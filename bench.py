@@ -121,7 +121,7 @@ def main():
     frame_bytes = W * H * 4
     pool = ThreadPool(lanes) if lanes > 1 else None
 
-    from sift_amd.gather import gather_finish, gather_start, pack_descriptors
+    from sift_amd.gather import device_results, gather_finish, gather_start
 
     def run_lane(i):
         ctxs[i].calculate_batch_device(d_frames.data_ptr() + first[i] * frame_bytes, share[i], W, H, params)
@@ -130,33 +130,27 @@ def main():
     # N > 1: the RCCL gather of step k (keypoint records + descriptors to rank 0, never images) is only
     # STARTED at the end of step k and overlaps the kernels of step k+1, which run on the library's own
     # streams; two result buffers alternate, and every gather is finished inside the timed region.
-    in_flight = []          # (GatherHandle, buffers kept alive)
-    bufs = [None, None]
-    step_no = [0]
+    in_flight = []          # (GatherHandle, tensors kept alive)
 
     def step():
         totals = pool.map(run_lane, range(lanes)) if pool else [run_lane(0)]   # ctypes calls release the GIL
         total = sum(totals)
         if world > 1:
-            b = step_no[0] & 1
-            step_no[0] += 1
-            while len(in_flight) > 1:      # the buffer pair about to be reused must have left
+            while len(in_flight) > 1:      # at most two gathers in flight
                 gather_finish(in_flight.pop(0)[0])
-            need = max(total, 1)
-            if bufs[b] is None or bufs[b][0].numel() < need * 20:
-                bufs[b] = (torch.empty(need * 20 * 5 // 4, dtype=torch.uint8, device=dev),
-                           torch.empty(need * 128 * 5 // 4, dtype=torch.float32, device=dev))
-            kp, desc = bufs[b]
-            off = 0
+            # The library's result arrays are read in place (no staging copy); packing / cloning them is queued on
+            # torch's stream right away and is long done when the next step's descriptor kernel rewrites them.
+            kps, descs = [], []
             for c, t in zip(ctxs, totals):   # lanes hold consecutive image ranges: concatenation keeps image order
                 if t:
-                    L.sift_hip_result_copy(c._h, C.c_void_p(kp.data_ptr() + off * 20), C.c_void_p(desc.data_ptr() + off * 512))
-                off += t
+                    k1, d1 = device_results(c, t, dev, packed=not args.full_descriptors)
+                    kps.append(k1)
+                    descs.append(d1)
+            fpk = 128 if args.full_descriptors else 112   # wire format: see pack_descriptors (lossless)
+            kp = torch.cat(kps) if len(kps) > 1 else (kps[0] if kps else torch.empty(0, dtype=torch.uint8, device=dev))
+            desc = torch.cat(descs) if len(descs) > 1 else (descs[0] if descs else torch.empty(0, dtype=torch.float32, device=dev))
+            need = total
             counts = torch.from_numpy(np.concatenate([c.counts() for c in ctxs])).to(comm_dev)
-            fpk = 128
-            if not args.full_descriptors:   # wire format: 112 floats per keypoint (lossless, see pack_descriptors)
-                desc = pack_descriptors(desc[:need * 128])
-                fpk = 112
             if comm_dev.type == "cpu":     # test backend: stage through host memory
                 kp, desc = kp[:need * 20].cpu(), desc[:need * fpk].cpu()
             in_flight.append((gather_start(kp, desc, counts, dst=0, floats_per_kp=fpk), (kp, desc)))

@@ -61,6 +61,26 @@ def unpack_descriptors(packed: torch.Tensor) -> torch.Tensor:
     return out.view(-1)
 
 
+class _DevArray:
+    """Zero-copy view of device memory owned by libsift_hip (through `__cuda_array_interface__`)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def device_results(ctx, total: int, device, packed: bool = True):
+    """The context's current results as torch tensors on `device`: (records uint8 [total*20], descriptors float32
+    [total*112] packed or [total*128]).  The library's arrays are read in place (no staging copy); the copies are
+    queued on torch's current stream, so the context may start its next batch right away (its result arrays are
+    only rewritten by the descriptor kernel at the end of that batch)."""
+    if total == 0:
+        return (torch.empty(0, dtype=torch.uint8, device=device), torch.empty(0, dtype=torch.float32, device=device))
+    kp_ptr, desc_ptr = ctx.result_device_ptrs()
+    kp = torch.as_tensor(_DevArray(kp_ptr, total * 20), device=device).clone()
+    d = torch.as_tensor(_DevArray(desc_ptr, total * 512), device=device).view(torch.float32)
+    return kp, (pack_descriptors(d) if packed else d.clone())
+
+
 class GatherHandle:
     """One gather in flight: the point-to-point works plus what `finish` needs to assemble the result."""
 

@@ -471,3 +471,49 @@ def test_config3_exception_and_nearest_runnable(ctx):
     want, wdesc = O.OracleRun(small, 3, 4, subpixel=True).points("final")
     assert kp.size == want.size and (kp["x"] == want["x"]).all() and (kp["y"] == want["y"]).all()
     assert desc.tobytes() == wdesc.tobytes()
+
+
+def _gather_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from sift_amd.gather import device_results, gather_finish, gather_start, unpack_descriptors
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    c = Context(0)
+    frames = np.stack([synth_frame(320, 240, 10 * rank + i + 1) for i in range(2)])
+    c.calculate_batch(frames, _lib.Params(3, 3, 1.6, O.K_SQRT2, 0))
+    kp, desc = device_results(c, c.total(), dev, packed=True)
+    h = gather_start(kp.cpu(), desc.cpu(), torch.from_numpy(c.counts()), dst=0, floats_per_kp=112)
+    res = gather_finish(h)
+    if rank == 0:
+        q.put((res[0].numpy().copy(), unpack_descriptors(res[1]).numpy().copy(), res[2].numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_of_device_results_two_ranks_sharing_the_gpu(ctx):
+    """The N > 1 path of bench.py end to end on real results: in-place views of the library's result arrays,
+    the 112-float wire format, the gather (gloo, because both ranks have to share this box's one GPU)."""
+    import socket
+    import torch.multiprocessing as mp
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    kp_all, desc_all, counts_all = q.get(timeout=300)
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    frames = np.stack([synth_frame(320, 240, s) for s in (1, 2, 11, 12)])   # rank 0's frames, then rank 1's
+    ctx.calculate_batch(frames, _lib.Params(3, 3, 1.6, O.K_SQRT2, 0))
+    kp, desc = ctx.results()
+    assert counts_all.tolist() == ctx.counts().tolist()
+    assert kp_all.tobytes() == kp.tobytes()
+    assert desc_all.tobytes() == desc.tobytes()
