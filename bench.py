@@ -27,6 +27,16 @@ sys.path.insert(0, ROOT)
 FRAMES_PER_GPU = 32          # BASELINE config 4: 256 frames over 8 GPUs
 W, H = 1920, 1080
 DOGS, OCTAVES, SIGMA = 3, 4, 1.6
+SUBPIXEL = 0
+# name -> (w, h, dogs, octaves, subpixel, frames per GPU, label)
+WORKLOADS = {
+    "config4": (1920, 1080, 3, 4, 0, 32, "batch of {n} synthetic 1920x1080 greyscale frames per GPU, sigma 1.6, k sqrt2, "
+                "4 octaves x 3 DoGs, subpixel off (BASELINE config 4 per-GPU share)"),
+    "config3": (1920, 1080, 3, 4, 1, 8, "batch of {n} synthetic 1920x1080 frames per GPU, subpixel=1 (3840x2160 base), 4 octaves x 3 DoGs: "
+                "BASELINE config 3 at its nearest non-throwing parameters (4 oct x 5 DoG throws in the reference, App. B-13)"),
+    "config5": (3840, 2160, 3, 5, 1, 8, "batch of {n} synthetic 3840x2160 frames per GPU, subpixel=1 (7680x4320 base), 5 octaves x 3 DoGs: "
+                "BASELINE config 5 at its nearest non-throwing parameters (6 octaves throws in the reference, App. B-14)"),
+}
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 CPU_SAMPLE_FRAMES = 8
 
@@ -63,7 +73,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU)
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--workload", default="config4", choices=sorted(WORKLOADS),
+                    help="config4 (default) is the headline workload; config3 / config5 are BASELINE.json's other GPU "
+                         "configurations at their nearest non-throwing parameters (SURVEY 8(d)), reported as labelled extra lines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "exercise the N > 1 flow where ranks have to share one GPU: results are staged through host memory)")
@@ -76,6 +89,10 @@ def main():
                          "lane's latency-bound stages overlap the other's bandwidth-bound ones")
     args = ap.parse_args()
 
+    global W, H, DOGS, OCTAVES, SUBPIXEL
+    W, H, DOGS, OCTAVES, SUBPIXEL, frames_default, label = WORKLOADS[args.workload]
+    if args.frames is None:
+        args.frames = frames_default
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,7 +133,7 @@ def main():
         name, value = kv.split("=")
         for c in ctxs:
             c.set_option(name, int(value))
-    params = _lib.Params(DOGS, OCTAVES, SIGMA, K_SQRT2, 0)
+    params = _lib.Params(DOGS, OCTAVES, SIGMA, K_SQRT2, SUBPIXEL)
     L = ctx._L
     frame_bytes = W * H * 4
     pool = ThreadPool(lanes) if lanes > 1 else None
@@ -194,7 +211,7 @@ def main():
         ms, launches, nbytes = (sum(p[i] for p in prof) for i in range(3))
         achieved = (nbytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0
         out = {
-            "metric": "keypoints/sec, 1920x1080 4oct/3DoG",
+            "metric": "keypoints/sec, 1920x1080 4oct/3DoG" if args.workload == "config4" else f"keypoints/sec, {args.workload} (not the headline metric)",
             "value": kps / dt,
             "unit": "keypoints/s",
             "n_gpus": world,
@@ -206,21 +223,20 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"batch of {nf} synthetic 1920x1080 greyscale frames per GPU, sigma 1.6, k sqrt2, "
-                                   f"4 octaves x 3 DoGs, subpixel off (BASELINE config 4 per-GPU share)",
+            "config": {"workload": label.format(n=nf),
                        "frames_per_gpu": nf, "frames_total": nf * world, "lanes_per_gpu": lanes, "keypoints_per_step": kps // max(args.steps, 1),
                        "frames_per_s": nf * world * args.steps / dt,
                        "gather": ("RCCL p2p of keypoint records + descriptors to rank 0, started per step and overlapped with the next step; "
                                   + ("128 floats per descriptor" if args.full_descriptors else "descriptors on the wire as 112 of 128 floats (bin 7 of each cell is structurally +0.0f; lossless)")) if world > 1 else "none (1 GPU)"},
             "roofline": {"kernel": "blur_stream_kernel / blur_fused_kernel (separable Gaussian + DoG; every launch of the pyramid)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if args.workload == "config4" else None,
                          "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench)",
                          "timing": "hipEventElapsedTime over start/stop events attached to each blur dispatch (hipExtLaunchKernelGGL) on the library's stream, inside the timed region",
                          "launches": launches, "avg_launch_ms": ms / launches if launches else None,
                          "algorithmic_bytes_per_launch": nbytes / launches if launches else None},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "config4":
             out["cpu_baseline"] = cpu_baseline(frames[:CPU_SAMPLE_FRAMES])
         print(json.dumps(out), flush=True)
     if world > 1:
