@@ -29,7 +29,8 @@ __device__ __forceinline__ int reflect_clamp(int p, int n) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused blur.  A persistent workgroup walks 64x64 output tiles:
+// Fused blur, tile form (radii above 14, small levels, small batches; the streaming form further down takes the
+// rest).  A persistent workgroup walks 64x64 output tiles:
 //   1. the (64+2*RA) x (64+2R) source tile (RA = R rounded up to 4, halo reflected at the image
 //      border) is fetched with row-coalesced 16-byte HBM loads into REGISTERS one tile ahead, so the
 //      HBM latency of tile t+1 hides under the arithmetic of tile t, then written to LDS;
