@@ -145,6 +145,8 @@ CASES = [
     ("synthetic 333x257 3oct odd sizes", 333, 257, 9, 3, 3, False),
     ("synthetic 320x240 subpixel", 320, 240, 5, 3, 3, True),
     ("synthetic 400x300 4 dogs", 400, 300, 6, 4, 2, False),
+    ("synthetic 322x250 widths 2 mod 4 / odd", 322, 250, 12, 3, 3, False),   # streaming blur with 2 columns per lane, unfused scan, scalar gradient
+    ("synthetic 1024x768 4x3", 1024, 768, 13, 3, 4, False),
 ]
 
 
