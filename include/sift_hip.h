@@ -71,7 +71,9 @@ void sift_hip_destroy(sift_hip_ctx* ctx);
  * 0: mask kernel + thread-per-candidate filter), "fused_reduce" (1 default: reduceToNextLevel's blur stores only the
  * pixels the decimation keeps; 0: blur into a temporary, then the resampling kernel), "gpu_cleanup" (1 default: cleanup steps as GPU kernels;
  * 0: std::sort on the host), "host_threads", "profile" (1: time every blur launch with events attached to
- * its dispatch), "desc_dbg" (diagnostics only). */
+ * its dispatch), "stream_min_waves" (process-wide; smallest launch, in waves, that takes the streaming blur instead of
+ * the LDS-tiled one; default 1024, <= 0 restores it; the parity tests set 1 to run the streaming form on small
+ * inputs), "desc_dbg" (diagnostics only). */
 int sift_hip_set_option(sift_hip_ctx* ctx, const char* name, int value);
 
 /* ---- Sift::calculate(), replaces sift.cpp:19-57 ---------------------------------------------- */

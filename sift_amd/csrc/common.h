@@ -98,6 +98,7 @@ void launch_blur(hipStream_t s, bool fused, const float* in, float* tmp, float* 
 bool launch_blur_reduce(hipStream_t s, const float* in, float* dst, int w, int h, int wd, int hd, int n, const float* d_taps,
                         int radius, const int* d_inv_x, const int* d_inv_y, float* d_dump, hipEvent_t ev_start = nullptr,
                         hipEvent_t ev_stop = nullptr);
+void set_stream_min_waves(int v);  // <= 0 restores the default
 void launch_resample(hipStream_t s, const float* src, float* dst, int ws, int hs, int wd, int hd, int n,
                      const int* d_lutx, const int* d_luty);
 void launch_dog(hipStream_t s, const float* lower, const float* higher, float* out, size_t count);

@@ -559,6 +559,8 @@ static int stream_waves() {
 
 constexpr int kMaxRadiusStream = 14;   // beyond: the 2R+1 partial sums per column no longer fit the register file
 constexpr int kMinStreamWaves = 1024;  // below one wave per SIMD the tile kernel's finer work units win
+static int g_stream_min_waves = kMinStreamWaves;  // option "stream_min_waves": tests lower it to run the streaming form on small inputs
+void set_stream_min_waves(int v) { g_stream_min_waves = v < 1 ? kMinStreamWaves : v; }
 
 template <int R, int CPL>
 static bool launch_stream_rc(hipStream_t s, const float* in, float* out, float* dog, int w, int h, int n,
@@ -580,7 +582,7 @@ static bool launch_stream_rc(hipStream_t s, const float* in, float* out, float* 
     if (chunk_h > h) return false;
     chunks = (h + chunk_h - 1) / chunk_h;
     const int total = n * strips * chunks;
-    if (total < kMinStreamWaves) return false;
+    if (total < g_stream_min_waves) return false;
     const int grid = (total + 3) / 4;
     const StreamDecimate none{nullptr, nullptr, 0, 0, nullptr};
     if (dec)

@@ -59,6 +59,22 @@ def test_convolve_with_gauss(ctx, sigma, fused):
         ctx.set_option("fused_blur", 1)
 
 
+@pytest.mark.parametrize("sigma", [0.3, 1.0, 1.6, 2.0, 2.2627418, 3.2, 4.0, 4.5254836])
+def test_convolve_with_gauss_streaming(ctx, sigma):
+    """The streaming blur (the form the bench workload runs, radius <= 14) forced onto small single frames: ragged
+    strips, one-chunk and many-chunk launches, widths that only the 2-columns-per-lane form accepts."""
+    ctx.set_option("stream_min_waves", 1)
+    try:
+        for (w, h, seed) in [(200, 150, 3), (64, 64, 5), (260, 301, 6), (1028, 97, 7), (130, 515, 8), (516, 40, 9)]:
+            img = synth_frame(w, h, seed)
+            r, _ = O.gauss_taps(sigma)
+            if min(w, h) < r + 1:
+                continue
+            assert_bits_equal(ctx.convolve_with_gauss(img, sigma), O.convolve(img, sigma), f"streaming blur s={sigma} {w}x{h}")
+    finally:
+        ctx.set_option("stream_min_waves", 0)
+
+
 def test_gauss_taps_match_oracle():
     for sigma in [0.0, 0.2, 1.0, 1.6, 2.2627418, 3.2, 4.5254836, 6.4, 9.050967, 12.8, 18.101934, 50.0]:
         r1, t1 = gauss_taps(sigma)
@@ -229,6 +245,35 @@ def test_pipeline_parity_separate_blur_and_decimation(ctx, report_dir):
         compare_run(ctx, synth_frame(1024, 512, 8), 3, 3, False, "separate blur / decimation 1024x512", report_dir, batch_of=4)
     finally:
         ctx.set_option("fused_reduce", 1)
+
+
+STREAM_CASES = [
+    ("streaming 320x250", 320, 250, 4, 3, 3, 1),
+    ("streaming 322x250 (2 columns per lane only)", 322, 250, 12, 3, 3, 1),
+    ("streaming 1024x768 4x3", 1024, 768, 13, 3, 4, 1),
+    ("streaming 640x480 x3 frames", 640, 480, 14, 3, 3, 3),
+    ("streaming 768x576 4 dogs x2 frames", 768, 576, 15, 4, 2, 2),
+]
+
+
+@pytest.mark.parametrize("case", STREAM_CASES, ids=[c[0] for c in STREAM_CASES])
+def test_pipeline_parity_streaming_blur(ctx, report_dir, case):
+    """Whole pipeline with every blur of radius <= 14 (and the decimating blur of reduceToNextLevel) forced onto the
+    streaming kernels, which otherwise only take launches of >= 1024 waves."""
+    name, w, h, seed, dogs, octaves, batch_of = case
+    ctx.set_option("stream_min_waves", 1)
+    try:
+        rep = compare_run(ctx, synth_frame(w, h, seed), dogs, octaves, False, name, report_dir, batch_of=batch_of)
+        assert rep["final"] > 0
+    finally:
+        ctx.set_option("stream_min_waves", 0)
+
+
+def test_pipeline_parity_bench_workload(ctx, report_dir):
+    """The bench's own launch shapes: 32 frames of 1920x1080, 3 DoGs x 4 octaves (BASELINE.json configs[4]); every
+    level, stage and descriptor of the first and last frame against the oracle."""
+    rep = compare_run(ctx, synth_frame(1920, 1080, 3), 3, 4, False, "bench workload 32 x 1080p", report_dir, batch_of=32)
+    assert rep["final"] > 0
 
 
 def test_batch_images_independent(ctx, report_dir):
