@@ -73,7 +73,8 @@ void sift_hip_destroy(sift_hip_ctx* ctx);
  * 0: std::sort on the host), "host_threads", "profile" (1: time every blur launch with events attached to
  * its dispatch), "stream_min_waves" (process-wide; smallest launch, in waves, that takes the streaming blur instead of
  * the LDS-tiled one; default 1024, <= 0 restores it; the parity tests set 1 to run the streaming form on small
- * inputs), "desc_dbg" (diagnostics only). */
+ * inputs), "orient_general" (0 default; 1: orientationHistogram36 reads every sample's bin even when the gradient pass
+ * found all bins of the frame to be 0, which is what the reference's radians-as-degrees maps always give), "desc_dbg" (diagnostics only). */
 int sift_hip_set_option(sift_hip_ctx* ctx, const char* name, int value);
 
 /* ---- Sift::calculate(), replaces sift.cpp:19-57 ---------------------------------------------- */

@@ -108,6 +108,7 @@ struct sift_hip_ctx {
     bool fused = true;
     bool fused_edge = true;   // extremum scan and edge filter in one LDS-tiled pass
     bool fused_reduce = true; // reduceToNextLevel: blur and decimation in one pass
+    bool orient_general = false;  // tests: orientation histogram with per-sample bins even when every bin is 0
     bool gpu_cleanup = true;
     bool profile = false;
     bool binned = false;   // this batch's keypoints are already binned to descriptor tiles
@@ -589,7 +590,7 @@ void mid_host(sift_hip_ctx* c) {
     launch_build_orient_in(s, c->d_cands.as<Candidate>(), dv.cand_capacity, c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
                            kListCap, n, c->d_order.as<OrientIn>());
     launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_order.as<OrientIn>(), c->d_list_cnt.as<int>(), kListCap,
-                       c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 3 * n, c->d_ocnt.as<int>() + 4 * n);
+                       c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 3 * n, (c->orient_general ? nullptr : c->d_ocnt.as<int>() + 4 * n));
     c->h_orient.ensure((size_t)n * kListCap * sizeof(OrientOut));
     for (int i = 0; i < n; ++i)
         if (cnt1[(size_t)i])
@@ -713,7 +714,7 @@ bool mid_gpu(sift_hip_ctx* c) {
     SIFT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_join, 0));
     // late launch: only the images whose survivor list was truncated (counts are 0 for the others)
     launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_order.as<OrientIn>(), d_late, kListCap,
-                       c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 3 * n, c->d_ocnt.as<int>() + 4 * n,
+                       c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 3 * n, (c->orient_general ? nullptr : c->d_ocnt.as<int>() + 4 * n),
                        0 /* its group counters were cleared together with the early launch's */);
     const bool fused_bin = cleanup2_can_bin(dv.desc_tiles_per_image);
     const size_t nt = (size_t)dv.desc_tiles_per_image * (size_t)n;
@@ -859,7 +860,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     for (int lvl : P.grad_levels) {
         const int o = lvl / (P.D + 1);
         launch_gradient(gs, dv.gauss[lvl], dv.mag[lvl], dv.ori[lvl], dv.prod[lvl], dv.obin[lvl], dv.w[o], dv.h[o], n,
-                        c->d_ocnt.as<int>() + 4 * n);
+                        (c->orient_general ? nullptr : c->d_ocnt.as<int>() + 4 * n));
         launch_w16(gs, dv, lvl, c->d_taps16.as<float>(), P.radius16);
     }
     // extrema + edge responses (sift.cpp:33-34)
@@ -885,7 +886,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
                               c->d_ochunk.as<int>(), c->d_cands.as<Candidate>(), kListCap, c->d_order.as<OrientIn>(),
                               c->d_ocnt.as<int>());
         launch_orientation(c->stream2, dpl, dv, c->d_cands.as<Candidate>(), c->d_order.as<OrientIn>(), c->d_ocnt.as<int>(),
-                           kListCap, c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 2 * n, c->d_ocnt.as<int>() + 4 * n,
+                           kListCap, c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 2 * n, (c->orient_general ? nullptr : c->d_ocnt.as<int>() + 4 * n),
                            2 /* also the late launch's counters, which follow */);
     }
     SIFT_HIP_CHECK(hipEventRecord(c->ev_join, c->stream2));
@@ -999,6 +1000,7 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     if (!std::strcmp(name, "desc_dbg")) { c->desc_dbg = value; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "gpu_cleanup")) { c->gpu_cleanup = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "profile")) { c->profile = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "orient_general")) { c->orient_general = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "stream_min_waves")) { set_stream_min_waves(value); return SIFT_HIP_OK; }
     if (!std::strcmp(name, "host_threads")) { c->host_threads = value; return SIFT_HIP_OK; }
     return SIFT_HIP_EINVAL;

@@ -269,6 +269,16 @@ def test_pipeline_parity_streaming_blur(ctx, report_dir, case):
         ctx.set_option("stream_min_waves", 0)
 
 
+def test_pipeline_parity_general_orientation_bins(ctx, report_dir):
+    """The orientation histogram's per-sample-bin form (never selected by real frames: App. B-9 puts every sample
+    in bin 0, which the gradient pass detects) gives the same results as the all-zero-bins fast path."""
+    ctx.set_option("orient_general", 1)
+    try:
+        compare_run(ctx, synth_frame(640, 480, 21), 3, 3, False, "general orientation bins 640x480", report_dir, batch_of=2)
+    finally:
+        ctx.set_option("orient_general", 0)
+
+
 def test_pipeline_parity_bench_workload(ctx, report_dir):
     """The bench's own launch shapes: 32 frames of 1920x1080, 3 DoGs x 4 octaves (BASELINE.json configs[4]); every
     level, stage and descriptor of the first and last frame against the oracle."""
