@@ -84,9 +84,11 @@ def main():
     ap.add_argument("--full-descriptors", action="store_true", help="N > 1: send all 128 floats per keypoint instead of the 112 "
                     "that carry information (bin 7 of every cell is structurally +0.0f)")
     ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE", help="library option (sift_hip_set_option), e.g. fused_edge=0")
-    ap.add_argument("--lanes", type=int, default=1,
-                    help="contexts (streams + host threads) per GPU, each taking an equal share of the batch, so one\n"
-                         "lane's latency-bound stages overlap the other's bandwidth-bound ones")
+    ap.add_argument("--pipeline-depth", type=int, default=1,
+                    help="batches in flight per GPU (sift_amd.pipeline.BatchPipeline: one context per slot).  1 (default): every\n"
+                         "step has the GPU to itself, which is what the per-launch roofline figure needs.  2: step k+1's pyramid\n"
+                         "fills the stretches of step k that cannot fill the chip (cleanup steps, small octaves) - more\n"
+                         "keypoints/s, but the blur launches then share the chip and their event times no longer measure the kernel")
     args = ap.parse_args()
 
     global W, H, DOGS, OCTAVES, SUBPIXEL
@@ -124,58 +126,53 @@ def main():
     d_frames = torch.from_numpy(frames).to(dev)
     torch.cuda.synchronize()
 
-    lanes = max(1, min(args.lanes, nf))
-    share = [nf // lanes + (1 if i < nf % lanes else 0) for i in range(lanes)]
-    first = [sum(share[:i]) for i in range(lanes)]
-    ctxs = [Context(local_rank) for _ in range(lanes)]
+    from sift_amd.pipeline import BatchPipeline
+
+    depth = max(1, args.pipeline_depth)
+    pipe = BatchPipeline(local_rank, depth, dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in args.set))
+    ctxs = pipe.contexts
     ctx = ctxs[0]
-    for kv in args.set:
-        name, value = kv.split("=")
-        for c in ctxs:
-            c.set_option(name, int(value))
     params = _lib.Params(DOGS, OCTAVES, SIGMA, K_SQRT2, SUBPIXEL)
     L = ctx._L
-    frame_bytes = W * H * 4
-    pool = ThreadPool(lanes) if lanes > 1 else None
 
     from sift_amd.gather import device_results, gather_finish, gather_start
-
-    def run_lane(i):
-        ctxs[i].calculate_batch_device(d_frames.data_ptr() + first[i] * frame_bytes, share[i], W, H, params)
-        return ctxs[i].total()
 
     # N > 1: the RCCL gather of step k (keypoint records + descriptors to rank 0, never images) is only
     # STARTED at the end of step k and overlaps the kernels of step k+1, which run on the library's own
     # streams; two result buffers alternate, and every gather is finished inside the timed region.
     in_flight = []          # (GatherHandle, tensors kept alive)
+    tickets = []            # submitted steps whose results have not been collected yet (at most depth - 1 between steps)
 
-    def step():
-        totals = pool.map(run_lane, range(lanes)) if pool else [run_lane(0)]   # ctypes calls release the GIL
-        total = sum(totals)
+    def collect(ticket):
+        """Finish one step: wait for its batch, hand its keypoint lists to the gather (N > 1), free its slot."""
+        c = ticket.result()
+        total = c.total()
         if world > 1:
             while len(in_flight) > 1:      # at most two gathers in flight
                 gather_finish(in_flight.pop(0)[0])
             # The library's result arrays are read in place (no staging copy); packing / cloning them is queued on
-            # torch's stream right away and is long done when the next step's descriptor kernel rewrites them.
-            kps, descs = [], []
-            for c, t in zip(ctxs, totals):   # lanes hold consecutive image ranges: concatenation keeps image order
-                if t:
-                    k1, d1 = device_results(c, t, dev, packed=not args.full_descriptors)
-                    kps.append(k1)
-                    descs.append(d1)
+            # torch's stream right away and is long done when the slot's next descriptor kernel rewrites them.
             fpk = 128 if args.full_descriptors else 112   # wire format: see pack_descriptors (lossless)
-            kp = torch.cat(kps) if len(kps) > 1 else (kps[0] if kps else torch.empty(0, dtype=torch.uint8, device=dev))
-            desc = torch.cat(descs) if len(descs) > 1 else (descs[0] if descs else torch.empty(0, dtype=torch.float32, device=dev))
-            need = total
-            counts = torch.from_numpy(np.concatenate([c.counts() for c in ctxs])).to(comm_dev)
+            kp, desc = device_results(c, total, dev, packed=not args.full_descriptors)
+            counts = torch.from_numpy(c.counts()).to(comm_dev)
             if comm_dev.type == "cpu":     # test backend: stage through host memory
-                kp, desc = kp[:need * 20].cpu(), desc[:need * fpk].cpu()
+                kp, desc = kp[:total * 20].cpu(), desc[:total * fpk].cpu()
             in_flight.append((gather_start(kp, desc, counts, dst=0, floats_per_kp=fpk), (kp, desc)))
+        ticket.release()
         return total
 
+    def step():
+        """Submit one pass over the batch; collect the oldest step once `depth` are in flight."""
+        tickets.append(pipe.submit_device(d_frames.data_ptr(), nf, W, H, params))
+        return collect(tickets.pop(0)) if len(tickets) >= depth else 0
+
     def drain():
+        total = 0
+        while tickets:
+            total += collect(tickets.pop(0))
         while in_flight:
             gather_finish(in_flight.pop(0)[0])
+        return total
 
     for _ in range(args.warmup):
         step()
@@ -190,7 +187,7 @@ def main():
     kps = 0
     for _ in range(args.steps):
         kps += step()
-    drain()
+    kps += drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -224,13 +221,13 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": label.format(n=nf),
-                       "frames_per_gpu": nf, "frames_total": nf * world, "lanes_per_gpu": lanes, "keypoints_per_step": kps // max(args.steps, 1),
+                       "frames_per_gpu": nf, "frames_total": nf * world, "pipeline_depth": depth, "keypoints_per_step": kps // max(args.steps, 1),
                        "frames_per_s": nf * world * args.steps / dt,
                        "gather": ("RCCL p2p of keypoint records + descriptors to rank 0, started per step and overlapped with the next step; "
                                   + ("128 floats per descriptor" if args.full_descriptors else "descriptors on the wire as 112 of 128 floats (bin 7 of each cell is structurally +0.0f; lossless)")) if world > 1 else "none (1 GPU)"},
             "roofline": {"kernel": "blur_stream_kernel / blur_fused_kernel (separable Gaussian + DoG; every launch of the pyramid)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if args.workload == "config4" else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if (args.workload == "config4" and nf == FRAMES_PER_GPU and depth == 1) else None,
                          "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench)",
                          "timing": "hipEventElapsedTime over start/stop events attached to each blur dispatch (hipExtLaunchKernelGGL) on the library's stream, inside the timed region",
                          "launches": launches, "avg_launch_ms": ms / launches if launches else None,
@@ -239,6 +236,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload == "config4":
             out["cpu_baseline"] = cpu_baseline(frames[:CPU_SAMPLE_FRAMES])
         print(json.dumps(out), flush=True)
+    pipe.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -1,0 +1,86 @@
+"""Batches in flight on one GPU: a ring of contexts, each with its own streams and host thread.
+
+One `Sift::calculate()` over a batch (sift.cpp:19-57) has two stretches that cannot fill the chip however the batch
+is laid out: the cleanup steps (one workgroup per image, a chain of partition rounds) and the tails of the small
+octaves.  They are filled by the NEXT batch's bandwidth-bound kernels when two batches are in flight, which a
+single context cannot do (its result arrays and level buffers belong to one batch at a time).  This module is the
+host-side scheduler for that: `depth` contexts, batch k goes to context k % depth, every context is driven by one
+worker thread of its own (the C ABI blocks until a batch is done and releases the GIL meanwhile).
+
+Results are those of the plain context, batch for batch — the contexts share nothing but the GPU.
+"""
+from __future__ import annotations
+
+from concurrent.futures import Future, ThreadPoolExecutor
+
+from .sift import Context
+
+
+class Ticket:
+    """One submitted batch.  `result()` waits for it and returns its context, which holds the results
+    (`total()`, `counts()`, `results()`, `result_device_ptrs()`) until `release()` hands the slot back."""
+
+    def __init__(self, pipe: "BatchPipeline", slot: int, future: Future):
+        self._pipe, self.slot, self._future, self._released = pipe, slot, future, False
+
+    def result(self) -> Context:
+        self._future.result()          # re-raises what calculate raised (PreconditionViolation, ...)
+        return self._pipe.contexts[self.slot]
+
+    def release(self) -> None:
+        if not self._released:
+            self._released = True
+            try:
+                self._future.result()
+            except Exception:
+                pass                   # the caller has seen it through result(), or does not care
+            self._pipe._busy[self.slot] = None
+
+
+class BatchPipeline:
+    def __init__(self, device: int = 0, depth: int = 2, options: dict | None = None):
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        self.depth = depth
+        self.contexts = [Context(device) for _ in range(depth)]
+        for c in self.contexts:
+            for name, value in (options or {}).items():
+                c.set_option(name, int(value))
+        # one single-thread executor per context: batches of a context run in submission order
+        self._workers = [ThreadPoolExecutor(1, thread_name_prefix=f"sift-pipe{i}") for i in range(depth)]
+        self._busy: list[Ticket | None] = [None] * depth
+        self._next = 0
+
+    def _submit(self, method: str, *args) -> Ticket:
+        slot = self._next
+        if self._busy[slot] is not None:
+            raise RuntimeError(f"pipeline slot {slot} still holds an unreleased batch: release() it before submitting batch number depth + 1")
+        self._next = (slot + 1) % self.depth
+        t = Ticket(self, slot, self._workers[slot].submit(getattr(self.contexts[slot], method), *args))
+        self._busy[slot] = t
+        return t
+
+    def submit_device(self, dev_ptr: int, n: int, w: int, h: int, params) -> Ticket:
+        """Queue one batch of n device-resident w x h float frames.  Returns at once.  The slot's previous
+        ticket must have been released (its results are overwritten by this batch)."""
+        return self._submit("calculate_batch_device", dev_ptr, n, w, h, params)
+
+    def submit(self, imgs, params) -> Ticket:
+        """Same for a host array [n, h, w] float32 (uploaded by the slot's worker thread)."""
+        return self._submit("calculate_batch", imgs, params)
+
+    def close(self) -> None:
+        for t in self._busy:
+            if t is not None:
+                t.release()
+        for w in self._workers:
+            w.shutdown(wait=True)
+        for c in self.contexts:
+            c.close()
+        self.contexts = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -286,6 +286,13 @@ def test_pipeline_parity_bench_workload(ctx, report_dir):
     assert rep["final"] > 0
 
 
+def test_pipeline_parity_256_frame_batch(ctx, report_dir):
+    """BASELINE.json configs[3]'s whole 256-frame batch on one GPU: every level buffer is larger than 2^31 bytes, so
+    any 32-bit byte offset would show in the last frame."""
+    rep = compare_run(ctx, synth_frame(1920, 1080, 5), 3, 4, False, "256 x 1080p on one GPU", report_dir, batch_of=256)
+    assert rep["final"] > 0
+
+
 def test_batch_images_independent(ctx, report_dir):
     """Every frame of a batch gets the single-frame result (frames differ)."""
     params = _lib.Params(3, 3, 1.6, O.K_SQRT2, 0)
@@ -574,3 +581,34 @@ def test_gather_of_device_results_two_ranks_sharing_the_gpu(ctx):
     assert counts_all.tolist() == ctx.counts().tolist()
     assert kp_all.tobytes() == kp.tobytes()
     assert desc_all.tobytes() == desc.tobytes()
+
+
+def test_batch_pipeline_matches_single_context(ctx):
+    """Batches in flight on a ring of contexts (sift_amd/pipeline.py) give, batch for batch, the single context's results."""
+    from sift_amd.pipeline import BatchPipeline
+    params = _lib.Params(3, 3, 1.6, O.K_SQRT2, 0)
+    batches = [np.stack([synth_frame(480, 360, 100 + 4 * b + i) for i in range(4)]) for b in range(5)]
+    got = []
+    with BatchPipeline(0, depth=2) as pipe:
+        tickets = []
+        for b in batches:
+            tickets.append(pipe.submit(b, params))
+            if len(tickets) == 2:
+                t = tickets.pop(0)
+                c = t.result()
+                got.append((c.counts().copy(),) + tuple(a.copy() for a in c.results()))
+                t.release()
+        with pytest.raises(RuntimeError):   # both slots taken: the third submit must be refused, not overwrite results
+            pipe.submit(batches[0], params)
+            pipe.submit(batches[0], params)
+        for t in tickets:
+            c = t.result()
+            got.append((c.counts().copy(),) + tuple(a.copy() for a in c.results()))
+            t.release()
+    assert len(got) == len(batches)
+    for b, (counts, kp, desc) in zip(batches, got):
+        ctx.calculate_batch(b, params)
+        wkp, wdesc = ctx.results()
+        assert counts.tolist() == ctx.counts().tolist() and counts.sum() > 0
+        assert kp.tobytes() == wkp.tobytes()
+        assert desc.tobytes() == wdesc.tobytes()
