@@ -145,10 +145,15 @@ __global__ __launch_bounds__(256, (R <= 8 ? 3 : (R <= 24 ? 2 : 1))) void blur_fu
                     const int ly = e / ROW4, c4 = e - ly * ROW4;
                     const size_t row = (size_t)reflect_clamp(y0 - R + ly, h) * (size_t)w;
                     const int gx = x0 - RA + 4 * c4;
-                    pre[i].x = src[row + (size_t)reflect_clamp(gx + 0, w)];
-                    pre[i].y = src[row + (size_t)reflect_clamp(gx + 1, w)];
-                    pre[i].z = src[row + (size_t)reflect_clamp(gx + 2, w)];
-                    pre[i].w = src[row + (size_t)reflect_clamp(gx + 3, w)];
+                    if (vec_ok && gx >= 0 && gx + 3 < w) {
+                        // only the row is reflected: the four columns lie inside the image (gx is a multiple of 4)
+                        pre[i] = *reinterpret_cast<const float4*>(src + row + (size_t)gx);
+                    } else {
+                        pre[i].x = src[row + (size_t)reflect_clamp(gx + 0, w)];
+                        pre[i].y = src[row + (size_t)reflect_clamp(gx + 1, w)];
+                        pre[i].z = src[row + (size_t)reflect_clamp(gx + 2, w)];
+                        pre[i].w = src[row + (size_t)reflect_clamp(gx + 3, w)];
+                    }
                 }
             }
         }
@@ -171,11 +176,14 @@ __global__ __launch_bounds__(256, (R <= 8 ? 3 : (R <= 24 ? 2 : 1))) void blur_fu
         // conflict-free for.
         constexpr int RG = 16 / gcd_ce(ROW4, 16);
         constexpr int NBLK = (SH + 4 * RG - 1) / (4 * RG);      // blocks of 4*RG rows
+        // the bottom tile row of an image needs only the source rows its (fewer) output rows reach
+        const int tile_y0 = ((t % tiles) / tiles_x) * TH;
+        const int rows_used = min(SH, h - tile_y0 + 2 * R);
 #pragma unroll 1
         for (int wi = tid >> 6; wi < NBLK * RG; wi += 4) {
             const int ly = (wi / RG) * (4 * RG) + (wi % RG) + RG * ((tid >> 4) & 3);
             const int q = tid & 15;
-            if (ly >= SH) continue;
+            if (ly >= rows_used) continue;
             constexpr int NV = PAD + 4 + 2 * R;
             constexpr int NV4 = (NV + 3) / 4;
             float v[NV4 * 4];
@@ -209,6 +217,7 @@ __global__ __launch_bounds__(256, (R <= 8 ? 3 : (R <= 24 ? 2 : 1))) void blur_fu
         float4 acc[PY];
 #pragma unroll
         for (int i = 0; i < PY; ++i) acc[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (tile_y0 + rg * PY < h)   // rows below the image: nothing to compute or store
 #pragma unroll
         for (int k = 0; k < PY + 2 * R; ++k) {
             const float4 m = s_mid4[(rg * PY + k) * (TW / 4) + cg];
