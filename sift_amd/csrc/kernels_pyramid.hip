@@ -84,7 +84,7 @@ __device__ __forceinline__ void lds_read_window(const float4* p, float4 (&f)[N])
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int R, bool DOG, int TH = 64>
-__global__ __launch_bounds__(256, (R <= 8 ? 3 : (R <= 24 ? 2 : 1))) void blur_fused_kernel(const float* __restrict__ in,
+__global__ __launch_bounds__(256, (R <= 8 ? 3 : ((R <= 24 || (TH <= 48 && R <= 28)) ? 2 : 1))) void blur_fused_kernel(const float* __restrict__ in,
                                                          float* __restrict__ out,
                                                          float* __restrict__ dog, int w, int h,
                                                          int tiles_x, int tiles_y, int total_tiles,
@@ -537,6 +537,8 @@ __global__ void dog_kernel(const float* __restrict__ lower, const float* __restr
 // from the dispatch packet itself (no extra barrier packets between back-to-back launches).
 static thread_local hipEvent_t t_ev_start = nullptr, t_ev_stop = nullptr;
 
+constexpr long long kSmallTileLaunch = 4096;   // 64x64 tiles: up to 16 per CU
+
 template <int R, int TH>
 static void launch_fused_rt(hipStream_t s, const float* in, float* out, float* dog, int w, int h, int n,
                             const float* d_taps) {
@@ -558,6 +560,11 @@ static void launch_fused_rt(hipStream_t s, const float* in, float* out, float* d
 template <int R>
 static void launch_fused_r(hipStream_t s, const float* in, float* out, float* dog, int w, int h, int n,
                            const float* d_taps) {
+    // Small launches (a few tiles per CU) are bound by the latency of one tile, not by throughput: 48-row tiles
+    // shorten it (and let two workgroups share a CU's LDS at the largest radii) at the price of more halo rows
+    // per output row, which only matters once the launch fills the chip several times over.
+    const long long tiles64 = (long long)((w + 63) / 64) * ((h + 63) / 64) * n;
+    if (tiles64 <= kSmallTileLaunch) return launch_fused_rt<R, 48>(s, in, out, dog, w, h, n, d_taps);
     launch_fused_rt<R, 64>(s, in, out, dog, w, h, n, d_taps);
 }
 
