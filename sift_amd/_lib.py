@@ -40,6 +40,24 @@ assert KEYPOINT_DTYPE.itemsize == 20
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so.7 (and HSA runtime) next to
+    libtorch; libsift_hip.so asks for the same SONAME and would otherwise pull in /opt/rocm's copy when it is
+    loaded before torch, after which torch finds no GPU ("No HIP GPUs are available": the second HSA runtime
+    cannot open the device).  Loading torch's copy first (without importing torch) makes the order irrelevant:
+    the dynamic linker then resolves our dependency to the runtime that is already there."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Load libsift_hip.so and declare prototypes.  Raises if the library is not built."""
     global _lib
@@ -48,6 +66,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the HIP path)")
+    _preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
     u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")

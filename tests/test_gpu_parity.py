@@ -612,3 +612,29 @@ def test_batch_pipeline_matches_single_context(ctx):
         assert counts.tolist() == ctx.counts().tolist() and counts.sum() > 0
         assert kp.tobytes() == wkp.tobytes()
         assert desc.tobytes() == wdesc.tobytes()
+
+
+def test_library_before_torch_in_one_process(tmp_path):
+    """libsift_hip loaded and used BEFORE torch initialises its GPU runtime: both must see the GPU (one HIP
+    runtime per process, sift_amd/_lib.py:_preload_hip_runtime)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from sift_amd import _lib\n"
+        "from sift_amd.sift import Context\n"
+        "from sift_amd.synthetic import synth_frame\n"
+        "c = Context(0)\n"
+        "c.calculate_batch(synth_frame(200, 160, 2)[None], _lib.Params(3, 2, 1.6, 2 ** 0.5, 0))\n"
+        "n = c.total()\n"
+        "import torch\n"
+        "assert torch.cuda.is_available(), 'torch lost the GPU'\n"
+        "t = torch.arange(8, device='cuda:0').sum().item()\n"
+        "c.calculate_batch(synth_frame(200, 160, 2)[None], _lib.Params(3, 2, 1.6, 2 ** 0.5, 0))\n"
+        "assert c.total() == n and n > 0 and t == 28\n"
+        "print('ok', n)\n"
+    )
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

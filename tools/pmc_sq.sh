@@ -19,5 +19,8 @@ for d in ("gpurun_out/pmc_sq", "gpurun_out/pmc_sq2"):
     for name in ("descriptor_kernel", "cleanup1_kernel", "orientation_kernel", "edge_filter_kernel", "gradient_kernel", "blur_stream_kernel<5, true, 4>", "blur_stream_kernel<10, true, 2>", "blur_stream_kernel<7, true, 2>", "extrema_mask_kernel"):
         if name in acc:
             print(name, {k: f"{v:.3g}" for k, v in sorted(acc[name].items())})
+    for name in sorted(acc):
+        if name.startswith("blur_fused") or name.startswith("extrema_edge") or name.startswith("gradient4"):
+            print(name, {k: f"{v:.3g}" for k, v in sorted(acc[name].items())})
 PY
 find gpurun_out/pmc_sq gpurun_out/pmc_sq2 -name "*.csv" -size +4M -delete
