@@ -596,31 +596,63 @@ __device__ void introsort_bits(CleanupShared& sh, int n, const LdsBitKeys K, uin
             __syncthreads();
             continue;
         }
+        // Filtered pivot on a long range, word-parallel.  (Kept pivots and short ranges were handled above.)
         const int q0 = F >> 6, q1 = (L - 1) >> 6;
-        const int chunk = (q1 - q0 + 1 + kCT - 1) / kCT;   // <= kMaxChunk
-        // 1. snapshot + count.  Thread order = hit order: words ascend from the left for p == 1, descend from the right for p == 0
+        const int nwords = q1 - q0 + 1;
+        const int chunk = (nwords + kCT - 1) / kCT;   // <= kMaxChunk
+        // 1. snapshot + count.  Thread order = hit order (words ascend from the left), which is what the workgroup
+        // scan needs: every thread owns `chunk` consecutive words.
         unsigned long long H[kMaxChunk];
         int cnt = 0;
 #pragma unroll
         for (int j = 0; j < kMaxChunk; ++j) {
             H[j] = 0ull;
             if (j < chunk) {
-                const int q = p == 1 ? q0 + tid * chunk + j : q1 - tid * chunk - j;
-                if (q >= q0 && q <= q1) {
+                const int q = q0 + tid * chunk + j;
+                if (q <= q1) {
                     const int base = q << 6;
                     const int lo = F > base ? F - base : 0;              // first position of the range inside the word
                     const int hi = L - base < 64 ? L - base : 64;        // one past the last
                     unsigned long long m = hi == 64 ? ~0ull : ((1ull << hi) - 1ull);
                     m &= ~0ull << lo;
-                    const unsigned long long bits = load_word64(K.w, q);
-                    H[j] = (p == 1 ? bits : ~bits) & m;
+                    H[j] = load_word64(K.w, q) & m;
                     cnt += __popcll(H[j]);
                 }
             }
         }
         int total;
-        int t = block_exclusive_scan(sh, cnt, total);
+        int t0 = block_exclusive_scan(sh, cnt, total);
+        // Only the words left of the point where the two scans meet have swaps to apply, i.e. the first half of the
+        // threads in the layout above.  The words are therefore re-dealt round-robin for the second phase; their
+        // snapshot and the rank of their first hit travel through the scratch array (3 words each, hit order).
+        uint32_t* __restrict__ W = P;
+#pragma unroll
+        for (int j = 0; j < kMaxChunk; ++j) {
+            if (j < chunk) {
+                const int wi = tid * chunk + j;
+                if (wi < nwords) {
+                    W[3 * wi + 0] = (uint32_t)H[j];
+                    W[3 * wi + 1] = (uint32_t)(H[j] >> 32);
+                    W[3 * wi + 2] = (uint32_t)t0;
+                }
+                t0 += __popcll(H[j]);
+            }
+        }
+        __syncthreads();
         if (round < 120) stamp(16 + 4 * round + 2);
+        int Tw[kMaxChunk];
+#pragma unroll
+        for (int j = 0; j < kMaxChunk; ++j) {
+            H[j] = 0ull;
+            Tw[j] = 0;
+            if (j < chunk) {
+                const int wi = j * kCT + tid;
+                if (wi < nwords) {
+                    H[j] = (unsigned long long)W[3 * wi + 0] | ((unsigned long long)W[3 * wi + 1] << 32);
+                    Tw[j] = (int)W[3 * wi + 2];
+                }
+            }
+        }
         // pending payload moves of this thread: (destination, source) pairs parked in LDS, so that all their loads
         // are in flight together and all stores follow (the moves of a round touch disjoint positions)
         uint2* myq = reinterpret_cast<uint2*>(K.w + kBitCap / 32) + tid * kMoveSlots;
@@ -641,92 +673,48 @@ __device__ void introsort_bits(CleanupShared& sh, int n, const LdsBitKeys K, uin
 #pragma unroll
         for (int j = 0; j < kMaxChunk; ++j) {
             const unsigned long long h = H[j];
-            const int q = p == 1 ? q0 + tid * chunk + j : q1 - tid * chunk - j;
-            const int base = q << 6;
+            const int t = Tw[j];
+            const int base = (q0 + j * kCT + tid) << 6;
             const int k = __popcll(h);
             int kp = 0;                  // participating hits of this word (a prefix in hit order)
-            unsigned long long M = 0ull; // p == 1: hits whose partner is kept (they receive it)
-            unsigned long long field = 0ull;
-            int bref = 0;                // p == 1: partner of hit 0 (bhi); p == 0: partner of hit 0 (blo)
+            unsigned long long M = 0ull; // hits whose partner is kept (they receive it)
+            int bref = 0;                // partner of hit 0
             if (j < chunk && h != 0ull) {
-                if (p == 1) {
-                    // hit i (ascending position): partner L-1-(t+i); takes part iff pos + t + i < L - 1
-                    const int pos_last = base + 63 - __clzll((long long)h);
-                    if (pos_last + t + k - 1 < L - 1) {
-                        kp = k;
-                    } else {
-                        unsigned long long r = h;
-                        int fpos = 0;
-                        while (r) {
-                            fpos = base + __ffsll((long long)r) - 1;
-                            if (fpos + t + kp >= L - 1) break;
-                            ++kp;
-                            r &= r - 1ull;
-                        }
-                        if (t + kp < sh.T) {   // (rank, position) of the first failing hit: both minimal together
-                            atomicMin(&sh.T, t + kp);
-                            atomicMin(&sh.flag, fpos);
-                        }
-                    }
-                    if (kp > 0) {
-                        bref = L - 1 - t;
-                        field = load_field(K.w, bref - kp + 1, kp);   // bit (kp-1-i) <-> partner of hit i
-                        const unsigned long long rev = __brevll(field) >> (64 - kp);
-                        M = ~rev & (kp == 64 ? ~0ull : ((1ull << kp) - 1ull));
-                    }
+                // hit i (ascending position): partner L-1-(t+i); takes part iff pos + t + i < L - 1
+                const int pos_last = base + 63 - __clzll((long long)h);
+                if (pos_last + t + k - 1 < L - 1) {
+                    kp = k;
                 } else {
-                    // hit i (descending position): partner F+(t+i); takes part iff F + t + i < pos
-                    const int pos_min = base + __ffsll((long long)h) - 1;
-                    if (F + t + k - 1 < pos_min) {
-                        kp = k;
-                    } else {
-                        unsigned long long r = h;
-                        while (r) {
-                            const int pos = base + 63 - __clzll((long long)r);
-                            if (!(F + t + kp < pos)) break;
-                            ++kp;
-                            r &= ~(1ull << (pos - base));
-                        }
-                        if (t + kp < sh.T) atomicMin(&sh.T, t + kp);
+                    unsigned long long r = h;
+                    int fpos = 0;
+                    while (r) {
+                        fpos = base + __ffsll((long long)r) - 1;
+                        if (fpos + t + kp >= L - 1) break;
+                        ++kp;
+                        r &= r - 1ull;
                     }
-                    if (kp > 0) {
-                        bref = F + t;
-                        field = load_field(K.w, bref, kp);   // bit i <-> partner of hit i
+                    if (t + kp < sh.T) {   // (rank, position) of the first failing hit: both minimal together
+                        atomicMin(&sh.T, t + kp);
+                        atomicMin(&sh.flag, fpos);
                     }
                 }
-                t += k;
+                if (kp > 0) {
+                    bref = L - 1 - t;
+                    const unsigned long long field = load_field(K.w, bref - kp + 1, kp);   // bit (kp-1-i) <-> partner of hit i
+                    const unsigned long long rev = __brevll(field) >> (64 - kp);
+                    M = ~rev & (kp == 64 ? ~0ull : ((1ull << kp) - 1ull));
+                }
             }
-            if (p == 1) {
-                while (__any(M != 0ull)) {
-                    if (M) {
-                        const int i = __ffsll((long long)M) - 1;
-                        M &= M - 1ull;
-                        const int a = base + select64(h, i), b = bref - i;
-                        key_clear(K, a);   // the kept element will sit at the hit's position
-                        key_set(K, b);
-                        myq[nmv++] = make_uint2((unsigned)a, (unsigned)b);   // I[a] = I[b]
-                    }
-                    if (__any(nmv == kMoveSlots)) flush_moves();
+            while (__any(M != 0ull)) {
+                if (M) {
+                    const int i = __ffsll((long long)M) - 1;
+                    M &= M - 1ull;
+                    const int a = base + select64(h, i), b = bref - i;
+                    key_clear(K, a);   // the kept element will sit at the hit's position
+                    key_set(K, b);
+                    myq[nmv++] = make_uint2((unsigned)a, (unsigned)b);   // I[a] = I[b]
                 }
-            } else {
-                unsigned long long r = h;
-                int i = 0;
-                while (__any(i < kp)) {
-                    if (i < kp) {
-                        const int pos = 63 - __clzll((long long)r);
-                        r &= ~(1ull << pos);
-                        const int a = base + pos, b = bref + i;
-                        myq[nmv++] = make_uint2((unsigned)b, (unsigned)a);       // I[b] = I[a]
-                        if ((field >> i) & 1ull) {   // partner filtered: the kept element moves there
-                            key_clear(K, b);
-                            key_set(K, a);
-                        } else {
-                            myq[nmv++] = make_uint2((unsigned)a, (unsigned)b);   // two kept elements trade places
-                        }
-                        ++i;
-                    }
-                    if (__any(nmv + 2 > kMoveSlots)) flush_moves();   // the two halves of a trade stay in one batch
-                }
+                if (__any(nmv == kMoveSlots)) flush_moves();
             }
         }
         flush_moves();
@@ -737,20 +725,9 @@ __device__ void introsort_bits(CleanupShared& sh, int n, const LdsBitKeys K, uin
         const int T = (sh.T == 0x7fffffff) ? total : sh.T;
         __syncthreads();
         if (tid == 0) {
-            if (p == 1) {
-                const int fail = sh.flag;
-                const int cut = (fail != 0x7fffffff && fail == L - 1 - T) ? L - 1 - T : L - T;
-                sh.l = cut;  // right part [cut, l) is all filtered: dead
-            } else {
-                const int cut = F + T;
-                if (sh.npure < kMaxPure) {
-                    sh.pure[sh.npure] = PureRange{f, cut - f, sh.d};
-                    sh.npure += 1;
-                } else {
-                    sh.fallback = 1;
-                }
-                sh.f = cut;  // left part [f, cut) is all kept
-            }
+            const int fail = sh.flag;
+            const int cut = (fail != 0x7fffffff && fail == L - 1 - T) ? L - 1 - T : L - T;
+            sh.l = cut;  // right part [cut, l) is all filtered: dead
         }
         __syncthreads();
     }
