@@ -8,8 +8,11 @@ One process per GPU (launched by torch.distributed.run for N > 1).  A "step" is 
 whole hot path (pyramid, DoG, extrema, edge filter, orientation, descriptors) over one batch of
 FRAMES_PER_GPU device-resident frames per GPU; for N > 1 every step's keypoint lists (records +
 descriptors, never images) are gathered on rank 0 over RCCL, the transfer of step k overlapping the
-kernels of step k+1, all inside the timed region.  Weak scaling: per-GPU work is fixed.  Rank 0
-prints ONE JSON line.
+kernels of step k+1, all inside the timed region.  Two steps are in flight per GPU (--pipeline-depth 2: two
+contexts joined by a phase gate, sift_amd/csrc/phase_gate.h): step k+1's extrema / gradient pass runs under step
+k's cleanup, which cannot fill the chip; pyramids never share the chip, so the roofline figure measured on the blur
+launches is that of the kernel alone.  Every step is complete inside the timed region.  Weak scaling: per-GPU work
+is fixed.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
@@ -23,6 +26,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Two batches in flight per GPU use 2 contexts x 2 streams (+ torch's): with the HIP runtime's default of 4 hardware
+# queues, streams of different contexts share a queue and pick up each other's ordering.  Must be set before the
+# runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 FRAMES_PER_GPU = 32          # BASELINE config 4: 256 frames over 8 GPUs
 W, H = 1920, 1080
@@ -71,7 +78,7 @@ def pmc_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=None)
     ap.add_argument("--workload", default="config4", choices=sorted(WORKLOADS),
@@ -84,11 +91,13 @@ def main():
     ap.add_argument("--full-descriptors", action="store_true", help="N > 1: send all 128 floats per keypoint instead of the 112 "
                     "that carry information (bin 7 of every cell is structurally +0.0f)")
     ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE", help="library option (sift_hip_set_option), e.g. fused_edge=0")
-    ap.add_argument("--pipeline-depth", type=int, default=1,
-                    help="batches in flight per GPU (sift_amd.pipeline.BatchPipeline: one context per slot).  1 (default): every\n"
-                         "step has the GPU to itself, which is what the per-launch roofline figure needs.  2: step k+1's pyramid\n"
-                         "fills the stretches of step k that cannot fill the chip (cleanup steps, small octaves) - more\n"
-                         "keypoints/s, but the blur launches then share the chip and their event times no longer measure the kernel")
+    ap.add_argument("--pipeline-depth", type=int, default=2,
+                    help="batches in flight per GPU (sift_amd.pipeline.BatchPipeline: one context and host thread per slot).\n"
+                         "2 (default): consecutive steps overlap under the phase gate - the next step's extrema / gradient pass\n"
+                         "fills the chip while this step's cleanup (one workgroup per image) cannot, and no pyramid shares\n"
+                         "the chip, so the per-launch roofline figure is that of the kernel alone.  1: one step at a time")
+    ap.add_argument("--pipeline-gate", type=int, default=1, choices=[0, 1],
+                    help="pipeline depth > 1: 1 (default) joins the contexts with a phase gate (no pyramid shares the chip); 0 leaves the interleaving to the GPU's queues")
     args = ap.parse_args()
 
     global W, H, DOGS, OCTAVES, SUBPIXEL
@@ -129,7 +138,7 @@ def main():
     from sift_amd.pipeline import BatchPipeline
 
     depth = max(1, args.pipeline_depth)
-    pipe = BatchPipeline(local_rank, depth, dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in args.set))
+    pipe = BatchPipeline(local_rank, depth, dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in args.set), gated=bool(args.pipeline_gate))
     ctxs = pipe.contexts
     ctx = ctxs[0]
     params = _lib.Params(DOGS, OCTAVES, SIGMA, K_SQRT2, SUBPIXEL)
@@ -221,13 +230,13 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": label.format(n=nf),
-                       "frames_per_gpu": nf, "frames_total": nf * world, "pipeline_depth": depth, "keypoints_per_step": kps // max(args.steps, 1),
+                       "frames_per_gpu": nf, "frames_total": nf * world, "pipeline_depth": depth, "pipeline_gate": bool(args.pipeline_gate) and depth > 1, "keypoints_per_step": kps // max(args.steps, 1),
                        "frames_per_s": nf * world * args.steps / dt,
                        "gather": ("RCCL p2p of keypoint records + descriptors to rank 0, started per step and overlapped with the next step; "
                                   + ("128 floats per descriptor" if args.full_descriptors else "descriptors on the wire as 112 of 128 floats (bin 7 of each cell is structurally +0.0f; lossless)")) if world > 1 else "none (1 GPU)"},
             "roofline": {"kernel": "blur_stream_kernel / blur_fused_kernel (separable Gaussian + DoG; every launch of the pyramid)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if (args.workload == "config4" and nf == FRAMES_PER_GPU and depth == 1) else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if (args.workload == "config4" and nf == FRAMES_PER_GPU and (depth == 1 or args.pipeline_gate)) else None,
                          "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench)",
                          "timing": "hipEventElapsedTime over start/stop events attached to each blur dispatch (hipExtLaunchKernelGGL) on the library's stream, inside the timed region",
                          "launches": launches, "avg_launch_ms": ms / launches if launches else None,

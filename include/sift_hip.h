@@ -77,6 +77,18 @@ void sift_hip_destroy(sift_hip_ctx* ctx);
  * found all bins of the frame to be 0, which is what the reference's radians-as-degrees maps always give), "desc_dbg" (diagnostics only). */
 int sift_hip_set_option(sift_hip_ctx* ctx, const char* name, int value);
 
+/* ---- several batches in flight on one GPU --------------------------------------------------------
+ * The reference runs one calculate() at a time (main.cpp:56-57).  A host that has the next batch ready can give
+ * every batch in flight a context of its own (one host thread each) and join the contexts with a gate: the gate
+ * orders the phases of consecutive batches on the device so that the next batch's extrema / gradient pass fills the
+ * chip while this batch's cleanup steps (one workgroup per image, sift.cpp:37-54) cannot, and no pyramid shares
+ * the chip with anything (sift_amd/csrc/phase_gate.h).  Results are unchanged.  Batches take their place in the
+ * order in which their calculate calls begin. */
+typedef struct sift_hip_gate sift_hip_gate;
+int sift_hip_gate_create(int device, sift_hip_gate** out);
+void sift_hip_gate_destroy(sift_hip_gate* gate);              /* after the contexts using it are detached or destroyed */
+int sift_hip_set_gate(sift_hip_ctx* ctx, sift_hip_gate* gate);   /* NULL detaches; not while a batch is running */
+
 /* ---- Sift::calculate(), replaces sift.cpp:19-57 ---------------------------------------------- */
 /* n frames of w x h from HOST memory.  Results stay in the context until the next calculate. */
 int sift_hip_calculate_batch(sift_hip_ctx* ctx, const float* host_imgs, int n, int w, int h,

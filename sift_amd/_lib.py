@@ -23,7 +23,7 @@ SYMBOLS = [
     "sift_hip_stage_count", "sift_hip_stage_copy", "sift_hip_gauss_taps", "sift_hip_convolve_with_gauss",
     "sift_hip_reduce_to_next_level", "sift_hip_increase_to_next_level", "sift_hip_dog", "sift_hip_gradient",
     "sift_hip_edge_responses", "sift_hip_vertex_parabola", "sift_hip_sort_by_filter", "sift_hip_cleanup_survivors", "sift_hip_profile_get",
-    "sift_hip_profile_reset", "sift_hip_version",
+    "sift_hip_profile_reset", "sift_hip_version", "sift_hip_gate_create", "sift_hip_gate_destroy", "sift_hip_set_gate",
 ]
 
 
@@ -77,6 +77,10 @@ def load():
     L.sift_hip_create.argtypes = [ci, C.POINTER(vp), cs, ci]
     L.sift_hip_destroy.argtypes = [vp]
     L.sift_hip_destroy.restype = None
+    L.sift_hip_gate_create.argtypes = [ci, C.POINTER(vp)]
+    L.sift_hip_gate_destroy.argtypes = [vp]
+    L.sift_hip_gate_destroy.restype = None
+    L.sift_hip_set_gate.argtypes = [vp, vp]
     L.sift_hip_set_option.argtypes = [vp, cs, ci]
     L.sift_hip_calculate_batch.argtypes = [vp, fp, ci, ci, ci, C.POINTER(Params), cs, ci]
     L.sift_hip_calculate_batch_device.argtypes = [vp, vp, ci, ci, ci, C.POINTER(Params), cs, ci]

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "common.h"
+#include "phase_gate.h"
 #include "host_glue.h"
 
 using namespace sift_hip;
@@ -104,7 +105,9 @@ struct sift_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;          // side stream: work that can overlap the 1-block-per-image cleanup
-    hipEvent_t ev_fork0 = nullptr, ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork0 = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_grad = nullptr;
+    sift_hip::PhaseGate* gate = nullptr;   // shared with the other contexts of a BatchPipeline, or null
+    long long gate_ticket = -1;             // this batch's ticket while it runs
     bool fused = true;
     bool fused_edge = true;   // extremum scan and edge filter in one LDS-tiled pass
     bool fused_reduce = true; // reduceToNextLevel: blur and decimation in one pass
@@ -732,6 +735,7 @@ bool mid_gpu(sift_hip_ctx* c) {
     launch_out_base(s, c->d_final_cnt.as<int>(), n, c->d_out_base.as<long long>());
     ensure_outputs(c, std::max<long long>(c->out_cap, (long long)n * 32768));
     launch_descriptor_stage(c);
+    if (c->gate) c->gate->mark(c->gate_ticket, sift_hip::PhaseGate::kD, s);
     c->described = true;
     c->h_status.ensure((size_t)n * 5 * sizeof(int));
     const int* st = c->h_status.as<int>();   // pinned: the copy is a real asynchronous DMA
@@ -837,7 +841,18 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     c->binned = false;
     c->described = false;
 
+    // Batches of several contexts in flight on this GPU: the gate orders their phases (phase_gate.h).  Whatever
+    // this batch owes its partners is released when the scope ends, however it ends.
+    struct GateScope {
+        sift_hip_ctx* c;
+        ~GateScope() {
+            if (c->gate && c->gate_ticket >= 0) c->gate->finish(c->gate_ticket, c->stream);
+            c->gate_ticket = -1;
+        }
+    } gate_scope{c};
+    c->gate_ticket = c->gate ? c->gate->begin_batch(s) : -1;
     run_pyramid(c, d_in);
+    if (c->gate) c->gate->mark(c->gate_ticket, sift_hip::PhaseGate::kP, s);
     c->have_pyramid = true;
     if (P.fail_status) {
         SIFT_HIP_CHECK(hipStreamSynchronize(s));
@@ -863,6 +878,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
                         (c->orient_general ? nullptr : c->d_ocnt.as<int>() + 4 * n));
         launch_w16(gs, dv, lvl, c->d_taps16.as<float>(), P.radius16);
     }
+    if (c->gate) SIFT_HIP_CHECK(hipEventRecord(c->ev_grad, gs));
     // extrema + edge responses (sift.cpp:33-34)
     if (c->fused_edge && extrema_edge_supported(dv)) {
         // one pass over the DoG levels: extremum test and edge-response filter from LDS tiles
@@ -879,6 +895,13 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     // The orientation stage is order-independent: it follows the gradient maps on the side stream, over
     // the kept candidates in scan order, while the one-workgroup-per-image cleanup kernel emulates the
     // reference's sort on the main stream (sift.cpp:37-47).
+    if (c->gate) {
+        // end of the chip-filling stretch E (main stream and the gradient maps of the side stream), start of the
+        // cleanup chain C
+        if (gs != s) SIFT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_grad, 0));
+        c->gate->mark(c->gate_ticket, sift_hip::PhaseGate::kE, s);
+        c->gate->before_cleanup(c->gate_ticket, s);
+    }
     SIFT_HIP_CHECK(hipEventRecord(c->ev_fork, s));
     SIFT_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     if (c->gpu_cleanup) {
@@ -965,6 +988,7 @@ int sift_hip_create(int device, sift_hip_ctx** out, char* err, int errlen) {
         SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork0, hipEventDisableTiming));
         SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_grad, hipEventDisableTiming));
         SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming));
         *out = c;
         return SIFT_HIP_OK;
@@ -983,12 +1007,39 @@ void sift_hip_destroy(sift_hip_ctx* c) {
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->ev_fork0);
+    (void)hipEventDestroy(c->ev_grad);
     (void)hipEventDestroy(c->ev_fork);
     (void)hipEventDestroy(c->ev_join);
     (void)hipEventDestroy(c->ev_sync);
     (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+struct sift_hip_gate {
+    int device;
+    sift_hip::PhaseGate gate;
+};
+
+int sift_hip_gate_create(int device, sift_hip_gate** out) {
+    if (!out) return SIFT_HIP_EINVAL;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return SIFT_HIP_EINVAL;
+    if (hipSetDevice(device) != hipSuccess) return SIFT_HIP_EHIP;
+    *out = new sift_hip_gate{device, {}};
+    return SIFT_HIP_OK;
+}
+
+void sift_hip_gate_destroy(sift_hip_gate* g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    delete g;
+}
+
+int sift_hip_set_gate(sift_hip_ctx* c, sift_hip_gate* g) {
+    if (!c || (g && g->device != c->device)) return SIFT_HIP_EINVAL;
+    c->gate = g ? &g->gate : nullptr;
+    return SIFT_HIP_OK;
 }
 
 int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {

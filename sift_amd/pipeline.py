@@ -7,13 +7,19 @@ single context cannot do (its result arrays and level buffers belong to one batc
 host-side scheduler for that: `depth` contexts, batch k goes to context k % depth, every context is driven by one
 worker thread of its own (the C ABI blocks until a batch is done and releases the GIL meanwhile).
 
+With `gated=True` (default) the contexts are joined by a phase gate (sift_amd/csrc/phase_gate.h): the device then
+runs  ... | pyramid(k+1) | cleanup(k) || extrema(k+1), descriptors(k) | pyramid(k+2) | ...  — the next batch's
+extrema / gradient pass fills the chip under this batch's cleanup, and no pyramid ever shares the chip, so the
+bandwidth-bound blur launches run exactly as they do alone.  `gated=False` leaves the interleaving to the GPU's
+queues (a little more throughput at depth 3, at the price of pyramids that share the chip).
+
 Results are those of the plain context, batch for batch — the contexts share nothing but the GPU.
 """
 from __future__ import annotations
 
 from concurrent.futures import Future, ThreadPoolExecutor
 
-from .sift import Context
+from .sift import Context, Gate
 
 
 class Ticket:
@@ -38,12 +44,15 @@ class Ticket:
 
 
 class BatchPipeline:
-    def __init__(self, device: int = 0, depth: int = 2, options: dict | None = None):
+    def __init__(self, device: int = 0, depth: int = 2, options: dict | None = None, gated: bool = True):
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self.depth = depth
         self.contexts = [Context(device) for _ in range(depth)]
+        self.gate = Gate(device) if (gated and depth > 1) else None
         for c in self.contexts:
+            if self.gate is not None:
+                c.set_gate(self.gate)
             for name, value in (options or {}).items():
                 c.set_option(name, int(value))
         # one single-thread executor per context: batches of a context run in submission order
@@ -78,6 +87,9 @@ class BatchPipeline:
         for c in self.contexts:
             c.close()
         self.contexts = []
+        if self.gate is not None:
+            self.gate.close()
+            self.gate = None
 
     def __enter__(self):
         return self

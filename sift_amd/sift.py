@@ -49,6 +49,28 @@ def _raise(rc, err):
     raise HipError(msg or f"sift_hip error {rc}")
 
 
+class Gate:
+    """sift_hip_gate: orders the phases of batches that run on different contexts of one GPU (include/sift_hip.h)."""
+
+    def __init__(self, device: int = 0):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        if self._L.sift_hip_gate_create(device, C.byref(self._h)):
+            self._h = C.c_void_p()
+            raise HipError(f"sift_hip_gate_create({device}) failed")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.sift_hip_gate_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
     """One sift_hip_ctx (one GPU, one stream)."""
 
@@ -72,6 +94,10 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def set_gate(self, gate: "Gate | None"):
+        if self._L.sift_hip_set_gate(self._h, gate._h if gate is not None else None):
+            raise ValueError("gate and context are on different devices")
 
     def set_option(self, name: str, value: int):
         if self._L.sift_hip_set_option(self._h, name.encode(), int(value)):
