@@ -13,7 +13,7 @@ timeout 900 python bench.py --steps ${STEPS:-3} --warmup 1 > gpurun_out/bench.lo
 timeout 600 python bench.py --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline --pipeline-depth 1 > gpurun_out/bench_depth1.log 2>/dev/null; echo "bench depth 1 exit $?"; grep -o "ms_per_step\": [0-9.]*" gpurun_out/bench_depth1.log
 if [ "${PROF:-1}" = "1" ]; then
   rm -rf gpurun_out/prof
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof_bench.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/prof_bench.log 2>&1
   echo "rocprof exit $?"
   find gpurun_out/prof -name "*kernel_stats*" | head -3
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f" | cut -c1-200
