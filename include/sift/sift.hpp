@@ -58,6 +58,13 @@ public:
         return collect();
     }
 
+    // Extension (not in the reference): Sift objects on one GPU, one host thread each, can be joined by a gate
+    // (sift_hip_gate_create) so that their calculate() calls overlap on the device while no pyramid shares the chip
+    // (include/sift_hip.h).  nullptr detaches.
+    void join(sift_hip_gate* gate) {
+        if (sift_hip_set_gate(_ctx, gate) != SIFT_HIP_OK) throw std::invalid_argument("sift::Sift::join: gate of another device");
+    }
+
 #ifdef SIFT_WITH_VIGRA
     std::vector<InterestPoint> calculate(vigra::MultiArray<2, f32_t>& img) {
         const int w = (int)img.width(), h = (int)img.height();

@@ -638,3 +638,47 @@ def test_library_before_torch_in_one_process(tmp_path):
     )
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("gated", [True, False], ids=["gated", "ungated"])
+def test_batch_pipeline_survives_a_failing_batch(ctx, gated):
+    """A batch that ends in the reference's exception (pyramid level smaller than the blur kernel, App. B-13; or the
+    dead 16x16 blur, B-14, which only shows after the cleanup) releases what it owes the phase gate: its neighbours in
+    the pipeline complete with the single context's results, the failing tickets raise."""
+    from sift_amd.pipeline import BatchPipeline
+    good = _lib.Params(3, 3, 1.6, O.K_SQRT2, 0)
+    plan_fail = _lib.Params(3, 4, 1.6, O.K_SQRT2, 0)     # 160x120, 4 octaves: fails when the plan is built
+    late_fail = _lib.Params(4, 3, 1.6, O.K_SQRT2, 0)     # 512x384, 4 DoGs: fails in the orientation stage, if at all
+    frames = [np.stack([synth_frame(160, 120, 200 + 2 * b + i) for i in range(2)]) for b in range(6)]
+    big = synth_frame(512, 384, 3)[None]
+    jobs = [(frames[0], good), (frames[1], plan_fail), (frames[2], good), (big, late_fail), (frames[4], good), (frames[5], good)]
+    out = []
+    with BatchPipeline(0, depth=2, gated=gated) as pipe:
+        tickets = []
+
+        def collect(t):
+            try:
+                c = t.result()
+                out.append((c.counts().copy(),) + tuple(a.copy() for a in c.results()))
+            except PreconditionViolation as e:
+                out.append(e)
+            t.release()
+
+        for imgs, prm in jobs:
+            tickets.append(pipe.submit(imgs, prm))
+            if len(tickets) == 2:
+                collect(tickets.pop(0))
+        for t in tickets:
+            collect(t)
+    assert len(out) == len(jobs)
+    for (imgs, prm), got in zip(jobs, out):
+        try:
+            ctx.calculate_batch(imgs, prm)
+            want = (ctx.counts().copy(),) + tuple(a.copy() for a in ctx.results())
+        except PreconditionViolation as e:
+            assert isinstance(got, PreconditionViolation) and str(got) == str(e)
+            continue
+        assert not isinstance(got, Exception), got
+        assert got[0].tolist() == want[0].tolist()
+        assert got[1].tobytes() == want[1].tobytes() and got[2].tobytes() == want[2].tobytes()
+    assert isinstance(out[1], PreconditionViolation) and not isinstance(out[0], Exception) and not isinstance(out[5], Exception)
