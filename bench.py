@@ -88,8 +88,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "exercise the N > 1 flow where ranks have to share one GPU: results are staged through host memory)")
     ap.add_argument("--share-device", action="store_true", help="testing: every rank uses GPU 0")
-    ap.add_argument("--full-descriptors", action="store_true", help="N > 1: send all 128 floats per keypoint instead of the 112 "
-                    "that carry information (bin 7 of every cell is structurally +0.0f)")
+    ap.add_argument("--wire", default="sparse", choices=["sparse", "packed", "full"],
+                    help="N > 1, descriptors on the wire (all lossless): sparse = presence bits + the floats that are set (about a third), "
+                         "packed = the 112 floats that can carry information, full = 128 floats")
     ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE", help="library option (sift_hip_set_option), e.g. fused_edge=0")
     ap.add_argument("--pipeline-depth", type=int, default=2,
                     help="batches in flight per GPU (sift_amd.pipeline.BatchPipeline: one context and host thread per slot).\n"
@@ -161,12 +162,13 @@ def main():
                 gather_finish(in_flight.pop(0)[0])
             # The library's result arrays are read in place (no staging copy); packing / cloning them is queued on
             # torch's stream right away and is long done when the slot's next descriptor kernel rewrites them.
-            fpk = 128 if args.full_descriptors else 112   # wire format: see pack_descriptors (lossless)
-            kp, desc = device_results(c, total, dev, packed=not args.full_descriptors)
+            # wire format (lossless, sift_amd/gather.py): bytes per record, floats per descriptor (None: as many as are set)
+            bpk, fpk = {"sparse": (34, None), "packed": (20, 112), "full": (20, 128)}[args.wire]
+            kp, desc = device_results(c, total, dev, wire=args.wire)
             counts = torch.from_numpy(c.counts()).to(comm_dev)
             if comm_dev.type == "cpu":     # test backend: stage through host memory
-                kp, desc = kp[:total * 20].cpu(), desc[:total * fpk].cpu()
-            in_flight.append((gather_start(kp, desc, counts, dst=0, floats_per_kp=fpk), (kp, desc)))
+                kp, desc = kp.cpu(), desc.cpu()
+            in_flight.append((gather_start(kp, desc, counts, dst=0, floats_per_kp=fpk, bytes_per_kp=bpk), (kp, desc)))
         ticket.release()
         return total
 
@@ -233,7 +235,8 @@ def main():
                        "frames_per_gpu": nf, "frames_total": nf * world, "pipeline_depth": depth, "pipeline_gate": bool(args.pipeline_gate) and depth > 1, "keypoints_per_step": kps // max(args.steps, 1),
                        "frames_per_s": nf * world * args.steps / dt,
                        "gather": ("RCCL p2p of keypoint records + descriptors to rank 0, started per step and overlapped with the next step; "
-                                  + ("128 floats per descriptor" if args.full_descriptors else "descriptors on the wire as 112 of 128 floats (bin 7 of each cell is structurally +0.0f; lossless)")) if world > 1 else "none (1 GPU)"},
+                                  + {"full": "128 floats per descriptor", "packed": "descriptors on the wire as 112 of 128 floats (bin 7 of each cell is structurally +0.0f; lossless)",
+                                     "sparse": "descriptors on the wire as 112 presence bits + the floats that are not +0.0f (about a third; lossless)"}[args.wire]) if world > 1 else "none (1 GPU)"},
             "roofline": {"kernel": "blur_stream_kernel / blur_fused_kernel (separable Gaussian + DoG; every launch of the pyramid)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if (args.workload == "config4" and nf == FRAMES_PER_GPU and (depth == 1 or args.pipeline_gate)) else None,

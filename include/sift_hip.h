@@ -107,6 +107,13 @@ int64_t sift_hip_result_total(sift_hip_ctx* ctx);
 int sift_hip_result_copy(sift_hip_ctx* ctx, sift_hip_keypoint* keypoints, float* descriptors);
 /* Device-resident packed results (valid until the next calculate) for a GPU-side gather. */
 int sift_hip_result_device(sift_hip_ctx* ctx, const void** dev_keypoints, const void** dev_descriptors);
+/* Wire format of a multi-GPU gather (lossless): per keypoint a 34-byte record = the 20-byte sift_hip_keypoint + 112
+ * presence bits (bit cell*7+bin <-> descriptor float cell*8+bin; bin 7 is never set, algorithms.cpp:135-150), and
+ * only the descriptor floats whose bit pattern is not +0.0f, in order (about a third of them on real frames).
+ * _size runs the counting pass and returns the number of floats; _pack then writes total*34 bytes and that many
+ * floats to DEVICE memory of the caller.  Both return when the device is done. */
+int sift_hip_result_sparse_size(sift_hip_ctx* ctx, int64_t* n_values);
+int sift_hip_result_sparse_pack(sift_hip_ctx* ctx, void* dev_records, void* dev_values);
 /* The image calculate() leaves in the caller's MultiArray: when params.subpixel it is the
  * sigma=1 blurred, 2x nearest-upsampled frame (sift.cpp:20-21); dims of it, then the pixels. */
 int sift_hip_image_dims(sift_hip_ctx* ctx, int* w, int* h);

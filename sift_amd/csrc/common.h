@@ -154,4 +154,10 @@ void launch_descriptors(hipStream_t s, const DevPlan* d_plan, const DevPlan& pla
                         const long long* d_out_base, sift_hip_keypoint* d_kp_out, float* d_desc_out, long long out_cap,
                         int dbg = 0);
 
+// wire format of the keypoint gather (kernels_wire.hip)
+size_t wire_blocks(long long total);
+void launch_wire_count(hipStream_t s, const float* d_desc, long long total, int* d_block_sums, long long* d_block_off);
+void launch_wire_emit(hipStream_t s, const sift_hip_keypoint* d_kp, const float* d_desc, long long total,
+                      const long long* d_block_off, uint8_t* d_records, float* d_values);
+
 }  // namespace sift_hip

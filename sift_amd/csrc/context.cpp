@@ -125,6 +125,9 @@ struct sift_hip_ctx {
     DevBuf d_wk, d_wi, d_wi2, d_wp, d_status, d_tile, d_pool;
     DevBuf d_order;
     DevBuf d_list, d_list_cnt, d_orient, d_peaks, d_final, d_final_cnt, d_out_base, d_kp, d_desc;
+    DevBuf d_wire_sums, d_wire_off;   // sparse wire format: floats per block of keypoints, their exclusive scan
+    HostBuf h_wire;
+    long long wire_values = -1, wire_for_total = -1;
     DevBuf d_lrank, d_ochunk, d_ocnt, d_recs;   // list position -> orientation result; kept counts per 1024 candidates; early/late counts
     HostBuf h_flags, h_orient, h_peaks, h_status;
     hipEvent_t ev_sync = nullptr;
@@ -840,6 +843,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     c->stages_on_host = false;
     c->binned = false;
     c->described = false;
+    c->wire_values = c->wire_for_total = -1;
 
     // Batches of several contexts in flight on this GPU: the gate orders their phases (phase_gate.h).  Whatever
     // this batch owes its partners is released when the scope ends, however it ends.
@@ -1001,9 +1005,9 @@ void sift_hip_destroy(sift_hip_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->arena, &c->d_plan, &c->d_taps, &c->d_luts, &c->d_taps16, &c->d_input, &c->d_base, &c->d_tmp, &c->d_tmp2,
                       &c->d_wk, &c->d_wi, &c->d_wi2, &c->d_wp, &c->d_status, &c->d_tile, &c->d_pool, &c->d_order, &c->d_masks, &c->d_fmasks, &c->d_counts, &c->d_totals, &c->d_cands, &c->d_flags, &c->d_list, &c->d_list_cnt, &c->d_orient,
-                      &c->d_peaks, &c->d_final, &c->d_final_cnt, &c->d_out_base, &c->d_kp, &c->d_desc, &c->d_lrank, &c->d_ochunk, &c->d_ocnt, &c->d_recs})
+                      &c->d_peaks, &c->d_final, &c->d_final_cnt, &c->d_out_base, &c->d_kp, &c->d_desc, &c->d_lrank, &c->d_ochunk, &c->d_ocnt, &c->d_recs, &c->d_wire_sums, &c->d_wire_off})
         b->release();
-    for (HostBuf* b : {&c->h_flags, &c->h_orient, &c->h_peaks, &c->h_status}) b->release();
+    for (HostBuf* b : {&c->h_flags, &c->h_orient, &c->h_peaks, &c->h_status, &c->h_wire}) b->release();
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->ev_fork0);
@@ -1112,6 +1116,38 @@ int sift_hip_result_device(sift_hip_ctx* c, const void** kp, const void** desc) 
     if (kp) *kp = c->d_kp.p;
     if (desc) *desc = c->d_desc.p;
     return SIFT_HIP_OK;
+}
+
+int sift_hip_result_sparse_size(sift_hip_ctx* c, int64_t* n_values) {
+    if (!c || !c->have_result || !n_values) return SIFT_HIP_EINVAL;
+    char err[256];
+    return guarded(err, sizeof(err), [&]() {
+        SIFT_HIP_CHECK(hipSetDevice(c->device));
+        const size_t nb = wire_blocks(c->total);
+        c->d_wire_sums.ensure((nb + 1) * sizeof(int));
+        c->d_wire_off.ensure((nb + 1) * sizeof(long long));
+        c->h_wire.ensure(sizeof(long long));
+        launch_wire_count(c->stream, c->d_desc.as<float>(), c->total, c->d_wire_sums.as<int>(), c->d_wire_off.as<long long>());
+        SIFT_HIP_CHECK(hipMemcpyAsync(c->h_wire.p, c->d_wire_off.as<long long>() + nb, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+        wait_stream(c, c->stream);
+        c->wire_values = *c->h_wire.as<long long>();
+        c->wire_for_total = c->total;
+        *n_values = c->wire_values;
+        return SIFT_HIP_OK;
+    });
+}
+
+int sift_hip_result_sparse_pack(sift_hip_ctx* c, void* d_records, void* d_values) {
+    if (!c || !c->have_result || c->wire_for_total != c->total || c->wire_values < 0) return SIFT_HIP_EINVAL;
+    if (c->total > 0 && (!d_records || (c->wire_values > 0 && !d_values))) return SIFT_HIP_EINVAL;
+    char err[256];
+    return guarded(err, sizeof(err), [&]() {
+        SIFT_HIP_CHECK(hipSetDevice(c->device));
+        launch_wire_emit(c->stream, c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->total, c->d_wire_off.as<long long>(),
+                         static_cast<uint8_t*>(d_records), static_cast<float*>(d_values));
+        wait_stream(c, c->stream);
+        return SIFT_HIP_OK;
+    });
 }
 
 int sift_hip_image_dims(sift_hip_ctx* c, int* w, int* h) {

@@ -153,6 +153,18 @@ class Context:
             raise HipError("no result")
         return a.value or 0, b.value or 0
 
+    def sparse_size(self) -> int:
+        """Number of descriptor floats the sparse wire format carries for the current results (include/sift_hip.h)."""
+        n = C.c_int64()
+        if self._L.sift_hip_result_sparse_size(self._h, C.byref(n)):
+            raise HipError("sift_hip_result_sparse_size failed")
+        return int(n.value)
+
+    def sparse_pack(self, dev_records: int, dev_values: int):
+        """Write total*34 record bytes and sparse_size() floats to the device addresses given."""
+        if self._L.sift_hip_result_sparse_pack(self._h, C.c_void_p(dev_records), C.c_void_p(dev_values)):
+            raise HipError("sift_hip_result_sparse_pack failed")
+
     def image(self, image: int = 0):
         w, h = C.c_int(), C.c_int()
         self._L.sift_hip_image_dims(self._h, C.byref(w), C.byref(h))

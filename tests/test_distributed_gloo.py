@@ -7,7 +7,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from sift_amd.gather import gather_finish, gather_keypoints, gather_start, pack_descriptors, unpack_descriptors
+from sift_amd.gather import (gather_finish, gather_keypoints, gather_start, join_records, pack_descriptors, pack_sparse,
+                             split_records, unpack_descriptors, unpack_sparse)
 
 
 def _fake_rank_data(rank):
@@ -17,6 +18,32 @@ def _fake_rank_data(rank):
     kp = rng.integers(0, 256, total * 20, dtype=np.uint8)
     desc = rng.random(total * 128).astype(np.float32)
     return counts, kp, desc
+
+
+def _sparsify(desc):
+    """Descriptor-like data: bin 7 of every cell +0.0f, most other bins too, a -0.0f and a NaN among the set ones."""
+    d = desc.reshape(-1, 16, 8).copy()
+    rng = np.random.default_rng(d.size)
+    d[rng.random(d.shape) < 0.6] = 0.0
+    d[:, :, 7] = 0.0
+    if d.shape[0]:
+        d[0, 0, 0] = -0.0
+        d[0, 1, 2] = np.nan
+    return d.reshape(-1)
+
+
+def test_sparse_wire_format_round_trip():
+    _, kp, desc = _fake_rank_data(0)
+    d = _sparsify(desc)
+    masks, values = pack_sparse(torch.from_numpy(d))
+    assert masks.numel() == (d.size // 128) * 14
+    assert values.numel() == int((d.view(np.int32) != 0).sum())          # -0.0f and NaN are sent, +0.0f is not
+    assert unpack_sparse(masks, values).numpy().tobytes() == d.tobytes()
+    rec = join_records(torch.from_numpy(kp), masks)
+    k2, m2 = split_records(rec)
+    assert k2.numpy().tobytes() == kp.tobytes() and bool((m2 == masks).all())
+    empty = pack_sparse(torch.zeros(0))
+    assert empty[0].numel() == 0 and empty[1].numel() == 0 and unpack_sparse(*empty).numel() == 0
 
 
 def _worker(rank, world, port, q):
@@ -41,7 +68,13 @@ def _worker(rank, world, port, q):
             assert unpack_descriptors(packed).numpy().tobytes() == d2.tobytes()
             hs.append((step, gather_start(torch.from_numpy(k2), packed, torch.from_numpy(c2), dst=0, floats_per_kp=112)))
             continue
-        hs.append((step, gather_start(torch.from_numpy(k2), torch.from_numpy(d2), torch.from_numpy(c2), dst=0)))
+        if step == 2:   # sparse wire format: presence bits joined to the records, set floats only (ragged per rank)
+            d2 = _sparsify(d2)
+            masks, values = pack_sparse(torch.from_numpy(d2))
+            hs.append((step, gather_start(join_records(torch.from_numpy(k2), masks), values, torch.from_numpy(c2), dst=0,
+                                          floats_per_kp=None, bytes_per_kp=34)))
+        else:
+            hs.append((step, gather_start(torch.from_numpy(k2), torch.from_numpy(d2), torch.from_numpy(c2), dst=0)))
         if len(hs) > 2:
             st, h = hs.pop(0)
             res = gather_finish(h)
@@ -79,11 +112,18 @@ def test_gather_two_ranks():
         a0, b0, e0 = _fake_rank_data(0 + 10 * (st + 1))
         a1, b1, e1 = _fake_rank_data(1 + 10 * (st + 1))
         assert (counts2 == np.concatenate([a0, a1])).all()
-        assert (kp2 == np.concatenate([b0, b1])).all()
+        if st != 2:
+            assert (kp2 == np.concatenate([b0, b1])).all()
         if st == 1:
             full = np.concatenate([e0, e1]).reshape(-1, 16, 8).copy()
             full[:, :, 7] = 0.0
             desc2 = unpack_descriptors(torch.from_numpy(desc2)).numpy()
             assert desc2.tobytes() == full.reshape(-1).tobytes()
+            continue
+        if st == 2:
+            full = np.concatenate([_sparsify(e0), _sparsify(e1)])
+            recs, masks = split_records(torch.from_numpy(kp2))
+            assert recs.numpy().tobytes() == np.concatenate([b0, b1]).tobytes()
+            assert unpack_sparse(masks, torch.from_numpy(desc2)).numpy().tobytes() == full.tobytes()
             continue
         assert (desc2 == np.concatenate([e0, e1])).all()

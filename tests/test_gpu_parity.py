@@ -540,7 +540,7 @@ def test_config3_exception_and_nearest_runnable(ctx):
 def _gather_worker(rank, world, port, q):
     import torch
     import torch.distributed as dist
-    from sift_amd.gather import device_results, gather_finish, gather_start, unpack_descriptors
+    from sift_amd.gather import device_results, gather_finish, gather_start, split_records, unpack_sparse
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -548,18 +548,19 @@ def _gather_worker(rank, world, port, q):
     c = Context(0)
     frames = np.stack([synth_frame(320, 240, 10 * rank + i + 1) for i in range(2)])
     c.calculate_batch(frames, _lib.Params(3, 3, 1.6, O.K_SQRT2, 0))
-    kp, desc = device_results(c, c.total(), dev, packed=True)
-    h = gather_start(kp.cpu(), desc.cpu(), torch.from_numpy(c.counts()), dst=0, floats_per_kp=112)
+    kp, desc = device_results(c, c.total(), dev, wire="sparse")
+    h = gather_start(kp.cpu(), desc.cpu(), torch.from_numpy(c.counts()), dst=0, floats_per_kp=None, bytes_per_kp=34)
     res = gather_finish(h)
     if rank == 0:
-        q.put((res[0].numpy().copy(), unpack_descriptors(res[1]).numpy().copy(), res[2].numpy().copy()))
+        recs, masks = split_records(res[0])
+        q.put((recs.numpy().copy(), unpack_sparse(masks, res[1]).numpy().copy(), res[2].numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_gather_of_device_results_two_ranks_sharing_the_gpu(ctx):
     """The N > 1 path of bench.py end to end on real results: in-place views of the library's result arrays,
-    the 112-float wire format, the gather (gloo, because both ranks have to share this box's one GPU)."""
+    the sparse wire format (packed on the GPU), the gather (gloo, because both ranks have to share this box's one GPU)."""
     import socket
     import torch.multiprocessing as mp
     sock = socket.socket()
@@ -682,3 +683,25 @@ def test_batch_pipeline_survives_a_failing_batch(ctx, gated):
         assert got[0].tolist() == want[0].tolist()
         assert got[1].tobytes() == want[1].tobytes() and got[2].tobytes() == want[2].tobytes()
     assert isinstance(out[1], PreconditionViolation) and not isinstance(out[0], Exception) and not isinstance(out[5], Exception)
+
+
+def test_sparse_wire_kernels_match_the_reference_packing(ctx):
+    """sift_hip_result_sparse_size / _pack (kernels_wire.hip) against the torch restatement of the wire format
+    (sift_amd/gather.py:pack_sparse) on real results, and the round trip back to the 128-float descriptors."""
+    import torch
+    from sift_amd.gather import device_results, join_records, pack_sparse, split_records, unpack_sparse
+    frames = np.stack([synth_frame(640, 480, 30 + i) for i in range(3)] + [np.full((480, 640), 7.0, np.float32)])   # last: no keypoints
+    ctx.calculate_batch(frames, _lib.Params(3, 3, 1.6, O.K_SQRT2, 0))
+    kp, desc = ctx.results()
+    total = ctx.total()
+    assert total > 0 and ctx.counts()[-1] == 0
+    rec, values = device_results(ctx, total, torch.device("cuda", 0), wire="sparse")
+    masks_ref, values_ref = pack_sparse(torch.from_numpy(desc.reshape(-1)))
+    rec_ref = join_records(torch.from_numpy(kp.view(np.uint8).reshape(-1)), masks_ref)
+    assert values.numel() == values_ref.numel() == ctx.sparse_size()
+    assert rec.cpu().numpy().tobytes() == rec_ref.numpy().tobytes()
+    assert values.cpu().numpy().tobytes() == values_ref.numpy().tobytes()
+    recs, masks = split_records(rec.cpu())
+    assert recs.numpy().tobytes() == kp.tobytes()
+    assert unpack_sparse(masks, values.cpu()).numpy().tobytes() == desc.tobytes()
+    assert 0.2 < values.numel() / (total * 112) < 0.6   # the saving the format exists for
