@@ -78,7 +78,7 @@ def pmc_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=None)
     ap.add_argument("--workload", default="config4", choices=sorted(WORKLOADS),
