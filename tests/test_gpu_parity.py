@@ -500,6 +500,21 @@ def test_cpp_dropin_example(ctx, tmp_path):
     assert "kernel longer than line" in out.stderr
 
 
+def test_cpp_gated_pair_example(ctx, tmp_path):
+    """examples/sift_pipeline.cpp: two sift::Sift objects on two threads joined by a gate (sift_hip_gate_*, Sift::join)
+    give, frame for frame, the single object's results."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "sift_pipeline"
+    subprocess.check_call(["g++", "-std=c++17", "-pthread", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "sift_pipeline.cpp"), "-L" + os.path.join(root, "sift_amd", "lib"),
+                           "-lsift_hip", "-Wl,-rpath," + os.path.join(root, "sift_amd", "lib"), "-o", str(exe)])
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    out = subprocess.run([str(exe), os.path.join(root, "tests", "golden", "parrot_r.pgm"), "9"], cwd=tmp_path, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok: 9 frames"), out.stdout + out.stderr
+
+
 def test_cli_result_file(ctx, tmp_path, monkeypatch):
     """sift_amd.cli (main.cpp's options, result writer and overlay)."""
     from sift_amd import cli
