@@ -1,4 +1,5 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see vigra_restate.hpp header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see vigra_restate.hpp header).  Parity pinned against the reference's own
+// prebuilt binary (oracle/refexec, tests/test_ref_pins.py).
 // extern "C" surface so tests/ and bench.py's cpu_baseline leg can drive the oracle via ctypes.
 #include <algorithm>
 #include <chrono>

@@ -1,4 +1,5 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see vigra_restate.hpp header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see vigra_restate.hpp header).  Parity pinned against the reference's own
+// prebuilt binary (oracle/refexec, tests/test_ref_pins.py).
 // CPU restatement of /root/reference/sift.cpp + algorithms.cpp.  Compile with -ffp-contract=off.
 #include "sift_oracle.hpp"
 

@@ -1,4 +1,5 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see vigra_restate.hpp header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see vigra_restate.hpp header).  Parity pinned against the reference's own
+// prebuilt binary (oracle/refexec, tests/test_ref_pins.py).
 //
 // CPU restatement of the reference's hot path sift::Sift::calculate() (sift.cpp:19-57) and the
 // sift::alg::* helpers it calls (algorithms.cpp), including every behavioural quirk listed in

@@ -2,11 +2,20 @@
 // product path (sift_amd/). Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
 // leg may use anything under oracle/.
 //
-// PARITY UNPINNED: the reference (snowiow/SIFT) has no tests/golden vectors and cannot be built
-// here (needs Vigra 1.11, OpenCV, Boost; none present, no network).  This file restates the
-// published algorithms of the Vigra 1.11 routines the reference calls, cross-checked against a
-// STATIC disassembly (objdump, never executed) of the un-stripped reference binary
-// /root/reference/bin/arch_x64/sift.  Addresses "bin@0x..." below refer to that binary.
+// PARITY PINNED AGAINST THE REFERENCE'S OWN BINARY.  The reference (snowiow/SIFT) has no tests or golden vectors and
+// cannot be rebuilt here (needs Vigra 1.11, OpenCV, Boost; none present, no network), and its prebuilt executable
+// /root/reference/bin/arch_x64/sift cannot be started (the same libraries are DT_NEEDED).  But Sift::calculate and
+// the sift::alg functions INSIDE that executable, with every Vigra template they use compiled in, only need libc /
+// libm / libstdc++: oracle/refexec maps the executable into its own process and calls them.  On every input of
+// tests/golden/make_ref_pins.py (12 calculate() cases up to 1000x760, three of them ending in Vigra's exception;
+// blur at 8 sigmas on 3 shapes, reduce / increaseToNextLevel, dog, vertexParabola) this oracle returns what the
+// reference binary returns, bit for bit: point records, orientations, descriptors, every Gaussian level, exception
+// text (tests/test_ref_pins.py against tests/golden/refpin.npz; the live comparison runs where the reference is
+// mounted).  Not covered by the pin: the `u16_t size` truncation (App. B-7 needs > 65535 survivors, i.e. ~8 Mpx,
+// hours in the reference's O(K x N) descriptor stage) and octaves > 4 at 4K.
+//
+// The restatement was written from the published algorithms of the Vigra 1.11 routines the reference calls,
+// cross-checked against a static disassembly (objdump) of that binary.  Addresses "bin@0x..." below refer to it.
 //
 // Restated routines (Vigra 1.11, soname libvigraimpex.so.11; call sites in the reference:
 // algorithms.cpp:13-19,33,46,175 and sift.cpp:306,311):

@@ -1,0 +1,116 @@
+"""The CPU oracle against what the reference's OWN prebuilt binary returned (tests/golden/refpin.npz, produced by
+tests/golden/make_ref_pins.py through oracle/refexec in the build container).  This is what pins the oracle:
+`Sift::calculate` and the `sift::alg` functions of /root/reference/bin/arch_x64/sift, executed in-process, on the
+same inputs.  Runs anywhere (the fixture is data); the last test re-runs the binary where the reference is mounted."""
+import ctypes as C
+import hashlib
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from golden_util import read_pgm, sha
+from sift_amd.synthetic import synth_frame
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PIN = np.load(os.path.join(HERE, "golden", "refpin.npz"))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_ref_pins as G  # noqa: E402  (case tables and image construction, shared with the generator)
+
+
+def vigra_text(msg: str) -> str:
+    """Vigra's what(): leading newline, message, '(header:line)' of the build machine's include path.  The oracle (and the
+    product) carry the message proper; file and line are properties of the machine the reference was built on."""
+    return re.sub(r"\n\(/[^)]*\)\n+$", "\n", msg.lstrip("\n"))
+
+
+CALC = sorted(G.CALC_CASES)
+
+
+@pytest.mark.parametrize("name", CALC)
+def test_calculate_matches_the_reference_binary(name):
+    spec, dogs, octaves, sub = G.CALC_CASES[name]
+    img = G.make_image(spec)
+    assert sha(img) == str(PIN[f"calc/{name}/image_sha"]), "input differs from the one the reference saw"
+    run = O.OracleRun(img, dogs, octaves, subpixel=bool(sub))
+    if f"calc/{name}/exception" in PIN.files:
+        assert run.status == 1
+        assert vigra_text(run.error).strip() == vigra_text(str(PIN[f"calc/{name}/exception"])).strip()
+        return
+    assert run.status == 0, run.error
+    ref = PIN[f"calc/{name}/points"]
+    got, gdesc = run.points("final")
+    assert got.size == ref.size
+    for f in ("x", "y", "octave", "index"):
+        assert (got[f] == ref[f]).all(), f
+    assert (got["filtered"].astype(bool) == ref["filtered"].astype(bool)).all()
+    assert got["scale"].tobytes() == ref["scale"].tobytes()
+    assert got["orientation"].tobytes() == ref["orientation"].tobytes()
+    assert (got["n_desc"] == ref["n_desc"]).all()
+    d = np.concatenate([gdesc[i, :got["n_desc"][i]] for i in range(got.size)]) if got.size else np.zeros(0, np.float32)
+    assert hashlib.sha256(d.astype(np.float32).tobytes()).hexdigest() == str(PIN[f"calc/{name}/desc_sha"])
+    # the Gaussian pyramid the reference object kept: Matrix<OctaveElem>(octaves, dogs + 1), element (o, j)
+    mw, mh = (int(v) for v in PIN[f"calc/{name}/levels_wh"])
+    assert (mw, mh) == (octaves, dogs + 1)
+    for o in range(mw):
+        for j in range(mh):
+            lv = run.level("gaussian", o, j)
+            k = o * mh + j
+            assert tuple(PIN[f"calc/{name}/level_dims"][k]) == (lv.shape[1], lv.shape[0])
+            assert np.float32(run.scale("gaussian", o, j)).view(np.uint32) == PIN[f"calc/{name}/level_scale_bits"][k]
+            assert sha(lv) == str(PIN[f"calc/{name}/level_sha"][k]), f"gaussian({o},{j})"
+    w, h = (int(v) for v in PIN[f"calc/{name}/image_dims"])
+    assert run.image().shape == (h, w)          # subpixel: the caller's image was replaced (sift.cpp:20-21)
+    if f"calc/{name}/desc" in PIN.files:        # the small case stored in full
+        assert d.tobytes() == PIN[f"calc/{name}/desc"].tobytes()
+        flat = np.concatenate([run.level("gaussian", o, j).reshape(-1) for o in range(mw) for j in range(mh)])
+        assert flat.tobytes() == PIN[f"calc/{name}/levels"].tobytes()
+
+
+@pytest.mark.parametrize("spec", G.BLUR_IMAGES, ids=[f"{s[1]}x{s[2]}" for s in G.BLUR_IMAGES])
+def test_operators_match_the_reference_binary(spec):
+    img = G.make_image(spec)
+    tag = f"{spec[1]}x{spec[2]}_s{spec[3]}"
+    for sigma in G.BLUR_SIGMAS:
+        key = f"blur/{tag}/{sigma!r}"
+        if key + "/exception" in PIN.files:
+            with pytest.raises(O.OracleError) as e:
+                O.convolve(img, sigma)
+            assert vigra_text(str(e.value.args[-1] if e.value.args else e.value)).strip() in vigra_text(str(PIN[key + "/exception"])).strip() or \
+                vigra_text(str(PIN[key + "/exception"])).strip() in str(e.value)
+            continue
+        assert sha(O.convolve(img, sigma)) == str(PIN[key + "/sha"]), f"convolveWithGauss sigma {sigma}"
+    for op, mode in (("reduce", 0), ("increase", 1)):
+        out = O.resample(img, 1.6, mode)
+        assert tuple(PIN[f"{op}/{tag}/dims"]) == (out.shape[1], out.shape[0])
+        assert sha(out) == str(PIN[f"{op}/{tag}/sha"]), op
+
+
+def test_dog_and_parabola_match_the_reference_binary():
+    a, b = synth_frame(200, 150, 3), synth_frame(200, 150, 9)
+    out = np.empty_like(a)
+    O.lib().oracle_dog(a, b, 200, 150, out)
+    assert sha(out) == str(PIN["dog/200x150_s3_s9/sha"])
+    L = O.lib()
+    L.oracle_vertex_parabola.restype = C.c_float
+    L.oracle_vertex_parabola.argtypes = [C.c_uint16, C.c_float, C.c_uint16, C.c_float, C.c_uint16, C.c_float]
+    for args, bits in zip(PIN["parabola/args"], PIN["parabola/bits"]):
+        r = np.float32(L.oracle_vertex_parabola(int(args[0]), float(args[1]), int(args[2]), float(args[3]), int(args[4]), float(args[5])))
+        assert r.view(np.uint32) == bits or (np.isnan(r) and np.isnan(np.uint32(bits).view(np.float32)))
+
+
+@pytest.mark.skipif(not os.path.exists(G.REF_BIN), reason="the reference is only mounted in the build container")
+def test_fixture_is_what_the_reference_binary_returns_now(tmp_path):
+    """Live: build oracle/refexec, run the reference's calculate on one case, compare with the committed fixture."""
+    root = os.path.dirname(HERE)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "_ref/refexec"])
+    name = "synth_200x160_3x2"
+    spec, dogs, octaves, sub = G.CALC_CASES[name]
+    r = G.ref_calculate(G.make_image(spec), dogs, octaves, sub, str(tmp_path))
+    assert r["points"].tobytes() == PIN[f"calc/{name}/points"].tobytes()
+    assert r["desc"].tobytes() == PIN[f"calc/{name}/desc"].tobytes()
+    assert r["levels"].tobytes() == PIN[f"calc/{name}/levels"].tobytes()
