@@ -720,3 +720,55 @@ def test_sparse_wire_kernels_match_the_reference_packing(ctx):
     assert recs.numpy().tobytes() == kp.tobytes()
     assert unpack_sparse(masks, values.cpu()).numpy().tobytes() == desc.tobytes()
     assert 0.2 < values.numel() / (total * 112) < 0.6   # the saving the format exists for
+
+
+# ------------------------------------------------------------------------------------------------
+# the HIP path against what the reference's own prebuilt binary returned (tests/golden/refpin.npz, see
+# tests/test_ref_pins.py): no oracle in between
+# ------------------------------------------------------------------------------------------------
+import make_ref_pins as REFPIN  # noqa: E402  (tests/golden is put on the path by conftest.py)
+
+
+def _refpin():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refpin.npz"))
+
+
+@pytest.mark.parametrize("name", sorted(REFPIN.CALC_CASES))
+def test_hip_matches_the_reference_binary(ctx, name):
+    import hashlib
+    import re
+    pin = _refpin()
+    spec, dogs, octaves, sub = REFPIN.CALC_CASES[name]
+    img = REFPIN.make_image(spec)
+    assert sha(img) == str(pin[f"calc/{name}/image_sha"])
+    params = _lib.Params(dogs, octaves, 1.6, O.K_SQRT2, sub)
+    if f"calc/{name}/exception" in pin.files:
+        with pytest.raises(PreconditionViolation) as e:
+            ctx.calculate_batch(img[None], params)
+        want = re.sub(r"\n\(/[^)]*\)\n+$", "\n", str(pin[f"calc/{name}/exception"]).lstrip("\n"))   # Vigra's what() minus (header:line)
+        assert str(e.value).strip() == want.strip()
+        return
+    ctx.calculate_batch(img[None], params)
+    ref = pin[f"calc/{name}/points"]
+    kp, desc = ctx.results()
+    assert kp.size == ref.size
+    for f in ("x", "y", "octave", "index"):
+        assert (kp[f] == ref[f]).all(), f
+    assert kp["scale"].tobytes() == ref["scale"].tobytes()
+    assert kp["orientation"].tobytes() == ref["orientation"].tobytes()
+    assert (kp["has_descriptor"].astype(bool) == (ref["n_desc"] == 128)).all()
+    d = desc[kp["has_descriptor"].astype(bool)].reshape(-1)
+    assert hashlib.sha256(d.tobytes()).hexdigest() == str(pin[f"calc/{name}/desc_sha"])
+    mw, mh = (int(v) for v in pin[f"calc/{name}/levels_wh"])
+    for o in range(mw):
+        for j in range(mh):
+            k = o * mh + j
+            lv = ctx.level("gaussian", o, j, 0)
+            assert tuple(pin[f"calc/{name}/level_dims"][k]) == (lv.shape[1], lv.shape[0])
+            assert np.float32(ctx.level_scale("gaussian", o, j)).view(np.uint32) == pin[f"calc/{name}/level_scale_bits"][k]
+            assert sha(lv) == str(pin[f"calc/{name}/level_sha"][k]), f"gaussian({o},{j})"
+    w, h = (int(v) for v in pin[f"calc/{name}/image_dims"])
+    if sub:   # the caller's image was replaced by the 2x frame (sift.cpp:20-21)
+        assert ctx.image(0).shape == (h, w)
+    else:
+        assert img.shape == (h, w)

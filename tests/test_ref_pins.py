@@ -18,7 +18,6 @@ from sift_amd.synthetic import synth_frame
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PIN = np.load(os.path.join(HERE, "golden", "refpin.npz"))
-sys.path.insert(0, os.path.join(HERE, "golden"))
 import make_ref_pins as G  # noqa: E402  (case tables and image construction, shared with the generator)
 
 
