@@ -12,6 +12,7 @@
 // binary is read where it lies, outputs go to files given on the command line.
 //
 //   refexec <reference binary> calculate <in.f32> <w> <h> <dogs> <octaves> <sigma> <k> <subpixel> <out prefix>
+//   refexec <reference binary> dogs      <in.f32> <w> <h> <dogs> <octaves> <sigma> <k> <subpixel> <out prefix>
 //   refexec <reference binary> blur      <in.f32> <w> <h> <sigma> <out.f32>
 //   refexec <reference binary> reduce|increase <in.f32> <w> <h> <sigma> <out prefix>
 //   refexec <reference binary> dog       <a.f32> <b.f32> <w> <h> <out.f32>
@@ -322,7 +323,56 @@ int run(int argc, char** argv) {
         write_file(out + ".levels", levels.data(), levels.size() * 4);
         const long dims[2] = {img.shape[0], img.shape[1]};
         write_file(out + ".image_dims", dims, sizeof(dims));
+        // the gradient maps the object keeps (Matrix<MultiArray>), in their final state: the descriptor stage has
+        // added to them in place (sift.cpp:_createDecriptors)
+        auto dump_images = [&](const Matrix& m, const std::string& tag) {
+            const auto* im = static_cast<const Image*>(m.data);
+            std::vector<long> mm = {m.w, m.h};
+            std::vector<float> px;
+            for (int i = 0; im && i < m.w * m.h; ++i) {
+                mm.push_back(im[i].shape[0]);
+                mm.push_back(im[i].shape[1]);
+                if (im[i].shape[0] * im[i].shape[1] > 0) {
+                    const std::vector<float> v = dense(im[i]);
+                    px.insert(px.end(), v.begin(), v.end());
+                }
+            }
+            write_file(out + "." + tag + "_meta", mm.data(), mm.size() * sizeof(long));
+            write_file(out + "." + tag, px.data(), px.size() * 4);
+        };
+        dump_images(s.magnitudes, "mag");
+        dump_images(s.orientations, "ori");
         std::printf("%zu\n", n);
+        return 0;
+    }
+    if (cmd == "dogs") {   // Sift::_createDOGs alone: the DoG pyramid (sift.cpp:_createDOGs)
+        if (argc != 12) die("usage");
+        const long w = std::atol(argv[4]), h = std::atol(argv[5]);
+        Image img = make_image(read_f32(argv[3], (size_t)(w * h)), w, h);
+        SiftObj s{};
+        s.dogs = (uint16_t)std::atoi(argv[6]);
+        s.octaves = (uint16_t)std::atoi(argv[7]);
+        s.sigma = (float)std::atof(argv[8]);
+        s.k = (float)std::atof(argv[9]);
+        s.subpixel = std::atoi(argv[10]) != 0;
+        const std::string out = argv[11];
+        Matrix dogs{};
+        using DogsFn = void (*)(Matrix*, SiftObj*, Image*);
+        fn<DogsFn>("_ZN4sift4Sift11_createDOGsERN5vigra10MultiArrayILj2EfSaIfEEE")(&dogs, &s, &img);
+        const auto* el = static_cast<const OctaveElem*>(dogs.data);
+        std::vector<long> meta = {dogs.w, dogs.h};
+        std::vector<float> levels;
+        for (int i = 0; el && i < dogs.w * dogs.h; ++i) {
+            meta.push_back(el[i].img.shape[0]);
+            meta.push_back(el[i].img.shape[1]);
+            uint32_t sb;
+            std::memcpy(&sb, &el[i].scale, 4);
+            meta.push_back((long)sb);
+            const std::vector<float> v = dense(el[i].img);
+            levels.insert(levels.end(), v.begin(), v.end());
+        }
+        write_file(out + ".dogs_meta", meta.data(), meta.size() * sizeof(long));
+        write_file(out + ".dogs", levels.data(), levels.size() * 4);
         return 0;
     }
     die("unknown command");

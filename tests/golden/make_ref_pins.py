@@ -7,7 +7,7 @@
 sources cannot be rebuilt for the same reason, but `Sift::calculate` and the `sift::alg` functions inside it only need
 libc / libm / libstdc++: oracle/refexec maps the executable in its own process and calls them (see its header).  This
 script runs it on the inputs below and stores WHAT THE REFERENCE RETURNED — point records, exception texts, SHA-256 of
-descriptors and of every Gaussian level, a few small arrays in full — in tests/golden/refpin.npz.  The fixture holds
+descriptors, of every Gaussian and DoG level and of the final (mutated) gradient maps, a few small arrays in full — in tests/golden/refpin.npz.  The fixture holds
 data only; tests/test_ref_pins.py checks the oracle against it anywhere (no reference needed), and against a live run
 of the binary where it is present.
 """
@@ -89,8 +89,29 @@ def ref_calculate(img, dogs, octaves, subpixel, tmp):
     for lw, lh, _ in per:
         level_sha.append(hashlib.sha256(levels[off:off + lw * lh].tobytes()).hexdigest())
         off += int(lw * lh)
-    return {"points": pts, "desc": desc, "levels_wh": (mw, mh), "level_dims": per[:, :2].copy(), "level_scale_bits": per[:, 2].astype(np.uint32),
-            "level_sha": level_sha, "image_dims": dims, "levels": levels}
+    res = {"points": pts, "desc": desc, "levels_wh": (mw, mh), "level_dims": per[:, :2].copy(), "level_scale_bits": per[:, 2].astype(np.uint32),
+           "level_sha": level_sha, "image_dims": dims, "levels": levels}
+    # gradient maps the object keeps, in their FINAL state (the descriptor stage adds to them in place)
+    for tag in ("mag", "ori"):
+        mm = np.fromfile(out + f".{tag}_meta", np.int64)
+        px = np.fromfile(out + f".{tag}", np.float32)
+        shas, off = [], 0
+        for lw, lh in mm[2:].reshape(-1, 2):
+            shas.append(hashlib.sha256(px[off:off + lw * lh].tobytes()).hexdigest() if lw * lh else "")
+            off += int(lw * lh)
+        res[f"{tag}_sha"] = shas
+    # the DoG pyramid: Sift::_createDOGs called on its own
+    rc, so, se = refexec("dogs", src, w, h, dogs, octaves, repr(float(np.float32(1.6))), repr(K_SQRT2), subpixel, out)
+    assert rc == 0, (rc, so, se)
+    dm = np.fromfile(out + ".dogs_meta", np.int64)
+    dl = np.fromfile(out + ".dogs", np.float32)
+    dper = dm[2:].reshape(int(dm[0]) * int(dm[1]), 3)
+    dsha, off = [], 0
+    for lw, lh, _ in dper:
+        dsha.append(hashlib.sha256(dl[off:off + lw * lh].tobytes()).hexdigest())
+        off += int(lw * lh)
+    res.update({"dogs_wh": (int(dm[0]), int(dm[1])), "dog_dims": dper[:, :2].copy(), "dog_scale_bits": dper[:, 2].astype(np.uint32), "dog_sha": dsha})
+    return res
 
 
 def main():
@@ -114,6 +135,12 @@ def main():
             store[f"calc/{name}/level_scale_bits"] = r["level_scale_bits"]
             store[f"calc/{name}/level_sha"] = np.array(r["level_sha"])
             store[f"calc/{name}/image_dims"] = r["image_dims"]
+            store[f"calc/{name}/mag_sha"] = np.array(r["mag_sha"])
+            store[f"calc/{name}/ori_sha"] = np.array(r["ori_sha"])
+            store[f"calc/{name}/dogs_wh"] = np.array(r["dogs_wh"], np.int64)
+            store[f"calc/{name}/dog_dims"] = r["dog_dims"]
+            store[f"calc/{name}/dog_scale_bits"] = r["dog_scale_bits"]
+            store[f"calc/{name}/dog_sha"] = np.array(r["dog_sha"])
             if name == "synth_200x160_3x2":      # one small case in full
                 store[f"calc/{name}/desc"] = r["desc"]
                 store[f"calc/{name}/levels"] = r["levels"]
@@ -149,8 +176,9 @@ def main():
             par.append(int(so.strip(), 16))
         store["parabola/args"] = np.array(PARABOLAS, np.float64)
         store["parabola/bits"] = np.array(par, np.uint32)
-    np.savez_compressed(os.path.join(HERE, "refpin.npz"), **store)
-    print("wrote", os.path.join(HERE, "refpin.npz"), os.path.getsize(os.path.join(HERE, "refpin.npz")), "bytes")
+    dst = os.path.join(HERE, os.environ.get("REFPIN_OUT", "refpin.npz"))
+    np.savez_compressed(dst, **store)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
 
 
 if __name__ == "__main__":

@@ -767,6 +767,13 @@ def test_hip_matches_the_reference_binary(ctx, name):
             assert tuple(pin[f"calc/{name}/level_dims"][k]) == (lv.shape[1], lv.shape[0])
             assert np.float32(ctx.level_scale("gaussian", o, j)).view(np.uint32) == pin[f"calc/{name}/level_scale_bits"][k]
             assert sha(lv) == str(pin[f"calc/{name}/level_sha"][k]), f"gaussian({o},{j})"
+    dw, dh = (int(v) for v in pin[f"calc/{name}/dogs_wh"])
+    for o in range(dw if not sub else 0):   # (the stand-alone _createDOGs call of the pin saw the raw frame)
+        for j in range(dh):
+            k = o * dh + j
+            lv = ctx.level("dog", o, j, 0)
+            assert np.float32(ctx.level_scale("dog", o, j)).view(np.uint32) == pin[f"calc/{name}/dog_scale_bits"][k]
+            assert sha(lv) == str(pin[f"calc/{name}/dog_sha"][k]), f"dog({o},{j})"
     w, h = (int(v) for v in pin[f"calc/{name}/image_dims"])
     if sub:   # the caller's image was replaced by the 2x frame (sift.cpp:20-21)
         assert ctx.image(0).shape == (h, w)

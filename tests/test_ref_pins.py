@@ -64,6 +64,28 @@ def test_calculate_matches_the_reference_binary(name):
             assert sha(lv) == str(PIN[f"calc/{name}/level_sha"][k]), f"gaussian({o},{j})"
     w, h = (int(v) for v in PIN[f"calc/{name}/image_dims"])
     assert run.image().shape == (h, w)          # subpixel: the caller's image was replaced (sift.cpp:20-21)
+    # the DoG pyramid (Sift::_createDOGs called on its own): Matrix<OctaveElem>(octaves, dogs)
+    # (with subpixel, calculate() upsamples before it calls _createDOGs, sift.cpp:20-22: the stand-alone call saw the raw frame)
+    dw, dh = (int(v) for v in PIN[f"calc/{name}/dogs_wh"])
+    assert (dw, dh) == (octaves, dogs)
+    for o in range(dw if not sub else 0):
+        for j in range(dh):
+            lv = run.level("dog", o, j)
+            k = o * dh + j
+            assert tuple(PIN[f"calc/{name}/dog_dims"][k]) == (lv.shape[1], lv.shape[0])
+            assert np.float32(run.scale("dog", o, j)).view(np.uint32) == PIN[f"calc/{name}/dog_scale_bits"][k]
+            assert sha(lv) == str(PIN[f"calc/{name}/dog_sha"][k]), f"dog({o},{j})"
+    # the gradient maps in their FINAL state: the descriptor stage has added to them in place, keypoint after keypoint.
+    # The reference keeps maps of every Gaussian level, the oracle of the levels some keypoint selects.
+    checked = 0
+    for o in range(mw):
+        for j in range(mh):
+            for kind, key in (("magnitude", "mag_sha"), ("orientation", "ori_sha")):
+                lv = run.level(kind, o, j)
+                if lv is not None:
+                    assert sha(lv) == str(PIN[f"calc/{name}/{key}"][o * mh + j]), f"{kind}({o},{j})"
+                    checked += 1
+    assert checked >= 2 or ref.size == 0
     if f"calc/{name}/desc" in PIN.files:        # the small case stored in full
         assert d.tobytes() == PIN[f"calc/{name}/desc"].tobytes()
         flat = np.concatenate([run.level("gaussian", o, j).reshape(-1) for o in range(mw) for j in range(mh)])
