@@ -779,3 +779,43 @@ def test_hip_matches_the_reference_binary(ctx, name):
         assert ctx.image(0).shape == (h, w)
     else:
         assert img.shape == (h, w)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refpin_bench_frame.npz")),
+                    reason="fixture not generated")
+def test_hip_bench_frame_matches_the_reference_binary(ctx):
+    """Frame 1 of the bench workload (1920x1080, 3 DoGs x 4 octaves) against what the reference binary returned for it."""
+    import hashlib
+    pin = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refpin_bench_frame.npz"))
+    img = synth_frame(1920, 1080, 1)
+    assert sha(img) == str(pin["image_sha"])
+    ctx.calculate_batch(img[None], _lib.Params(3, 4, 1.6, O.K_SQRT2, 0))
+    kp, desc = ctx.results()
+    ref = pin["points"]
+    assert kp.size == ref.size
+    for f in ("x", "y", "octave", "index"):
+        assert (kp[f] == ref[f]).all(), f
+    assert kp["scale"].tobytes() == ref["scale"].tobytes() and kp["orientation"].tobytes() == ref["orientation"].tobytes()
+    assert hashlib.sha256(desc[kp["has_descriptor"].astype(bool)].tobytes()).hexdigest() == str(pin["desc_sha"])
+    mw, mh = (int(v) for v in pin["levels_wh"])
+    for o in range(mw):
+        for j in range(mh):
+            assert sha(ctx.level("gaussian", o, j, 0)) == str(pin["level_sha"][o * mh + j]), f"gaussian({o},{j})"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refpin_u16_truncation.npz")),
+                    reason="fixture not generated")
+def test_hip_u16_truncation_matches_the_reference_binary(ctx):
+    """App. B-7 against the reference binary itself: 65594 survivors, `u16_t size` keeps 58 of them."""
+    pin = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refpin_u16_truncation.npz"))
+    w, h, seed = (int(v) for v in pin["params"][3:6])
+    img = synth_frame(w, h, seed)
+    assert sha(img) == str(pin["image_sha"]) and int(pin["rc"]) == 0
+    ctx.calculate_batch(img[None], _lib.Params(3, 4, 1.6, O.K_SQRT2, 0))
+    kp, desc = ctx.results()
+    ref = pin["points"]
+    assert kp.size == ref.size
+    for f in ("x", "y", "octave", "index"):
+        assert (kp[f] == ref[f]).all(), f
+    assert kp["scale"].tobytes() == ref["scale"].tobytes() and kp["orientation"].tobytes() == ref["orientation"].tobytes()
+    assert desc[kp["has_descriptor"].astype(bool)].reshape(-1).tobytes() == pin["desc"].tobytes()

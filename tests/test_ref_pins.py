@@ -135,3 +135,52 @@ def test_fixture_is_what_the_reference_binary_returns_now(tmp_path):
     assert r["points"].tobytes() == PIN[f"calc/{name}/points"].tobytes()
     assert r["desc"].tobytes() == PIN[f"calc/{name}/desc"].tobytes()
     assert r["levels"].tobytes() == PIN[f"calc/{name}/levels"].tobytes()
+
+
+# ---- two long-running pins (tens of minutes to hours in the reference: it copies three DoG images per candidate and
+# re-blurs a whole level per keypoint); generated once in the build container, skipped when their fixture is absent ----
+BENCH_PIN = os.path.join(HERE, "golden", "refpin_bench_frame.npz")
+TRUNC_PIN = os.path.join(HERE, "golden", "refpin_u16_truncation.npz")
+
+
+def _compare_points(got, gdesc, ref):
+    assert got.size == ref.size
+    for f in ("x", "y", "octave", "index"):
+        assert (got[f] == ref[f]).all(), f
+    assert got["scale"].tobytes() == ref["scale"].tobytes()
+    assert got["orientation"].tobytes() == ref["orientation"].tobytes()
+    assert (got["n_desc"] == ref["n_desc"]).all()
+    return np.concatenate([gdesc[i, :got["n_desc"][i]] for i in range(got.size)]).astype(np.float32) if got.size else np.zeros(0, np.float32)
+
+
+@pytest.mark.skipif(not os.path.exists(BENCH_PIN), reason="fixture not generated")
+def test_bench_frame_matches_the_reference_binary():
+    """Frame 1 of the bench workload itself: 1920x1080, 3 DoGs x 4 octaves (BASELINE.json's metric configuration)."""
+    pin = np.load(BENCH_PIN)
+    img = synth_frame(1920, 1080, 1)
+    assert sha(img) == str(pin["image_sha"])
+    run = O.OracleRun(img, 3, 4)
+    got, gdesc = run.points("final")
+    d = _compare_points(got, gdesc, pin["points"])
+    assert hashlib.sha256(d.tobytes()).hexdigest() == str(pin["desc_sha"])
+    mw, mh = (int(v) for v in pin["levels_wh"])
+    for o in range(mw):
+        for j in range(mh):
+            assert sha(run.level("gaussian", o, j)) == str(pin["level_sha"][o * mh + j]), f"gaussian({o},{j})"
+
+
+@pytest.mark.skipif(not os.path.exists(TRUNC_PIN), reason="fixture not generated")
+def test_u16_size_truncation_matches_the_reference_binary():
+    """App. B-7: 65594 points survive the first cleanup of this 3488x1960 frame; `u16_t size` (sift.cpp:41) keeps 58."""
+    pin = np.load(TRUNC_PIN)
+    w, h, seed = (int(v) for v in pin["params"][3:6])
+    img = synth_frame(w, h, seed)
+    assert sha(img) == str(pin["image_sha"]) and int(pin["rc"]) == 0
+    run = O.OracleRun(img, 3, 4)
+    cand, _ = run.points("candidates")
+    kept = int((~cand["filtered"].astype(bool)).sum())
+    after, _ = run.points("after_sort1")
+    assert kept > 65535 and after.size == kept - 65536
+    got, gdesc = run.points("final")
+    d = _compare_points(got, gdesc, pin["points"])
+    assert d.tobytes() == pin["desc"].tobytes()
