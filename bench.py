@@ -59,7 +59,16 @@ def cpu_baseline(frames):
         secs += run.seconds
         kps += run.points("final")[0].size
         run.close()
-    return {"value": kps / secs, "unit": "keypoints/s", "cores": 1, "kind": "port",
+    ref = None
+    try:   # what the reference's own binary needed for frame 1 of this workload (measured once in the build container)
+        pin = np.load(os.path.join(ROOT, "tests", "golden", "refpin_bench_frame.npz"))
+        ref = {"value": float(pin["points"].size / float(pin["seconds"])), "unit": "keypoints/s", "cores": 1,
+               "seconds_per_frame": float(pin["seconds"]), "keypoints": int(pin["points"].size),
+               "how": "Sift::calculate of the reference's prebuilt binary, called in-process through oracle/refexec in the build "
+                      "container (not on this box: the reference does not travel); same keypoints and descriptors, bit for bit"}
+    except Exception:
+        pass
+    return {"reference_binary": ref, "value": kps / secs, "unit": "keypoints/s", "cores": 1, "kind": "port",
             "sample": f"{len(frames)} of the {FRAMES_PER_GPU} synthetic 1920x1080 frames, 4 oct x 3 DoG, oracle in lean mode "
                       f"(reference's per-candidate image copies and per-keypoint re-blur hoisted; same results), "
                       f"{secs:.1f} s CPU, {kps} keypoints"}
