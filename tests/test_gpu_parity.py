@@ -819,3 +819,22 @@ def test_hip_u16_truncation_matches_the_reference_binary(ctx):
         assert (kp[f] == ref[f]).all(), f
     assert kp["scale"].tobytes() == ref["scale"].tobytes() and kp["orientation"].tobytes() == ref["orientation"].tobytes()
     assert desc[kp["has_descriptor"].astype(bool)].reshape(-1).tobytes() == pin["desc"].tobytes()
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refpin_configs_as_written.npz")),
+                    reason="fixture not generated")
+@pytest.mark.parametrize("name", ["config3_as_written", "config5_as_written"])
+def test_hip_baseline_configs_as_written_end_like_in_the_reference_binary(ctx, name):
+    """BASELINE.json configs[2] and configs[4] exactly as written throw in the reference binary; so does the HIP path, with
+    the same text."""
+    import re
+    pin = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refpin_configs_as_written.npz"))
+    if name + "/rc" not in pin.files:
+        pytest.skip("case not in the fixture")
+    dogs, octaves, sub, w, h, seed = (int(v) for v in pin[name + "/params"])
+    so = str(pin[name + "/stdout"])
+    assert int(pin[name + "/rc"]) == 5 and so.startswith("EXCEPTION ")
+    with pytest.raises(PreconditionViolation) as e:
+        ctx.calculate_batch(synth_frame(w, h, seed)[None], _lib.Params(dogs, octaves, 1.6, O.K_SQRT2, sub))
+    want = re.sub(r"\n\(/[^)]*\)\n+$", "\n", so[len("EXCEPTION "):].lstrip("\n"))
+    assert str(e.value).strip() == want.strip()

@@ -184,3 +184,22 @@ def test_u16_size_truncation_matches_the_reference_binary():
     got, gdesc = run.points("final")
     d = _compare_points(got, gdesc, pin["points"])
     assert d.tobytes() == pin["desc"].tobytes()
+
+
+CFG_PIN = os.path.join(HERE, "golden", "refpin_configs_as_written.npz")
+
+
+@pytest.mark.skipif(not os.path.exists(CFG_PIN), reason="fixture not generated")
+@pytest.mark.parametrize("name", ["config3_as_written", "config5_as_written"])
+def test_baseline_configs_as_written_end_like_in_the_reference_binary(name):
+    """BASELINE.json configs[2] (1080p, subpixel, 4 octaves x 5 DoGs) and configs[4] (4K, subpixel, 6 octaves) as written:
+    what the reference binary does with them (App. B-13 / B-14) is what the oracle does."""
+    pin = np.load(CFG_PIN)
+    if name + "/rc" not in pin.files:
+        pytest.skip("case not in the fixture")
+    dogs, octaves, sub, w, h, seed = (int(v) for v in pin[name + "/params"])
+    rc, so = int(pin[name + "/rc"]), str(pin[name + "/stdout"])
+    assert rc == 5 and so.startswith("EXCEPTION "), "the reference did not throw: regenerate and compare results instead"
+    run = O.OracleRun(synth_frame(w, h, seed), dogs, octaves, subpixel=bool(sub))
+    assert run.status == 1
+    assert vigra_text(run.error).strip() == vigra_text(so[len("EXCEPTION "):]).strip()
