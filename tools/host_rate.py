@@ -25,3 +25,21 @@ for name, fn in (("device-resident input, results left on device", dev), ("pagea
                  ("pinned host input + results to host", host_pinned)):
     ms, n = run(fn)
     print(f"{name}: {ms:.2f} ms per 32-frame batch, {n / ms * 1e3 / 1e6:.1f} M keypoints/s", flush=True)
+
+# the same through the BatchPipeline: slot k+1's worker uploads while slot k computes and its results are read back
+from sift_amd.pipeline import BatchPipeline
+for depth in (2, 3):
+    with BatchPipeline(0, depth=depth) as pipe:
+        def stream(reps, src):
+            tickets, n = [], 0
+            for _ in range(reps):
+                tickets.append(pipe.submit(src, p))
+                if len(tickets) == depth:
+                    t = tickets.pop(0); c = t.result(); kp, desc = c.results(); n = kp.size; t.release()
+            for t in tickets:
+                c = t.result(); kp, desc = c.results(); n = kp.size; t.release()
+            return n
+        for label, src in (("pageable", frames), ("pinned", pinned)):
+            stream(3, src)
+            t0 = time.perf_counter(); n = stream(10, src); ms = (time.perf_counter() - t0) / 10 * 1e3
+            print(f"BatchPipeline depth {depth}, {label} host input + results to host: {ms:.2f} ms per 32-frame batch, {n / ms * 1e3 / 1e6:.1f} M keypoints/s", flush=True)
