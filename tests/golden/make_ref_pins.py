@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Pins for the CPU oracle, produced by the reference's OWN prebuilt binary.
 
-    python tests/golden/make_ref_pins.py        (in the build container, where /root/reference is mounted)
+    python tests/golden/make_ref_pins.py                                   (in the build container, where /root/reference is mounted)
+    python tests/golden/make_ref_pins.py bench_frame | truncation | configs   (the long-running pins, one fixture each)
 
 /root/reference/bin/arch_x64/sift cannot be started here (Vigra, OpenCV, Boost are DT_NEEDED and absent) and the
 sources cannot be rebuilt for the same reason, but `Sift::calculate` and the `sift::alg` functions inside it only need
@@ -181,5 +182,58 @@ def main():
     print("wrote", dst, os.path.getsize(dst), "bytes")
 
 
+def long_running(which):
+    """The pins that take the reference tens of minutes to hours (it copies three DoG images per candidate and re-blurs a
+    level per keypoint); each goes to its own fixture.
+        bench_frame   frame 1 of the bench workload, 1920x1080, 3 DoGs x 4 octaves          (51 minutes)
+        truncation    3488x1960 seed 13: 65594 survivors of the first cleanup, `u16_t size` keeps 58 (App. B-7)
+        configs       BASELINE.json configs[2] exactly as written (throws after 14 s; configs[4] as written would run for days)"""
+    import time
+    assert os.path.exists(REF_BIN), "the reference is not mounted here"
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_ref/refexec"])
+    with tempfile.TemporaryDirectory() as tmp:
+        if which == "bench_frame":
+            img = synth_frame(1920, 1080, 1)
+            t0 = time.time()
+            r = ref_calculate(img, 3, 4, 0, tmp)
+            store = {"params": np.array([3, 4, 0, 1920, 1080], np.int64), "image_sha": np.array(sha(img)), "seconds": np.array(time.time() - t0),
+                     "points": r["points"], "desc_sha": np.array(hashlib.sha256(r["desc"].tobytes()).hexdigest()),
+                     "levels_wh": np.array(r["levels_wh"], np.int64), "level_dims": r["level_dims"],
+                     "level_scale_bits": r["level_scale_bits"], "level_sha": np.array(r["level_sha"])}
+            np.savez_compressed(os.path.join(HERE, "refpin_bench_frame.npz"), **store)
+        elif which == "truncation":
+            w, h, seed = 3488, 1960, 13
+            img = synth_frame(w, h, seed)
+            src, out = os.path.join(tmp, "in.f32"), os.path.join(tmp, "out")
+            img.tofile(src)
+            t0 = time.time()
+            rc, so, se = refexec("calculate", src, w, h, 3, 4, repr(float(np.float32(1.6))), repr(K_SQRT2), 0, out)
+            store = {"params": np.array([3, 4, 0, w, h, seed], np.int64), "image_sha": np.array(sha(img)), "seconds": np.array(time.time() - t0),
+                     "rc": np.array(rc), "stdout": np.array(so)}
+            if rc == 0:
+                store["points"] = np.fromfile(out + ".points", np.uint8).view(POINT_DTYPE).reshape(-1)
+                store["desc"] = np.fromfile(out + ".desc", np.float32)
+            np.savez_compressed(os.path.join(HERE, "refpin_u16_truncation.npz"), **store)
+        elif which == "configs":
+            store = {}
+            for name, (w, h, seed, dogs, octaves, sub) in {"config3_as_written": (1920, 1080, 3, 5, 4, 1)}.items():
+                img = synth_frame(w, h, seed)
+                src, out = os.path.join(tmp, "in.f32"), os.path.join(tmp, "out")
+                img.tofile(src)
+                t0 = time.time()
+                rc, so, se = refexec("calculate", src, w, h, dogs, octaves, repr(float(np.float32(1.6))), repr(K_SQRT2), sub, out)
+                store[name + "/params"] = np.array([dogs, octaves, sub, w, h, seed], np.int64)
+                store[name + "/image_sha"] = np.array(sha(img))
+                store[name + "/rc"] = np.array(rc)
+                store[name + "/stdout"] = np.array(so)
+                store[name + "/seconds"] = np.array(time.time() - t0)
+            np.savez_compressed(os.path.join(HERE, "refpin_configs_as_written.npz"), **store)
+        else:
+            raise SystemExit("bench_frame | truncation | configs")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:
+        long_running(sys.argv[1])
+    else:
+        main()
