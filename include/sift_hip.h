@@ -74,7 +74,11 @@ void sift_hip_destroy(sift_hip_ctx* ctx);
  * its dispatch), "stream_min_waves" (process-wide; smallest launch, in waves, that takes the streaming blur instead of
  * the LDS-tiled one; default 1024, <= 0 restores it; the parity tests set 1 to run the streaming form on small
  * inputs), "orient_general" (0 default; 1: orientationHistogram36 reads every sample's bin even when the gradient pass
- * found all bins of the frame to be 0, which is what the reference's radians-as-degrees maps always give), "desc_dbg" (diagnostics only). */
+ * found all bins of the frame to be 0, which is what the reference's radians-as-degrees maps always give); measurement
+ * aids, results unchanged unless stated: "stream_waves" (process-wide; waves a streaming blur launch is cut into, default
+ * 2048, 0 = tile kernel only), "desc_dbg" / "orient_dbg" (phases switched off: timing only, WRONG results),
+ * "diag_pyramid_span", "diag_serial_gradient", "diag_cleanup_stamps" (print to stderr).  The library reads no
+ * environment variable. */
 int sift_hip_set_option(sift_hip_ctx* ctx, const char* name, int value);
 
 /* ---- several batches in flight on one GPU --------------------------------------------------------
@@ -87,7 +91,12 @@ int sift_hip_set_option(sift_hip_ctx* ctx, const char* name, int value);
 typedef struct sift_hip_gate sift_hip_gate;
 int sift_hip_gate_create(int device, sift_hip_gate** out);
 void sift_hip_gate_destroy(sift_hip_gate* gate);              /* after the contexts using it are detached or destroyed */
-int sift_hip_set_gate(sift_hip_ctx* ctx, sift_hip_gate* gate);   /* NULL detaches; not while a batch is running */
+/* NULL detaches; not while a batch is running.  SIFT_HIP_EINVAL for a gate of another device and for the fifth
+ * context on one gate (a gate tells at most four batches in flight apart). */
+int sift_hip_set_gate(sift_hip_ctx* ctx, sift_hip_gate* gate);
+/* Contexts that run side by side need hardware queues of their own: sift_hip_create / sift_hip_gate_create put
+ * GPU_MAX_HW_QUEUES=8 into the environment unless the host has set it, which the HIP runtime honours if it has not
+ * been initialised yet (i.e. when one of these is the process's first HIP call); otherwise export it yourself. */
 
 /* ---- Sift::calculate(), replaces sift.cpp:19-57 ---------------------------------------------- */
 /* n frames of w x h from HOST memory.  Results stay in the context until the next calculate. */
@@ -97,10 +106,14 @@ int sift_hip_calculate_batch(sift_hip_ctx* ctx, const float* host_imgs, int n, i
 int sift_hip_calculate_batch_device(sift_hip_ctx* ctx, const void* dev_imgs, int n, int w, int h,
                                     const sift_hip_params* params, char* err, int errlen);
 
-/* Per-image status of the last batch (an image that "threw" has count 0). */
-int sift_hip_result_status(sift_hip_ctx* ctx, int32_t* status /* n */);
+/* Images of the last batch whose results the context holds; -1 when it holds none (no batch yet, or the last calculate
+ * call failed before it ran: a failed call never leaves an earlier batch's results readable). */
+int sift_hip_result_images(sift_hip_ctx* ctx);
+/* Per-image status of the last batch (an image that "threw" has count 0).  `cap` = entries the caller's array holds;
+ * SIFT_HIP_EINVAL if that is fewer than sift_hip_result_images(). */
+int sift_hip_result_status(sift_hip_ctx* ctx, int32_t* status, int cap);
 /* Number of returned InterestPoints per image, and their sum. */
-int sift_hip_result_counts(sift_hip_ctx* ctx, int32_t* counts /* n */);
+int sift_hip_result_counts(sift_hip_ctx* ctx, int32_t* counts, int cap);
 int64_t sift_hip_result_total(sift_hip_ctx* ctx);
 /* Copy results (keypoints concatenated in image order, descriptors 128 floats each) to caller
  * buffers, which may be host or device memory. */
@@ -161,6 +174,28 @@ int sift_hip_sort_by_filter(sift_hip_ctx* ctx, const uint8_t* flags, int n, int3
  * std::sort glue; all must agree. */
 int sift_hip_cleanup_survivors(sift_hip_ctx* ctx, const uint8_t* flags, int n, int32_t* survivors,
                                int32_t* count, int on_gpu);
+
+/* ---- image files and the result overlay (host code, no GPU) ------------------------------------------
+ * What /root/reference/main.cpp does around calculate(): vigra::importImage (main.cpp:52-54), cv::imread (:59), the
+ * rotated boxes (:60-73) and cv::imwrite (:75).  Read: binary / ASCII PGM and PPM, PNG (every colour type, 1-16 bit,
+ * Adam7); a JPEG is refused (no libjpeg here).  Errors: SIFT_HIP_EPRECONDITION with a text in err. */
+int sift_hip_image_info(const char* path, int* w, int* h, int* bands, int* bits, char* err, int errlen);
+/* vigra::importImage into a scalar float array: band 0 of a multi-band file (red of RGB / palette), sample values
+ * unscaled (0..255; 0..65535 for 16-bit files), x fastest.  `cap` = floats `out` holds (>= w*h). */
+int sift_hip_image_read_band0(const char* path, float* out, long long cap, char* err, int errlen);
+/* cv::imread(path, CV_LOAD_IMAGE_COLOR): w*h*3 bytes in B,G,R order, grey replicated, alpha dropped, 16 -> 8 bit. */
+int sift_hip_image_read_bgr8(const char* path, uint8_t* out, long long cap, char* err, int errlen);
+/* cv::imwrite(path + ".png"): 8-bit RGB PNG of a B,G,R buffer. */
+int sift_hip_png_write_bgr8(const char* path, const uint8_t* bgr, int w, int h, char* err, int errlen);
+/* cv::RotatedRect(center, size, angle).points(): pts = x0 y0 x1 y1 x2 y2 x3 y3 (OpenCV 3.2 order: bottom-left,
+ * top-left, top-right, bottom-right for angle 0). */
+void sift_hip_rotated_rect_points(float cx, float cy, float width, float height, float angle, float* pts);
+/* The box main.cpp:60-67 builds for a keypoint: centre (loc * 2^octave) / (subpixel ? 2 : 1) stored in u16_t (wraps
+ * modulo 65536), side = (int)(scale * 10) (cv::Size holds ints), angle = orientation; any output may be NULL. */
+void sift_hip_overlay_box(const sift_hip_keypoint* kp, int subpixel, uint16_t* cx, uint16_t* cy, int* side, float* pts);
+/* main.cpp:60-73 on a B,G,R image: per keypoint the lines 0-1, 0-3, 2-3, 1-2 of its box, colour Scalar(255,0,0),
+ * drawn like cv::line's defaults (corner coordinates rounded to nearest even, clipped, 8-connected, 1 px). */
+int sift_hip_overlay_draw(uint8_t* bgr, int w, int h, const sift_hip_keypoint* kps, long long n, int subpixel);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* HIP-event timings of the pyramid kernels collected while option "profile" is 1.

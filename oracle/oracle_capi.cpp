@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <fstream>
 #include <memory>
 
 #include "sift_oracle.hpp"
@@ -149,6 +150,23 @@ void oracle_points_copy(const oracle_handle* h, int stage, oracle_point* out, fl
             for (int t = 0; t < 128; ++t) d[t] = t < (int)p.descriptors.size() ? p.descriptors[(size_t)t] : 0.0f;
         }
     }
+}
+
+// The result file of the reference's command line program (main.cpp:78-89), written with the same iostream inserters
+// (operator<< of u16_t and f32_t at the default precision): the expected text of the CLI parity tests.
+int oracle_write_result(const oracle_handle* h, const char* path) {
+    std::ofstream out(path);
+    if (!out) return 1;
+    out << "Location\tscale\torientation\tdescriptors\n";
+    for (const InterestPoint& p : h->result) {
+        out << "[" << p.x << ", " << p.y << "]\t" << p.scale << "\t" << p.orientation << "\t" << "[";
+        for (f32 d : p.descriptors) {
+            out << d << ", ";
+        }
+        out << "]\n";
+    }
+    out.close();
+    return out ? 0 : 1;
 }
 
 // ---- known-answer-test helpers -------------------------------------------------------------

@@ -17,7 +17,7 @@ OK, EPRECONDITION, EASSERT, EINVAL, EHIP = 0, 1, 2, 3, 4
 # every symbol include/sift_hip.h declares
 SYMBOLS = [
     "sift_hip_create", "sift_hip_destroy", "sift_hip_set_option", "sift_hip_calculate_batch",
-    "sift_hip_calculate_batch_device", "sift_hip_result_status", "sift_hip_result_counts",
+    "sift_hip_calculate_batch_device", "sift_hip_result_images", "sift_hip_result_status", "sift_hip_result_counts",
     "sift_hip_result_total", "sift_hip_result_copy", "sift_hip_result_device", "sift_hip_image_dims",
     "sift_hip_image_copy", "sift_hip_level_dims", "sift_hip_level_copy", "sift_hip_level_scale",
     "sift_hip_stage_count", "sift_hip_stage_copy", "sift_hip_gauss_taps", "sift_hip_convolve_with_gauss",
@@ -25,6 +25,8 @@ SYMBOLS = [
     "sift_hip_edge_responses", "sift_hip_vertex_parabola", "sift_hip_sort_by_filter", "sift_hip_cleanup_survivors", "sift_hip_profile_get",
     "sift_hip_profile_reset", "sift_hip_version", "sift_hip_gate_create", "sift_hip_gate_destroy", "sift_hip_set_gate",
     "sift_hip_result_sparse_size", "sift_hip_result_sparse_pack",
+    "sift_hip_image_info", "sift_hip_image_read_band0", "sift_hip_image_read_bgr8", "sift_hip_png_write_bgr8",
+    "sift_hip_rotated_rect_points", "sift_hip_overlay_box", "sift_hip_overlay_draw",
 ]
 
 
@@ -87,8 +89,9 @@ def load():
     L.sift_hip_set_option.argtypes = [vp, cs, ci]
     L.sift_hip_calculate_batch.argtypes = [vp, fp, ci, ci, ci, C.POINTER(Params), cs, ci]
     L.sift_hip_calculate_batch_device.argtypes = [vp, vp, ci, ci, ci, C.POINTER(Params), cs, ci]
-    L.sift_hip_result_status.argtypes = [vp, i32p]
-    L.sift_hip_result_counts.argtypes = [vp, i32p]
+    L.sift_hip_result_images.argtypes = [vp]
+    L.sift_hip_result_status.argtypes = [vp, i32p, ci]
+    L.sift_hip_result_counts.argtypes = [vp, i32p, ci]
     L.sift_hip_result_total.argtypes = [vp]
     L.sift_hip_result_total.restype = C.c_int64
     L.sift_hip_result_copy.argtypes = [vp, vp, vp]
@@ -113,5 +116,15 @@ def load():
     L.sift_hip_cleanup_survivors.argtypes = [vp, u8p, ci, i32p, C.POINTER(C.c_int32), ci]
     L.sift_hip_profile_get.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.sift_hip_profile_reset.argtypes = [vp]
+    ll = C.c_longlong
+    L.sift_hip_image_info.argtypes = [cs, ip, ip, ip, ip, cs, ci]
+    L.sift_hip_image_read_band0.argtypes = [cs, fp, ll, cs, ci]
+    L.sift_hip_image_read_bgr8.argtypes = [cs, u8p, ll, cs, ci]
+    L.sift_hip_png_write_bgr8.argtypes = [cs, u8p, ci, ci, cs, ci]
+    L.sift_hip_rotated_rect_points.argtypes = [C.c_float] * 5 + [fp]
+    L.sift_hip_rotated_rect_points.restype = None
+    L.sift_hip_overlay_box.argtypes = [vp, ci, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), ip, fp]
+    L.sift_hip_overlay_box.restype = None
+    L.sift_hip_overlay_draw.argtypes = [u8p, ci, ci, vp, ll, ci]
     _lib = L
     return L

@@ -3,38 +3,54 @@ overlay :59-76) on top of the GPU path — SURVEY.md §8(f) rows 1-3.
 
     python -m sift_amd.cli -i image.pgm [-s 1.6] [-k 1.41421354] [-o 4] [-d 3] [-p 0] [-r 1]
 
-Image ingest follows Vigra's scalar import: band 0 of multi-band files, values
-0..255 unscaled.  Needs PIL for anything but binary PGM.
+Image ingest follows Vigra's scalar import: band 0 of multi-band files, values unscaled.  PGM,
+PPM and PNG are decoded by the library itself (sift_amd/csrc/image_io.cpp: no PIL, no OpenCV); JPEG is refused.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import math
 import sys
 
 import numpy as np
 
+from . import _lib
 from .sift import K_SQRT2, PreconditionViolation, Sift
 
 
+def _err_call(fn, *args):
+    err = C.create_string_buffer(512)
+    rc = fn(*args, err, 512)
+    if rc:
+        raise OSError(err.value.decode(errors="replace") or f"sift_hip image call failed ({rc})")
+
+
+def image_info(path: str):
+    """(width, height, bands, bits per sample) of a PGM / PPM / PNG file."""
+    L = _lib.load()
+    w, h, b, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    _err_call(L.sift_hip_image_info, path.encode(), C.byref(w), C.byref(h), C.byref(b), C.byref(d))
+    return w.value, h.value, b.value, d.value
+
+
 def read_image(path: str) -> np.ndarray:
-    with open(path, "rb") as f:
-        head = f.read(2)
-    if head == b"P5":
-        with open(path, "rb") as f:
-            assert f.readline().strip() == b"P5"
-            line = f.readline()
-            while line.startswith(b"#"):
-                line = f.readline()
-            w, h = map(int, line.split())
-            maxv = int(f.readline())
-            data = np.frombuffer(f.read(), np.uint8 if maxv < 256 else ">u2").reshape(h, w)
-        return np.ascontiguousarray(data, dtype=np.float32)
-    from PIL import Image
-    img = np.asarray(Image.open(path))
-    if img.ndim == 3:
-        img = img[:, :, 0]  # band 0, like vigra::importImage into a scalar array
-    return np.ascontiguousarray(img, dtype=np.float32)
+    """vigra::importImage into a scalar float array (main.cpp:52-54): band 0, values unscaled.  Decoded by the
+    library's own PGM / PPM / PNG reader (sift_amd/csrc/image_io.cpp), no PIL."""
+    L = _lib.load()
+    w, h, _, _ = image_info(path)
+    out = np.empty((h, w), np.float32)
+    _err_call(L.sift_hip_image_read_band0, path.encode(), out.reshape(-1), out.size)
+    return out
+
+
+def read_image_bgr(path: str) -> np.ndarray:
+    """cv::imread(path, CV_LOAD_IMAGE_COLOR) (main.cpp:59): [h, w, 3] uint8 in B, G, R order."""
+    L = _lib.load()
+    w, h, _, _ = image_info(path)
+    out = np.empty((h, w, 3), np.uint8)
+    _err_call(L.sift_hip_image_read_bgr8, path.encode(), out.reshape(-1), out.size)
+    return out
 
 
 def fmt(v: float) -> str:
@@ -57,23 +73,33 @@ def write_result(path: str, points) -> None:
             out.write("]\n")
 
 
+def keypoint_records(points) -> np.ndarray:
+    kp = np.zeros(len(points), _lib.KEYPOINT_DTYPE)
+    for i, p in enumerate(points):
+        kp[i] = (p.scale, p.orientation, p.loc[0], p.loc[1], p.octave, p.index, p.filtered, bool(p.descriptors), 0)
+    return kp
+
+
+def overlay_box(kp_record, subpixel: bool):
+    """The box main.cpp:60-67 draws for one keypoint: (cx, cy, side, corner points [4, 2])."""
+    L = _lib.load()
+    rec = np.asarray(kp_record, _lib.KEYPOINT_DTYPE).reshape(1)
+    cx, cy, side = C.c_uint16(), C.c_uint16(), C.c_int()
+    pts = np.zeros(8, np.float32)
+    L.sift_hip_overlay_box(rec.ctypes.data, int(subpixel), C.byref(cx), C.byref(cy), C.byref(side), pts)
+    return cx.value, cy.value, side.value, pts.reshape(4, 2)
+
+
 def draw_overlay(src_path: str, points, subpixel: bool, dst_path: str) -> None:
-    """Rotated boxes of side 10*scale at (loc * 2^octave) / subpixel_divisor, 1-px blue lines
-    (main.cpp:59-76; OpenCV's Scalar(255,0,0) is BGR blue)."""
-    from PIL import Image, ImageDraw
-    img = Image.open(src_path).convert("RGB")
-    draw = ImageDraw.Draw(img)
-    div = 2 if subpixel else 1
-    for p in points:
-        x = int((p.loc[0] * 2 ** p.octave) / div) & 0xFFFF
-        y = int((p.loc[1] * 2 ** p.octave) / div) & 0xFFFF
-        half = int(p.scale * 10) / 2.0
-        a = math.radians(p.orientation) if not math.isnan(p.orientation) else 0.0
-        ca, sa = math.cos(a), math.sin(a)
-        corners = [(-half, -half), (half, -half), (half, half), (-half, half)]
-        pts = [(x + cx * ca - cy * sa, y + cx * sa + cy * ca) for cx, cy in corners]
-        draw.line(pts + [pts[0]], fill=(0, 0, 255), width=1)
-    img.save(dst_path)
+    """main.cpp:59-76: rotated boxes of side (int)(10*scale) at (loc * 2^octave) / subpixel_divisor on the colour image,
+    1-px lines of Scalar(255, 0, 0) (blue in OpenCV's BGR), written as PNG."""
+    L = _lib.load()
+    img = read_image_bgr(src_path)
+    kp = points if isinstance(points, np.ndarray) else keypoint_records(points)
+    h, w, _ = img.shape
+    if L.sift_hip_overlay_draw(img.reshape(-1), w, h, kp.ctypes.data, kp.size, int(subpixel)):
+        raise ValueError("sift_hip_overlay_draw failed")
+    _err_call(L.sift_hip_png_write_bgr8, dst_path.encode(), img.reshape(-1), w, h)
 
 
 def main(argv=None) -> int:
@@ -97,10 +123,7 @@ def main(argv=None) -> int:
         sift = Sift(args.dogsPerEpoch, args.octaves, args.sigma, args.k, bool(args.subpixel))
         points = sift.calculate(img)
         if not args.no_overlay:
-            try:
-                draw_overlay(path, points, sift.subpixel, path + "_orientation.png")
-            except ImportError:
-                print("PIL not available: overlay skipped", file=sys.stderr)
+            draw_overlay(path, points, sift.subpixel, path + "_orientation.png")
         if args.result:
             write_result("interstpoints.txt", points)
         print(f"{len(points)} interest points")

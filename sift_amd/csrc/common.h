@@ -99,6 +99,8 @@ bool launch_blur_reduce(hipStream_t s, const float* in, float* dst, int w, int h
                         int radius, const int* d_inv_x, const int* d_inv_y, float* d_dump, hipEvent_t ev_start = nullptr,
                         hipEvent_t ev_stop = nullptr);
 void set_stream_min_waves(int v);  // <= 0 restores the default
+void set_stream_waves(int v);      // < 0 restores the default; 0 = tile kernel only
+void set_orient_dbg(int v);        // timing ablations of the orientation kernel (results are wrong when != 0)
 void launch_resample(hipStream_t s, const float* src, float* dst, int ws, int hs, int wd, int hd, int n,
                      const int* d_lutx, const int* d_luty);
 void launch_dog(hipStream_t s, const float* lower, const float* higher, float* out, size_t count);

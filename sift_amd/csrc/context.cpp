@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -107,6 +108,7 @@ struct sift_hip_ctx {
     hipStream_t stream2 = nullptr;          // side stream: work that can overlap the 1-block-per-image cleanup
     hipEvent_t ev_fork0 = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_grad = nullptr;
     sift_hip::PhaseGate* gate = nullptr;   // shared with the other contexts of a BatchPipeline, or null
+    struct sift_hip_gate* gate_owner = nullptr;
     long long gate_ticket = -1;             // this batch's ticket while it runs
     bool fused = true;
     bool fused_edge = true;   // extremum scan and edge filter in one LDS-tiled pass
@@ -132,6 +134,8 @@ struct sift_hip_ctx {
     HostBuf h_flags, h_orient, h_peaks, h_status;
     hipEvent_t ev_sync = nullptr;
     bool spin_wait = true;    // poll an event instead of sleeping in hipStreamSynchronize (tens of microseconds per batch)
+    // diagnostics (options "diag_pyramid_span", "diag_serial_gradient", "diag_cleanup_stamps"): all off by default
+    bool diag_pyramid_span = false, diag_serial_gradient = false, diag_cleanup_stamps = false;
     // results of the last batch
     std::vector<int32_t> status, counts;
     std::vector<std::string> messages;
@@ -142,6 +146,7 @@ struct sift_hip_ctx {
     std::vector<std::vector<PointRec>> final_list;      // after second cleanup
     std::vector<long long> out_base;
     long long total = 0;
+    long long last_total = 0;   // of the previous batch: sizes the output arrays before this batch's counts are known
     bool have_result = false;
     bool have_pyramid = false;
     bool stages_on_host = false;
@@ -178,7 +183,7 @@ hipEvent_t get_event(sift_hip_ctx* c) {
 }
 
 void resolve_events(sift_hip_ctx* c) {
-    if (c->pending.size() >= 2 && getenv("SIFT_PYRAMID_SPAN")) {   // diagnostics: wall time of the blur chain vs the sum of its kernels
+    if (c->pending.size() >= 2 && c->diag_pyramid_span) {   // diagnostics: wall time of the blur chain vs the sum of its kernels
         float span = 0, sum = 0;
         (void)hipEventSynchronize(c->pending.back().b);
         (void)hipEventElapsedTime(&span, c->pending.front().a, c->pending.back().b);
@@ -665,9 +670,10 @@ void bin_keypoints(sift_hip_ctx* c) {
 
 void ensure_outputs(sift_hip_ctx* c, long long keypoints) {
     if (keypoints <= c->out_cap) return;
-    c->out_cap = keypoints;
+    c->out_cap = 0;   // until both arrays exist at the new size (an allocation that throws leaves them freed)
     c->d_kp.ensure((size_t)keypoints * sizeof(sift_hip_keypoint));
     c->d_desc.ensure((size_t)keypoints * 128 * sizeof(float));
+    c->out_cap = keypoints;
 }
 
 void launch_descriptor_stage(sift_hip_ctx* c) {
@@ -736,8 +742,11 @@ bool mid_gpu(sift_hip_ctx* c) {
     // scan and the output arrays keep a generous capacity; should a batch ever exceed it, the (idempotent: the
     // mutated maps only live in LDS) stage is simply run again after growing them.
     launch_out_base(s, c->d_final_cnt.as<int>(), n, c->d_out_base.as<long long>());
-    ensure_outputs(c, std::max<long long>(c->out_cap, (long long)n * 32768));
+    // capacity guess: a quarter above what this context's previous batch returned; before the first one 24576 keypoints
+    // per image (a 1080p frame returns ~20 k; 13 MB of results per image)
+    ensure_outputs(c, std::max<long long>(c->out_cap, c->last_total > 0 ? c->last_total + c->last_total / 4 : (long long)n * 24576));
     launch_descriptor_stage(c);
+    SIFT_HIP_CHECK(hipGetLastError());
     if (c->gate) c->gate->mark(c->gate_ticket, sift_hip::PhaseGate::kD, s);
     c->described = true;
     c->h_status.ensure((size_t)n * 5 * sizeof(int));
@@ -745,7 +754,7 @@ bool mid_gpu(sift_hip_ctx* c) {
     SIFT_HIP_CHECK(hipMemcpyAsync(c->h_status.p, c->d_status.p, (size_t)n * 5 * sizeof(int), hipMemcpyDeviceToHost, s));
     resolve_events(c);   // the pyramid's timing events completed long ago: read them while the GPU is still busy
     wait_stream(c, s);
-    if (getenv("SIFT_CLEANUP2_STAMPS")) {   // diagnostics: phases of the second cleanup (image 0)
+    if (c->diag_cleanup_stamps) {   // diagnostics: phases of the second cleanup (image 0)
         static unsigned long long* dst = nullptr;
         if (!dst) { (void)hipMalloc(&dst, 512 * sizeof(unsigned long long)); (void)hipMemset(dst, 0, 512 * sizeof(unsigned long long)); cleanup_set_stamp_buffer(dst); }
         else {
@@ -856,6 +865,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     } gate_scope{c};
     c->gate_ticket = c->gate ? c->gate->begin_batch(s) : -1;
     run_pyramid(c, d_in);
+    SIFT_HIP_CHECK(hipGetLastError());   // a rejected launch configuration must not go unnoticed
     if (c->gate) c->gate->mark(c->gate_ticket, sift_hip::PhaseGate::kP, s);
     c->have_pyramid = true;
     if (P.fail_status) {
@@ -871,7 +881,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     // Gradient maps and W16 only need the pyramid: side stream, from here on.  (Not earlier: sharing the
     // CUs with the HBM-bound blur kernels slows those by more than the overlap wins.)
     const DevPlan* dpl = c->d_plan.as<DevPlan>();
-    static const bool serial_gradient = getenv("SIFT_SERIAL_GRADIENT") != nullptr;   // diagnostics: no overlap
+    const bool serial_gradient = c->diag_serial_gradient;   // diagnostics: no overlap
     hipStream_t gs = serial_gradient ? s : c->stream2;
     SIFT_HIP_CHECK(hipEventRecord(c->ev_fork0, s));
     SIFT_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork0, 0));
@@ -917,6 +927,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
                            2 /* also the late launch's counters, which follow */);
     }
     SIFT_HIP_CHECK(hipEventRecord(c->ev_join, c->stream2));
+    SIFT_HIP_CHECK(hipGetLastError());
     // cleanup, orientation assignment, cleanup (sift.cpp:37-54)
     if (!(c->gpu_cleanup && mid_gpu(c))) {
         for (int i = 0; i < n; ++i) { c->status[(size_t)i] = 0; c->messages[(size_t)i].clear(); }
@@ -931,6 +942,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
         total += c->counts[(size_t)i];
     }
     c->total = total;
+    c->last_total = total;
     if (c->described && total > c->out_cap) c->described = false;   // outputs were too small: grow and redo
     if (!c->described) {
         ensure_outputs(c, std::max<long long>(total, 1));
@@ -970,6 +982,12 @@ int guarded(char* err, int errlen, F&& f) {
 }  // namespace
 
 // =====================================================================================================
+// Contexts that run batches side by side need hardware queues of their own: with the HIP runtime's default of 4, streams
+// of different contexts share a queue and inherit each other's ordering (the phase gate then loses what it arranges).
+// The runtime reads GPU_MAX_HW_QUEUES when it initialises, so this only has an effect if it comes before the process's
+// first HIP call; a value the host has set is left alone.
+static void default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 extern "C" {
 
 const char* sift_hip_version(void) { return "sift_hip 0.1 (gfx950)"; }
@@ -977,6 +995,7 @@ const char* sift_hip_version(void) { return "sift_hip 0.1 (gfx950)"; }
 int sift_hip_create(int device, sift_hip_ctx** out, char* err, int errlen) {
     if (!out) return SIFT_HIP_EINVAL;
     *out = nullptr;
+    default_hw_queues();
     return guarded(err, errlen, [&]() {
         int count = 0;
         SIFT_HIP_CHECK(hipGetDeviceCount(&count));
@@ -1003,6 +1022,7 @@ void sift_hip_destroy(sift_hip_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    (void)sift_hip_set_gate(c, nullptr);
     for (DevBuf* b : {&c->arena, &c->d_plan, &c->d_taps, &c->d_luts, &c->d_taps16, &c->d_input, &c->d_base, &c->d_tmp, &c->d_tmp2,
                       &c->d_wk, &c->d_wi, &c->d_wi2, &c->d_wp, &c->d_status, &c->d_tile, &c->d_pool, &c->d_order, &c->d_masks, &c->d_fmasks, &c->d_counts, &c->d_totals, &c->d_cands, &c->d_flags, &c->d_list, &c->d_list_cnt, &c->d_orient,
                       &c->d_peaks, &c->d_final, &c->d_final_cnt, &c->d_out_base, &c->d_kp, &c->d_desc, &c->d_lrank, &c->d_ochunk, &c->d_ocnt, &c->d_recs, &c->d_wire_sums, &c->d_wire_off})
@@ -1023,14 +1043,20 @@ void sift_hip_destroy(sift_hip_ctx* c) {
 struct sift_hip_gate {
     int device;
     sift_hip::PhaseGate gate;
+    std::mutex m;
+    int attached = 0;     // contexts joined by this gate (at most PhaseGate::kMaxContexts: its slot ring)
 };
+
 
 int sift_hip_gate_create(int device, sift_hip_gate** out) {
     if (!out) return SIFT_HIP_EINVAL;
+    default_hw_queues();
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return SIFT_HIP_EINVAL;
     if (hipSetDevice(device) != hipSuccess) return SIFT_HIP_EHIP;
-    *out = new sift_hip_gate{device, {}};
+    auto* g = new sift_hip_gate();
+    g->device = device;
+    *out = g;
     return SIFT_HIP_OK;
 }
 
@@ -1042,6 +1068,18 @@ void sift_hip_gate_destroy(sift_hip_gate* g) {
 
 int sift_hip_set_gate(sift_hip_ctx* c, sift_hip_gate* g) {
     if (!c || (g && g->device != c->device)) return SIFT_HIP_EINVAL;
+    if (c->gate_owner == g) return SIFT_HIP_OK;
+    if (g) {
+        std::lock_guard<std::mutex> lk(g->m);
+        // more contexts than the gate's ring can tell apart would reuse the slot of a batch that is still live
+        if (g->attached >= sift_hip::PhaseGate::kMaxContexts) return SIFT_HIP_EINVAL;
+        g->attached++;
+    }
+    if (c->gate_owner) {
+        std::lock_guard<std::mutex> lk(c->gate_owner->m);
+        c->gate_owner->attached--;
+    }
+    c->gate_owner = g;
     c->gate = g ? &g->gate : nullptr;
     return SIFT_HIP_OK;
 }
@@ -1057,6 +1095,11 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     if (!std::strcmp(name, "profile")) { c->profile = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "orient_general")) { c->orient_general = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "stream_min_waves")) { set_stream_min_waves(value); return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "stream_waves")) { set_stream_waves(value); return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "orient_dbg")) { set_orient_dbg(value); return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "diag_pyramid_span")) { c->diag_pyramid_span = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "diag_serial_gradient")) { c->diag_serial_gradient = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "diag_cleanup_stamps")) { c->diag_cleanup_stamps = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "host_threads")) { c->host_threads = value; return SIFT_HIP_OK; }
     return SIFT_HIP_EINVAL;
 }
@@ -1066,6 +1109,7 @@ int sift_hip_calculate_batch_device(sift_hip_ctx* c, const void* dev_imgs, int n
     if (!c || !dev_imgs || !params) return SIFT_HIP_EINVAL;
     return guarded(err, errlen, [&]() {
         SIFT_HIP_CHECK(hipSetDevice(c->device));
+        c->have_result = c->have_pyramid = false;   // whatever happens next, the previous batch's results are gone
         std::string msg;
         const int rc = build_plan(c, n, w, h, *params, msg);
         if (rc) { set_err(err, errlen, msg); return rc; }
@@ -1078,6 +1122,7 @@ int sift_hip_calculate_batch(sift_hip_ctx* c, const float* host_imgs, int n, int
     if (!c || !host_imgs || !params || n <= 0 || w <= 0 || h <= 0) return SIFT_HIP_EINVAL;
     return guarded(err, errlen, [&]() {
         SIFT_HIP_CHECK(hipSetDevice(c->device));
+        c->have_result = c->have_pyramid = false;   // whatever happens next, the previous batch's results are gone
         const size_t bytes = (size_t)n * (size_t)w * (size_t)h * sizeof(float);
         c->d_input.ensure(bytes);
         SIFT_HIP_CHECK(hipMemcpyAsync(c->d_input.p, host_imgs, bytes, hipMemcpyHostToDevice, c->stream));
@@ -1088,13 +1133,14 @@ int sift_hip_calculate_batch(sift_hip_ctx* c, const float* host_imgs, int n, int
     });
 }
 
-int sift_hip_result_status(sift_hip_ctx* c, int32_t* status) {
-    if (!c || !c->have_result) return SIFT_HIP_EINVAL;
+int sift_hip_result_images(sift_hip_ctx* c) { return (c && c->have_result) ? (int)c->status.size() : -1; }
+int sift_hip_result_status(sift_hip_ctx* c, int32_t* status, int cap) {
+    if (!c || !c->have_result || !status || cap < (int)c->status.size()) return SIFT_HIP_EINVAL;
     std::copy(c->status.begin(), c->status.end(), status);
     return SIFT_HIP_OK;
 }
-int sift_hip_result_counts(sift_hip_ctx* c, int32_t* counts) {
-    if (!c || !c->have_result) return SIFT_HIP_EINVAL;
+int sift_hip_result_counts(sift_hip_ctx* c, int32_t* counts, int cap) {
+    if (!c || !c->have_result || !counts || cap < (int)c->counts.size()) return SIFT_HIP_EINVAL;
     std::copy(c->counts.begin(), c->counts.end(), counts);
     return SIFT_HIP_OK;
 }
@@ -1205,7 +1251,7 @@ int sift_hip_level_copy(sift_hip_ctx* c, int image, int kind, int octave, int le
     });
 }
 float sift_hip_level_scale(sift_hip_ctx* c, int kind, int octave, int level) {
-    if (!c || !c->plan.valid) return NAN;
+    if (!c || !c->plan.valid || octave < 0 || octave >= c->plan.O || level < 0 || level >= (kind == 1 ? c->plan.D : c->plan.D + 1)) return NAN;
     return kind == 1 ? c->plan.dev.dog_scale[octave * c->plan.D + level] : c->plan.dev.gauss_scale[octave * (c->plan.D + 1) + level];
 }
 
@@ -1465,7 +1511,7 @@ int sift_hip_cleanup_survivors(sift_hip_ctx* c, const uint8_t* flags, int n, int
         uint32_t* out = s.dev<uint32_t>(m);
         int* info = s.dev<int>(2);
         unsigned long long* st = nullptr;
-        if (getenv("SIFT_CLEANUP_STAMPS")) {
+        if (c->diag_cleanup_stamps) {
             st = s.dev<unsigned long long>(512);
             SIFT_HIP_CHECK(hipMemset(st, 0, 512 * sizeof(unsigned long long)));
             cleanup_set_stamp_buffer(st);

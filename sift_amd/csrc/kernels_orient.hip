@@ -430,12 +430,15 @@ void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, floa
     hipLaunchKernelGGL(gradient_kernel, grid, dim3(256), 0, s, g, mag, ori, prod, obin, w, h, d_any_bin);
 }
 
+static int g_orient_dbg = 0;
+void set_orient_dbg(int v) { g_orient_dbg = v; }
+
 void launch_orientation(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const Candidate* d_cands,
                         const OrientIn* d_oin, const int* d_list_cnt, int list_cap, OrientOut* d_out,
                         float* d_peaks, int* d_next_group, const int* d_any_bin, int zero_counters) {
     (void)d_cands;
     const dim3 grid(128, (unsigned)plan.n_images);
-    static const int dbg = [] { const char* e = getenv("SIFT_ORIENT_DBG"); return e ? atoi(e) : 0; }();   // timing ablations only
+    const int dbg = g_orient_dbg;   // option "orient_dbg": timing ablations only
     // zero_counters: how many consecutive per-image counter arrays to clear first (0: the caller already did)
     if (zero_counters > 0) (void)hipMemsetAsync(d_next_group, 0, sizeof(int) * (size_t)plan.n_images * (size_t)zero_counters, s);
     hipLaunchKernelGGL(orientation_kernel, grid, dim3(256), 0, s, d_plan, d_oin, d_list_cnt, list_cap, d_out,

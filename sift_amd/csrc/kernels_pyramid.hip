@@ -568,10 +568,10 @@ static void launch_fused_r(hipStream_t s, const float* in, float* out, float* do
     launch_fused_rt<R, 64>(s, in, out, dog, w, h, n, d_taps);
 }
 
-static int stream_waves() {
-    static int v = [] { const char* e = getenv("SIFT_STREAM_WAVES"); return e ? atoi(e) : 2048; }();
-    return v;
-}
+constexpr int kStreamWaves = 2048;     // waves a streaming launch is cut into (8 per CU)
+static int g_stream_waves = kStreamWaves;   // option "stream_waves" (process-wide; 0: tile kernel only): A/B measurements
+void set_stream_waves(int v) { g_stream_waves = v < 0 ? kStreamWaves : v; }
+static int stream_waves() { return g_stream_waves; }
 
 constexpr int kMaxRadiusStream = 14;   // beyond: the 2R+1 partial sums per column no longer fit the register file
 constexpr int kMinStreamWaves = 1024;  // below one wave per SIMD the tile kernel's finer work units win

@@ -115,8 +115,12 @@ public:
         cv_.notify_all();
     }
 
-private:
     static constexpr int kRing = 8;
+    // every batch is waited for by its owner before the owner submits again, so with at most kRing / 2 contexts a slot's
+    // previous user (ticket g - kRing) is long done when ticket g takes it; sift_hip_set_gate enforces the limit
+    static constexpr int kMaxContexts = kRing / 2;
+
+private:
     struct Slot {
         long long g = -1;
         hipEvent_t ev[3] = {nullptr, nullptr, nullptr};

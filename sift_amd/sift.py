@@ -97,7 +97,7 @@ class Context:
 
     def set_gate(self, gate: "Gate | None"):
         if self._L.sift_hip_set_gate(self._h, gate._h if gate is not None else None):
-            raise ValueError("gate and context are on different devices")
+            raise ValueError("gate and context are on different devices, or the gate already joins its maximum of four contexts")
 
     def set_option(self, name: str, value: int):
         if self._L.sift_hip_set_option(self._h, name.encode(), int(value)):
@@ -111,7 +111,6 @@ class Context:
         n, h, w = imgs.shape
         err = C.create_string_buffer(512)
         rc = self._L.sift_hip_calculate_batch(self._h, imgs.reshape(-1), n, w, h, C.byref(params), err, 512)
-        self._n = n
         if rc and raise_on_error:
             _raise(rc, err)
         return rc, err.value.decode(errors="replace")
@@ -119,20 +118,26 @@ class Context:
     def calculate_batch_device(self, dev_ptr: int, n: int, w: int, h: int, params, raise_on_error=True):
         err = C.create_string_buffer(512)
         rc = self._L.sift_hip_calculate_batch_device(self._h, C.c_void_p(dev_ptr), n, w, h, C.byref(params), err, 512)
-        self._n = n
         if rc and raise_on_error:
             _raise(rc, err)
         return rc, err.value.decode(errors="replace")
 
+    def n_images(self) -> int:
+        """Images of the batch whose results the context holds (the library's count, not the caller's)."""
+        n = int(self._L.sift_hip_result_images(self._h))
+        if n < 0:
+            raise HipError("no result")
+        return n
+
     def counts(self):
-        out = np.zeros(self._n, np.int32)
-        if self._L.sift_hip_result_counts(self._h, out):
+        out = np.zeros(self.n_images(), np.int32)
+        if self._L.sift_hip_result_counts(self._h, out, out.size):
             raise HipError("no result")
         return out
 
     def status(self):
-        out = np.zeros(self._n, np.int32)
-        if self._L.sift_hip_result_status(self._h, out):
+        out = np.zeros(self.n_images(), np.int32)
+        if self._L.sift_hip_result_status(self._h, out, out.size):
             raise HipError("no result")
         return out
 

@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from golden_util import read_pgm, sha  # noqa: E402
-from sift_amd.synthetic import synth_frame  # noqa: E402
+from sift_amd.synthetic import blob_frame, synth_frame  # noqa: E402
 
 REF_BIN = "/root/reference/bin/arch_x64/sift"
 REFEXEC = os.path.join(ROOT, "oracle", "_ref", "refexec")
@@ -186,7 +186,8 @@ def long_running(which):
     """The pins that take the reference tens of minutes to hours (it copies three DoG images per candidate and re-blurs a
     level per keypoint); each goes to its own fixture.
         bench_frame   frame 1 of the bench workload, 1920x1080, 3 DoGs x 4 octaves          (51 minutes)
-        truncation    3488x1960 seed 13: 65594 survivors of the first cleanup, `u16_t size` keeps 58 (App. B-7)
+        truncation    blob_frame 1024x1088 seed 5: 66260 survivors of the first cleanup, `u16_t size` keeps 724 (App. B-7); the
+                      reference copies three DoG images per candidate (2.7 TB of copies for the 220 716 candidates)
         configs       BASELINE.json configs[2] exactly as written (throws after 14 s; configs[4] as written would run for days)"""
     import time
     assert os.path.exists(REF_BIN), "the reference is not mounted here"
@@ -202,8 +203,8 @@ def long_running(which):
                      "level_scale_bits": r["level_scale_bits"], "level_sha": np.array(r["level_sha"])}
             np.savez_compressed(os.path.join(HERE, "refpin_bench_frame.npz"), **store)
         elif which == "truncation":
-            w, h, seed = 3488, 1960, 13
-            img = synth_frame(w, h, seed)
+            w, h, seed = 1024, 1088, 5
+            img = blob_frame(w, h, seed)
             src, out = os.path.join(tmp, "in.f32"), os.path.join(tmp, "out")
             img.tofile(src)
             t0 = time.time()

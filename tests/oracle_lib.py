@@ -54,6 +54,7 @@ def lib():
         L.oracle_level_scale.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.oracle_points_count.argtypes = [C.c_void_p, C.c_int]
         L.oracle_points_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_write_result.argtypes = [C.c_void_p, C.c_char_p]
         L.oracle_gauss_taps.argtypes = [C.c_float, fp, C.c_int]
         L.oracle_convolve.argtypes = [fp, C.c_int, C.c_int, C.c_float, fp, C.c_char_p, C.c_int]
         L.oracle_resize_index_map.argtypes = [C.c_int, C.c_int, ip]
@@ -122,6 +123,11 @@ class OracleRun:
 
     def scale(self, kind, o, i):
         return lib().oracle_level_scale(self._h, self.KINDS[kind], o, i)
+
+    def write_result(self, path):
+        """interstpoints.txt as the reference's main.cpp:78-89 writes it (C++ iostream formatting)."""
+        if lib().oracle_write_result(self._h, os.fsencode(path)):
+            raise OSError(f"cannot write {path}")
 
     def points(self, stage="final"):
         s = self.STAGES[stage]

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
+from golden_util import read_pgm
 from sift_amd import _lib
 from sift_amd.sift import Context, PreconditionViolation, Sift, gauss_taps
 from sift_amd.synthetic import synth_frame
@@ -474,25 +475,57 @@ def test_pipeline_parity_host_glue_path(ctx, report_dir):
         ctx.set_option("gpu_cleanup", 1)
 
 
+def expected_result_file(tmp_path, img, dogs, octaves, subpixel=False):
+    """interstpoints.txt as the reference's main.cpp:78-89 writes it for the oracle's points (C++ iostream formatting)."""
+    run = O.OracleRun(img, dogs, octaves, subpixel=subpixel)
+    path = tmp_path / "expected_interstpoints.txt"
+    run.write_result(path)
+    return open(path, "rb").read(), run
+
+
+def check_overlay(png_path, src_bgr, run, subpixel):
+    """<img>_orientation.png = the colour image with the boxes of main.cpp:60-73 for the oracle's points."""
+    from sift_amd import cli
+    pts, desc = run.points("final")
+    kp = np.zeros(pts.size, _lib.KEYPOINT_DTYPE)
+    for f in ("scale", "orientation", "x", "y", "octave", "index"):
+        kp[f] = pts[f]
+    want = src_bgr.copy()
+    h, w, _ = want.shape
+    assert _lib.load().sift_hip_overlay_draw(want.reshape(-1), w, h, kp.ctypes.data, kp.size, int(subpixel)) == 0
+    got = cli.read_image_bgr(str(png_path))
+    assert np.array_equal(got, want)
+    assert (got != src_bgr).any()
+
+
 def test_cpp_dropin_example(ctx, tmp_path):
-    """examples/sift_points.cpp (the C++ sift::Sift drop-in over the C ABI) on the parrot fixture."""
+    """examples/sift_points.cpp (the C++ sift::Sift drop-in over the C ABI, shaped like the reference's main.cpp) on the parrot
+    fixture: interstpoints.txt equals, byte for byte, what main.cpp:78-89 writes for the oracle's points; the overlay PNG
+    holds main.cpp:60-73's boxes; a PNG input is read without PIL; exceptions reach the caller with Vigra's text."""
+    import shutil
     import subprocess
+    from sift_amd import cli
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = tmp_path / "sift_points"
     subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(root, "include"),
                            os.path.join(root, "examples", "sift_points.cpp"), "-L" + os.path.join(root, "sift_amd", "lib"),
                            "-lsift_hip", "-Wl,-rpath," + os.path.join(root, "sift_amd", "lib"), "-o", str(exe)])
-    out = subprocess.run([str(exe), os.path.join(root, "tests", "golden", "parrot_r.pgm"), "4", "3", "0"],
-                         cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    shutil.copy(os.path.join(root, "tests", "golden", "parrot_r.pgm"), tmp_path / "parrot_r.pgm")
+    out = subprocess.run([str(exe), "parrot_r.pgm", "4", "3", "0"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    g = np.load(os.path.join(root, "tests", "golden", "case_parrot.npz"))
-    lines = open(tmp_path / "interstpoints.txt").read().splitlines()
-    assert lines[0] == "Location\tscale\torientation\tdescriptors"
-    assert len(lines) - 1 == int(g["counts"][-1])
-    first = lines[1].split("\t")
-    assert first[0] == f"[{int(g['kp_x'][0])}, {int(g['kp_y'][0])}]"
+    img = read_pgm(os.path.join(root, "tests", "golden", "parrot_r.pgm"))
+    want, run = expected_result_file(tmp_path, img, 3, 4)
+    assert open(tmp_path / "interstpoints.txt", "rb").read() == want
+    check_overlay(tmp_path / "parrot_r.pgm_orientation.png", cli.read_image_bgr(str(tmp_path / "parrot_r.pgm")), run, False)
+    # an RGB PNG: band 0 (red) is what the pipeline sees, the overlay keeps the colours
+    rgb = np.stack([synth_frame(200, 150, 7), synth_frame(200, 150, 8), synth_frame(200, 150, 9)], axis=2).astype(np.uint8)
+    cli._err_call(_lib.load().sift_hip_png_write_bgr8, str(tmp_path / "rgb.png").encode(), np.ascontiguousarray(rgb[:, :, ::-1]).reshape(-1), 200, 150)
+    out = subprocess.run([str(exe), "rgb.png", "3", "3", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    want, run = expected_result_file(tmp_path, synth_frame(200, 150, 7), 3, 3, subpixel=True)
+    assert open(tmp_path / "interstpoints.txt", "rb").read() == want
+    check_overlay(tmp_path / "rgb.png_orientation.png", np.ascontiguousarray(rgb[:, :, ::-1]), run, True)
     # exception text reaches the caller like vigra's would: 160x120 cannot carry 4 octaves
-    from sift_amd.synthetic import synth_frame
     small = synth_frame(160, 120, 1).astype(np.uint8)
     with open(tmp_path / "small.pgm", "wb") as f:
         f.write(b"P5\n160 120\n255\n" + small.tobytes())
@@ -516,21 +549,19 @@ def test_cpp_gated_pair_example(ctx, tmp_path):
 
 
 def test_cli_result_file(ctx, tmp_path, monkeypatch):
-    """sift_amd.cli (main.cpp's options, result writer and overlay)."""
+    """sift_amd.cli (main.cpp's options, ingest, result writer and overlay): whole result file and overlay."""
     from sift_amd import cli
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     monkeypatch.chdir(tmp_path)
     import shutil
     shutil.copy(os.path.join(root, "tests", "golden", "parrot_r.pgm"), tmp_path / "parrot_r.pgm")
     assert cli.main(["-i", "parrot_r.pgm", "-o", "4", "-d", "3", "-r", "1"]) == 0
-    g = np.load(os.path.join(root, "tests", "golden", "case_parrot.npz"))
-    lines = open(tmp_path / "interstpoints.txt").read().splitlines()
-    assert len(lines) - 1 == int(g["counts"][-1])
-    loc, scale, ori, desc = lines[1].split("\t")
-    assert loc == f"[{int(g['kp_x'][0])}, {int(g['kp_y'][0])}]"
-    assert abs(float(ori) - float(g["kp_orientation"][0])) < 1e-3
-    assert len(desc.strip("[]").rstrip(", ").split(", ")) == 128
-    assert os.path.exists(tmp_path / "parrot_r.pgm_orientation.png")
+    want, run = expected_result_file(tmp_path, read_pgm(os.path.join(root, "tests", "golden", "parrot_r.pgm")), 3, 4)
+    assert open(tmp_path / "interstpoints.txt", "rb").read() == want
+    check_overlay(tmp_path / "parrot_r.pgm_orientation.png", cli.read_image_bgr("parrot_r.pgm"), run, False)
+    # the reference's defaults (main.cpp:33-38: sigma 1.6, k sqrt2, 4 octaves, 3 DoGs, no subpixel, no result file), positional image
+    os.remove(tmp_path / "interstpoints.txt")
+    assert cli.main(["parrot_r.pgm", "--no-overlay"]) == 0 and not os.path.exists(tmp_path / "interstpoints.txt")
 
 
 def test_config3_exception_and_nearest_runnable(ctx):

@@ -1,9 +1,9 @@
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-os.environ["SIFT_CLEANUP_STAMPS"] = "1"
 from sift_amd.sift import Context
 ctx = Context(0)
+ctx.set_option("diag_cleanup_stamps", 1)
 rng = np.random.default_rng(0)
 for n, p in [(345000, 0.94), (345000, 0.94)]:
     flags = (rng.random(n) < p).astype(np.uint8)
