@@ -76,7 +76,8 @@ void sift_hip_destroy(sift_hip_ctx* ctx);
  * inputs), "orient_general" (0 default; 1: orientationHistogram36 reads every sample's bin even when the gradient pass
  * found all bins of the frame to be 0, which is what the reference's radians-as-degrees maps always give); measurement
  * aids, results unchanged unless stated: "stream_waves" (process-wide; waves a streaming blur launch is cut into, default
- * 2048, 0 = tile kernel only), "desc_dbg" / "orient_dbg" (phases switched off: timing only, WRONG results),
+ * 2048, 0 = tile kernel only), "desc_kernel" (1 default: one wave per keypoint over a grid of 16 px cells; 0: one workgroup
+ * per 48 px tile walking the ordered keypoint list), "desc_dbg" / "orient_dbg" (phases switched off: timing only, WRONG results),
  * "diag_pyramid_span", "diag_serial_gradient", "diag_cleanup_stamps" (print to stderr).  The library reads no
  * environment variable. */
 int sift_hip_set_option(sift_hip_ctx* ctx, const char* name, int value);

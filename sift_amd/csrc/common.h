@@ -50,6 +50,9 @@ struct DevPlan {
     // descriptor tiles (64x64 core) of the levels some keypoint scale selects, per image
     int desc_tile_base[kMaxLevels], desc_ntx[kMaxLevels], desc_nty[kMaxLevels];
     int desc_tiles_per_image;
+    // grid of 16 px cells over the same levels (wave-per-keypoint descriptor kernel): cells across / down, first cell of the level
+    int desc_cell_base[kMaxLevels], desc_cw[kMaxLevels], desc_ch[kMaxLevels];
+    int desc_cells_per_image;
 };
 
 #define SIFT_HIP_CHECK(expr)                                                        \
@@ -155,6 +158,13 @@ void launch_descriptors(hipStream_t s, const DevPlan* d_plan, const DevPlan& pla
                         const int* d_tile_cnt, const int* d_tile_off, const FinalKp* d_pool, int pool_cap,
                         const long long* d_out_base, sift_hip_keypoint* d_kp_out, float* d_desc_out, long long out_cap,
                         int dbg = 0);
+
+void launch_desc_grid(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const FinalKp* d_final, const int* d_final_cnt,
+                      int final_cap, int* d_cell_cnt, int* d_cell_off, FinalKp* d_pool, int pool_cap, const long long* d_out_base,
+                      sift_hip_keypoint* d_kp_out, float* d_desc_out, long long out_cap, bool counts_are_clear);
+void launch_descriptors_wave(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level, const int* d_cell_off,
+                             const FinalKp* d_pool, int pool_cap, const long long* d_out_base, sift_hip_keypoint* d_kp_out,
+                             float* d_desc_out, long long out_cap, int dbg = 0);
 
 // wire format of the keypoint gather (kernels_wire.hip)
 size_t wire_blocks(long long total);

@@ -126,6 +126,8 @@ struct sift_hip_ctx {
     DevBuf d_masks, d_fmasks, d_counts, d_totals, d_cands, d_flags;
     DevBuf d_wk, d_wi, d_wi2, d_wp, d_status, d_tile, d_pool;
     DevBuf d_order;
+    DevBuf d_cell_cnt, d_cell_off;   // descriptor grid: keypoints per 16 px cell, exclusive scan (+ total)
+    bool desc_wave = true;           // option "desc_kernel": 1 wave-per-keypoint kernel (default), 0 tile kernel
     DevBuf d_list, d_list_cnt, d_orient, d_peaks, d_final, d_final_cnt, d_out_base, d_kp, d_desc;
     DevBuf d_wire_sums, d_wire_off;   // sparse wire format: floats per block of keypoints, their exclusive scan
     HostBuf h_wire;
@@ -383,6 +385,15 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
             tb += dv.desc_ntx[lvl] * dv.desc_nty[lvl];
         }
         dv.desc_tiles_per_image = std::max(tb, 1);
+        int cb = 0;
+        for (int lvl : P.grad_levels) {   // 16 px cells (wave-per-keypoint descriptor kernel)
+            const int o = lvl / (D + 1);
+            dv.desc_cw[lvl] = (dv.w[o] + 15) / 16;
+            dv.desc_ch[lvl] = (dv.h[o] + 15) / 16;
+            dv.desc_cell_base[lvl] = cb;
+            cb += dv.desc_cw[lvl] * dv.desc_ch[lvl];
+        }
+        dv.desc_cells_per_image = std::max(cb, 1);
     }
     dv.words_per_image = std::max(words, 1);
     dv.cand_capacity = (std::max(cap, 1LL) + 15) / 16 * 16;   // every image's flag bytes start 16-byte aligned
@@ -453,6 +464,8 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
     c->d_out_base.ensure((size_t)n * sizeof(long long));
     c->d_tile.ensure((size_t)dv.desc_tiles_per_image * (size_t)n * 3 * sizeof(int));
     c->d_pool.ensure((size_t)kPoolCap * (size_t)n * sizeof(FinalKp));
+    c->d_cell_cnt.ensure((size_t)(dv.desc_cells_per_image + 1) * (size_t)n * sizeof(int));
+    c->d_cell_off.ensure((size_t)(dv.desc_cells_per_image + 1) * (size_t)n * sizeof(int));
     SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
     P.valid = true;
     return SIFT_HIP_OK;
@@ -679,6 +692,16 @@ void ensure_outputs(sift_hip_ctx* c, long long keypoints) {
 void launch_descriptor_stage(sift_hip_ctx* c) {
     Plan& P = c->plan;
     const DevPlan& dv = P.dev;
+    if (c->desc_wave) {
+        // grid of 16 px cells over the final keypoints, then one wave per keypoint (kernels_desc.hip)
+        launch_desc_grid(c->stream, c->d_plan.as<DevPlan>(), dv, c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(), kListCap,
+                         c->d_cell_cnt.as<int>(), c->d_cell_off.as<int>(), c->d_pool.as<FinalKp>(), kPoolCap, c->d_out_base.as<long long>(),
+                         c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->out_cap, false);
+        for (int lvl : P.grad_levels)
+            launch_descriptors_wave(c->stream, c->d_plan.as<DevPlan>(), dv, lvl, c->d_cell_off.as<int>(), c->d_pool.as<FinalKp>(), kPoolCap,
+                                    c->d_out_base.as<long long>(), c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->out_cap, c->desc_dbg);
+        return;
+    }
     const size_t nt = (size_t)dv.desc_tiles_per_image * (size_t)P.n;
     int* t_cnt = c->d_tile.as<int>();
     int* t_off = t_cnt + nt;
@@ -728,7 +751,7 @@ bool mid_gpu(sift_hip_ctx* c) {
     launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_order.as<OrientIn>(), d_late, kListCap,
                        c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 3 * n, (c->orient_general ? nullptr : c->d_ocnt.as<int>() + 4 * n),
                        0 /* its group counters were cleared together with the early launch's */);
-    const bool fused_bin = cleanup2_can_bin(dv.desc_tiles_per_image);
+    const bool fused_bin = !c->desc_wave && cleanup2_can_bin(dv.desc_tiles_per_image);
     const size_t nt = (size_t)dv.desc_tiles_per_image * (size_t)n;
     launch_cleanup2(s, n, dpl, fused_bin ? 1 : 0, c->d_tile.as<int>(), c->d_tile.as<int>() + nt, c->d_pool.as<FinalKp>(), kPoolCap,
                     c->d_cands.as<Candidate>(), dv.cand_capacity, c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
@@ -736,7 +759,7 @@ bool mid_gpu(sift_hip_ctx* c) {
                     c->d_wi.as<uint32_t>(), c->d_wi2.as<uint32_t>(), c->d_wp.as<uint32_t>(), c->d_final.as<FinalKp>(),
                     c->d_final_cnt.as<int>(), c->d_status.as<int>(), c->d_recs.as<FinalKp>());
     // the tile binning only needs the device-side lists: it keeps the GPU busy while the host waits for the counts
-    if (!fused_bin) bin_keypoints(c);
+    if (!fused_bin && !c->desc_wave) bin_keypoints(c);
     c->binned = true;
     // The descriptor stage does not wait for the counts to reach the host: output slots come from a device-side
     // scan and the output arrays keep a generous capacity; should a batch ever exceed it, the (idempotent: the
@@ -948,7 +971,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
         ensure_outputs(c, std::max<long long>(total, 1));
         SIFT_HIP_CHECK(hipMemcpyAsync(c->d_out_base.p, c->out_base.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice, s));
         if (total > 0) {
-            if (!c->binned) bin_keypoints(c);
+            if (!c->binned && !c->desc_wave) bin_keypoints(c);
             launch_descriptor_stage(c);
         }
     }
@@ -1025,7 +1048,7 @@ void sift_hip_destroy(sift_hip_ctx* c) {
     (void)sift_hip_set_gate(c, nullptr);
     for (DevBuf* b : {&c->arena, &c->d_plan, &c->d_taps, &c->d_luts, &c->d_taps16, &c->d_input, &c->d_base, &c->d_tmp, &c->d_tmp2,
                       &c->d_wk, &c->d_wi, &c->d_wi2, &c->d_wp, &c->d_status, &c->d_tile, &c->d_pool, &c->d_order, &c->d_masks, &c->d_fmasks, &c->d_counts, &c->d_totals, &c->d_cands, &c->d_flags, &c->d_list, &c->d_list_cnt, &c->d_orient,
-                      &c->d_peaks, &c->d_final, &c->d_final_cnt, &c->d_out_base, &c->d_kp, &c->d_desc, &c->d_lrank, &c->d_ochunk, &c->d_ocnt, &c->d_recs, &c->d_wire_sums, &c->d_wire_off})
+                      &c->d_peaks, &c->d_final, &c->d_final_cnt, &c->d_out_base, &c->d_kp, &c->d_desc, &c->d_lrank, &c->d_ochunk, &c->d_ocnt, &c->d_recs, &c->d_wire_sums, &c->d_wire_off, &c->d_cell_cnt, &c->d_cell_off})
         b->release();
     for (HostBuf* b : {&c->h_flags, &c->h_orient, &c->h_peaks, &c->h_status, &c->h_wire}) b->release();
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -1091,6 +1114,7 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     if (!std::strcmp(name, "fused_reduce")) { c->fused_reduce = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "spin_wait")) { c->spin_wait = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "desc_dbg")) { c->desc_dbg = value; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "desc_kernel")) { c->desc_wave = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "gpu_cleanup")) { c->gpu_cleanup = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "profile")) { c->profile = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "orient_general")) { c->orient_general = value != 0; return SIFT_HIP_OK; }

@@ -518,6 +518,327 @@ __global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __res
     }
 }
 
+// =====================================================================================================
+// Wave-per-keypoint form (the default).  The tile kernel above walks an ordered list per 64x64 tile, so a keypoint near a
+// tile border is processed by up to four workgroups and every tile pays barriers per batch of its list.  Here ONE WAVE
+// owns ONE keypoint p and recomputes, for the 256 pixels of p's window, the float chains the reference's in-place updates
+// build (sift.cpp:80-92): a pixel's value when p's histograms are taken is
+//     initial value (+ orientation_q, + weighting(window-local position in q))   for every keypoint q that precedes p in the
+//     vector AND whose 16x16 window covers the pixel, in vector order, then p's own update.
+// Only keypoints within 15 px of p in x and y can cover a pixel of p's window; they are found through a uniform grid of
+// 16 px cells (the 3x3 cells around p's) that holds every keypoint of the level once.  The preceding neighbours are taken
+// in ascending vector index by repeated wave-wide minimum (DPP), each applied to the lane's four pixels with its fields in
+// scalar registers.  Chains are short (a pixel is covered by ~2.4 windows on the bench frames), nothing is shared between
+// waves, there is no barrier, no tile fringe and no redundant update; the price is that overlapping windows recompute
+// each other's additions.
+// Lane l owns the pixels (4*(l>>4) + i, l & 15), i = 0..3, of the window (window-local x, y): four consecutive x of one row
+// (one 16-byte load per map), and the four lanes of a DPP quad hold the four rows of one 4x4 cell: the cell's 16 samples
+// reach every lane of the quad by quad-broadcast in the reference's order (x outer, y inner), lane y of the quad
+// accumulating bins 2y and 2y+1.  The 8 bins of a cell then sit in one quad in bin order: lane l stores floats 2l, 2l+1 of
+// the descriptor, 512 contiguous bytes per wave.
+// =====================================================================================================
+constexpr int kCellShift = 4;            // 16 px grid cells
+constexpr int kW16Stride = 20;           // weighting table, x-major with padded columns: conflict-free for a half-wave
+constexpr int kW16Bias = 16 * kW16Stride;   // window-local coordinates of a neighbour's window run from -15 to 30
+constexpr int kW16Size = kW16Bias + 31 * kW16Stride + 32;
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at a 4-byte aligned address
+
+struct DescGridLevel {
+    int w, h, dogs;
+    int cw, ch, cell_base, cells_per_image;   // this level's cells inside an image's cell array
+    const float* mag;
+    const float* ori;
+    const float* gauss;
+    const float* w16;
+};
+
+// cell of a keypoint, or -1 if the descriptor stage's own bounds test fails (sift.cpp:65-70)
+__device__ __forceinline__ int desc_cell_of(const DevPlan* __restrict__ plan, const FinalKp& f, int& level) {
+    const int D = plan->dogs;
+    level = plan->nearest_level[f.octave * D + f.index];
+    const int o = level / (D + 1);
+    const int w = plan->w[o], h = plan->h[o];
+    const int kx = f.x, ky = f.y;
+    if (kx < kRegion || kx > w - kRegion || ky < kRegion || ky > h - kRegion) return -1;
+    return plan->desc_cell_base[level] + (ky >> kCellShift) * plan->desc_cw[level] + (kx >> kCellShift);
+}
+
+// counts per cell (FILL = false), then the records into their cells (FILL = true); a keypoint that fails the bounds test
+// is emitted right here: filtered, no descriptor
+template <bool FILL>
+__global__ __launch_bounds__(256) void desc_cell_kernel(const DevPlan* __restrict__ plan, const FinalKp* __restrict__ finals,
+                                                        const int* __restrict__ final_cnt, int final_cap,
+                                                        int* __restrict__ cell_cnt, const int* __restrict__ cell_off,
+                                                        FinalKp* __restrict__ pool, int pool_cap,
+                                                        const long long* __restrict__ out_base,
+                                                        sift_hip_keypoint* __restrict__ kp_out, float* __restrict__ desc_out,
+                                                        long long out_cap) {
+    const int img = blockIdx.y;
+    const int K = final_cnt[img];
+    const int cpi = plan->desc_cells_per_image;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+        const FinalKp f = finals[(size_t)img * (size_t)final_cap + k];
+        int level;
+        const int cell = desc_cell_of(plan, f, level);
+        if (cell < 0) {
+            if (FILL) {
+                const long long ok = out_base[img] + k;
+                if (ok < out_cap) {
+                    sift_hip_keypoint r;
+                    r.scale = plan->dog_scale[f.octave * plan->dogs + f.index];
+                    r.orientation = f.orientation;
+                    r.x = f.x; r.y = f.y; r.octave = f.octave; r.index = f.index;
+                    r.filtered = 1; r.has_descriptor = 0; r.reserved = 0;
+                    kp_out[ok] = r;
+                    float4* d = reinterpret_cast<float4*>(desc_out + (size_t)ok * 128);
+                    for (int i = 0; i < 32; ++i) d[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+            }
+            continue;
+        }
+        int* cnt = cell_cnt + (size_t)img * (size_t)(cpi + 1) + cell;
+        if (!FILL) {
+            atomicAdd(cnt, 1);
+        } else {
+            const int p = atomicAdd(cnt, 1);   // the counts were cleared again by the scan: now the fill cursor
+            FinalKp rec = f;
+            rec.cand = (uint32_t)k;            // vector index: the order the chains follow, and the output slot
+            pool[(size_t)img * (size_t)pool_cap + (size_t)cell_off[(size_t)img * (size_t)(cpi + 1) + cell] + (size_t)p] = rec;
+        }
+    }
+}
+
+// exclusive scan of one image's cell counts into cell_off[0 .. cpi] (the last entry is the total); clears the counts
+__global__ __launch_bounds__(1024) void desc_cell_scan_kernel(int* __restrict__ cell_cnt, int* __restrict__ cell_off, int cpi) {
+    __shared__ int s_part[1024];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    int* c = cell_cnt + (size_t)img * (size_t)(cpi + 1);
+    int* o = cell_off + (size_t)img * (size_t)(cpi + 1);
+    const int chunk = (cpi + 1023) / 1024;
+    const int lo = tid * chunk, hi = min(lo + chunk, cpi);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += c[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = (tid >= off) ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = s_part[tid] - sum;
+    for (int i = lo; i < hi; ++i) {
+        const int v = c[i];
+        o[i] = run;
+        c[i] = 0;
+        run += v;
+    }
+    if (tid == 1023) o[cpi] = s_part[1023];
+}
+
+// minimum of a non-negative int over the wave, in a scalar register: butterfly inside each row of 16 lanes (DPP), then the
+// four rows by readlane
+__device__ __forceinline__ int wave_min_nonneg(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x141, 0xf, 0xf, false));   // row_half_mirror
+    v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x140, 0xf, 0xf, false));   // row_mirror
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+template <int Y>
+__device__ __forceinline__ float quad_bcast_f(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), Y * 0x55, 0xF, 0xF, true));
+}
+template <int Y>
+__device__ __forceinline__ unsigned quad_bcast_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, Y * 0x55, 0xF, 0xF, true);
+}
+// value of the previous lane of the quad (lane 0 receives lane 3's: unused)
+__device__ __forceinline__ float quad_prev_f(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x93 /* quad_perm [3,0,1,2] */, 0xF, 0xF, true));
+}
+
+__global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* __restrict__ plan, DescGridLevel lv,
+                                                                 const int* __restrict__ cell_off,
+                                                                 const FinalKp* __restrict__ pool, int pool_cap,
+                                                                 const long long* __restrict__ out_base,
+                                                                 sift_hip_keypoint* __restrict__ kp_out,
+                                                                 float* __restrict__ desc_out, long long out_cap, int dbg) {
+    __shared__ float s_w16t[kW16Size];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int img = blockIdx.y;
+    const int w = lv.w, h = lv.h, D = lv.dogs;
+    const int* __restrict__ coff = cell_off + (size_t)img * (size_t)(lv.cells_per_image + 1) + lv.cell_base;
+    const int e_begin = coff[0], e_end = coff[lv.cw * lv.ch];
+    if (e_begin + (int)blockIdx.x * 4 >= e_end) return;   // nothing for this workgroup
+    // weighting(x, y) (sift.cpp:87-90), x-major: index bias + 20 * x + y.  Entries outside 0..15 x 0..15 are only ever
+    // read by lanes that then discard them.
+    for (int i = tid; i < kW16Size; i += 256) s_w16t[i] = 0.0f;
+    __syncthreads();
+    s_w16t[kW16Bias + (tid & 15) * kW16Stride + (tid >> 4)] = lv.w16[(size_t)img * 256 + tid];
+    __syncthreads();
+
+    const int ly = lane & 15, lx0 = (lane >> 4) * 4;   // this lane's row and first column inside a window
+    const int tbase = kW16Bias + lx0 * kW16Stride + ly;
+    float wself[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wself[i] = s_w16t[tbase + i * kW16Stride];
+    const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
+    const float* __restrict__ gm = lv.mag + img_off;
+    const float* __restrict__ go = lv.ori + img_off;
+    const float* __restrict__ gg = lv.gauss + img_off;
+    const FinalKp* __restrict__ pl = pool + (size_t)img * (size_t)pool_cap;
+    const long long obase = out_base[img];
+    const unsigned b0 = 2u * (unsigned)(lane & 3), b1 = b0 + 1u;   // the two bins this lane accumulates for its cell
+
+    for (int e = e_begin + (int)blockIdx.x * 4 + wave; e < e_end; e += (int)gridDim.x * 4) {
+        // ---- this wave's keypoint (wave-uniform: scalar registers) ----------------------------------------------
+        const uint4 me = *reinterpret_cast<const uint4*>(&pl[e]);
+        const int myk = __builtin_amdgcn_readfirstlane((int)me.x);
+        const float mytheta = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)me.y));
+        const unsigned myxy = (unsigned)__builtin_amdgcn_readfirstlane((int)me.z);
+        const unsigned myoi = (unsigned)__builtin_amdgcn_readfirstlane((int)me.w);   // octave | index << 16
+        const int px = (int)(myxy & 0xffffu), py = (int)(myxy >> 16);
+        // ---- the window's pixels: initial maps and the Gaussian level (every keypoint of the grid passed the bounds test,
+        // so the window lies inside the image) ------------------------------------------------------------------------
+        const size_t o = (size_t)(py - kRegion + ly) * (size_t)w + (size_t)(px - kRegion + lx0);
+        const f4u o4 = *reinterpret_cast<const f4u*>(go + o);
+        const f4u m4 = *reinterpret_cast<const f4u*>(gm + o);
+        const f4u g4 = *reinterpret_cast<const f4u*>(gg + o);
+        float vo[4] = {o4.x, o4.y, o4.z, o4.w}, vm[4] = {m4.x, m4.y, m4.z, m4.w};
+        const float vg[4] = {g4.x, g4.y, g4.z, g4.w};
+
+        // one preceding neighbour q: the lane's pixels that q's window covers receive q's additions (sift.cpp:80-92)
+        auto apply = [&](unsigned qxy, float qtheta) {
+            const int dx = px - (int)(qxy & 0xffffu), dy = py - (int)(qxy >> 16);   // window-local offset: p's (x, y) is q's (x + dx, y + dy)
+            const bool row_in = (unsigned)(ly + dy) < 16u;
+            const int tq = tbase + dx * kW16Stride + dy;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float wq = s_w16t[tq + i * kW16Stride];
+                const bool in = row_in && (unsigned)(lx0 + i + dx) < 16u;
+                const float no = vo[i] + qtheta, nm = vm[i] + wq;
+                vo[i] = in ? no : vo[i];
+                vm[i] = in ? nm : vm[i];
+            }
+        };
+
+        // ---- neighbours: the 3x3 cells around p's --------------------------------------------------------------------
+        if (!(dbg & 1)) {
+            const int ccx = px >> kCellShift, ccy = py >> kCellShift;
+            const int c0 = max(ccx - 1, 0), c1 = min(ccx + 1, lv.cw - 1);
+            int rs[3], rn[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int cy = ccy + r - 1;
+                const bool ok = cy >= 0 && cy < lv.ch;
+                const int a = ok ? coff[cy * lv.cw + c0] : 0, b = ok ? coff[cy * lv.cw + c1 + 1] : 0;
+                rs[r] = a;
+                rn[r] = b - a;
+            }
+            const int T = rn[0] + rn[1] + rn[2];
+            auto entry_of = [&](int i) {   // i-th record of the three ranges
+                return i < rn[0] ? rs[0] + i : (i < rn[0] + rn[1] ? rs[1] + (i - rn[0]) : rs[2] + (i - rn[0] - rn[1]));
+            };
+            auto precedes = [&](const uint4& c) {   // earlier in the vector and close enough to share a pixel
+                const int qx = (int)(c.z & 0xffffu), qy = (int)(c.z >> 16);
+                return (int)c.x < myk && (unsigned)(qx - px + 15) < 31u && (unsigned)(qy - py + 15) < 31u;
+            };
+            if (T <= 64) {
+                // one record per lane, kept in registers; key = vector index | lane
+                uint4 c = make_uint4(0u, 0u, 0u, 0u);
+                if (lane < T) c = *reinterpret_cast<const uint4*>(&pl[entry_of(lane)]);
+                int key = (lane < T && precedes(c)) ? (int)((c.x << 6) | (unsigned)lane) : 0x7fffffff;
+                for (;;) {
+                    const int m = wave_min_nonneg(key);
+                    if (m == 0x7fffffff) break;
+                    const int src = m & 63;
+                    apply((unsigned)__builtin_amdgcn_readlane((int)c.z, src), __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)c.y, src)));
+                    key = lane == src ? 0x7fffffff : key;
+                }
+            } else {
+                // crowded neighbourhood: take the preceding neighbours in order by rescanning the records
+                int last = -1;
+                for (;;) {
+                    int bk = 0x7fffffff;
+                    unsigned bxy = 0u, bth = 0u;
+                    for (int base = 0; base < T; base += 64) {
+                        const int i = base + lane;
+                        if (i < T) {
+                            const uint4 c = *reinterpret_cast<const uint4*>(&pl[entry_of(i)]);
+                            if (precedes(c) && (int)c.x > last && (int)c.x < bk) { bk = (int)c.x; bxy = c.z; bth = c.y; }
+                        }
+                    }
+                    const int m = wave_min_nonneg(bk);
+                    if (m == 0x7fffffff) break;
+                    const int src = (int)__builtin_ctzll(__ballot(bk == m));
+                    apply((unsigned)__builtin_amdgcn_readlane((int)bxy, src), __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)bth, src)));
+                    last = m;
+                }
+            }
+        }
+        // ---- p's own update (sift.cpp:80-92) and the histogram inputs (algorithms.cpp:135-150) ---------------------------
+        float val[4];
+        unsigned bin[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float no = vo[i] + mytheta;
+            const float nm = vm[i] + wself[i];
+            val[i] = nm * vg[i];
+            bin[i] = f32_to_u16_x86_d(__builtin_floorf(no / 45.0f)) % 7u;
+        }
+        // ---- 16 cell histograms: a quad holds one cell; samples in x-outer / y-inner order ------------------------------
+        float h0 = 0.0f, h1 = 0.0f;
+        if (!(dbg & 2)) {
+#define SIFT_DESC_SAMPLE(I, Y)                                            \
+            {                                                             \
+                const float v = quad_bcast_f<Y>(val[I]);                  \
+                const unsigned b = quad_bcast_u<Y>(bin[I]);               \
+                h0 = (b == b0) ? h0 + v : h0;                             \
+                h1 = (b == b1) ? h1 + v : h1;                             \
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                SIFT_DESC_SAMPLE(i, 0) SIFT_DESC_SAMPLE(i, 1) SIFT_DESC_SAMPLE(i, 2) SIFT_DESC_SAMPLE(i, 3)
+            }
+#undef SIFT_DESC_SAMPLE
+            // alg::normalizeVector (algorithms.cpp:210-223): length = ((0 + b0) + b1) + ... + b7, handed along the quad
+            float run = 0.0f;
+            run += h0; run += h1;                       // lane 0 of the quad: bins 0, 1
+            float acc = run;
+#pragma unroll
+            for (int step = 1; step < 4; ++step) {      // lane `step` continues from lane step-1's sum
+                const float prev = quad_prev_f(acc);
+                float t = prev;
+                t += h0; t += h1;
+                acc = ((lane & 3) == step) ? t : acc;
+            }
+            const float length = quad_bcast_f<3>(acc);
+            if (!(length == 0.0f)) {
+                h0 = h0 / length;
+                h1 = h1 / length;
+            }
+        }
+        const long long ok = obase + (long long)myk;
+        if (ok < out_cap) {   // (the output arrays are sized before the final counts reach the host: see run_batch)
+            *reinterpret_cast<float2*>(desc_out + (size_t)ok * 128 + (size_t)(2 * lane)) = make_float2(h0, h1);
+            if (lane == 0) {
+                sift_hip_keypoint r;
+                r.scale = plan->dog_scale[(myoi & 0xffffu) * (unsigned)D + (myoi >> 16)];
+                r.orientation = mytheta;
+                r.x = (uint16_t)px; r.y = (uint16_t)py;
+                r.octave = (uint16_t)(myoi & 0xffffu); r.index = (uint16_t)(myoi >> 16);
+                r.filtered = 0; r.has_descriptor = 1; r.reserved = 0;
+                kp_out[ok] = r;
+            }
+        }
+    }
+}
+
 void launch_w16(hipStream_t s, const DevPlan& plan, int level, const float* d_taps16, int radius16) {
     const int oct = level / (plan.dogs + 1);
     hipLaunchKernelGGL(w16_kernel, dim3((unsigned)plan.n_images), dim3(256), 0, s,
@@ -581,6 +902,36 @@ void launch_descriptors(hipStream_t s, const DevPlan* d_plan, const DevPlan& pla
     lv.mag = plan.mag[level]; lv.ori = plan.ori[level]; lv.gauss = plan.gauss[level]; lv.w16 = plan.w16[level];
     hipLaunchKernelGGL(descriptor_kernel, grid, dim3(256), 0, s, d_plan, lv, level, d_final, d_final_cnt, final_cap,
                        d_tile_cnt, d_tile_off, d_pool, pool_cap, d_out_base, d_kp_out, d_desc_out, out_cap, dbg);
+}
+
+// grid of 16 px cells over the final keypoints of every image (counts, scan, fill)
+void launch_desc_grid(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const FinalKp* d_final, const int* d_final_cnt,
+                      int final_cap, int* d_cell_cnt, int* d_cell_off, FinalKp* d_pool, int pool_cap, const long long* d_out_base,
+                      sift_hip_keypoint* d_kp_out, float* d_desc_out, long long out_cap, bool counts_are_clear) {
+    const int cpi = plan.desc_cells_per_image;
+    if (!counts_are_clear) (void)hipMemsetAsync(d_cell_cnt, 0, (size_t)(cpi + 1) * (size_t)plan.n_images * sizeof(int), s);
+    const dim3 grid(64, (unsigned)plan.n_images);
+    hipLaunchKernelGGL(desc_cell_kernel<false>, grid, dim3(256), 0, s, d_plan, d_final, d_final_cnt, final_cap, d_cell_cnt,
+                       (const int*)d_cell_off, d_pool, pool_cap, d_out_base, d_kp_out, d_desc_out, out_cap);
+    hipLaunchKernelGGL(desc_cell_scan_kernel, dim3((unsigned)plan.n_images), dim3(1024), 0, s, d_cell_cnt, d_cell_off, cpi);
+    hipLaunchKernelGGL(desc_cell_kernel<true>, grid, dim3(256), 0, s, d_plan, d_final, d_final_cnt, final_cap, d_cell_cnt,
+                       (const int*)d_cell_off, d_pool, pool_cap, d_out_base, d_kp_out, d_desc_out, out_cap);
+}
+
+void launch_descriptors_wave(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level, const int* d_cell_off,
+                             const FinalKp* d_pool, int pool_cap, const long long* d_out_base, sift_hip_keypoint* d_kp_out,
+                             float* d_desc_out, long long out_cap, int dbg) {
+    DescGridLevel lv;
+    const int oct = level / (plan.dogs + 1);
+    lv.w = plan.w[oct]; lv.h = plan.h[oct]; lv.dogs = plan.dogs;
+    lv.cw = plan.desc_cw[level]; lv.ch = plan.desc_ch[level]; lv.cell_base = plan.desc_cell_base[level];
+    lv.cells_per_image = plan.desc_cells_per_image;
+    lv.mag = plan.mag[level]; lv.ori = plan.ori[level]; lv.gauss = plan.gauss[level]; lv.w16 = plan.w16[level];
+    // 2048 workgroups of four waves over the batch: 8 per CU, every wave strides through its image's records
+    int gx = 2048 / (plan.n_images > 0 ? plan.n_images : 1);
+    gx = gx < 16 ? 16 : (gx > 4096 ? 4096 : gx);
+    hipLaunchKernelGGL(descriptor_wave_kernel, dim3((unsigned)gx, (unsigned)plan.n_images), dim3(256), 0, s, d_plan, lv, d_cell_off,
+                       d_pool, pool_cap, d_out_base, d_kp_out, d_desc_out, out_cap, dbg);
 }
 
 }  // namespace sift_hip

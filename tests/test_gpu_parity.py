@@ -222,6 +222,30 @@ def test_pipeline_parity(ctx, report_dir, case):
     assert rep["final"] > 0
 
 
+def test_pipeline_parity_tile_descriptor_kernel(ctx, report_dir):
+    """The descriptor stage's other form (option desc_kernel = 0: one workgroup per 48 px tile walking the ordered list)."""
+    ctx.set_option("desc_kernel", 0)
+    try:
+        compare_run(ctx, synth_frame(640, 480, 1), 3, 4, False, "tile descriptor kernel 640x480", report_dir)
+        compare_run(ctx, synth_frame(400, 300, 6), 4, 2, False, "tile descriptor kernel 400x300 4 dogs", report_dir)
+    finally:
+        ctx.set_option("desc_kernel", 1)
+
+
+@pytest.mark.parametrize("desc_kernel", [1, 0])
+def test_pipeline_parity_dense_keypoints(ctx, report_dir, desc_kernel):
+    """A lattice of blobs (sift_amd.synthetic.blob_frame): 0.06 keypoints per pixel, ~140 records in the 3x3 grid cells around
+    a keypoint and windows covered tens of times over: the wave-per-keypoint descriptor kernel's crowded-neighbourhood path
+    (more than 64 records) and long per-pixel chains (sift.cpp:80-92), bit for bit."""
+    from sift_amd.synthetic import blob_frame
+    ctx.set_option("desc_kernel", desc_kernel)
+    try:
+        rep = compare_run(ctx, blob_frame(352, 264, 5), 3, 3, False, f"blob lattice 352x264 desc_kernel={desc_kernel}", report_dir)
+        assert rep["final"] > 3000
+    finally:
+        ctx.set_option("desc_kernel", 1)
+
+
 def test_pipeline_parity_two_pass_blur(ctx, report_dir):
     ctx.set_option("fused_blur", 0)
     try:
@@ -564,7 +588,7 @@ def test_cli_result_file(ctx, tmp_path, monkeypatch):
     assert cli.main(["parrot_r.pgm", "--no-overlay"]) == 0 and not os.path.exists(tmp_path / "interstpoints.txt")
 
 
-def test_config3_exception_and_nearest_runnable(ctx):
+def test_config3_exception_and_nearest_runnable(ctx, report_dir):
     """BASELINE config 3: 1920x1080, subpixel, 4 oct x 5 DoG throws in the reference (App. B-13);
     the nearest runnable setting (subpixel, 4 x 3) is compared in full."""
     img = synth_frame(1920, 1080, 7)
@@ -575,12 +599,33 @@ def test_config3_exception_and_nearest_runnable(ctx):
     assert str(e.value) == run.error
     im = ctx.image(0)                              # the caller's image was already replaced (B-16)
     assert im is not None and im.shape == (2160, 3840)
-    small = synth_frame(960, 540, 7)               # same pipeline at a quarter of the pixels (oracle time)
-    ctx.calculate_batch(small[None], _lib.Params(3, 4, 1.6, O.K_SQRT2, 1))
+    # the nearest runnable setting at FULL size: every level of the 3840x2160-base pyramid, every stage list, descriptors
+    rep = compare_run(ctx, img, 3, 4, True, "config3 1920x1080 subpixel 4x3", report_dir)
+    assert rep["final"] > 5000
+
+
+def test_config5_batch_of_eight_4k_frames(ctx):
+    """BASELINE config 5's per-GPU share (64 frames over 8 GPUs = 8 per GPU): a batch of eight 3840x2160 frames, subpixel
+    (7680x4320 base), 5 octaves (6 throw, App. B-14).  First and last frame of the batch are the digest frame
+    (tests/golden/digest_config5_4k.npz, oracle): stage counts and SHA-256 of keypoints, orientations, scales and
+    descriptors per image; the frames in between are different images (sift.cpp:37-54 runs per image)."""
+    from golden_util import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "digest_config5_4k.npz"))
+    dogs, octaves, subpixel, w, h, seed = (int(v) for v in g["meta"])
+    frames = np.stack([synth_frame(w, h, s) for s in (seed, 21, 22, 23, 24, 25, 26, seed)])
+    ctx.calculate_batch(frames, _lib.Params(dogs, octaves, 1.6, O.K_SQRT2, subpixel))
+    counts = ctx.counts()
+    assert counts.size == 8 and (ctx.status() == 0).all()
     kp, desc = ctx.results()
-    want, wdesc = O.OracleRun(small, 3, 4, subpixel=True).points("final")
-    assert kp.size == want.size and (kp["x"] == want["x"]).all() and (kp["y"] == want["y"]).all()
-    assert desc.tobytes() == wdesc.tobytes()
+    base = np.concatenate([[0], np.cumsum(counts)])
+    for image in (0, 7):
+        got = [ctx.stage(s, image).size for s in ("candidates", "after_sort1", "after_orient", "after_sort2", "final")]
+        assert got == g["counts"].tolist(), image
+        k, d = kp[base[image]:base[image + 1]], desc[base[image]:base[image + 1]]
+        assert sha(np.stack([k["x"], k["y"], k["octave"], k["index"]], 1).astype(np.uint16)) == str(g["kp_sha"])
+        assert sha(k["orientation"]) == str(g["orientation_sha"]) and sha(k["scale"]) == str(g["scale_sha"])
+        assert sha(d) == str(g["descriptors_sha"])
+    assert len(set(counts[1:7].tolist())) > 1 and counts[1] != counts[0]     # the other frames are other images
 
 
 def _gather_worker(rank, world, port, q):
@@ -837,15 +882,18 @@ def test_hip_bench_frame_matches_the_reference_binary(ctx):
 @pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refpin_u16_truncation.npz")),
                     reason="fixture not generated")
 def test_hip_u16_truncation_matches_the_reference_binary(ctx):
-    """App. B-7 against the reference binary itself: 65594 survivors, `u16_t size` keeps 58 of them."""
+    """App. B-7 against the reference binary itself: 66260 survivors of the first cleanup on a 1024x1088 blob lattice,
+    `u16_t size` (sift.cpp:41) keeps 724 of them, 720 are returned; keypoints, orientations and descriptors bit for bit."""
+    from sift_amd.synthetic import blob_frame
     pin = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refpin_u16_truncation.npz"))
     w, h, seed = (int(v) for v in pin["params"][3:6])
-    img = synth_frame(w, h, seed)
+    img = blob_frame(w, h, seed)
     assert sha(img) == str(pin["image_sha"]) and int(pin["rc"]) == 0
     ctx.calculate_batch(img[None], _lib.Params(3, 4, 1.6, O.K_SQRT2, 0))
+    assert ctx.stage("after_sort1").size == 724
     kp, desc = ctx.results()
     ref = pin["points"]
-    assert kp.size == ref.size
+    assert kp.size == ref.size == 720
     for f in ("x", "y", "octave", "index"):
         assert (kp[f] == ref[f]).all(), f
     assert kp["scale"].tobytes() == ref["scale"].tobytes() and kp["orientation"].tobytes() == ref["orientation"].tobytes()

@@ -14,7 +14,7 @@ import pytest
 
 import oracle_lib as O
 from golden_util import read_pgm, sha
-from sift_amd.synthetic import synth_frame
+from sift_amd.synthetic import blob_frame, synth_frame
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PIN = np.load(os.path.join(HERE, "golden", "refpin.npz"))
@@ -171,17 +171,20 @@ def test_bench_frame_matches_the_reference_binary():
 
 @pytest.mark.skipif(not os.path.exists(TRUNC_PIN), reason="fixture not generated")
 def test_u16_size_truncation_matches_the_reference_binary():
-    """App. B-7: 65594 points survive the first cleanup of this 3488x1960 frame; `u16_t size` (sift.cpp:41) keeps 58."""
+    """App. B-7 against the reference binary itself: 66260 points survive the first cleanup of this 1024x1088 blob lattice
+    (sift_amd.synthetic.blob_frame, seed 5); `u16_t size` (sift.cpp:41) keeps 66260 - 65536 = 724 of them, 720 are returned
+    (23 minutes in the reference: it copies three DoG images per candidate)."""
     pin = np.load(TRUNC_PIN)
     w, h, seed = (int(v) for v in pin["params"][3:6])
-    img = synth_frame(w, h, seed)
+    img = blob_frame(w, h, seed)
     assert sha(img) == str(pin["image_sha"]) and int(pin["rc"]) == 0
     run = O.OracleRun(img, 3, 4)
     cand, _ = run.points("candidates")
     kept = int((~cand["filtered"].astype(bool)).sum())
     after, _ = run.points("after_sort1")
-    assert kept > 65535 and after.size == kept - 65536
+    assert kept > 65535 and after.size == kept - 65536 == 724
     got, gdesc = run.points("final")
+    assert got.size == 720 == pin["points"].size
     d = _compare_points(got, gdesc, pin["points"])
     assert d.tobytes() == pin["desc"].tobytes()
 
