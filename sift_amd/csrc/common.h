@@ -161,7 +161,7 @@ void launch_descriptors(hipStream_t s, const DevPlan* d_plan, const DevPlan& pla
 
 void launch_desc_grid(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const FinalKp* d_final, const int* d_final_cnt,
                       int final_cap, int* d_cell_cnt, int* d_cell_off, FinalKp* d_pool, int pool_cap, const long long* d_out_base,
-                      sift_hip_keypoint* d_kp_out, float* d_desc_out, long long out_cap, bool counts_are_clear);
+                      sift_hip_keypoint* d_kp_out, float* d_desc_out, long long out_cap);
 void launch_descriptors_wave(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level, const int* d_cell_off,
                              const FinalKp* d_pool, int pool_cap, const long long* d_out_base, sift_hip_keypoint* d_kp_out,
                              float* d_desc_out, long long out_cap, int dbg = 0);

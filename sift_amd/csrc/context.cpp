@@ -696,7 +696,7 @@ void launch_descriptor_stage(sift_hip_ctx* c) {
         // grid of 16 px cells over the final keypoints, then one wave per keypoint (kernels_desc.hip)
         launch_desc_grid(c->stream, c->d_plan.as<DevPlan>(), dv, c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(), kListCap,
                          c->d_cell_cnt.as<int>(), c->d_cell_off.as<int>(), c->d_pool.as<FinalKp>(), kPoolCap, c->d_out_base.as<long long>(),
-                         c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->out_cap, false);
+                         c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->out_cap);
         for (int lvl : P.grad_levels)
             launch_descriptors_wave(c->stream, c->d_plan.as<DevPlan>(), dv, lvl, c->d_cell_off.as<int>(), c->d_pool.as<FinalKp>(), kPoolCap,
                                     c->d_out_base.as<long long>(), c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->out_cap, c->desc_dbg);

@@ -564,77 +564,84 @@ __device__ __forceinline__ int desc_cell_of(const DevPlan* __restrict__ plan, co
     return plan->desc_cell_base[level] + (ky >> kCellShift) * plan->desc_cw[level] + (kx >> kCellShift);
 }
 
-// counts per cell (FILL = false), then the records into their cells (FILL = true); a keypoint that fails the bounds test
-// is emitted right here: filtered, no descriptor
-template <bool FILL>
-__global__ __launch_bounds__(256) void desc_cell_kernel(const DevPlan* __restrict__ plan, const FinalKp* __restrict__ finals,
-                                                        const int* __restrict__ final_cnt, int final_cap,
-                                                        int* __restrict__ cell_cnt, const int* __restrict__ cell_off,
-                                                        FinalKp* __restrict__ pool, int pool_cap,
-                                                        const long long* __restrict__ out_base,
-                                                        sift_hip_keypoint* __restrict__ kp_out, float* __restrict__ desc_out,
-                                                        long long out_cap) {
-    const int img = blockIdx.y;
+// The grid of one image, by one workgroup: counts per cell, exclusive scan (cell_off[0 .. cpi], the last entry is the
+// total), records into their cells.  No workgroup shares an image, so the counters live in LDS while the image's cells fit
+// (LDS_COUNTS) and in the image's slice of cell_cnt otherwise; after the scan a cell's counter holds its first free pool
+// slot, so the fill needs one atomic per record and no second array.  A keypoint that fails the descriptor stage's own
+// bounds test (sift.cpp:65-70) is emitted right here: filtered, no descriptor.
+constexpr int kGridThreads = 1024;
+constexpr int kGridLdsCells = 16384;   // 64 KB of counters: 1080p has 8160 cells, 4K 32400 (global counters)
+
+template <bool LDS_COUNTS>
+__global__ __launch_bounds__(kGridThreads) void desc_grid_kernel(const DevPlan* __restrict__ plan, const FinalKp* __restrict__ finals,
+                                                                 const int* __restrict__ final_cnt, int final_cap,
+                                                                 int* __restrict__ cell_cnt, int* __restrict__ cell_off,
+                                                                 FinalKp* __restrict__ pool, int pool_cap,
+                                                                 const long long* __restrict__ out_base,
+                                                                 sift_hip_keypoint* __restrict__ kp_out, float* __restrict__ desc_out,
+                                                                 long long out_cap) {
+    __shared__ int s_cnt[LDS_COUNTS ? kGridLdsCells : 1];
+    __shared__ int s_part[kGridThreads];
+    const int img = blockIdx.x, tid = threadIdx.x;
     const int K = final_cnt[img];
     const int cpi = plan->desc_cells_per_image;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
-        const FinalKp f = finals[(size_t)img * (size_t)final_cap + k];
+    int* cnt = LDS_COUNTS ? s_cnt : cell_cnt + (size_t)img * (size_t)(cpi + 1);
+    int* off = cell_off + (size_t)img * (size_t)(cpi + 1);
+    const FinalKp* __restrict__ fin = finals + (size_t)img * (size_t)final_cap;
+    for (int i = tid; i < cpi; i += kGridThreads) cnt[i] = 0;
+    __syncthreads();
+    for (int k = tid; k < K; k += kGridThreads) {
+        const FinalKp f = fin[k];
         int level;
         const int cell = desc_cell_of(plan, f, level);
-        if (cell < 0) {
-            if (FILL) {
-                const long long ok = out_base[img] + k;
-                if (ok < out_cap) {
-                    sift_hip_keypoint r;
-                    r.scale = plan->dog_scale[f.octave * plan->dogs + f.index];
-                    r.orientation = f.orientation;
-                    r.x = f.x; r.y = f.y; r.octave = f.octave; r.index = f.index;
-                    r.filtered = 1; r.has_descriptor = 0; r.reserved = 0;
-                    kp_out[ok] = r;
-                    float4* d = reinterpret_cast<float4*>(desc_out + (size_t)ok * 128);
-                    for (int i = 0; i < 32; ++i) d[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                }
-            }
-            continue;
-        }
-        int* cnt = cell_cnt + (size_t)img * (size_t)(cpi + 1) + cell;
-        if (!FILL) {
-            atomicAdd(cnt, 1);
+        if (cell >= 0) {
+            atomicAdd(&cnt[cell], 1);
         } else {
-            const int p = atomicAdd(cnt, 1);   // the counts were cleared again by the scan: now the fill cursor
-            FinalKp rec = f;
-            rec.cand = (uint32_t)k;            // vector index: the order the chains follow, and the output slot
-            pool[(size_t)img * (size_t)pool_cap + (size_t)cell_off[(size_t)img * (size_t)(cpi + 1) + cell] + (size_t)p] = rec;
+            const long long ok = out_base[img] + k;
+            if (ok < out_cap) {
+                sift_hip_keypoint r;
+                r.scale = plan->dog_scale[f.octave * plan->dogs + f.index];
+                r.orientation = f.orientation;
+                r.x = f.x; r.y = f.y; r.octave = f.octave; r.index = f.index;
+                r.filtered = 1; r.has_descriptor = 0; r.reserved = 0;
+                kp_out[ok] = r;
+                float4* d = reinterpret_cast<float4*>(desc_out + (size_t)ok * 128);
+                for (int i = 0; i < 32; ++i) d[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
         }
     }
-}
-
-// exclusive scan of one image's cell counts into cell_off[0 .. cpi] (the last entry is the total); clears the counts
-__global__ __launch_bounds__(1024) void desc_cell_scan_kernel(int* __restrict__ cell_cnt, int* __restrict__ cell_off, int cpi) {
-    __shared__ int s_part[1024];
-    const int img = blockIdx.x, tid = threadIdx.x;
-    int* c = cell_cnt + (size_t)img * (size_t)(cpi + 1);
-    int* o = cell_off + (size_t)img * (size_t)(cpi + 1);
-    const int chunk = (cpi + 1023) / 1024;
+    __syncthreads();
+    // exclusive scan: each thread owns a run of consecutive cells
+    const int chunk = (cpi + kGridThreads - 1) / kGridThreads;
     const int lo = tid * chunk, hi = min(lo + chunk, cpi);
     int sum = 0;
-    for (int i = lo; i < hi; ++i) sum += c[i];
+    for (int i = lo; i < hi; ++i) sum += cnt[i];
     s_part[tid] = sum;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int v = (tid >= off) ? s_part[tid - off] : 0;
+    for (int o = 1; o < kGridThreads; o <<= 1) {
+        const int v = tid >= o ? s_part[tid - o] : 0;
         __syncthreads();
         s_part[tid] += v;
         __syncthreads();
     }
     int run = s_part[tid] - sum;
     for (int i = lo; i < hi; ++i) {
-        const int v = c[i];
-        o[i] = run;
-        c[i] = 0;
+        const int v = cnt[i];
+        off[i] = run;
+        cnt[i] = run;   // from here on: the cell's next free pool slot
         run += v;
     }
-    if (tid == 1023) o[cpi] = s_part[1023];
+    if (tid == kGridThreads - 1) off[cpi] = s_part[kGridThreads - 1];
+    __syncthreads();
+    FinalKp* pl = pool + (size_t)img * (size_t)pool_cap;
+    for (int k = tid; k < K; k += kGridThreads) {
+        FinalKp f = fin[k];
+        int level;
+        const int cell = desc_cell_of(plan, f, level);
+        if (cell < 0) continue;
+        f.cand = (uint32_t)k;   // vector index: the order the chains follow, and the output slot
+        pl[atomicAdd(&cnt[cell], 1)] = f;
+    }
 }
 
 // minimum of a non-negative int over the wave, in a scalar register: butterfly inside each row of 16 lanes (DPP), then the
@@ -695,20 +702,69 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
     const long long obase = out_base[img];
     const unsigned b0 = 2u * (unsigned)(lane & 3), b1 = b0 + 1u;   // the two bins this lane accumulates for its cell
 
-    for (int e = e_begin + (int)blockIdx.x * 4 + wave; e < e_end; e += (int)gridDim.x * 4) {
+    // Two-stage scalar prefetch: a keypoint's record is fetched two iterations ahead and the bounds of its three cell-row
+    // ranges one iteration ahead, so that no iteration waits for a dependent pair of loads (record -> ranges -> neighbour
+    // records would be three round trips per keypoint, which is what a wave's time went to without this).
+    const int estride = (int)gridDim.x * 4;
+    const int e0 = e_begin + (int)blockIdx.x * 4 + wave;
+    struct Rec { int k; float theta; unsigned xy, oi; };
+    struct Ranges { int s0, s1, s2, n0, n1, n2; };
+    auto load_rec = [&](int e) {
+        const uint4 v = *reinterpret_cast<const uint4*>(&pl[min(e, e_end - 1)]);   // past the end: a harmless repeat
+        Rec r;
+        r.k = (int)v.x; r.theta = __uint_as_float(v.y); r.xy = v.z; r.oi = v.w;
+        return r;
+    };
+    auto load_ranges = [&](unsigned xy) {   // the 3x3 cells around (x, y): three runs of consecutive records, one per cell row
+        const int ccx = (int)(xy & 0xffffu) >> kCellShift, ccy = (int)(xy >> 16) >> kCellShift;
+        const int c0 = max(ccx - 1, 0), c1 = min(ccx + 1, lv.cw - 1);
+        const int y0 = max(ccy - 1, 0), y2 = min(ccy + 1, lv.ch - 1);
+        // unconditional loads (rows clamped into the grid), the counts of rows outside it zeroed afterwards
+        const int a0 = coff[y0 * lv.cw + c0], b0_ = coff[y0 * lv.cw + c1 + 1];
+        const int a1 = coff[ccy * lv.cw + c0], b1_ = coff[ccy * lv.cw + c1 + 1];
+        const int a2 = coff[y2 * lv.cw + c0], b2_ = coff[y2 * lv.cw + c1 + 1];
+        Ranges g;
+        g.s0 = a0; g.n0 = ccy - 1 >= 0 ? b0_ - a0 : 0;
+        g.s1 = a1; g.n1 = b1_ - a1;
+        g.s2 = a2; g.n2 = ccy + 1 < lv.ch ? b2_ - a2 : 0;
+        return g;
+    };
+    auto uniform_rec = [](const Rec& r) {   // the record is the same in every lane: keep it in scalar registers
+        Rec u;
+        u.k = __builtin_amdgcn_readfirstlane(r.k);
+        u.theta = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(r.theta)));
+        u.xy = (unsigned)__builtin_amdgcn_readfirstlane((int)r.xy);
+        u.oi = (unsigned)__builtin_amdgcn_readfirstlane((int)r.oi);
+        return u;
+    };
+    Rec cur = uniform_rec(load_rec(e0));
+    Ranges cur_rg = load_ranges(cur.xy);
+    Rec nxt = load_rec(e0 + estride);
+
+    for (int e = e0; e < e_end; e += estride) {
         // ---- this wave's keypoint (wave-uniform: scalar registers) ----------------------------------------------
-        const uint4 me = *reinterpret_cast<const uint4*>(&pl[e]);
-        const int myk = __builtin_amdgcn_readfirstlane((int)me.x);
-        const float mytheta = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)me.y));
-        const unsigned myxy = (unsigned)__builtin_amdgcn_readfirstlane((int)me.z);
-        const unsigned myoi = (unsigned)__builtin_amdgcn_readfirstlane((int)me.w);   // octave | index << 16
-        const int px = (int)(myxy & 0xffffu), py = (int)(myxy >> 16);
+        const int myk = cur.k;
+        const float mytheta = cur.theta;
+        const unsigned myoi = cur.oi;   // octave | index << 16
+        const int px = (int)(cur.xy & 0xffffu), py = (int)(cur.xy >> 16);
+        const int rs[3] = {cur_rg.s0, cur_rg.s1, cur_rg.s2}, rn[3] = {cur_rg.n0, cur_rg.n1, cur_rg.n2};
+        const int T = rn[0] + rn[1] + rn[2];
+        auto entry_of = [&](int i) {   // i-th record of the three ranges
+            return i < rn[0] ? rs[0] + i : (i < rn[0] + rn[1] ? rs[1] + (i - rn[0]) : rs[2] + (i - rn[0] - rn[1]));
+        };
+        // the neighbour records (one per lane) travel together with the window's pixels
+        uint4 c = make_uint4(0u, 0u, 0u, 0u);
+        if (lane < T && T <= 64) c = *reinterpret_cast<const uint4*>(&pl[entry_of(lane)]);
         // ---- the window's pixels: initial maps and the Gaussian level (every keypoint of the grid passed the bounds test,
         // so the window lies inside the image) ------------------------------------------------------------------------
         const size_t o = (size_t)(py - kRegion + ly) * (size_t)w + (size_t)(px - kRegion + lx0);
         const f4u o4 = *reinterpret_cast<const f4u*>(go + o);
         const f4u m4 = *reinterpret_cast<const f4u*>(gm + o);
         const f4u g4 = *reinterpret_cast<const f4u*>(gg + o);
+        // prefetch: ranges of the next keypoint (its record arrived during the previous iteration), record of the one after
+        const Rec nxt_u = uniform_rec(nxt);
+        const Ranges nxt_rg = load_ranges(nxt_u.xy);
+        nxt = load_rec(e + 2 * estride);
         float vo[4] = {o4.x, o4.y, o4.z, o4.w}, vm[4] = {m4.x, m4.y, m4.z, m4.w};
         const float vg[4] = {g4.x, g4.y, g4.z, g4.w};
 
@@ -729,29 +785,12 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
 
         // ---- neighbours: the 3x3 cells around p's --------------------------------------------------------------------
         if (!(dbg & 1)) {
-            const int ccx = px >> kCellShift, ccy = py >> kCellShift;
-            const int c0 = max(ccx - 1, 0), c1 = min(ccx + 1, lv.cw - 1);
-            int rs[3], rn[3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int cy = ccy + r - 1;
-                const bool ok = cy >= 0 && cy < lv.ch;
-                const int a = ok ? coff[cy * lv.cw + c0] : 0, b = ok ? coff[cy * lv.cw + c1 + 1] : 0;
-                rs[r] = a;
-                rn[r] = b - a;
-            }
-            const int T = rn[0] + rn[1] + rn[2];
-            auto entry_of = [&](int i) {   // i-th record of the three ranges
-                return i < rn[0] ? rs[0] + i : (i < rn[0] + rn[1] ? rs[1] + (i - rn[0]) : rs[2] + (i - rn[0] - rn[1]));
-            };
             auto precedes = [&](const uint4& c) {   // earlier in the vector and close enough to share a pixel
                 const int qx = (int)(c.z & 0xffffu), qy = (int)(c.z >> 16);
                 return (int)c.x < myk && (unsigned)(qx - px + 15) < 31u && (unsigned)(qy - py + 15) < 31u;
             };
             if (T <= 64) {
                 // one record per lane, kept in registers; key = vector index | lane
-                uint4 c = make_uint4(0u, 0u, 0u, 0u);
-                if (lane < T) c = *reinterpret_cast<const uint4*>(&pl[entry_of(lane)]);
                 int key = (lane < T && precedes(c)) ? (int)((c.x << 6) | (unsigned)lane) : 0x7fffffff;
                 for (;;) {
                     const int m = wave_min_nonneg(key);
@@ -836,6 +875,8 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
                 kp_out[ok] = r;
             }
         }
+        cur = nxt_u;
+        cur_rg = nxt_rg;
     }
 }
 
@@ -904,18 +945,16 @@ void launch_descriptors(hipStream_t s, const DevPlan* d_plan, const DevPlan& pla
                        d_tile_cnt, d_tile_off, d_pool, pool_cap, d_out_base, d_kp_out, d_desc_out, out_cap, dbg);
 }
 
-// grid of 16 px cells over the final keypoints of every image (counts, scan, fill)
+// grid of 16 px cells over the final keypoints of every image
 void launch_desc_grid(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const FinalKp* d_final, const int* d_final_cnt,
                       int final_cap, int* d_cell_cnt, int* d_cell_off, FinalKp* d_pool, int pool_cap, const long long* d_out_base,
-                      sift_hip_keypoint* d_kp_out, float* d_desc_out, long long out_cap, bool counts_are_clear) {
-    const int cpi = plan.desc_cells_per_image;
-    if (!counts_are_clear) (void)hipMemsetAsync(d_cell_cnt, 0, (size_t)(cpi + 1) * (size_t)plan.n_images * sizeof(int), s);
-    const dim3 grid(64, (unsigned)plan.n_images);
-    hipLaunchKernelGGL(desc_cell_kernel<false>, grid, dim3(256), 0, s, d_plan, d_final, d_final_cnt, final_cap, d_cell_cnt,
-                       (const int*)d_cell_off, d_pool, pool_cap, d_out_base, d_kp_out, d_desc_out, out_cap);
-    hipLaunchKernelGGL(desc_cell_scan_kernel, dim3((unsigned)plan.n_images), dim3(1024), 0, s, d_cell_cnt, d_cell_off, cpi);
-    hipLaunchKernelGGL(desc_cell_kernel<true>, grid, dim3(256), 0, s, d_plan, d_final, d_final_cnt, final_cap, d_cell_cnt,
-                       (const int*)d_cell_off, d_pool, pool_cap, d_out_base, d_kp_out, d_desc_out, out_cap);
+                      sift_hip_keypoint* d_kp_out, float* d_desc_out, long long out_cap) {
+    if (plan.desc_cells_per_image <= kGridLdsCells)
+        hipLaunchKernelGGL(desc_grid_kernel<true>, dim3((unsigned)plan.n_images), dim3(kGridThreads), 0, s, d_plan, d_final, d_final_cnt,
+                           final_cap, d_cell_cnt, d_cell_off, d_pool, pool_cap, d_out_base, d_kp_out, d_desc_out, out_cap);
+    else
+        hipLaunchKernelGGL(desc_grid_kernel<false>, dim3((unsigned)plan.n_images), dim3(kGridThreads), 0, s, d_plan, d_final, d_final_cnt,
+                           final_cap, d_cell_cnt, d_cell_off, d_pool, pool_cap, d_out_base, d_kp_out, d_desc_out, out_cap);
 }
 
 void launch_descriptors_wave(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level, const int* d_cell_off,
