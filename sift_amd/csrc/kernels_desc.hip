@@ -644,6 +644,19 @@ __global__ __launch_bounds__(kGridThreads) void desc_grid_kernel(const DevPlan* 
     }
 }
 
+// alg::orientationHistogram8's bin index `u16_t i = std::floor(orientation / 45); i = i % 7` (algorithms.cpp:143-145).  The
+// quotient is formed without the division sequence: q0 = v * RN(1/45), one Newton correction with the exact residual
+// (Markstein): for every one of the 2^32 float inputs the bin equals the one the IEEE division gives (checked exhaustively
+// on the host, tests/test_host_math.py; the quotient itself differs only for -0.0 and the infinities, which land in the same
+// bin).  Needs fused multiply-adds and f32 denormals, both on in this build.
+__device__ __forceinline__ unsigned hist8_bin(float v) {
+    const float r = 1.0f / 45.0f;
+    const float q0 = v * r;
+    const float e = __builtin_fmaf(-q0, 45.0f, v);
+    const float q = __builtin_fmaf(e, r, q0);
+    return f32_to_u16_x86_d(__builtin_floorf(q)) % 7u;
+}
+
 // minimum of a non-negative int over the wave, in a scalar register: butterfly inside each row of 16 lanes (DPP), then the
 // four rows by readlane
 __device__ __forceinline__ int wave_min_nonneg(int v) {
@@ -673,24 +686,34 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
                                                                  const FinalKp* __restrict__ pool, int pool_cap,
                                                                  const long long* __restrict__ out_base,
                                                                  sift_hip_keypoint* __restrict__ kp_out,
-                                                                 float* __restrict__ desc_out, long long out_cap, int dbg) {
+                                                                 float* __restrict__ desc_out, long long out_cap, int n_images,
+                                                                 int chunks, int dbg) {
     __shared__ float s_w16t[kW16Size];
+    __shared__ uint2 s_list[4][64];   // per wave: preceding neighbours (x | y << 16, orientation bits) in vector order
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int img = blockIdx.y;
     const int w = lv.w, h = lv.h, D = lv.dogs;
-    const int* __restrict__ coff = cell_off + (size_t)img * (size_t)(lv.cells_per_image + 1) + lv.cell_base;
-    const int e_begin = coff[0], e_end = coff[lv.cw * lv.ch];
-    if (e_begin + (int)blockIdx.x * 4 >= e_end) return;   // nothing for this workgroup
-    // weighting(x, y) (sift.cpp:87-90), x-major: index bias + 20 * x + y.  Entries outside 0..15 x 0..15 are only ever
-    // read by lanes that then discard them.
-    for (int i = tid; i < kW16Size; i += 256) s_w16t[i] = 0.0f;
-    __syncthreads();
-    s_w16t[kW16Bias + (tid & 15) * kW16Stride + (tid >> 4)] = lv.w16[(size_t)img * 256 + tid];
-    __syncthreads();
-
     const int ly = lane & 15, lx0 = (lane >> 4) * 4;   // this lane's row and first column inside a window
     const int tbase = kW16Bias + lx0 * kW16Stride + ly;
+    const unsigned b0 = 2u * (unsigned)(lane & 3), b1 = b0 + 1u;   // the two bins this lane accumulates for its cell
+    for (int i = tid; i < kW16Size; i += 256) s_w16t[i] = 0.0f;
+    // Work units = (image, chunk of the image's records): workgroups with equal blockIdx % 8 (observed to share an XCD and
+    // its 4 MB L2; a different placement only costs speed) take the units u = blockIdx % 8, + 8, + 16 ... one after the
+    // other, all of them striding through the SAME unit at a time.  The records of a unit are consecutive grid cells, i.e. a
+    // band of the image a few cells high, so the windows the XCD's waves read at any moment overlap in its L2 instead of
+    // every L2 holding a slice of every image of the batch.
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3, nslots = (int)gridDim.x >> 3;
+    for (int unit = xcd; unit < n_images * chunks; unit += 8) {
+    const int img = unit / chunks, chunk = unit - img * chunks;
+    const int* __restrict__ coff = cell_off + (size_t)img * (size_t)(lv.cells_per_image + 1) + lv.cell_base;
+    const int r_begin = coff[0], r_count = coff[lv.cw * lv.ch] - r_begin;
+    const int e_begin = r_begin + (int)((long long)r_count * chunk / chunks), e_end = r_begin + (int)((long long)r_count * (chunk + 1) / chunks);
+    if (e_begin + slot * 4 >= e_end) continue;   // nothing for this workgroup in this unit
+    // weighting(x, y) (sift.cpp:87-90), x-major: index bias + 20 * x + y.  Entries outside 0..15 x 0..15 are only ever
+    // read by lanes that then discard them.
+    __syncthreads();   // the previous unit's readers are done
+    s_w16t[kW16Bias + (tid & 15) * kW16Stride + (tid >> 4)] = lv.w16[(size_t)img * 256 + tid];
+    __syncthreads();
     float wself[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) wself[i] = s_w16t[tbase + i * kW16Stride];
@@ -700,15 +723,17 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
     const float* __restrict__ gg = lv.gauss + img_off;
     const FinalKp* __restrict__ pl = pool + (size_t)img * (size_t)pool_cap;
     const long long obase = out_base[img];
-    const unsigned b0 = 2u * (unsigned)(lane & 3), b1 = b0 + 1u;   // the two bins this lane accumulates for its cell
 
-    // Two-stage scalar prefetch: a keypoint's record is fetched two iterations ahead and the bounds of its three cell-row
-    // ranges one iteration ahead, so that no iteration waits for a dependent pair of loads (record -> ranges -> neighbour
-    // records would be three round trips per keypoint, which is what a wave's time went to without this).
-    const int estride = (int)gridDim.x * 4;
-    const int e0 = e_begin + (int)blockIdx.x * 4 + wave;
+    // Scalar prefetch over the wave's keypoints: a keypoint's record (x, y, orientation, vector index) is fetched two
+    // iterations ahead and the bounds of its three cell-row runs of records one iteration ahead, so an iteration starts with
+    // everything its vector loads (window pixels of the three maps, one neighbour record per lane) need and never waits for a
+    // chain of dependent loads.  (Fetching the window pixels an iteration ahead as well was measured: no gain, the extra
+    // registers spill.)
+    const int estride = nslots * 4;
+    const int e0 = e_begin + slot * 4 + wave;
     struct Rec { int k; float theta; unsigned xy, oi; };
     struct Ranges { int s0, s1, s2, n0, n1, n2; };
+    struct Window { f4u o, m, g; };
     auto load_rec = [&](int e) {
         const uint4 v = *reinterpret_cast<const uint4*>(&pl[min(e, e_end - 1)]);   // past the end: a harmless repeat
         Rec r;
@@ -737,51 +762,73 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
         u.oi = (unsigned)__builtin_amdgcn_readfirstlane((int)r.oi);
         return u;
     };
-    Rec cur = uniform_rec(load_rec(e0));
-    Ranges cur_rg = load_ranges(cur.xy);
-    Rec nxt = load_rec(e0 + estride);
+    // (every keypoint of the grid passed the bounds test, so its window lies inside the image)
+    auto load_window = [&](unsigned xy) {
+        size_t o = (size_t)((int)(xy >> 16) - kRegion + ly) * (size_t)w + (size_t)((int)(xy & 0xffffu) - kRegion + lx0);
+        if (dbg & 8) o &= ~(size_t)3;   // timing only: 16-byte aligned window loads (wrong pixels)
+        Window wd;
+        wd.o = (f4u)(1.0f); wd.m = (f4u)(2.0f); wd.g = (f4u)(3.0f);
+        if (!(dbg & 4)) {               // timing only: no window loads
+            wd.o = *reinterpret_cast<const f4u*>(go + o);
+            wd.m = *reinterpret_cast<const f4u*>(gm + o);
+            wd.g = *reinterpret_cast<const f4u*>(gg + o);
+        }
+        return wd;
+    };
+    auto entry_of = [](const Ranges& g, int i) {   // i-th record of the three runs
+        return i < g.n0 ? g.s0 + i : (i < g.n0 + g.n1 ? g.s1 + (i - g.n0) : g.s2 + (i - g.n0 - g.n1));
+    };
+    auto load_cand = [&](const Ranges& g) {   // one neighbour record per lane (crowded neighbourhoods are rescanned instead)
+        const int T = g.n0 + g.n1 + g.n2;
+        uint4 c = make_uint4(0u, 0u, 0u, 0u);
+        if (lane < T && T <= 64) c = *reinterpret_cast<const uint4*>(&pl[entry_of(g, lane)]);
+        return c;
+    };
+    Rec u0 = uniform_rec(load_rec(e0));
+    Rec r1 = load_rec(e0 + estride);
+    Ranges g0 = load_ranges(u0.xy);
 
     for (int e = e0; e < e_end; e += estride) {
-        // ---- this wave's keypoint (wave-uniform: scalar registers) ----------------------------------------------
-        const int myk = cur.k;
-        const float mytheta = cur.theta;
-        const unsigned myoi = cur.oi;   // octave | index << 16
-        const int px = (int)(cur.xy & 0xffffu), py = (int)(cur.xy >> 16);
-        const int rs[3] = {cur_rg.s0, cur_rg.s1, cur_rg.s2}, rn[3] = {cur_rg.n0, cur_rg.n1, cur_rg.n2};
-        const int T = rn[0] + rn[1] + rn[2];
-        auto entry_of = [&](int i) {   // i-th record of the three ranges
-            return i < rn[0] ? rs[0] + i : (i < rn[0] + rn[1] ? rs[1] + (i - rn[0]) : rs[2] + (i - rn[0] - rn[1]));
-        };
         // the neighbour records (one per lane) travel together with the window's pixels
-        uint4 c = make_uint4(0u, 0u, 0u, 0u);
-        if (lane < T && T <= 64) c = *reinterpret_cast<const uint4*>(&pl[entry_of(lane)]);
-        // ---- the window's pixels: initial maps and the Gaussian level (every keypoint of the grid passed the bounds test,
-        // so the window lies inside the image) ------------------------------------------------------------------------
-        const size_t o = (size_t)(py - kRegion + ly) * (size_t)w + (size_t)(px - kRegion + lx0);
-        const f4u o4 = *reinterpret_cast<const f4u*>(go + o);
-        const f4u m4 = *reinterpret_cast<const f4u*>(gm + o);
-        const f4u g4 = *reinterpret_cast<const f4u*>(gg + o);
-        // prefetch: ranges of the next keypoint (its record arrived during the previous iteration), record of the one after
-        const Rec nxt_u = uniform_rec(nxt);
-        const Ranges nxt_rg = load_ranges(nxt_u.xy);
-        nxt = load_rec(e + 2 * estride);
-        float vo[4] = {o4.x, o4.y, o4.z, o4.w}, vm[4] = {m4.x, m4.y, m4.z, m4.w};
-        const float vg[4] = {g4.x, g4.y, g4.z, g4.w};
+        const uint4 c0v = load_cand(g0);
+        const Window w0 = load_window(u0.xy);
+        // ---- prefetch stages --------------------------------------------------------------------------------------
+        const Rec u1 = uniform_rec(r1);             // arrived during the previous iteration
+        r1 = load_rec(e + 2 * estride);
+        const Ranges g1 = load_ranges(u1.xy);
+        // ---- this wave's keypoint (wave-uniform: scalar registers) ----------------------------------------------
+        const int myk = u0.k;
+        const float mytheta = u0.theta;
+        const unsigned myoi = u0.oi;   // octave | index << 16
+        const int px = (int)(u0.xy & 0xffffu), py = (int)(u0.xy >> 16);
+        const int T = g0.n0 + g0.n1 + g0.n2;
+        const uint4 c = c0v;
+        float vo[4] = {w0.o.x, w0.o.y, w0.o.z, w0.o.w}, vm[4] = {w0.m.x, w0.m.y, w0.m.z, w0.m.w};
+        const float vg[4] = {w0.g.x, w0.g.y, w0.g.z, w0.g.w};
 
-        // one preceding neighbour q: the lane's pixels that q's window covers receive q's additions (sift.cpp:80-92)
-        auto apply = [&](unsigned qxy, float qtheta) {
+        // one preceding neighbour q: the lane's pixels that q's window covers receive q's additions (sift.cpp:80-92).
+        // The four weighting values are fetched by `weights_of` (which can run one neighbour ahead) and consumed by `apply`.
+        struct Wq { float v[4]; };
+        auto weights_of = [&](unsigned qxy) {
             const int dx = px - (int)(qxy & 0xffffu), dy = py - (int)(qxy >> 16);   // window-local offset: p's (x, y) is q's (x + dx, y + dy)
-            const bool row_in = (unsigned)(ly + dy) < 16u;
             const int tq = tbase + dx * kW16Stride + dy;
+            Wq r;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r.v[i] = s_w16t[tq + i * kW16Stride];
+            return r;
+        };
+        auto apply_w = [&](unsigned qxy, float qtheta, const Wq& wq) {
+            const int dx = px - (int)(qxy & 0xffffu), dy = py - (int)(qxy >> 16);
+            const bool row_in = (unsigned)(ly + dy) < 16u;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float wq = s_w16t[tq + i * kW16Stride];
                 const bool in = row_in && (unsigned)(lx0 + i + dx) < 16u;
-                const float no = vo[i] + qtheta, nm = vm[i] + wq;
+                const float no = vo[i] + qtheta, nm = vm[i] + wq.v[i];
                 vo[i] = in ? no : vo[i];
                 vm[i] = in ? nm : vm[i];
             }
         };
+        auto apply = [&](unsigned qxy, float qtheta) { apply_w(qxy, qtheta, weights_of(qxy)); };
 
         // ---- neighbours: the 3x3 cells around p's --------------------------------------------------------------------
         if (!(dbg & 1)) {
@@ -790,14 +837,29 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
                 return (int)c.x < myk && (unsigned)(qx - px + 15) < 31u && (unsigned)(qy - py + 15) < 31u;
             };
             if (T <= 64) {
-                // one record per lane, kept in registers; key = vector index | lane
-                int key = (lane < T && precedes(c)) ? (int)((c.x << 6) | (unsigned)lane) : 0x7fffffff;
-                for (;;) {
-                    const int m = wave_min_nonneg(key);
-                    if (m == 0x7fffffff) break;
-                    const int src = m & 63;
-                    apply((unsigned)__builtin_amdgcn_readlane((int)c.z, src), __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)c.y, src)));
-                    key = lane == src ? 0x7fffffff : key;
+                // One record per lane.  The preceding neighbours are ranked by vector index (every lane counts the smaller
+                // indices among them: one readlane + compare + add per neighbour), dropped into this wave's LDS list at their
+                // rank and then simply walked: the loop body has no wave-wide minimum and no lane search, only a broadcast LDS
+                // read of the next neighbour.  (Measured alternatives, no faster: a wave minimum per neighbour; finding the lane
+                // of rank r by ballot with the weighting values fetched one neighbour ahead.)
+                const bool pass = lane < T && precedes(c);
+                unsigned long long todo = __ballot(pass);
+                const int n_prev = __popcll(todo);
+                if (n_prev) {
+                    int rank = 0;
+                    while (todo) {
+                        const int j = (int)__builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        rank += (unsigned)__builtin_amdgcn_readlane((int)c.x, j) < c.x ? 1 : 0;
+                    }
+                    uint2* list = s_list[wave];
+                    if (pass) list[rank] = make_uint2(c.z, c.y);
+                    __builtin_amdgcn_wave_barrier();
+                    for (int r = 0; r < n_prev; ++r) {
+                        const uint2 q = list[r];
+                        apply(q.x, __uint_as_float(q.y));
+                    }
+                    __builtin_amdgcn_wave_barrier();   // the list is rewritten for the wave's next keypoint
                 }
             } else {
                 // crowded neighbourhood: take the preceding neighbours in order by rescanning the records
@@ -808,7 +870,7 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
                     for (int base = 0; base < T; base += 64) {
                         const int i = base + lane;
                         if (i < T) {
-                            const uint4 c = *reinterpret_cast<const uint4*>(&pl[entry_of(i)]);
+                            const uint4 c = *reinterpret_cast<const uint4*>(&pl[entry_of(g0, i)]);
                             if (precedes(c) && (int)c.x > last && (int)c.x < bk) { bk = (int)c.x; bxy = c.z; bth = c.y; }
                         }
                     }
@@ -828,7 +890,7 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
             const float no = vo[i] + mytheta;
             const float nm = vm[i] + wself[i];
             val[i] = nm * vg[i];
-            bin[i] = f32_to_u16_x86_d(__builtin_floorf(no / 45.0f)) % 7u;
+            bin[i] = hist8_bin(no);
         }
         // ---- 16 cell histograms: a quad holds one cell; samples in x-outer / y-inner order ------------------------------
         float h0 = 0.0f, h1 = 0.0f;
@@ -863,7 +925,7 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
             }
         }
         const long long ok = obase + (long long)myk;
-        if (ok < out_cap) {   // (the output arrays are sized before the final counts reach the host: see run_batch)
+        if (ok < out_cap && !((dbg & 16) && h0 == 12345.0f)) {   // (the output arrays are sized before the final counts reach the host: see run_batch)
             *reinterpret_cast<float2*>(desc_out + (size_t)ok * 128 + (size_t)(2 * lane)) = make_float2(h0, h1);
             if (lane == 0) {
                 sift_hip_keypoint r;
@@ -875,9 +937,10 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
                 kp_out[ok] = r;
             }
         }
-        cur = nxt_u;
-        cur_rg = nxt_rg;
+        u0 = u1;
+        g0 = g1;
     }
+    }   // units
 }
 
 void launch_w16(hipStream_t s, const DevPlan& plan, int level, const float* d_taps16, int radius16) {
@@ -966,11 +1029,11 @@ void launch_descriptors_wave(hipStream_t s, const DevPlan* d_plan, const DevPlan
     lv.cw = plan.desc_cw[level]; lv.ch = plan.desc_ch[level]; lv.cell_base = plan.desc_cell_base[level];
     lv.cells_per_image = plan.desc_cells_per_image;
     lv.mag = plan.mag[level]; lv.ori = plan.ori[level]; lv.gauss = plan.gauss[level]; lv.w16 = plan.w16[level];
-    // 2048 workgroups of four waves over the batch: 8 per CU, every wave strides through its image's records
-    int gx = 2048 / (plan.n_images > 0 ? plan.n_images : 1);
-    gx = gx < 16 ? 16 : (gx > 4096 ? 4096 : gx);
-    hipLaunchKernelGGL(descriptor_wave_kernel, dim3((unsigned)gx, (unsigned)plan.n_images), dim3(256), 0, s, d_plan, lv, d_cell_off,
-                       d_pool, pool_cap, d_out_base, d_kp_out, d_desc_out, out_cap, dbg);
+    // 2048 workgroups of four waves (8 per CU); whole images per XCD when there are at least 8, eighths of an image otherwise
+    const int chunks = plan.n_images >= 8 ? 1 : 8;
+    const unsigned nwg = (dbg & 64) ? 512u : ((dbg & 32) ? 1024u : 2048u);   // timing only: fewer resident waves
+    hipLaunchKernelGGL(descriptor_wave_kernel, dim3(nwg), dim3(256), 0, s, d_plan, lv, d_cell_off, d_pool, pool_cap, d_out_base,
+                       d_kp_out, d_desc_out, out_cap, plan.n_images, chunks, dbg);
 }
 
 }  // namespace sift_hip
