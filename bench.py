@@ -48,9 +48,22 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 CPU_SAMPLE_FRAMES = 8
 
 
-def cpu_baseline(frames):
-    """Oracle (lean mode: identical results to the reference, redundant copies hoisted) on a
-    bounded sample of the same workload, 1 thread."""
+def host_cpu():
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"host_cores": os.cpu_count(), "host_cpu": model}
+
+
+def cpu_baseline(frames, faithful=True):
+    """Oracle on a bounded sample of the same workload, 1 thread, on this box's host cores: lean mode (identical results to
+    the reference, its redundant copies hoisted) on 8 frames, and faithful mode (the reference's own cost structure: three
+    DoG images copied per extremum candidate, sift.cpp:297-298, a level re-blurred per keypoint, sift.cpp:87) on one."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     kps, secs = 0, 0.0
@@ -58,6 +71,20 @@ def cpu_baseline(frames):
         run = O.OracleRun(f, DOGS, OCTAVES, SIGMA)
         secs += run.seconds
         kps += run.points("final")[0].size
+        run.close()
+    faith = None
+    if faithful:
+        # bounded: the cost is O(candidates x pixels), a whole 1080p frame takes this mode 456 s on the MI355X box's EPYC 9575F
+        # (profiles/r02_bench_full.json; 19764 keypoints: 43 keypoints/s) — its top-left 480x270 sixteenth a few tens of seconds
+        h, w = frames[0].shape
+        crop = np.ascontiguousarray(frames[0][:h // 4, :w // 4])
+        run = O.OracleRun(crop, DOGS, OCTAVES, SIGMA, faithful=True)
+        n = run.points("final")[0].size
+        faith = {"value": n / run.seconds, "unit": "keypoints/s", "cores": 1, "seconds": run.seconds, "keypoints": int(n),
+                 "sample": f"the top-left {w // 4}x{h // 4} sixteenth of frame 1, oracle in faithful mode (the reference's own cost structure: "
+                           "three DoG images copied per extremum candidate, a level re-blurred per keypoint), timed on this box; the cost "
+                           "grows with candidates x pixels, so a whole 1080p frame is several times slower per keypoint (measured once on "
+                           "this box type: 456 s for frame 1, 43 keypoints/s, profiles/r02_bench_full.json)"}
         run.close()
     ref = None
     try:   # what the reference's own binary needed for frame 1 of this workload (measured once in the build container)
@@ -68,20 +95,47 @@ def cpu_baseline(frames):
                       "container (not on this box: the reference does not travel); same keypoints and descriptors, bit for bit"}
     except Exception:
         pass
-    return {"reference_binary": ref, "value": kps / secs, "unit": "keypoints/s", "cores": 1, "kind": "port",
+    return {"reference_binary": ref, "faithful": faith, **host_cpu(), "value": kps / secs, "unit": "keypoints/s", "cores": 1, "kind": "port",
             "sample": f"{len(frames)} of the {FRAMES_PER_GPU} synthetic 1920x1080 frames, 4 oct x 3 DoG, oracle in lean mode "
                       f"(reference's per-candidate image copies and per-keypoint re-blur hoisted; same results), "
                       f"{secs:.1f} s CPU, {kps} keypoints"}
 
 
-def pmc_traffic():
-    """HBM bytes per blur launch from the committed rocprofv3 PMC pass (tools/pmc_round.sh; FETCH_SIZE x2
-    corrected + WRITE_SIZE, MI355X_MICROARCH.md section HBM).  bench.py itself cannot read PMC counters."""
-    p = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    try:
-        return json.load(open(p))["_blur_fused_all"]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+def pmc_traffic_live(extra_args):  # noqa: C901
+    """HBM bytes per blur launch, measured now: two child runs of this script (one step each) under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes; FETCH_SIZE x2 for 16-byte-per-lane reads on gfx950,
+    MI355X_MICROARCH.md section HBM), averaged over the blur launches.  None when rocprofv3 is missing or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not found"
+    tot, launches = {}, 0
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, c)
+            cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--pipeline-depth", "1"] + extra_args
+            env = dict(os.environ, TMPDIR="/tmp")
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            except Exception as ex:   # noqa: BLE001
+                return None, f"rocprofv3 pass {c}: {ex}"
+            if r.returncode != 0:
+                return None, f"rocprofv3 pass {c} exited {r.returncode}"
+            s, n = 0.0, 0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == c and ("blur_stream_kernel" in row["Kernel_Name"] or "blur_fused_kernel" in row["Kernel_Name"]):
+                        s += float(row["Counter_Value"])
+                        n += 1
+            if not n:
+                return None, f"no blur launches in the {c} pass"
+            tot[c], launches = s / n, n
+    return tot["FETCH_SIZE"] * 1024 * 2 + tot["WRITE_SIZE"] * 1024, f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this bench on this box ({launches} blur launches each; FETCH_SIZE x2)"
 
 
 def main():
@@ -94,6 +148,7 @@ def main():
                     help="config4 (default) is the headline workload; config3 / config5 are BASELINE.json's other GPU "
                          "configurations at their nearest non-throwing parameters (SURVEY 8(d)), reported as labelled extra lines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the legs beside the headline: host-buffer rate, single-frame latency, live PMC traffic")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "exercise the N > 1 flow where ranks have to share one GPU: results are staged through host memory)")
     ap.add_argument("--share-device", action="store_true", help="testing: every rank uses GPU 0")
@@ -154,30 +209,34 @@ def main():
     params = _lib.Params(DOGS, OCTAVES, SIGMA, K_SQRT2, SUBPIXEL)
     L = ctx._L
 
-    from sift_amd.gather import device_results, gather_finish, gather_start
+    from sift_amd.gather import KeypointGather, device_results
 
-    # N > 1: the RCCL gather of step k (keypoint records + descriptors to rank 0, never images) is only
-    # STARTED at the end of step k and overlaps the kernels of step k+1, which run on the library's own
-    # streams; two result buffers alternate, and every gather is finished inside the timed region.
-    in_flight = []          # (GatherHandle, tensors kept alive)
+    # N > 1: the gather of step k (keypoint records + descriptors to rank 0 over RCCL point-to-point, never images) rides
+    # behind the header of step k+1 and overlaps the kernels of the following steps, which run on the library's own
+    # streams (sift_amd/gather.py: KeypointGather, no per-step collective); every transfer completes inside the timed region.
+    gatherer = KeypointGather(nf, comm_dev, dst=0) if world > 1 else None
+    gathered = [0, 0]       # steps and keypoints that have arrived on rank 0
+    keep = []               # tensors of the last pushes (the gather reads them until two pushes later)
     tickets = []            # submitted steps whose results have not been collected yet (at most depth - 1 between steps)
+
+    def note(done):
+        for recs, vals, counts in done:
+            gathered[0] += 1
+            gathered[1] += int(counts.sum())
 
     def collect(ticket):
         """Finish one step: wait for its batch, hand its keypoint lists to the gather (N > 1), free its slot."""
         c = ticket.result()
         total = c.total()
         if world > 1:
-            while len(in_flight) > 1:      # at most two gathers in flight
-                gather_finish(in_flight.pop(0)[0])
-            # The library's result arrays are read in place (no staging copy); packing / cloning them is queued on
-            # torch's stream right away and is long done when the slot's next descriptor kernel rewrites them.
-            # wire format (lossless, sift_amd/gather.py): bytes per record, floats per descriptor (None: as many as are set)
-            bpk, fpk = {"sparse": (34, None), "packed": (20, 112), "full": (20, 128)}[args.wire]
+            # wire format (lossless, sift_amd/gather.py): sparse = 34-byte records (20 + 112 presence bits) + the floats that are set
             kp, desc = device_results(c, total, dev, wire=args.wire)
-            counts = torch.from_numpy(c.counts()).to(comm_dev)
+            counts = c.counts()
             if comm_dev.type == "cpu":     # test backend: stage through host memory
                 kp, desc = kp.cpu(), desc.cpu()
-            in_flight.append((gather_start(kp, desc, counts, dst=0, floats_per_kp=fpk, bytes_per_kp=bpk), (kp, desc)))
+            keep.append((kp, desc))
+            del keep[:-3]
+            note(gatherer.push(kp, desc, counts))
         ticket.release()
         return total
 
@@ -190,13 +249,15 @@ def main():
         total = 0
         while tickets:
             total += collect(tickets.pop(0))
-        while in_flight:
-            gather_finish(in_flight.pop(0)[0])
         return total
 
     for _ in range(args.warmup):
         step()
     drain()
+    if gatherer is not None:     # the warm-up steps' lists are gathered too, before the clock starts
+        note(gatherer.flush())
+        gatherer = KeypointGather(nf, comm_dev, dst=0)
+        gatherer_t0 = (gathered[0], gathered[1])
     for c in ctxs:
         c.set_option("profile", 1)
         c.profile_reset()
@@ -208,6 +269,8 @@ def main():
     for _ in range(args.steps):
         kps += step()
     kps += drain()
+    if gatherer is not None:
+        note(gatherer.flush())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -243,17 +306,70 @@ def main():
             "config": {"workload": label.format(n=nf),
                        "frames_per_gpu": nf, "frames_total": nf * world, "pipeline_depth": depth, "pipeline_gate": bool(args.pipeline_gate) and depth > 1, "keypoints_per_step": kps // max(args.steps, 1),
                        "frames_per_s": nf * world * args.steps / dt,
-                       "gather": ("RCCL p2p of keypoint records + descriptors to rank 0, started per step and overlapped with the next step; "
+                       "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0,
+                       "gather_steps_on_rank0": (gathered[0] - gatherer_t0[0]) if world > 1 else None,
+                       "gather_keypoints_on_rank0": (gathered[1] - gatherer_t0[1]) if world > 1 else None,
+                       "gather_ms_per_step": (gatherer.wait_s / args.steps * 1e3) if world > 1 else None,
+                       "wire_bytes_per_step": (gatherer.wire_bytes / args.steps) if world > 1 else None,
+                       "gather": ("RCCL p2p of keypoint records + descriptors to rank 0, no per-step collective (sizes ride one step ahead), overlapped with the following steps; "
                                   + {"full": "128 floats per descriptor", "packed": "descriptors on the wire as 112 of 128 floats (bin 7 of each cell is structurally +0.0f; lossless)",
                                      "sparse": "descriptors on the wire as 112 presence bits + the floats that are not +0.0f (about a third; lossless)"}[args.wire]) if world > 1 else "none (1 GPU)"},
             "roofline": {"kernel": "blur_stream_kernel / blur_fused_kernel (separable Gaussian + DoG; every launch of the pyramid)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic() if (args.workload == "config4" and nf == FRAMES_PER_GPU and (depth == 1 or args.pipeline_gate)) else None,
-                         "traffic_source": "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                          "timing": "hipEventElapsedTime over start/stop events attached to each blur dispatch (hipExtLaunchKernelGGL) on the library's stream, inside the timed region",
                          "launches": launches, "avg_launch_ms": ms / launches if launches else None,
                          "algorithmic_bytes_per_launch": nbytes / launches if launches else None},
         }
+        if world == 1 and not args.no_extras:
+            # ---- the boundary as a host caller sees it (main.cpp:56-57 hands over host memory and reads the vector back):
+            # frames from host memory in, keypoints + descriptors to host memory out, two batches in flight
+            from sift_amd.sift import pinned_array
+
+            def host_loop(src, outs, n_steps):
+                pend, total = [], 0
+                t_0 = time.perf_counter()
+                for i in range(n_steps + depth - 1):
+                    if i < n_steps:
+                        pend.append(pipe.submit(src, params))
+                    if len(pend) >= depth or i >= n_steps:
+                        tk = pend.pop(0)
+                        c = tk.result()
+                        kp_o, de_o = outs[tk.slot] if outs else (None, None)
+                        total += c.results(kp_o, de_o)[0].size
+                        tk.release()
+                return (time.perf_counter() - t_0) / n_steps, total // n_steps
+
+            cap = int(out["config"]["keypoints_per_step"] * 1.25) + 1024
+            pin_frames = pinned_array(frames.shape, np.float32)
+            pin_frames[...] = frames
+            pin_out = [(pinned_array((cap,), _lib.KEYPOINT_DTYPE), pinned_array((cap, 128), np.float32)) for _ in range(depth)]
+            hs = max(2, min(args.steps, 20))
+            host_loop(pin_frames, pin_out, 2)
+            t_pin, k_pin = host_loop(pin_frames, pin_out, hs)
+            host_loop(frames, None, 1)
+            t_page, _ = host_loop(frames, None, max(2, hs // 4))
+            nbytes_io = frames.nbytes + k_pin * (20 + 512)
+            out["host_inclusive"] = {"ms_per_step": t_pin * 1e3, "keypoints_per_s": k_pin / t_pin,
+                                     "pcie_gbytes_per_step": nbytes_io / 1e9, "pcie_gb_per_s": nbytes_io / 1e9 / t_pin,
+                                     "what": "frames from page-locked host memory (sift_hip_host_alloc) in, keypoints + 128-float descriptors to page-locked host "
+                                             "memory out, per step; two batches in flight, transfers overlapped with the other batch's kernels",
+                                     "pageable_ms_per_step": t_page * 1e3,
+                                     "pageable_what": "the same with ordinary (pageable) numpy arrays on both sides: chunked through the library's pinned staging buffers"}
+            one = pinned_array((1,) + frames.shape[1:], np.float32)
+            one[...] = frames[:1]
+            lat = []
+            for _ in range(12):
+                t_0 = time.perf_counter()
+                ctx.calculate_batch(one, params)
+                ctx.results(pin_out[0][0], pin_out[0][1])
+                lat.append(time.perf_counter() - t_0)
+            out["single_frame_ms"] = float(np.median(lat[2:]) * 1e3)
+            if args.workload == "config4" or True:
+                extra = ["--workload", args.workload, "--frames", str(nf)] + [a for kv in args.set for a in ("--set", kv)]
+                traffic, src = pmc_traffic_live(extra)
+                out["roofline"]["traffic"] = traffic
+                out["roofline"]["traffic_source"] = src
         if world == 1 and not args.no_cpu_baseline and args.workload == "config4":
             out["cpu_baseline"] = cpu_baseline(frames[:CPU_SAMPLE_FRAMES])
         print(json.dumps(out), flush=True)

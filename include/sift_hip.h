@@ -23,6 +23,7 @@
 #ifndef SIFT_HIP_H
 #define SIFT_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -99,6 +100,13 @@ int sift_hip_set_gate(sift_hip_ctx* ctx, sift_hip_gate* gate);
  * GPU_MAX_HW_QUEUES=8 into the environment unless the host has set it, which the HIP runtime honours if it has not
  * been initialised yet (i.e. when one of these is the process's first HIP call); otherwise export it yourself. */
 
+/* ---- host memory the copy engines can reach directly ------------------------------------------------------
+ * calculate / result_copy accept any host pointer.  Memory from sift_hip_host_alloc (page-locked) moves at the PCIe rate
+ * in one asynchronous copy; ordinary (pageable) memory is moved in chunks through the context's own pinned staging
+ * buffers with the host-side copies overlapped, about half as fast.  NULL when the allocation fails. */
+void* sift_hip_host_alloc(size_t bytes);
+void sift_hip_host_free(void* p);
+
 /* ---- Sift::calculate(), replaces sift.cpp:19-57 ---------------------------------------------- */
 /* n frames of w x h from HOST memory.  Results stay in the context until the next calculate. */
 int sift_hip_calculate_batch(sift_hip_ctx* ctx, const float* host_imgs, int n, int w, int h,
@@ -125,8 +133,11 @@ int sift_hip_result_device(sift_hip_ctx* ctx, const void** dev_keypoints, const 
  * presence bits (bit cell*7+bin <-> descriptor float cell*8+bin; bin 7 is never set, algorithms.cpp:135-150), and
  * only the descriptor floats whose bit pattern is not +0.0f, in order (about a third of them on real frames).
  * _size runs the counting pass and returns the number of floats; _pack then writes total*34 bytes and that many
- * floats to DEVICE memory of the caller.  Both return when the device is done. */
-int sift_hip_result_sparse_size(sift_hip_ctx* ctx, int64_t* n_values);
+ * floats to DEVICE memory of the caller.  Both return when the device is done.
+ * The format drops bin 7 of every cell, which is +0.0f unless a cell's bin sum is negative or NaN (normalizeVector then
+ * turns the never-written bin into -0.0f or NaN: frames with negative pixels, inf * 0).  *lossless (may be NULL) is 0 when
+ * the current results hold such a value: send the plain arrays of sift_hip_result_device instead. */
+int sift_hip_result_sparse_size(sift_hip_ctx* ctx, int64_t* n_values, int* lossless);
 int sift_hip_result_sparse_pack(sift_hip_ctx* ctx, void* dev_records, void* dev_values);
 /* The image calculate() leaves in the caller's MultiArray: when params.subpixel it is the
  * sigma=1 blurred, 2x nearest-upsampled frame (sift.cpp:20-21); dims of it, then the pixels. */

@@ -25,6 +25,7 @@ SYMBOLS = [
     "sift_hip_edge_responses", "sift_hip_vertex_parabola", "sift_hip_sort_by_filter", "sift_hip_cleanup_survivors", "sift_hip_profile_get",
     "sift_hip_profile_reset", "sift_hip_version", "sift_hip_gate_create", "sift_hip_gate_destroy", "sift_hip_set_gate",
     "sift_hip_result_sparse_size", "sift_hip_result_sparse_pack",
+    "sift_hip_host_alloc", "sift_hip_host_free",
     "sift_hip_image_info", "sift_hip_image_read_band0", "sift_hip_image_read_bgr8", "sift_hip_png_write_bgr8",
     "sift_hip_rotated_rect_points", "sift_hip_overlay_box", "sift_hip_overlay_draw",
 ]
@@ -84,7 +85,7 @@ def load():
     L.sift_hip_gate_destroy.argtypes = [vp]
     L.sift_hip_gate_destroy.restype = None
     L.sift_hip_set_gate.argtypes = [vp, vp]
-    L.sift_hip_result_sparse_size.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.sift_hip_result_sparse_size.argtypes = [vp, C.POINTER(C.c_int64), ip]
     L.sift_hip_result_sparse_pack.argtypes = [vp, vp, vp]
     L.sift_hip_set_option.argtypes = [vp, cs, ci]
     L.sift_hip_calculate_batch.argtypes = [vp, fp, ci, ci, ci, C.POINTER(Params), cs, ci]
@@ -117,6 +118,10 @@ def load():
     L.sift_hip_profile_get.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.sift_hip_profile_reset.argtypes = [vp]
     ll = C.c_longlong
+    L.sift_hip_host_alloc.argtypes = [C.c_size_t]
+    L.sift_hip_host_alloc.restype = vp
+    L.sift_hip_host_free.argtypes = [vp]
+    L.sift_hip_host_free.restype = None
     L.sift_hip_image_info.argtypes = [cs, ip, ip, ip, ip, cs, ci]
     L.sift_hip_image_read_band0.argtypes = [cs, fp, ll, cs, ci]
     L.sift_hip_image_read_bgr8.argtypes = [cs, u8p, ll, cs, ci]

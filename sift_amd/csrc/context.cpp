@@ -126,6 +126,8 @@ struct sift_hip_ctx {
     DevBuf d_masks, d_fmasks, d_counts, d_totals, d_cands, d_flags;
     DevBuf d_wk, d_wi, d_wi2, d_wp, d_status, d_tile, d_pool;
     DevBuf d_order;
+    HostBuf h_stage[2];              // pinned staging of pageable caller memory (host <-> device in chunks)
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
     DevBuf d_cell_cnt, d_cell_off;   // descriptor grid: keypoints per 16 px cell, exclusive scan (+ total)
     bool desc_wave = true;           // option "desc_kernel": 1 wave-per-keypoint kernel (default), 0 tile kernel
     DevBuf d_list, d_list_cnt, d_orient, d_peaks, d_final, d_final_cnt, d_out_base, d_kp, d_desc;
@@ -856,6 +858,92 @@ void ensure_host_stages(sift_hip_ctx* c) {
     c->stages_on_host = true;
 }
 
+// ---- host <-> device transfers of the boundary ---------------------------------------------------------------
+// The reference's caller hands calculate() an image in ordinary memory (main.cpp:52-57).  A copy engine reads pinned
+// memory at the PCIe rate but pageable memory only through the runtime's own bounce buffer, at a fraction of it, so:
+//   * memory the caller got from sift_hip_host_alloc (or registered itself) goes to the device in one asynchronous copy;
+//   * anything else is moved in 16 MB chunks through two pinned staging buffers, the host-side copy of chunk i+1
+//     (several threads) running while the copy engine moves chunk i.
+constexpr size_t kStageChunk = 16u << 20;
+
+bool is_pinned(const void* p) {
+    hipPointerAttribute_t a;
+    std::memset(&a, 0, sizeof(a));
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();   // ordinary memory: "invalid value", not an error of ours
+        return false;
+    }
+    return a.type == hipMemoryTypeHost || a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+struct CopyJob { char* dst; const char* src; size_t bytes; int parts; };
+void copy_part(int i, void* arg) {
+    const CopyJob* j = static_cast<const CopyJob*>(arg);
+    const size_t per = (j->bytes + (size_t)j->parts - 1) / (size_t)j->parts;
+    const size_t lo = std::min(j->bytes, per * (size_t)i), hi = std::min(j->bytes, lo + per);
+    if (hi > lo) std::memcpy(j->dst + lo, j->src + lo, hi - lo);
+}
+void host_copy(sift_hip_ctx* c, void* dst, const void* src, size_t bytes) {
+    const int threads = std::max(1, std::min(c->host_threads > 0 ? c->host_threads : 4, (int)(bytes >> 20) + 1));
+    CopyJob j{static_cast<char*>(dst), static_cast<const char*>(src), bytes, threads};
+    parallel_for(threads, threads, copy_part, &j);
+}
+
+void ensure_staging(sift_hip_ctx* c) {
+    for (int i = 0; i < 2; ++i) {
+        c->h_stage[i].ensure(kStageChunk);
+        if (!c->ev_stage[i]) SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming));
+    }
+}
+
+// host -> device on stream s; returns once `host` may be reused (pageable) or at once (pinned: the caller keeps the
+// buffer until the batch is done, which calculate only returns after)
+void upload(sift_hip_ctx* c, void* dev, const void* host, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return;
+    if (is_pinned(host)) {
+        SIFT_HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s));
+        return;
+    }
+    ensure_staging(c);
+    size_t off = 0;
+    for (int k = 0; off < bytes; ++k, off += kStageChunk) {
+        const int b = k & 1;
+        const size_t n = std::min(kStageChunk, bytes - off);
+        if (k >= 2) SIFT_HIP_CHECK(hipEventSynchronize(c->ev_stage[b]));   // the copy engine is done with this buffer
+        host_copy(c, c->h_stage[b].p, static_cast<const char*>(host) + off, n);
+        SIFT_HIP_CHECK(hipMemcpyAsync(static_cast<char*>(dev) + off, c->h_stage[b].p, n, hipMemcpyHostToDevice, s));
+        SIFT_HIP_CHECK(hipEventRecord(c->ev_stage[b], s));
+    }
+}
+
+// device -> caller memory (host or device), complete on return
+void download(sift_hip_ctx* c, void* dst, const void* dev, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return;
+    if (is_pinned(dst)) {
+        SIFT_HIP_CHECK(hipMemcpyAsync(dst, dev, bytes, hipMemcpyDefault, s));
+        wait_stream(c, s);
+        return;
+    }
+    ensure_staging(c);
+    size_t off = 0;
+    const size_t chunks = (bytes + kStageChunk - 1) / kStageChunk;
+    for (size_t k = 0; k <= chunks; ++k) {
+        if (k < chunks) {
+            const int b = (int)(k & 1);
+            const size_t n = std::min(kStageChunk, bytes - k * kStageChunk);
+            SIFT_HIP_CHECK(hipMemcpyAsync(c->h_stage[b].p, static_cast<const char*>(dev) + k * kStageChunk, n, hipMemcpyDeviceToHost, s));
+            SIFT_HIP_CHECK(hipEventRecord(c->ev_stage[b], s));
+        }
+        if (k >= 1) {   // chunk k-1 has landed (or lands now) while chunk k is on its way
+            const int b = (int)((k - 1) & 1);
+            const size_t n = std::min(kStageChunk, bytes - off);
+            SIFT_HIP_CHECK(hipEventSynchronize(c->ev_stage[b]));
+            host_copy(c, static_cast<char*>(dst) + off, c->h_stage[b].p, n);
+            off += n;
+        }
+    }
+}
+
 int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     Plan& P = c->plan;
     const DevPlan& dv = P.dev;
@@ -1050,7 +1138,8 @@ void sift_hip_destroy(sift_hip_ctx* c) {
                       &c->d_wk, &c->d_wi, &c->d_wi2, &c->d_wp, &c->d_status, &c->d_tile, &c->d_pool, &c->d_order, &c->d_masks, &c->d_fmasks, &c->d_counts, &c->d_totals, &c->d_cands, &c->d_flags, &c->d_list, &c->d_list_cnt, &c->d_orient,
                       &c->d_peaks, &c->d_final, &c->d_final_cnt, &c->d_out_base, &c->d_kp, &c->d_desc, &c->d_lrank, &c->d_ochunk, &c->d_ocnt, &c->d_recs, &c->d_wire_sums, &c->d_wire_off, &c->d_cell_cnt, &c->d_cell_off})
         b->release();
-    for (HostBuf* b : {&c->h_flags, &c->h_orient, &c->h_peaks, &c->h_status, &c->h_wire}) b->release();
+    for (HostBuf* b : {&c->h_flags, &c->h_orient, &c->h_peaks, &c->h_status, &c->h_wire, &c->h_stage[0], &c->h_stage[1]}) b->release();
+    for (auto& e : c->ev_stage) if (e) (void)hipEventDestroy(e);
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     (void)hipEventDestroy(c->ev_fork0);
@@ -1149,12 +1238,24 @@ int sift_hip_calculate_batch(sift_hip_ctx* c, const float* host_imgs, int n, int
         c->have_result = c->have_pyramid = false;   // whatever happens next, the previous batch's results are gone
         const size_t bytes = (size_t)n * (size_t)w * (size_t)h * sizeof(float);
         c->d_input.ensure(bytes);
-        SIFT_HIP_CHECK(hipMemcpyAsync(c->d_input.p, host_imgs, bytes, hipMemcpyHostToDevice, c->stream));
+        upload(c, c->d_input.p, host_imgs, bytes, c->stream);
         std::string msg;
         const int rc = build_plan(c, n, w, h, *params, msg);
         if (rc) { set_err(err, errlen, msg); return rc; }
         return run_batch(c, c->d_input.as<float>(), err, errlen);
     });
+}
+
+void* sift_hip_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+void sift_hip_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int sift_hip_result_images(sift_hip_ctx* c) { return (c && c->have_result) ? (int)c->status.size() : -1; }
@@ -1175,8 +1276,8 @@ int sift_hip_result_copy(sift_hip_ctx* c, sift_hip_keypoint* kp, float* desc) {
     return guarded(nullptr, 0, [&]() {
         SIFT_HIP_CHECK(hipSetDevice(c->device));
         if (c->total > 0) {
-            if (kp) SIFT_HIP_CHECK(hipMemcpy(kp, c->d_kp.p, (size_t)c->total * sizeof(sift_hip_keypoint), hipMemcpyDefault));
-            if (desc) SIFT_HIP_CHECK(hipMemcpy(desc, c->d_desc.p, (size_t)c->total * 128 * sizeof(float), hipMemcpyDefault));
+            if (kp) download(c, kp, c->d_kp.p, (size_t)c->total * sizeof(sift_hip_keypoint), c->stream);
+            if (desc) download(c, desc, c->d_desc.p, (size_t)c->total * 128 * sizeof(float), c->stream);
         }
         return SIFT_HIP_OK;
     });
@@ -1188,7 +1289,7 @@ int sift_hip_result_device(sift_hip_ctx* c, const void** kp, const void** desc) 
     return SIFT_HIP_OK;
 }
 
-int sift_hip_result_sparse_size(sift_hip_ctx* c, int64_t* n_values) {
+int sift_hip_result_sparse_size(sift_hip_ctx* c, int64_t* n_values, int* lossless) {
     if (!c || !c->have_result || !n_values) return SIFT_HIP_EINVAL;
     char err[256];
     return guarded(err, sizeof(err), [&]() {
@@ -1196,11 +1297,13 @@ int sift_hip_result_sparse_size(sift_hip_ctx* c, int64_t* n_values) {
         const size_t nb = wire_blocks(c->total);
         c->d_wire_sums.ensure((nb + 1) * sizeof(int));
         c->d_wire_off.ensure((nb + 1) * sizeof(long long));
-        c->h_wire.ensure(sizeof(long long));
+        c->h_wire.ensure(2 * sizeof(long long));
         launch_wire_count(c->stream, c->d_desc.as<float>(), c->total, c->d_wire_sums.as<int>(), c->d_wire_off.as<long long>());
         SIFT_HIP_CHECK(hipMemcpyAsync(c->h_wire.p, c->d_wire_off.as<long long>() + nb, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+        SIFT_HIP_CHECK(hipMemcpyAsync(c->h_wire.as<long long>() + 1, c->d_wire_sums.as<int>() + nb, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         wait_stream(c, c->stream);
         c->wire_values = *c->h_wire.as<long long>();
+        if (lossless) *lossless = *reinterpret_cast<const int*>(c->h_wire.as<long long>() + 1) ? 0 : 1;
         c->wire_for_total = c->total;
         *n_values = c->wire_values;
         return SIFT_HIP_OK;

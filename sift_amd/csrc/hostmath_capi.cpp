@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "fdlibm_atan2f.h"
+#include "hist_bins.h"
 #include "linalg3.h"
 
 extern "C" {
@@ -38,6 +39,18 @@ int hostmath_solve3(const float* a, const float* b, float* res) {
     const bool ok = sift_hip::solve3<true>(A, B, R);
     res[0] = R[0]; res[1] = R[1]; res[2] = R[2];
     return ok ? 1 : 0;
+}
+// inputs with bit patterns first .. first + count - 1 whose fast bin differs from the division's; *example = one of them
+long long hostmath_hist8_bin_mismatches(unsigned long long first, unsigned long long count, unsigned* example) {
+    long long bad = 0;
+    for (unsigned long long i = first; i < first + count; ++i) {
+        const float v = sift_hip::i2f((int32_t)(uint32_t)i);
+        if (sift_hip::hist8_bin(v) != sift_hip::hist8_bin_div(v)) {
+            ++bad;
+            if (example) *example = (uint32_t)i;
+        }
+    }
+    return bad;
 }
 float hostmath_vertex_parabola(uint16_t lnx, float lny, uint16_t px, float py, uint16_t rnx, float rny) {
     return sift_hip::vertex_parabola(lnx, lny, px, py, rnx, rny);

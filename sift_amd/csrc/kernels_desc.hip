@@ -20,19 +20,11 @@
 // Pixels in the fringe are updated redundantly by the neighbouring tiles; nothing is written back
 // to HBM except the descriptors (the reference's mutated pyramids are private state).
 #include "common.h"
+#include "hist_bins.h"
 
 #pragma clang fp contract(off)
 
 namespace sift_hip {
-
-__device__ __forceinline__ unsigned f32_to_u16_x86_d(float v) {
-    int i;
-    if (v > -2147483904.0f && v < 2147483648.0f)
-        i = (int)v;
-    else
-        i = (int)0x80000000;
-    return (unsigned)i & 0xffffu;
-}
 
 __device__ __forceinline__ int reflect_idx(int p, int n) {
     p = p < 0 ? -p : p;
@@ -375,7 +367,7 @@ __global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __res
                         // alg::orientationHistogram8 inputs in descriptor order: cell = (x/4)*4 + y/4
                         // (x outer, sift.cpp:95-96), inside a cell x outer, y inner
                         const float sum = nm[j] * pg[hb + j];
-                        unsigned i = f32_to_u16_x86_d(__builtin_floorf(no[j] / 45.0f));
+                        unsigned i = f32_to_u16_x86(__builtin_floorf(no[j] / 45.0f));
                         i = i % 7u;
                         s_val[stg[j]] = sum;
                         s_bin[stg[j]] = (unsigned char)i;
@@ -642,19 +634,6 @@ __global__ __launch_bounds__(kGridThreads) void desc_grid_kernel(const DevPlan* 
         f.cand = (uint32_t)k;   // vector index: the order the chains follow, and the output slot
         pl[atomicAdd(&cnt[cell], 1)] = f;
     }
-}
-
-// alg::orientationHistogram8's bin index `u16_t i = std::floor(orientation / 45); i = i % 7` (algorithms.cpp:143-145).  The
-// quotient is formed without the division sequence: q0 = v * RN(1/45), one Newton correction with the exact residual
-// (Markstein): for every one of the 2^32 float inputs the bin equals the one the IEEE division gives (checked exhaustively
-// on the host, tests/test_host_math.py; the quotient itself differs only for -0.0 and the infinities, which land in the same
-// bin).  Needs fused multiply-adds and f32 denormals, both on in this build.
-__device__ __forceinline__ unsigned hist8_bin(float v) {
-    const float r = 1.0f / 45.0f;
-    const float q0 = v * r;
-    const float e = __builtin_fmaf(-q0, 45.0f, v);
-    const float q = __builtin_fmaf(e, r, q0);
-    return f32_to_u16_x86_d(__builtin_floorf(q)) % 7u;
 }
 
 // minimum of a non-negative int over the wave, in a scalar register: butterfly inside each row of 16 lanes (DPP), then the

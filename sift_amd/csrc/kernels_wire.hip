@@ -23,6 +23,10 @@ __device__ __forceinline__ void wire_presence(const float2 v, int lane, bool& b0
     b1 = (((2 * lane + 1) & 7) != 7) && __float_as_uint(v.y) != 0u;
 }
 
+// block_sums[gridDim.x] (cleared by the launcher) is raised when some descriptor carries anything but +0.0f in bin 7 of a
+// cell: normalizeVector divides every bin by the cell's sum (algorithms.cpp:210-223), so a negative or NaN sum (negative
+// pixels, inf * 0 after the cumulative `magnitudes += weighting`) turns the never-written bin into -0.0f or NaN, which
+// this format cannot carry
 __global__ __launch_bounds__(256) void wire_count_kernel(const float* __restrict__ desc, long long total,
                                                         int* __restrict__ block_sums) {
     __shared__ int s_sum[4];
@@ -36,6 +40,7 @@ __global__ __launch_bounds__(256) void wire_count_kernel(const float* __restrict
             bool b0, b1;
             wire_presence(v, lane, b0, b1);
             sum += __popcll(__ballot(b0)) + __popcll(__ballot(b1));
+            if (__ballot((lane & 3) == 3 && __float_as_uint(v.y) != 0u) != 0ull && lane == 0) atomicOr(&block_sums[gridDim.x], 1);
         }
     }
     if (lane == 0) s_sum[wave] = sum;
@@ -132,6 +137,7 @@ size_t wire_blocks(long long total) { return (size_t)((total + kWireBlock - 1) /
 
 void launch_wire_count(hipStream_t s, const float* d_desc, long long total, int* d_block_sums, long long* d_block_off) {
     const size_t nb = wire_blocks(total);
+    (void)hipMemsetAsync(d_block_sums + nb, 0, sizeof(int), s);   // "bin 7 is not +0.0f somewhere"
     if (nb) hipLaunchKernelGGL(wire_count_kernel, dim3((unsigned)nb), dim3(256), 0, s, d_desc, total, d_block_sums);
     hipLaunchKernelGGL(wire_scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)d_block_sums, (int)nb, d_block_off);
 }

@@ -110,8 +110,9 @@ def device_results(ctx, total: int, device, packed: bool = True, wire: str | Non
         "packed"  (records uint8 [total*20], descriptors float32 [total*112])            see pack_descriptors
         "sparse"  (records uint8 [total*34] = record + presence mask, set floats [nnz])   see pack_sparse
     (`packed=True/False` selects "packed"/"full" when `wire` is not given.)  The library's arrays are read in place
-    (no staging copy); the copies are queued on torch's current stream, so the context may start its next batch right
-    away (its result arrays are only rewritten by the descriptor kernel at the end of that batch)."""
+    (no staging copy) by copies on torch's current stream, which this function waits for: nothing orders torch's stream
+    against the library's own (non-blocking) streams, so the context must not start its next batch before the copies are
+    done.  On return the tensors own their data and the context's slot may be released."""
     wire = wire or ("packed" if packed else "full")
     if total == 0:
         return (torch.empty(0, dtype=torch.uint8, device=device), torch.empty(0, dtype=torch.float32, device=device))
@@ -125,7 +126,166 @@ def device_results(ctx, total: int, device, packed: bool = True, wire: str | Non
         torch.cuda.current_stream(device).synchronize()   # the allocator may hand out memory still in use on torch's stream
         ctx.sparse_pack(rec.data_ptr(), values.data_ptr())
         return rec, values
-    return kp.clone(), (pack_descriptors(d) if wire == "packed" else d.clone())
+    out = kp.clone(), (pack_descriptors(d) if wire == "packed" else d.clone())
+    torch.cuda.current_stream(device).synchronize()   # the library may rewrite its arrays as soon as the slot is released
+    return out
+
+
+class KeypointGather:
+    """Gather of every step's keypoint lists on rank `dst` with NO per-step collective and no size exchange of its own.
+
+    What rank `dst` must know before it can post a receive is how many bytes are coming.  Instead of exchanging sizes first
+    (a blocking all_gather and a device-to-host read per step), a rank's message of step k carries, in one buffer,
+        [ header(k): keypoints, record bytes, descriptor floats and per-image counts of ITS step k | records of step k-1 ]
+    followed by a second message with the descriptor floats of step k-1 — so the sizes of a payload always arrive one step
+    before the payload, and every receive is posted with its exact size.  `dst` reads a header (a few hundred bytes, long
+    arrived) at the NEXT push; results therefore come out two pushes after they went in, and `flush` drains the rest.
+    Point-to-point only (RCCL over xGMI: every rank has its own link to `dst`); the one all_gather is at
+    construction (images per rank).  All ranks must call `push` the same number of times, then `flush` once.
+    """
+
+    def __init__(self, n_images_local: int, device, dst: int = 0):
+        self.world, self.rank, self.dst, self.dev = dist.get_world_size(), dist.get_rank(), dst, device
+        t = torch.tensor([n_images_local], dtype=torch.int64, device=device)
+        allt = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(allt, t)                       # once, at construction
+        self.n_img = [int(v.item()) for v in allt]
+        self.hdr_words = 3 + max(self.n_img)
+        self.hdr_bytes = 8 * self.hdr_words
+        self.step = 0
+        self.wire_bytes = 0            # received (dst) or sent (others), payload and headers
+        self.wait_s = 0.0              # host time spent waiting for transfers / reading headers
+        # sender side
+        self._prev = None              # (records, values) of the previous push: they ride with the next header
+        self._sends = []               # works + the tensors they read
+        # receiver side
+        self._own = {}                 # step -> (records, values, counts) of dst itself
+        self._sizes = {}               # step -> {src: (n_rec_bytes, n_val_floats, counts)}   (from headers)
+        self._msgs = None              # in flight: (step k of the headers, works, {src: A buffer}, values_all, rec sizes of step k-1)
+        self._assembled = {}           # step -> values_all whose remote slices are complete once the message carrying them is
+
+    # ---- helpers -------------------------------------------------------------------------------------------------
+    def _header(self, total, n_rec, n_val, counts):
+        h = torch.zeros(self.hdr_words, dtype=torch.int64)
+        h[0], h[1], h[2] = total, n_rec, n_val
+        if counts is not None and len(counts):
+            h[3:3 + len(counts)] = torch.as_tensor(counts, dtype=torch.int64)
+        return h.view(torch.uint8).to(self.dev)
+
+    def _timed_wait(self, works):
+        import time
+        t0 = time.perf_counter()
+        for w in works:
+            w.wait()
+        self.wait_s += time.perf_counter() - t0
+
+    def _send(self, total, records, values, counts):
+        """non-dst: message = [header of this step | records of the previous step], then the previous step's values"""
+        self._timed_wait([w for w, _ in self._sends])
+        self._sends = []
+        prev_rec, prev_val = self._prev if self._prev is not None else (torch.empty(0, dtype=torch.uint8, device=self.dev), torch.empty(0, dtype=torch.float32, device=self.dev))
+        a = torch.cat([self._header(total, 0 if records is None else records.numel(), 0 if values is None else values.numel(), counts), prev_rec])
+        ops = [dist.P2POp(dist.isend, a, self.dst)]
+        keep = [a]
+        if prev_val.numel():
+            ops.append(dist.P2POp(dist.isend, prev_val, self.dst))
+            keep.append(prev_val)
+        for w in dist.batch_isend_irecv(ops):
+            self._sends.append((w, keep))
+        self.wire_bytes += a.numel() + 4 * prev_val.numel()
+        self._prev = (records, values) if records is not None else None
+
+    def _receive_round(self, k, have_own):
+        """dst, at push k (or the flush rounds): finish the messages of round k-1 (headers of step k-1, payload of step k-2),
+        emit step k-2, post the receives of round k (headers of step k, payload of step k-1)."""
+        import time
+        out = []
+        others = [r for r in range(self.world) if r != self.dst]
+        if self._msgs is not None:
+            hk, works, bufs, rec_sizes = self._msgs
+            self._timed_wait(works)
+            t0 = time.perf_counter()
+            heads = torch.stack([bufs[r][:self.hdr_bytes] for r in others]).cpu().view(torch.int64).reshape(len(others), self.hdr_words)
+            self.wait_s += time.perf_counter() - t0
+            self._sizes[hk] = {r: (int(heads[i, 1]), int(heads[i, 2]), heads[i, 3:3 + self.n_img[r]].to(torch.int32), int(heads[i, 0])) for i, r in enumerate(others)}
+            if hk - 1 in self._assembled:      # the payload of step hk-1 rode in these messages
+                out.append(self._finish(hk - 1, bufs, rec_sizes))
+            self._msgs = None
+        # receives of round k: payload sizes are those of step k-1
+        prev = self._sizes.get(k - 1)
+        rec_sizes = {r: (prev[r][0] if prev else 0) for r in others}
+        bufs = {r: torch.empty(self.hdr_bytes + rec_sizes[r], dtype=torch.uint8, device=self.dev) for r in others}
+        ops = [dist.P2POp(dist.irecv, bufs[r], r) for r in others]
+        if prev:
+            own_rec, own_val, own_cnt = self._own[k - 1]
+            n_val = {r: prev[r][1] for r in others}
+            n_val[self.dst] = own_val.numel()
+            offs, run = {}, 0
+            for r in range(self.world):
+                offs[r] = run
+                run += n_val[r]
+            vals = torch.empty(run, dtype=torch.float32, device=self.dev)
+            vals[offs[self.dst]:offs[self.dst] + n_val[self.dst]].copy_(own_val)
+            for r in others:
+                if n_val[r]:
+                    ops.append(dist.P2POp(dist.irecv, vals[offs[r]:offs[r] + n_val[r]], r))
+            self._assembled[k - 1] = vals
+            self.wire_bytes += sum(rec_sizes.values()) + 4 * sum(n_val[r] for r in others)
+        self.wire_bytes += self.hdr_bytes * len(others)
+        works = dist.batch_isend_irecv(ops) if ops else []
+        self._msgs = (k, works, bufs, rec_sizes)
+        return out
+
+    def _finish(self, j, bufs, rec_sizes):
+        """records of step j arrived behind the headers in `bufs`, its values straight into their slices"""
+        own_rec, own_val, own_cnt = self._own.pop(j)
+        sizes = self._sizes.pop(j)
+        parts, counts = [], []
+        for r in range(self.world):
+            if r == self.dst:
+                parts.append(own_rec)
+                counts.append(torch.as_tensor(own_cnt, dtype=torch.int32))
+            else:
+                parts.append(bufs[r][self.hdr_bytes:self.hdr_bytes + rec_sizes[r]])
+                counts.append(sizes[r][2])
+        return torch.cat(parts), self._assembled.pop(j), torch.cat(counts)
+
+    # ---- API ---------------------------------------------------------------------------------------------------------
+    def push(self, records: torch.Tensor, values: torch.Tensor, counts):
+        """Hand over this rank's lists of one step (records uint8, descriptor values float32, per-image counts).  Returns the
+        list of steps completed on `dst` by this call, each (records_all, values_all, counts_all) in rank order (= global
+        image order for block sharding); always [] on the other ranks.  The tensors must stay untouched until two pushes (or
+        the flush) later."""
+        k = self.step
+        self.step += 1
+        total = int(sum(int(c) for c in counts))
+        if self.world == 1:
+            return [(records, values, torch.as_tensor(counts, dtype=torch.int32))]
+        if self.rank != self.dst:
+            self._send(total, records, values, counts)
+            return []
+        self._own[k] = (records, values, counts)
+        return self._receive_round(k, True)
+
+    def flush(self):
+        """After the last push: moves the payloads still on their way.  Returns the remaining completed steps on `dst`."""
+        if self.world == 1:
+            return []
+        k = self.step
+        if self.rank != self.dst:
+            self._send(-1, None, None, None)      # an end header carrying the last step's payload
+            self._timed_wait([w for w, _ in self._sends])
+            self._sends = []
+            return []
+        out = self._receive_round(k, False)        # finishes round k-1, posts round k (payload of step k-1)
+        if self._msgs is not None:
+            hk, works, bufs, rec_sizes = self._msgs
+            self._timed_wait(works)
+            if hk - 1 in self._assembled:
+                self._sizes.setdefault(hk, None)
+                out.append(self._finish(hk - 1, bufs, rec_sizes))
+            self._msgs = None
+        return out
 
 
 class GatherHandle:

@@ -49,6 +49,22 @@ def _raise(rc, err):
     raise HipError(msg or f"sift_hip error {rc}")
 
 
+def pinned_array(shape, dtype=np.float32) -> np.ndarray:
+    """numpy array in page-locked host memory (sift_hip_host_alloc): the copy engines move it at the PCIe rate in one
+    asynchronous copy, where ordinary memory goes through the library's staging buffers (include/sift_hip.h).  The memory
+    is released when the array (and every view of it) is gone."""
+    import weakref
+    L = _lib.load()
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    p = L.sift_hip_host_alloc(max(n, 1))
+    if not p:
+        raise MemoryError(f"sift_hip_host_alloc({n}) failed")
+    buf = (C.c_char * max(n, 1)).from_address(p)
+    weakref.finalize(buf, L.sift_hip_host_free, p)
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
 class Gate:
     """sift_hip_gate: orders the phases of batches that run on different contexts of one GPU (include/sift_hip.h)."""
 
@@ -144,10 +160,14 @@ class Context:
     def total(self) -> int:
         return int(self._L.sift_hip_result_total(self._h))
 
-    def results(self):
-        t = self.total()
-        kp = np.zeros(max(t, 0), _lib.KEYPOINT_DTYPE)
-        desc = np.zeros((max(t, 0), 128), np.float32)
+    def results(self, kp_out=None, desc_out=None):
+        """(keypoints, descriptors [total, 128]).  `kp_out` / `desc_out`: caller arrays to fill (e.g. `pinned_array`s with
+        room for at least total() entries); views of their first total() entries are returned."""
+        t = max(self.total(), 0)
+        kp = np.zeros(t, _lib.KEYPOINT_DTYPE) if kp_out is None else kp_out.reshape(-1)[:t]
+        desc = np.zeros((t, 128), np.float32) if desc_out is None else desc_out.reshape(-1, 128)[:t]
+        if kp.size < t or desc.shape[0] < t:
+            raise ValueError("result arrays too small")
         if t > 0 and self._L.sift_hip_result_copy(self._h, kp.ctypes.data, desc.ctypes.data):
             raise HipError("sift_hip_result_copy failed")
         return kp, desc
@@ -158,11 +178,14 @@ class Context:
             raise HipError("no result")
         return a.value or 0, b.value or 0
 
-    def sparse_size(self) -> int:
-        """Number of descriptor floats the sparse wire format carries for the current results (include/sift_hip.h)."""
-        n = C.c_int64()
-        if self._L.sift_hip_result_sparse_size(self._h, C.byref(n)):
+    def sparse_size(self, require_lossless: bool = True) -> int:
+        """Number of descriptor floats the sparse wire format carries for the current results (include/sift_hip.h).
+        Raises ValueError when the format cannot carry them (some bin 7 is not +0.0f): use the "full" wire then."""
+        n, ok = C.c_int64(), C.c_int()
+        if self._L.sift_hip_result_sparse_size(self._h, C.byref(n), C.byref(ok)):
             raise HipError("sift_hip_result_sparse_size failed")
+        if require_lossless and not ok.value:
+            raise ValueError("the sparse wire format would lose a bin 7 that is not +0.0f: send the full descriptors")
         return int(n.value)
 
     def sparse_pack(self, dev_records: int, dev_values: int):

@@ -127,3 +127,71 @@ def test_gather_two_ranks():
             assert unpack_sparse(masks, torch.from_numpy(desc2)).numpy().tobytes() == full.tobytes()
             continue
         assert (desc2 == np.concatenate([e0, e1])).all()
+
+
+def _step_data(rank, step):
+    """ragged per rank and step; rank 1 has nothing at step 2, everybody nothing at step 3"""
+    rng = np.random.default_rng(1000 * step + rank)
+    n_img = 2 + rank
+    counts = rng.integers(0, 6, n_img).astype(np.int32)
+    if (rank == 1 and step == 2) or step == 3:
+        counts[:] = 0
+    total = int(counts.sum())
+    rec = rng.integers(0, 256, total * 34, dtype=np.uint8)
+    val = rng.random(int(rng.integers(0, 40 * total + 1))).astype(np.float32)
+    return counts, rec, val
+
+
+def _kg_worker(rank, world, port, q, steps):
+    from sift_amd.gather import KeypointGather
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = KeypointGather(2 + rank, torch.device("cpu"), dst=0)
+    done = []
+    for step in range(steps):
+        c, r, v = _step_data(rank, step)
+        done += g.push(torch.from_numpy(r), torch.from_numpy(v), c)
+    done += g.flush()
+    if rank == 0:
+        q.put([(a.numpy().copy(), b.numpy().copy(), cc.numpy().copy()) for a, b, cc in done] + [g.wire_bytes])
+    else:
+        assert done == []
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_kg(world, steps):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_kg_worker, args=(r, world, port, q, steps)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    wire = got.pop()
+    assert len(got) == steps                    # every step comes out exactly once, in order
+    want_bytes = 0
+    for step, (rec, val, counts) in enumerate(got):
+        parts = [_step_data(r, step) for r in range(world)]
+        assert counts.tolist() == np.concatenate([p[0] for p in parts]).tolist()
+        assert rec.tobytes() == np.concatenate([p[1] for p in parts]).tobytes()
+        assert val.tobytes() == np.concatenate([p[2] for p in parts]).tobytes()
+        want_bytes += sum(p[1].size + 4 * p[2].size for p in parts[1:])
+    hdr = 8 * (3 + (2 + world - 1))
+    assert wire == want_bytes + hdr * (world - 1) * (steps + 1)   # payload once, one header per message, nothing else
+
+
+def test_keypoint_gather_without_per_step_collectives_two_ranks():
+    """sift_amd.gather.KeypointGather: sizes ride one step ahead of the payload, so no all_gather / size read per step."""
+    _run_kg(2, 5)
+
+
+def test_keypoint_gather_three_ranks_single_step():
+    _run_kg(3, 1)
