@@ -71,8 +71,9 @@ void sift_hip_destroy(sift_hip_ctx* ctx);
  * row/col kernels), "fused_edge" (1 default: extremum scan and edge-response filter in one LDS-tiled pass;
  * 0: mask kernel + thread-per-candidate filter), "fused_reduce" (1 default: reduceToNextLevel's blur stores only the
  * pixels the decimation keeps; 0: blur into a temporary, then the resampling kernel), "gpu_cleanup" (1 default: cleanup steps as GPU kernels;
- * 0: std::sort on the host), "host_threads", "profile" (1: time every blur launch with events attached to
- * its dispatch), "stream_min_waves" (process-wide; smallest launch, in waves, that takes the streaming blur instead of
+ * 0: std::sort on the host), "host_threads", "profile" (N > 0: the blur launches of every N-th batch carry timing
+ * events on their dispatch packets, read with sift_hip_profile_get; the events keep consecutive launches ~10 us apart, which
+ * is why a measurement run samples, e.g. N = 4; 0: off), "stream_min_waves" (process-wide; smallest launch, in waves, that takes the streaming blur instead of
  * the LDS-tiled one; default 1024, <= 0 restores it; the parity tests set 1 to run the streaming form on small
  * inputs), "orient_general" (0 default; 1: orientationHistogram36 reads every sample's bin even when the gradient pass
  * found all bins of the frame to be 0, which is what the reference's radians-as-degrees maps always give); measurement

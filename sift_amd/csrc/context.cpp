@@ -115,7 +115,9 @@ struct sift_hip_ctx {
     bool fused_reduce = true; // reduceToNextLevel: blur and decimation in one pass
     bool orient_general = false;  // tests: orientation histogram with per-sample bins even when every bin is 0
     bool gpu_cleanup = true;
-    bool profile = false;
+    bool profile = false;     // this batch's blur launches carry timing events
+    int profile_every = 0;    // option "profile": 0 off, N > 0: every N-th batch is timed (the events cost ~10 us per launch)
+    long long profile_batches = 0;
     bool binned = false;   // this batch's keypoints are already binned to descriptor tiles
     bool described = false;   // ... and their descriptors are already computed
     long long out_cap = 0;    // keypoints d_kp / d_desc hold
@@ -473,6 +475,16 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
     return SIFT_HIP_OK;
 }
 
+// The top-left 16x16 of convolveWithGauss(level, 1.6) (sift.cpp:87) only needs the level itself: one small workgroup per
+// image on the side stream as soon as the level exists, long before the descriptor stage asks for it.
+void early_w16(sift_hip_ctx* c, int level) {
+    Plan& P = c->plan;
+    if (std::find(P.grad_levels.begin(), P.grad_levels.end(), level) == P.grad_levels.end()) return;
+    SIFT_HIP_CHECK(hipEventRecord(c->ev_fork0, c->stream));
+    SIFT_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork0, 0));
+    launch_w16(c->stream2, P.dev, level, c->d_taps16.as<float>(), P.radius16);
+}
+
 // ---- pyramid (Sift::_createDOGs, sift.cpp:381-417) ---------------------------------------------
 void run_pyramid(sift_hip_ctx* c, const float* d_in) {
     Plan& P = c->plan;
@@ -492,10 +504,12 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
             }
             case 1:
                 run_blur(c, base, dv.gauss[0], nullptr, op.w, op.h, n, op.tap_off, op.radius);
+                early_w16(c, 0);
                 break;
             case 2: {
                 const int l = op.octave * (D + 1) + op.j;
                 run_blur(c, dv.gauss[l - 1], dv.gauss[l], dv.dog[op.octave * D + op.j - 1], op.w, op.h, n, op.tap_off, op.radius);
+                early_w16(c, l);
                 break;
             }
             case 3: {  // reduceToNextLevel(g(o, D-1), g(o, D-1).scale)
@@ -964,6 +978,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     c->binned = false;
     c->described = false;
     c->wire_values = c->wire_for_total = -1;
+    c->profile = c->profile_every > 0 && (c->profile_batches++ % c->profile_every) == 0;
 
     // Batches of several contexts in flight on this GPU: the gate orders their phases (phase_gate.h).  Whatever
     // this batch owes its partners is released when the scope ends, however it ends.
@@ -1001,7 +1016,6 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
         const int o = lvl / (P.D + 1);
         launch_gradient(gs, dv.gauss[lvl], dv.mag[lvl], dv.ori[lvl], dv.prod[lvl], dv.obin[lvl], dv.w[o], dv.h[o], n,
                         (c->orient_general ? nullptr : c->d_ocnt.as<int>() + 4 * n));
-        launch_w16(gs, dv, lvl, c->d_taps16.as<float>(), P.radius16);
     }
     if (c->gate) SIFT_HIP_CHECK(hipEventRecord(c->ev_grad, gs));
     // extrema + edge responses (sift.cpp:33-34)
@@ -1205,7 +1219,7 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     if (!std::strcmp(name, "desc_dbg")) { c->desc_dbg = value; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "desc_kernel")) { c->desc_wave = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "gpu_cleanup")) { c->gpu_cleanup = value != 0; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "profile")) { c->profile = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "profile")) { c->profile_every = value > 0 ? value : 0; c->profile_batches = 0; c->profile = false; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "orient_general")) { c->orient_general = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "stream_min_waves")) { set_stream_min_waves(value); return SIFT_HIP_OK; }
     if (!std::strcmp(name, "stream_waves")) { set_stream_waves(value); return SIFT_HIP_OK; }

@@ -274,9 +274,17 @@ constexpr int kFxPitch = kFxCols + 2 * kFxLead; // 40 floats per staged row: x0-
 constexpr int kFxRows = 64 + 2;
 constexpr int kFxRow4 = kFxPitch / 4;
 
+__device__ __forceinline__ void fx_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Persistent form: a workgroup walks tiles (image, 64-row block, 32-column strip) and fetches the NEXT tile's three DoG
+// levels into registers before it starts on the current one, so the HBM latency of a tile hides under the scan and the QR
+// bodies of the previous tile (barriers wait for LDS only: the fetch stays in flight).  Workgroups with equal
+// blockIdx % 8 (observed to share an XCD) own a contiguous run of tiles, whose one-pixel halos then meet in that L2.
+constexpr int kFxLoads = (kFxRows * kFxRow4 + 255) / 256;   // float4 per thread, level and tile
+
 __global__ __launch_bounds__(256) void extrema_edge_kernel(const float* __restrict__ d0, const float* __restrict__ d1,
                                                            const float* __restrict__ d2, int w, int h, int nyb,
-                                                           int word_base, int words_per_image,
+                                                           int word_base, int words_per_image, int tiles_x, int total_tiles,
                                                            unsigned long long* __restrict__ masks,
                                                            unsigned long long* __restrict__ fmasks,
                                                            int* __restrict__ counts) {
@@ -286,24 +294,63 @@ __global__ __launch_bounds__(256) void extrema_edge_kernel(const float* __restri
     __shared__ unsigned long long s_fm[kFxCols];
     __shared__ int s_qn[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int x0 = blockIdx.x * kFxCols, yb = blockIdx.y, img = blockIdx.z;
-    const int ya = yb * 64;
-    const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
-    const float* __restrict__ src[3] = {d0 + img_off, d1 + img_off, d2 + img_off};
+    int t, t_end, t_step;
+    if ((gridDim.x & 7u) == 0) {
+        const int chunk = (total_tiles + 7) >> 3;
+        const int xcd = (int)blockIdx.x & 7;
+        t = xcd * chunk + (int)(blockIdx.x >> 3);
+        t_end = min(xcd * chunk + chunk, total_tiles);
+        t_step = (int)(gridDim.x >> 3);
+    } else {
+        t = (int)blockIdx.x;
+        t_end = total_tiles;
+        t_step = (int)gridDim.x;
+    }
+    const int tiles_img = tiles_x * nyb;
+    static_assert(kFxLoads == 3, "the prefetch registers are spelled out (an array here ends up in scratch memory)");
+    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 pa0 = z4, pa1 = z4, pa2 = z4, pb0 = z4, pb1 = z4, pb2 = z4, pc0 = z4, pc1 = z4, pc2 = z4;
     // tile: rows ya-1 .. ya+64, columns x0-4 .. x0+35 as 16-byte groups (w is a multiple of 4 here).  Rows
     // and groups outside the image are clamped; clamped samples are only read by non-candidates.
-    for (int e = tid; e < kFxRows * kFxRow4; e += 256) {
-        const int r = e / kFxRow4, c4 = e - r * kFxRow4;
-        int gy = ya - 1 + r, gx = x0 - kFxLead + 4 * c4;
-        gy = gy < 0 ? 0 : (gy >= h ? h - 1 : gy);
-        gx = gx < 0 ? 0 : (gx > w - 4 ? w - 4 : gx);
-        const size_t o = (size_t)gy * (size_t)w + (size_t)gx;
-#pragma unroll
-        for (int l = 0; l < 3; ++l)
-            *reinterpret_cast<float4*>(&s_t[l][r * kFxPitch + 4 * c4]) = *reinterpret_cast<const float4*>(src[l] + o);
+#define SIFT_FX_LOAD(I, A, B, C)                                                                     \
+    {                                                                                                \
+        const int e = tid + 256 * (I);                                                               \
+        if (e < kFxRows * kFxRow4) {                                                                 \
+            const int r = e / kFxRow4, c4 = e - r * kFxRow4;                                         \
+            int gy = ya_ - 1 + r, gx = x0_ - kFxLead + 4 * c4;                                       \
+            gy = gy < 0 ? 0 : (gy >= h ? h - 1 : gy);                                                \
+            gx = gx < 0 ? 0 : (gx > w - 4 ? w - 4 : gx);                                             \
+            const size_t o = img_off_ + (size_t)gy * (size_t)w + (size_t)gx;                         \
+            A = *reinterpret_cast<const float4*>(d0 + o);                                            \
+            B = *reinterpret_cast<const float4*>(d1 + o);                                            \
+            C = *reinterpret_cast<const float4*>(d2 + o);                                            \
+        }                                                                                            \
     }
-    if (tid < kFxCols) s_fm[tid] = 0ull;
-    __syncthreads();
+#define SIFT_FX_LOAD_TILE(TILE)                                                                      \
+    {                                                                                                \
+        const int img_ = (TILE) / tiles_img, rem_ = (TILE) - img_ * tiles_img;                       \
+        const int yb_ = rem_ / tiles_x, x0_ = (rem_ - yb_ * tiles_x) * kFxCols, ya_ = yb_ * 64;      \
+        const size_t img_off_ = (size_t)img_ * (size_t)w * (size_t)h;                                \
+        SIFT_FX_LOAD(0, pa0, pb0, pc0) SIFT_FX_LOAD(1, pa1, pb1, pc1) SIFT_FX_LOAD(2, pa2, pb2, pc2) \
+    }
+#define SIFT_FX_STORE(I, A, B, C)                                                                    \
+    {                                                                                                \
+        const int e = tid + 256 * (I);                                                               \
+        if (e < kFxRows * kFxRow4) { /* r * kFxPitch + 4 * c4 == 4 * e */                            \
+            *reinterpret_cast<float4*>(&s_t[0][4 * e]) = A;                                          \
+            *reinterpret_cast<float4*>(&s_t[1][4 * e]) = B;                                          \
+            *reinterpret_cast<float4*>(&s_t[2][4 * e]) = C;                                          \
+        }                                                                                            \
+    }
+    if (t < t_end) SIFT_FX_LOAD_TILE(t)
+    while (t < t_end) {
+        const int img = t / tiles_img, rem = t - img * tiles_img;
+        const int yb = rem / tiles_x, x0 = (rem - yb * tiles_x) * kFxCols, ya = yb * 64;
+        SIFT_FX_STORE(0, pa0, pb0, pc0) SIFT_FX_STORE(1, pa1, pb1, pc1) SIFT_FX_STORE(2, pa2, pb2, pc2)
+        if (tid < kFxCols) s_fm[tid] = 0ull;
+        fx_lds_barrier();
+        const int tn = t + t_step;
+        if (tn < t_end) SIFT_FX_LOAD_TILE(tn)   // stays in flight through the scan and the QR bodies
 
     const int col = lane & 31, sub = lane >> 5;
     const int x = x0 + col;
@@ -337,7 +384,7 @@ __global__ __launch_bounds__(256) void extrema_edge_kernel(const float* __restri
     mask |= __shfl_xor(mask, 32);   // the two half-waves hold alternate rows of the same column
     if (lane < kFxCols) s_cm[wv][lane] = mask;
     if (lane == 0) s_qn[wv] = qn;
-    __syncthreads();
+    fx_lds_barrier();
     // the four queues are walked as one list so that the 3x3 QR body runs on (nearly) full waves
     const int n0 = s_qn[0], n1 = n0 + s_qn[1], n2 = n1 + s_qn[2], n3 = n2 + s_qn[3];
     for (int g = tid; g < n3; g += 256) {
@@ -347,14 +394,14 @@ __global__ __launch_bounds__(256) void extrema_edge_kernel(const float* __restri
         const int qc = (int)(e & 31u), qr = (int)(e >> 5);
         const int at = (qr + 1) * kFxPitch + (qc + kFxLead);
         const int up = at - kFxPitch, dn = at + kFxPitch;
-        EdgeTaps t;
-        t.i1c = s_t[1][at]; t.i1l = s_t[1][at - 1]; t.i1r = s_t[1][at + 1]; t.i1u = s_t[1][up]; t.i1d = s_t[1][dn];
-        t.i1ul = s_t[1][up - 1]; t.i1ur = s_t[1][up + 1]; t.i1dl = s_t[1][dn - 1]; t.i1dr = s_t[1][dn + 1];
-        t.i0c = s_t[0][at]; t.i0l = s_t[0][at - 1]; t.i0r = s_t[0][at + 1]; t.i0u = s_t[0][up]; t.i0d = s_t[0][dn];
-        t.i2c = s_t[2][at]; t.i2l = s_t[2][at - 1]; t.i2r = s_t[2][at + 1]; t.i2d = s_t[2][dn];
-        if (edge_response_core(t)) atomicOr(&s_fm[qc], 1ull << qr);
+        EdgeTaps tp;
+        tp.i1c = s_t[1][at]; tp.i1l = s_t[1][at - 1]; tp.i1r = s_t[1][at + 1]; tp.i1u = s_t[1][up]; tp.i1d = s_t[1][dn];
+        tp.i1ul = s_t[1][up - 1]; tp.i1ur = s_t[1][up + 1]; tp.i1dl = s_t[1][dn - 1]; tp.i1dr = s_t[1][dn + 1];
+        tp.i0c = s_t[0][at]; tp.i0l = s_t[0][at - 1]; tp.i0r = s_t[0][at + 1]; tp.i0u = s_t[0][up]; tp.i0d = s_t[0][dn];
+        tp.i2c = s_t[2][at]; tp.i2l = s_t[2][at - 1]; tp.i2r = s_t[2][at + 1]; tp.i2d = s_t[2][dn];
+        if (edge_response_core(tp)) atomicOr(&s_fm[qc], 1ull << qr);
     }
-    __syncthreads();
+    fx_lds_barrier();
     if (tid < kFxCols && x0 + tid < w) {
         const unsigned long long m = s_cm[0][tid] | s_cm[1][tid] | s_cm[2][tid] | s_cm[3][tid];
         const size_t wi = (size_t)img * (size_t)words_per_image + (size_t)word_base + (size_t)(x0 + tid) * (size_t)nyb +
@@ -363,6 +410,11 @@ __global__ __launch_bounds__(256) void extrema_edge_kernel(const float* __restri
         fmasks[wi] = s_fm[tid];
         counts[wi] = __popcll(m);
     }
+        t = tn;
+    }
+#undef SIFT_FX_STORE
+#undef SIFT_FX_LOAD_TILE
+#undef SIFT_FX_LOAD
 }
 
 __global__ __launch_bounds__(256) void edge_filter_kernel(const DevPlan* __restrict__ plan,
@@ -434,10 +486,13 @@ void launch_extrema_edge(hipStream_t s, const DevPlan& plan, unsigned long long*
         const int o = plan.scan_octave[k], i = plan.scan_dog[k];
         const int w = plan.w[o], h = plan.h[o];
         const int l = o * plan.dogs + i;
-        const dim3 grid((unsigned)((w + kFxCols - 1) / kFxCols), (unsigned)plan.scan_nyb[k], (unsigned)plan.n_images);
-        hipLaunchKernelGGL(extrema_edge_kernel, grid, dim3(256), 0, s, (const float*)plan.dog[l - 1],
+        const int tiles_x = (w + kFxCols - 1) / kFxCols;
+        const long long total = (long long)tiles_x * plan.scan_nyb[k] * plan.n_images;
+        int grid = total < 1024 ? (int)total : 1024;   // persistent workgroups: 4 per CU
+        if (grid >= 8) grid &= ~7;
+        hipLaunchKernelGGL(extrema_edge_kernel, dim3((unsigned)grid), dim3(256), 0, s, (const float*)plan.dog[l - 1],
                            (const float*)plan.dog[l], (const float*)plan.dog[l + 1], w, h, plan.scan_nyb[k],
-                           plan.scan_word_base[k], plan.words_per_image, d_masks, d_fmasks, d_counts);
+                           plan.scan_word_base[k], plan.words_per_image, tiles_x, (int)total, d_masks, d_fmasks, d_counts);
     }
 }
 

@@ -2,7 +2,7 @@
 export TMPDIR=/tmp
 for d in 0 1 2 4 7; do
   rm -rf gpurun_out/prof_o
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_o -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --set orient_dbg=$d > /dev/null 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_o -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --set orient_dbg=$d > /dev/null 2>&1
   f=$(find gpurun_out/prof_o -name "*kernel_stats.csv" | head -1)
   echo "dbg $d: $(grep orientation_kernel $f | sed "s/.*)\",//" | cut -d, -f1-3) cleanup1: $(grep cleanup1_kernel $f | sed 's/.*)",//' | cut -d, -f1-3)"
 done

@@ -2,7 +2,7 @@
 # HBM-side traffic and L2 hit rate per kernel (separate passes): FETCH_SIZE (x2 on gfx950 for wide reads), WRITE_SIZE, TCC_HIT/TCC_MISS
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-ARGS="${BENCH_ARGS:---steps 1 --warmup 1 --no-cpu-baseline --pipeline-depth 1}"
+ARGS="${BENCH_ARGS:---steps 1 --warmup 1 --no-cpu-baseline --no-extras --pipeline-depth 1}"
 for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   d=gpurun_out/pmck_$(echo $c | cut -d' ' -f1); rm -rf $d
   timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- python3 bench.py $ARGS > /dev/null 2>&1

@@ -10,7 +10,7 @@ names = [short(r["Kernel_Name"]) for r in rows]
 first = next(i for i in range(len(rows) - 1, -1, -1) if names[i].startswith("blur_") and (i == 0 or not names[i - 1].startswith(("blur_", "resample"))) and
              all(not n.startswith("descriptor") for n in names[max(0, i - 3):i]) or i == 0)
 # simpler: last kernel named descriptor_kernel ends a step; walk back to the previous descriptor_kernel
-desc = [i for i, n in enumerate(names) if n.startswith("descriptor_kernel")]
+desc = [i for i, n in enumerate(names) if n.startswith(("descriptor_kernel", "descriptor_wave_kernel"))]
 end = desc[-1]
 begin = desc[-2] + 1 if len(desc) > 1 else 0
 t0 = int(rows[begin]["Start_Timestamp"])
