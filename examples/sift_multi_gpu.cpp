@@ -1,0 +1,77 @@
+// A batch of frames over every GPU of the node from ONE C++ process, no Python, no MPI: the layout of SURVEY.md 8(e) through
+// the C ABI (sift_hip_group_*: one context and host thread per GPU, contiguous blocks of frames, keypoint lists gathered
+// device-to-device on the first GPU in global image order).  Each frame also goes through a plain sift::Sift object and the
+// two results are compared, so the program doubles as a check.
+//   g++ -std=c++17 -pthread -Iinclude examples/sift_multi_gpu.cpp -Lsift_amd/lib -lsift_hip -Wl,-rpath,$PWD/sift_amd/lib -o sift_multi_gpu
+//   ./sift_multi_gpu image.pgm [frames=16] [shards=number of GPUs]        (shards > GPUs: several shards per GPU)
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <vector>
+
+#include "sift/sift.hpp"
+
+extern "C" int hipGetDeviceCount(int*);
+
+int main(int argc, char** argv) {
+    if (argc < 2) {
+        std::cerr << "usage: " << argv[0] << " image.{pgm,ppm,png} [frames] [shards]\n";
+        return 1;
+    }
+    const int frames = argc > 2 ? std::atoi(argv[2]) : 16;
+    int gpus = 0;
+    if (hipGetDeviceCount(&gpus) != 0 || gpus < 1) { std::cerr << "no GPU\n"; return 1; }
+    const int shards = argc > 3 ? std::atoi(argv[3]) : gpus;
+    char err[512] = "";
+    int w = 0, h = 0;
+    if (sift_hip_image_info(argv[1], &w, &h, nullptr, nullptr, err, sizeof(err)) != SIFT_HIP_OK) { std::cerr << err << "\n"; return 1; }
+    std::vector<float> base((size_t)w * h);
+    if (sift_hip_image_read_band0(argv[1], base.data(), (long long)base.size(), err, sizeof(err)) != SIFT_HIP_OK) { std::cerr << err << "\n"; return 1; }
+    // frames that differ: the image shifted cyclically by a few columns each
+    std::vector<float> batch((size_t)frames * base.size());
+    for (int f = 0; f < frames; ++f)
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) batch[(size_t)f * base.size() + (size_t)y * w + x] = base[(size_t)y * w + (size_t)((x + 7 * f) % w)];
+
+    std::vector<int> devices(shards);
+    for (int s = 0; s < shards; ++s) devices[s] = s % gpus;
+    sift_hip_group* g = nullptr;
+    if (sift_hip_group_create(devices.data(), shards, &g, err, sizeof(err)) != SIFT_HIP_OK) { std::cerr << err << "\n"; return 1; }
+    sift_hip_params p{};
+    p.dogs_per_epoch = 3; p.octaves = 4; p.sigma = 1.6f; p.k = std::sqrt(2.0f); p.subpixel = 0;
+    const int rc = sift_hip_group_calculate(g, batch.data(), frames, w, h, &p, err, sizeof(err));
+    if (rc != SIFT_HIP_OK) { std::cerr << "group calculate: " << err << "\n"; return 1; }
+    const long long total = sift_hip_group_result_total(g);
+    std::vector<int32_t> counts(frames);
+    sift_hip_group_result_counts(g, counts.data(), frames);
+    std::vector<sift_hip_keypoint> kp((size_t)total);
+    std::vector<float> desc((size_t)total * 128);
+    sift_hip_group_result_copy(g, kp.data(), desc.data());
+    double cms = 0, gms = 0;
+    int64_t gb = 0;
+    sift_hip_group_timing(g, &cms, &gms, &gb);
+
+    // the same frames one by one through the drop-in class
+    sift::Sift single(3, 4, 1.6f, std::sqrt(2.0f), false, 0);
+    long long at = 0;
+    for (int f = 0; f < frames; ++f) {
+        sift::Image2f img(w, h);
+        std::memcpy(img.data(), batch.data() + (size_t)f * base.size(), base.size() * sizeof(float));
+        const std::vector<sift::InterestPoint> pts = single.calculate(img);
+        if ((long long)pts.size() != counts[f]) { std::cerr << "frame " << f << ": " << pts.size() << " points vs " << counts[f] << "\n"; return 2; }
+        for (size_t i = 0; i < pts.size(); ++i, ++at) {
+            const sift_hip_keypoint& k = kp[(size_t)at];
+            if (k.x != pts[i].loc.x || k.y != pts[i].loc.y || k.octave != pts[i].octave ||
+                std::memcmp(&k.orientation, &pts[i].orientation, 4) != 0 ||
+                (pts[i].descriptors.size() == 128 && std::memcmp(pts[i].descriptors.data(), &desc[(size_t)at * 128], 512) != 0)) {
+                std::cerr << "frame " << f << " point " << i << " differs\n";
+                return 2;
+            }
+        }
+    }
+    std::printf("ok: %d frames over %d shards on %d GPU(s), %lld keypoints; shards %.2f ms, gather %.2f ms, %lld bytes across devices\n", frames,
+                shards, gpus, total, cms, gms, (long long)gb);
+    sift_hip_group_destroy(g);
+    return 0;
+}

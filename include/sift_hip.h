@@ -188,6 +188,30 @@ int sift_hip_sort_by_filter(sift_hip_ctx* ctx, const uint8_t* flags, int n, int3
 int sift_hip_cleanup_survivors(sift_hip_ctx* ctx, const uint8_t* flags, int n, int32_t* survivors,
                                int32_t* count, int on_gpu);
 
+/* ---- a batch over several GPUs of one node, from one process ----------------------------------
+ * The reference runs one calculate() on one image (main.cpp:56-57) and keeps no state between images, so a batch shards
+ * by image.  A group holds one context per entry of `devices` (a device may be listed more than once), each driven by a
+ * host thread of its own inside sift_hip_group_calculate; frames are dealt in contiguous blocks (frame i to shard
+ * i / ceil(n / shards)); afterwards the shards' keypoint lists — records and descriptors, never images — are copied
+ * device to device (over xGMI between GPUs) into one array on devices[0], in global image order.  There is no collective
+ * and no step in which shards wait for each other except that gather.  Status / error behaviour as sift_hip_calculate_batch:
+ * the return value and err are those of the first image (in global order) that "threw". */
+typedef struct sift_hip_group sift_hip_group;
+int sift_hip_group_create(const int* devices, int n_devices, sift_hip_group** out, char* err, int errlen);
+void sift_hip_group_destroy(sift_hip_group* group);
+int sift_hip_group_shards(sift_hip_group* group);
+int sift_hip_group_set_option(sift_hip_group* group, const char* name, int value);   /* sift_hip_set_option on every shard */
+int sift_hip_group_calculate(sift_hip_group* group, const float* host_imgs, int n, int w, int h, const sift_hip_params* params,
+                             char* err, int errlen);
+int sift_hip_group_result_images(sift_hip_group* group);
+int sift_hip_group_result_status(sift_hip_group* group, int32_t* status, int cap);
+int sift_hip_group_result_counts(sift_hip_group* group, int32_t* counts, int cap);
+int64_t sift_hip_group_result_total(sift_hip_group* group);
+int sift_hip_group_result_copy(sift_hip_group* group, sift_hip_keypoint* keypoints, float* descriptors);   /* to host or device memory */
+int sift_hip_group_result_device(sift_hip_group* group, const void** dev_keypoints, const void** dev_descriptors);   /* on devices[0] */
+/* wall time of the shards' calculate calls and of the gather of the last batch, bytes that crossed devices in it */
+int sift_hip_group_timing(sift_hip_group* group, double* compute_ms, double* gather_ms, int64_t* gather_bytes);
+
 /* ---- image files and the result overlay (host code, no GPU) ------------------------------------------
  * What /root/reference/main.cpp does around calculate(): vigra::importImage (main.cpp:52-54), cv::imread (:59), the
  * rotated boxes (:60-73) and cv::imwrite (:75).  Read: binary / ASCII PGM and PPM, PNG (every colour type, 1-16 bit,

@@ -26,6 +26,9 @@ SYMBOLS = [
     "sift_hip_profile_reset", "sift_hip_version", "sift_hip_gate_create", "sift_hip_gate_destroy", "sift_hip_set_gate",
     "sift_hip_result_sparse_size", "sift_hip_result_sparse_pack",
     "sift_hip_host_alloc", "sift_hip_host_free",
+    "sift_hip_group_create", "sift_hip_group_destroy", "sift_hip_group_shards", "sift_hip_group_set_option", "sift_hip_group_calculate",
+    "sift_hip_group_result_images", "sift_hip_group_result_status", "sift_hip_group_result_counts", "sift_hip_group_result_total",
+    "sift_hip_group_result_copy", "sift_hip_group_result_device", "sift_hip_group_timing",
     "sift_hip_image_info", "sift_hip_image_read_band0", "sift_hip_image_read_bgr8", "sift_hip_png_write_bgr8",
     "sift_hip_rotated_rect_points", "sift_hip_overlay_box", "sift_hip_overlay_draw",
 ]
@@ -118,6 +121,20 @@ def load():
     L.sift_hip_profile_get.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.sift_hip_profile_reset.argtypes = [vp]
     ll = C.c_longlong
+    L.sift_hip_group_create.argtypes = [ip, ci, C.POINTER(vp), cs, ci]
+    L.sift_hip_group_destroy.argtypes = [vp]
+    L.sift_hip_group_destroy.restype = None
+    L.sift_hip_group_shards.argtypes = [vp]
+    L.sift_hip_group_set_option.argtypes = [vp, cs, ci]
+    L.sift_hip_group_calculate.argtypes = [vp, fp, ci, ci, ci, C.POINTER(Params), cs, ci]
+    L.sift_hip_group_result_images.argtypes = [vp]
+    L.sift_hip_group_result_status.argtypes = [vp, i32p, ci]
+    L.sift_hip_group_result_counts.argtypes = [vp, i32p, ci]
+    L.sift_hip_group_result_total.argtypes = [vp]
+    L.sift_hip_group_result_total.restype = C.c_int64
+    L.sift_hip_group_result_copy.argtypes = [vp, vp, vp]
+    L.sift_hip_group_result_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.sift_hip_group_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.sift_hip_host_alloc.argtypes = [C.c_size_t]
     L.sift_hip_host_alloc.restype = vp
     L.sift_hip_host_free.argtypes = [vp]

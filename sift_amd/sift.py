@@ -294,6 +294,76 @@ class Context:
         self._L.sift_hip_profile_reset(self._h)
 
 
+class Group:
+    """sift_hip_group: one batch block-sharded over several GPUs of this node from one process (one context and host thread
+    per entry of `devices`; a device may be listed more than once), keypoint lists gathered device-to-device on devices[0] in
+    global image order (include/sift_hip.h)."""
+
+    def __init__(self, devices):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        devs = (C.c_int * len(devices))(*devices)
+        err = C.create_string_buffer(512)
+        rc = self._L.sift_hip_group_create(devs, len(devices), C.byref(self._h), err, 512)
+        if rc:
+            self._h = C.c_void_p()
+            _raise(rc, err)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.sift_hip_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, name: str, value: int):
+        if self._L.sift_hip_group_set_option(self._h, name.encode(), int(value)):
+            raise ValueError(f"unknown option {name}")
+
+    def calculate_batch(self, imgs, params, raise_on_error=True):
+        imgs = np.ascontiguousarray(imgs, dtype=np.float32)
+        n, h, w = imgs.shape
+        err = C.create_string_buffer(512)
+        rc = self._L.sift_hip_group_calculate(self._h, imgs.reshape(-1), n, w, h, C.byref(params), err, 512)
+        if rc and raise_on_error:
+            _raise(rc, err)
+        return rc, err.value.decode(errors="replace")
+
+    def counts(self):
+        out = np.zeros(max(self._L.sift_hip_group_result_images(self._h), 0), np.int32)
+        if self._L.sift_hip_group_result_counts(self._h, out, out.size):
+            raise HipError("no result")
+        return out
+
+    def status(self):
+        out = np.zeros(max(self._L.sift_hip_group_result_images(self._h), 0), np.int32)
+        if self._L.sift_hip_group_result_status(self._h, out, out.size):
+            raise HipError("no result")
+        return out
+
+    def total(self) -> int:
+        return int(self._L.sift_hip_group_result_total(self._h))
+
+    def results(self):
+        t = max(self.total(), 0)
+        kp = np.zeros(t, _lib.KEYPOINT_DTYPE)
+        desc = np.zeros((t, 128), np.float32)
+        if t and self._L.sift_hip_group_result_copy(self._h, kp.ctypes.data, desc.ctypes.data):
+            raise HipError("sift_hip_group_result_copy failed")
+        return kp, desc
+
+    def timing(self):
+        """(ms in the shards' calculate calls, ms in the gather, bytes that crossed devices) of the last batch"""
+        a, b, n = C.c_double(), C.c_double(), C.c_int64()
+        if self._L.sift_hip_group_timing(self._h, C.byref(a), C.byref(b), C.byref(n)):
+            raise HipError("no result")
+        return a.value, b.value, n.value
+
+
 def gauss_taps(sigma: float):
     L = _lib.load()
     buf = np.zeros(8192, np.float32)

@@ -572,6 +572,49 @@ def test_cpp_gated_pair_example(ctx, tmp_path):
     assert out.returncode == 0 and out.stdout.startswith("ok: 9 frames"), out.stdout + out.stderr
 
 
+def test_group_of_shards_matches_single_context(ctx):
+    """sift_hip_group (SURVEY.md 8(e) as native host code): a batch block-sharded over three shards — all on this box's one
+    GPU, which exercises the threads, the sharding, the per-image bookkeeping and the device-to-device gather — returns the
+    single context's keypoints, descriptors, counts and status in global image order; a frame that "throws" (App. B-14) is
+    reported like sift_hip_calculate_batch reports it."""
+    from sift_amd.sift import Group
+    params = _lib.Params(3, 3, 1.6, O.K_SQRT2, 0)
+    frames = np.stack([synth_frame(320, 240, 40 + i) for i in range(7)])       # 7 frames over 3 shards: 3 + 3 + 1
+    g = Group([0, 0, 0])
+    try:
+        g.calculate_batch(frames, params)
+        ctx.calculate_batch(frames, params)
+        assert g.counts().tolist() == ctx.counts().tolist() and g.total() == ctx.total()
+        kp, desc = g.results()
+        wkp, wdesc = ctx.results()
+        assert kp.tobytes() == wkp.tobytes() and desc.tobytes() == wdesc.tobytes()
+        assert (g.status() == 0).all()
+        cms, gms, nbytes = g.timing()
+        assert cms > 0 and gms >= 0 and nbytes == 0                        # same device: nothing crossed a link
+        g.calculate_batch(frames[:2], params)                              # fewer frames than shards
+        ctx.calculate_batch(frames[:2], params)
+        assert g.results()[1].tobytes() == ctx.results()[1].tobytes()
+        with pytest.raises(PreconditionViolation) as e:                    # 160x120 cannot carry 4 octaves
+            g.calculate_batch(np.stack([synth_frame(160, 120, 1)] * 4), _lib.Params(3, 4, 1.6, O.K_SQRT2, 0))
+        assert "kernel longer than line" in str(e.value)
+    finally:
+        g.close()
+
+
+def test_cpp_multi_gpu_example(ctx, tmp_path):
+    """examples/sift_multi_gpu.cpp: the group API from C++ (two shards on this box's GPU), checked frame by frame against
+    sift::Sift inside the program."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "sift_multi_gpu"
+    subprocess.check_call(["g++", "-std=c++17", "-pthread", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "sift_multi_gpu.cpp"), "-L" + os.path.join(root, "sift_amd", "lib"),
+                           "-lsift_hip", "-Wl,-rpath," + os.path.join(root, "sift_amd", "lib"), "-L/opt/rocm/lib", "-lamdhip64", "-o", str(exe)])
+    out = subprocess.run([str(exe), os.path.join(root, "tests", "golden", "parrot_r.pgm"), "5", "2"], cwd=tmp_path,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok: 5 frames over 2 shards"), out.stdout + out.stderr
+
+
 def test_cli_result_file(ctx, tmp_path, monkeypatch):
     """sift_amd.cli (main.cpp's options, ingest, result writer and overlay): whole result file and overlay."""
     from sift_amd import cli
