@@ -745,6 +745,7 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
     auto load_window = [&](unsigned xy) {
         size_t o = (size_t)((int)(xy >> 16) - kRegion + ly) * (size_t)w + (size_t)((int)(xy & 0xffffu) - kRegion + lx0);
         if (dbg & 8) o &= ~(size_t)3;   // timing only: 16-byte aligned window loads (wrong pixels)
+        if (dbg & 128) o = (size_t)ly * (size_t)w + (size_t)lx0 + (size_t)((xy >> 4) & 0xfffu) * 16u;   // timing only: every window from the image's first rows (cache hits)
         Window wd;
         wd.o = (f4u)(1.0f); wd.m = (f4u)(2.0f); wd.g = (f4u)(3.0f);
         if (!(dbg & 4)) {               // timing only: no window loads

@@ -203,6 +203,22 @@ struct EdgeTaps {   // the 18 DoG samples the per-point body reads
     float i2c, i2l, i2r, i2d;
 };
 
+// The two tests of _eliminateEdgeResponses that only need the 3x3 neighbourhood in the candidate's own DoG level
+// (sift.cpp:334-343: determinant of the 2x2 Hessian negative, or trace^2 / determinant above 12.1).  Every test of the
+// per-point body only ever SETS `filtered`, and none has a side effect, so the body's verdict is the OR of its tests in any
+// order: a candidate these two already filter does not need the 3x3 QR solve at all.
+__device__ __forceinline__ bool edge_curvature_filtered(float i1c, float i1l, float i1r, float i1u, float i1d, float i1ul, float i1ur,
+                                                        float i1dl, float i1dr) {
+    const float dxx = i1r + i1l - 2.0f * i1c;
+    const float dyy = i1d + i1u - 2.0f * i1c;
+    const float dxy = (i1dr - i1dl - i1ur + i1ul) / 2.0f;
+    const float tr = dxx + dyy;
+    const float prod = dxx * dyy;
+    const float det = (float)((double)prod - (double)dxy * (double)dxy);
+    if (det < 0.0f) return true;
+    return (double)tr * (double)tr / (double)det > (double)12.1f;
+}
+
 __device__ __forceinline__ bool edge_response_core(const EdgeTaps& tp) {
     const float i1c = tp.i1c, i1l = tp.i1l, i1r = tp.i1r, i1u = tp.i1u, i1d = tp.i1d;
     const float i1ul = tp.i1ul, i1ur = tp.i1ur, i1dl = tp.i1dl, i1dr = tp.i1dr;
@@ -355,7 +371,7 @@ __global__ __launch_bounds__(256) void extrema_edge_kernel(const float* __restri
     const int col = lane & 31, sub = lane >> 5;
     const int x = x0 + col;
     const bool x_ok = x >= 1 && x <= w - 2;
-    unsigned long long mask = 0ull;
+    unsigned long long mask = 0ull, fmask = 0ull;
     int qn = 0;   // wave-uniform
     unsigned short* q = s_q[wv];
 #pragma unroll 2
@@ -377,12 +393,22 @@ __global__ __launch_bounds__(256) void extrema_edge_kernel(const float* __restri
         const bool any_gt = nmax > c, any_lt = nmin < c;
         const bool cand = x_ok && y >= 1 && y <= h - 2 && (!any_gt || !any_lt);
         mask |= (unsigned long long)(cand ? 1u : 0u) << row;
-        const unsigned long long bal = __ballot(cand);
-        if (cand) q[qn + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(col | (row << 5));
+        // the curvature tests of the edge filter right here (most candidates fail them): only the others queue for the QR body
+        bool curved = false;
+        if (cand)
+            curved = edge_curvature_filtered(c, s_t[1][at - 1], s_t[1][at + 1], s_t[1][at - kFxPitch], s_t[1][at + kFxPitch],
+                                             s_t[1][at - kFxPitch - 1], s_t[1][at - kFxPitch + 1], s_t[1][at + kFxPitch - 1],
+                                             s_t[1][at + kFxPitch + 1]);
+        fmask |= (unsigned long long)(curved ? 1u : 0u) << row;
+        const bool need_qr = cand && !curved;
+        const unsigned long long bal = __ballot(need_qr);
+        if (need_qr) q[qn + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(col | (row << 5));
         qn += __popcll(bal);
     }
     mask |= __shfl_xor(mask, 32);   // the two half-waves hold alternate rows of the same column
+    fmask |= __shfl_xor(fmask, 32);
     if (lane < kFxCols) s_cm[wv][lane] = mask;
+    if (lane < kFxCols && fmask) atomicOr(&s_fm[lane], fmask);
     if (lane == 0) s_qn[wv] = qn;
     fx_lds_barrier();
     // the four queues are walked as one list so that the 3x3 QR body runs on (nearly) full waves

@@ -2,7 +2,7 @@
 # descriptor_wave_kernel: time with phases switched off (desc_dbg bits: 1 no neighbour chains, 2 no histograms; WRONG results) and SQ counters
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-for dbg in ${DBGS:-0 1 2 3}; do
+for dbg in ${DBGS-0 1 2 3}; do
   rm -rf gpurun_out/prof_p
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --pipeline-depth 1 --set desc_dbg=$dbg > /dev/null 2>&1
   f=$(find gpurun_out/prof_p -name "*kernel_stats.csv" | head -1)

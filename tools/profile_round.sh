@@ -1,0 +1,38 @@
+#!/bin/bash
+# Everything profiles/ keeps for a round, from one box: kernel stats + blur launches of the default (pipelined) bench, timelines,
+# per-kernel HBM traffic / L2 hit rate, SQ counters of the big non-blur kernels.   bash tools/profile_round.sh r02
+set -u
+export TMPDIR=/tmp
+R=${1:-r02}
+O=gpurun_out/$R
+rm -rf $O; mkdir -p $O
+rocminfo 2>/dev/null | grep -m2 -E "gfx|Marketing" > $O/device.txt; lscpu | grep -E "Model name|^CPU\(s\)" >> $O/device.txt
+# 1. default bench under the kernel trace (same command as the stats in profiles/README.md)
+rm -rf gpurun_out/prof
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_profiled.json 2> /dev/null
+f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); cp "$f" $O/kernel_stats.csv
+t=$(find gpurun_out/prof -name "*kernel_trace.csv" | head -1)
+python3 tools/roofline_from_stats.py --stats $O/kernel_stats.csv > $O/roofline.txt
+python3 tools/roofline_from_stats.py --trace "$t" --dump $O/blur_launches.csv >> $O/roofline.txt
+python3 tools/timeline_window.py "$t" 8000 500 > $O/timeline_pipelined.txt 2>&1
+# 2. one step at a time: per-kernel timeline
+rm -rf gpurun_out/prof
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --pipeline-depth 1 > /dev/null 2>&1
+t=$(find gpurun_out/prof -name "*kernel_trace.csv" | head -1); python3 tools/timeline.py "$t" > $O/timeline_single_step.txt 2>&1
+rm -rf gpurun_out/prof
+# 3. unprofiled bench lines
+timeout 900 python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> /dev/null
+timeout 600 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --pipeline-depth 1 > $O/bench_depth1.json 2> /dev/null
+timeout 600 python3 bench.py --workload config3 --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_config3.json 2> /dev/null
+timeout 600 python3 bench.py --workload config5 --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_config5.json 2> /dev/null
+# 4. counters
+bash tools/pmc_kernel.sh > $O/pmc_hbm_traffic.txt 2>&1
+DBGS="" bash tools/desc_probe.sh 2>&1 | grep -vE "^dbg" > $O/pmc_sq_counters.txt
+rm -rf gpurun_out/pmck_* gpurun_out/pmc_d1 gpurun_out/pmc_d2
+cat $O/roofline.txt; python3 -c "
+import json
+for n in ('bench','bench_depth1','bench_config3','bench_config5'):
+    try:
+        d=json.load(open('$O/'+n+'.json')); print(n, round(d['ms_per_step'],3),'ms/step', round(d['value']/1e6,1),'Mkp/s frac', round(d['roofline']['frac'],3))
+    except Exception as e: print(n, 'failed', e)
+"
