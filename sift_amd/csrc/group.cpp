@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <thread>
 #include <vector>
@@ -104,8 +105,19 @@ int sift_hip_group_set_option(sift_hip_group* g, const char* name, int value) {
     return rc;
 }
 
+static int group_calculate(sift_hip_group* g, const float* host_imgs, int n, int w, int h, const sift_hip_params* params, char* err, int errlen);
+
 int sift_hip_group_calculate(sift_hip_group* g, const float* host_imgs, int n, int w, int h, const sift_hip_params* params,
                              char* err, int errlen) {
+    try {   // no C++ exception (thread creation, allocation) leaves the C ABI
+        return group_calculate(g, host_imgs, n, w, h, params, err, errlen);
+    } catch (const std::exception& e) {
+        set_err(err, errlen, std::string("sift_hip_group_calculate: ") + e.what());
+        return SIFT_HIP_EHIP;
+    }
+}
+
+static int group_calculate(sift_hip_group* g, const float* host_imgs, int n, int w, int h, const sift_hip_params* params, char* err, int errlen) {
     if (!g || !host_imgs || !params || n <= 0 || w <= 0 || h <= 0) return SIFT_HIP_EINVAL;
     const int S = (int)g->ctx.size();
     g->have_result = false;
@@ -121,7 +133,11 @@ int sift_hip_group_calculate(sift_hip_group* g, const float* host_imgs, int n, i
     }
     const size_t frame = (size_t)w * (size_t)h;
     const double t0 = now_ms();
-    std::vector<std::thread> th;
+    struct Joiner {
+        std::vector<std::thread> th;
+        ~Joiner() { for (auto& t : th) if (t.joinable()) t.join(); }
+    } threads;
+    std::vector<std::thread>& th = threads.th;
     for (int s = 0; s < S; ++s) {
         if (g->count[(size_t)s] == 0) continue;
         th.emplace_back([g, s, host_imgs, frame, w, h, params]() {

@@ -13,6 +13,7 @@
 // JPEG is not decoded (libjpeg is absent; SURVEY App. B-15: decode parity of the reference's libjpeg v8 is unpinned anyway).
 #include <zlib.h>
 
+#include <cctype>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -67,7 +68,7 @@ bool decode_pnm(const std::vector<uint8_t>& b, Raster& r, std::string& msg) {
     const int kind = b[1] - '0';   // 2 grey ascii, 3 rgb ascii, 5 grey raw, 6 rgb raw
     PnmCursor c{b, 2};
     long w, h, maxv;
-    if (!c.token(w) || !c.token(h) || !c.token(maxv) || w <= 0 || h <= 0 || maxv <= 0 || maxv > 65535) { msg = "bad PNM header"; return false; }
+    if (!c.token(w) || !c.token(h) || !c.token(maxv) || w <= 0 || h <= 0 || w > (1L << 20) || h > (1L << 20) || maxv <= 0 || maxv > 65535) { msg = "bad PNM header"; return false; }
     r.w = (int)w; r.h = (int)h; r.bands = (kind == 3 || kind == 6) ? 3 : 1; r.bits = maxv < 256 ? 8 : 16;
     const size_t n = (size_t)w * (size_t)h * (size_t)r.bands;
     r.px.resize(n);
@@ -139,7 +140,7 @@ bool decode_png(const std::vector<uint8_t>& b, Raster& r, bool expand_low_grey, 
         }
         i += 12 + len;
     }
-    if (!have_hdr || w <= 0 || h <= 0) { msg = "bad PNG header"; return false; }
+    if (!have_hdr || w <= 0 || h <= 0 || (long long)w * (long long)h > (1LL << 31)) { msg = "bad PNG header"; return false; }
     const int chans = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     const bool depth_ok = (ctype == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) ||
                           (ctype == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) ||
@@ -211,7 +212,19 @@ bool decode_png(const std::vector<uint8_t>& b, Raster& r, bool expand_low_grey, 
     return true;
 }
 
+bool decode_file_unguarded(const char* path, Raster& r, std::string& msg);
+
+// nothing may leave the C ABI as a C++ exception: a header that asks for more memory than there is becomes an error text
 bool decode_file(const char* path, Raster& r, std::string& msg) {
+    try {
+        return decode_file_unguarded(path, r, msg);
+    } catch (const std::exception& e) {
+        msg = std::string("cannot decode '") + path + "': " + e.what();
+        return false;
+    }
+}
+
+bool decode_file_unguarded(const char* path, Raster& r, std::string& msg) {
     std::vector<uint8_t> b;
     if (!read_file(path, b, msg)) return false;
     static const uint8_t png_sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
@@ -337,7 +350,7 @@ int sift_hip_image_read_bgr8(const char* path, uint8_t* out, long long cap, char
     return SIFT_HIP_OK;
 }
 
-int sift_hip_png_write_bgr8(const char* path, const uint8_t* bgr, int w, int h, char* err, int errlen) {
+int sift_hip_png_write_bgr8(const char* path, const uint8_t* bgr, int w, int h, char* err, int errlen) try {
     if (!path || !bgr || w <= 0 || h <= 0) return SIFT_HIP_EINVAL;
     const size_t stride = (size_t)w * 3;
     std::vector<uint8_t> raw((stride + 1) * (size_t)h);
@@ -372,6 +385,9 @@ int sift_hip_png_write_bgr8(const char* path, const uint8_t* bgr, int w, int h, 
     const bool ok = std::fclose(f) == 0;
     if (!ok) set_err(err, errlen, "write failed");
     return ok ? SIFT_HIP_OK : SIFT_HIP_EPRECONDITION;
+} catch (const std::exception& e) {
+    set_err(err, errlen, e.what());
+    return SIFT_HIP_EHIP;
 }
 
 // cv::RotatedRect::points (OpenCV 3.2 matrix.cpp): bottomLeft, topLeft, topRight, bottomRight
