@@ -1,5 +1,5 @@
 // C++ user of the drop-in API shaped like the reference's main() (/root/reference/main.cpp:47-92): image ingest (band 0 of
-// a PGM / PPM / PNG, main.cpp:52-54), sift::Sift::calculate() on the GPU, the overlay <img>_orientation.png (:59-76) and the
+// a PGM / PPM / PNG / JPEG, main.cpp:52-54), sift::Sift::calculate() on the GPU, the overlay <img>_orientation.png (:59-76) and the
 // result file interstpoints.txt (:78-89).  Everything the reference gets from Vigra impex / OpenCV comes from the C ABI.
 //   g++ -std=c++17 -Iinclude examples/sift_points.cpp -Lsift_amd/lib -lsift_hip -Wl,-rpath,$PWD/sift_amd/lib -o sift_points
 //   ./sift_points tests/golden/parrot_r.pgm [octaves=4] [dogsPerEpoch=3] [subpixel=0]

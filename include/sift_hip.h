@@ -215,7 +215,8 @@ int sift_hip_group_timing(sift_hip_group* group, double* compute_ms, double* gat
 /* ---- image files and the result overlay (host code, no GPU) ------------------------------------------
  * What /root/reference/main.cpp does around calculate(): vigra::importImage (main.cpp:52-54), cv::imread (:59), the
  * rotated boxes (:60-73) and cv::imwrite (:75).  Read: binary / ASCII PGM and PPM, PNG (every colour type, 1-16 bit,
- * Adam7); a JPEG is refused (no libjpeg here).  Errors: SIFT_HIP_EPRECONDITION with a text in err. */
+ * Adam7), JPEG (baseline and progressive Huffman files, 8 bit, greyscale or three components: libjpeg's default decode —
+ * islow IDCT, fancy upsampling — restated in sift_amd/csrc/jpeg_decode.cpp, pixel-identical to libjpeg-turbo).  Errors: SIFT_HIP_EPRECONDITION with a text in err. */
 int sift_hip_image_info(const char* path, int* w, int* h, int* bands, int* bits, char* err, int errlen);
 /* vigra::importImage into a scalar float array: band 0 of a multi-band file (red of RGB / palette), sample values
  * unscaled (0..255; 0..65535 for 16-bit files), x fastest.  `cap` = floats `out` holds (>= w*h). */

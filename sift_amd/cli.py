@@ -4,7 +4,7 @@ overlay :59-76) on top of the GPU path — SURVEY.md §8(f) rows 1-3.
     python -m sift_amd.cli -i image.pgm [-s 1.6] [-k 1.41421354] [-o 4] [-d 3] [-p 0] [-r 1]
 
 Image ingest follows Vigra's scalar import: band 0 of multi-band files, values unscaled.  PGM,
-PPM and PNG are decoded by the library itself (sift_amd/csrc/image_io.cpp: no PIL, no OpenCV); JPEG is refused.
+PPM, PNG and JPEG are decoded by the library itself (sift_amd/csrc/image_io.cpp, jpeg_decode.cpp: no PIL, no OpenCV, no libjpeg).
 """
 from __future__ import annotations
 
@@ -27,7 +27,7 @@ def _err_call(fn, *args):
 
 
 def image_info(path: str):
-    """(width, height, bands, bits per sample) of a PGM / PPM / PNG file."""
+    """(width, height, bands, bits per sample) of a PGM / PPM / PNG / JPEG file."""
     L = _lib.load()
     w, h, b, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
     _err_call(L.sift_hip_image_info, path.encode(), C.byref(w), C.byref(h), C.byref(b), C.byref(d))
@@ -36,7 +36,7 @@ def image_info(path: str):
 
 def read_image(path: str) -> np.ndarray:
     """vigra::importImage into a scalar float array (main.cpp:52-54): band 0, values unscaled.  Decoded by the
-    library's own PGM / PPM / PNG reader (sift_amd/csrc/image_io.cpp), no PIL."""
+    library's own PGM / PPM / PNG / JPEG reader (sift_amd/csrc/image_io.cpp), no PIL."""
     L = _lib.load()
     w, h, _, _ = image_info(path)
     out = np.empty((h, w), np.float32)

@@ -133,6 +133,7 @@ struct sift_hip_ctx {
     DevBuf d_cell_cnt, d_cell_off;   // descriptor grid: keypoints per 16 px cell, exclusive scan (+ total)
     bool desc_wave = true;           // option "desc_kernel": 1 wave-per-keypoint kernel (default), 0 tile kernel
     bool gate_early_chain = false;   // option "gate_early_chain" (measured alternative, off)
+    int gate_schedule = 0;           // option "gate_schedule" (phase_gate.h): applies to the gate this context is joined to
     DevBuf d_list, d_list_cnt, d_orient, d_peaks, d_final, d_final_cnt, d_out_base, d_kp, d_desc;
     DevBuf d_wire_sums, d_wire_off;   // sparse wire format: floats per block of keypoints, their exclusive scan
     HostBuf h_wire;
@@ -785,6 +786,7 @@ bool mid_gpu(sift_hip_ctx* c) {
     // capacity guess: a quarter above what this context's previous batch returned; before the first one 24576 keypoints
     // per image (a 1080p frame returns ~20 k; 13 MB of results per image)
     ensure_outputs(c, std::max<long long>(c->out_cap, c->last_total > 0 ? c->last_total + c->last_total / 4 : (long long)n * 24576));
+    if (c->gate) c->gate->before_descriptors(c->gate_ticket, s);
     launch_descriptor_stage(c);
     SIFT_HIP_CHECK(hipGetLastError());
     if (c->gate) c->gate->mark(c->gate_ticket, sift_hip::PhaseGate::kD, s);
@@ -1214,6 +1216,7 @@ int sift_hip_set_gate(sift_hip_ctx* c, sift_hip_gate* g) {
     }
     c->gate_owner = g;
     c->gate = g ? &g->gate : nullptr;
+    if (c->gate && c->gate_schedule) c->gate->set_schedule(c->gate_schedule);
     return SIFT_HIP_OK;
 }
 
@@ -1226,6 +1229,12 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     if (!std::strcmp(name, "desc_dbg")) { c->desc_dbg = value; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "desc_kernel")) { c->desc_wave = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "gate_early_chain")) { c->gate_early_chain = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "gate_schedule")) {
+        if (value < 0 || value > 1) return SIFT_HIP_EINVAL;
+        c->gate_schedule = value;
+        if (c->gate) c->gate->set_schedule(value);
+        return SIFT_HIP_OK;
+    }
     if (!std::strcmp(name, "gpu_cleanup")) { c->gpu_cleanup = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "profile")) { c->profile_every = value > 0 ? value : 0; c->profile_batches = 0; c->profile = false; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "orient_general")) { c->orient_general = value != 0; return SIFT_HIP_OK; }

@@ -2,7 +2,8 @@
 // ingest, :59-76 overlay, :75 imwrite) — SURVEY.md §8(f) rows 2 and 3.  Host code only (no HIP): the reference does these
 // steps with vigra::importImage, cv::imread, cv::RotatedRect, cv::line and cv::imwrite; none of those libraries exists
 // here, so their documented behaviour is restated:
-//   * PGM / PPM (P2, P3, P5, P6) and PNG (all colour types, 1-16 bit, Adam7) decoding, zlib for the inflate;
+//   * PGM / PPM (P2, P3, P5, P6) and PNG (all colour types, 1-16 bit, Adam7) decoding, zlib for the inflate; JPEG
+//     (baseline and progressive Huffman files) in jpeg_decode.cpp, libjpeg's default decode restated;
 //   * vigra::importImage into a scalar float array: band 0 of multi-band files (red of RGB / palette files, grey of
 //     grey+alpha), sample values unscaled (0..255, 0..65535 for 16-bit files), grey samples below 8 bit expanded to
 //     0..255 (png_set_expand_gray_1_2_4_to_8), SURVEY App. B-15;
@@ -10,7 +11,6 @@
 //     high byte of 16-bit samples;
 //   * cv::RotatedRect::points, the Point2f -> Point rounding of cv::line, its clipping and 8-connected Bresenham walk
 //     (OpenCV 3.2 drawing.cpp: LineIterator), cv::Size's float -> int truncation and main.cpp's u16_t coordinates.
-// JPEG is not decoded (libjpeg is absent; SURVEY App. B-15: decode parity of the reference's libjpeg v8 is unpinned anyway).
 #include <zlib.h>
 
 #include <cctype>
@@ -22,6 +22,11 @@
 #include <vector>
 
 #include "../../include/sift_hip.h"
+
+namespace sift_hip {
+// jpeg_decode.cpp: libjpeg's default decode (islow IDCT, fancy upsampling, YCbCr -> RGB) restated
+bool decode_jpeg(const uint8_t* data, size_t n, int& w, int& h, int& bands, std::vector<uint16_t>& px, std::string& msg);
+}
 
 namespace {
 
@@ -230,8 +235,11 @@ bool decode_file_unguarded(const char* path, Raster& r, std::string& msg) {
     static const uint8_t png_sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
     if (b.size() >= 8 && !std::memcmp(b.data(), png_sig, 8)) return decode_png(b, r, true, msg);
     if (b.size() >= 3 && b[0] == 'P' && (b[1] == '2' || b[1] == '3' || b[1] == '5' || b[1] == '6')) return decode_pnm(b, r, msg);
-    if (b.size() >= 2 && b[0] == 0xff && b[1] == 0xd8) { msg = "JPEG files are not decoded here (no libjpeg): convert to PNG or PGM"; return false; }
-    msg = "did not find a matching codec for the given file (PGM, PPM and PNG are read)";
+    if (b.size() >= 2 && b[0] == 0xff && b[1] == 0xd8) {
+        r.bits = 8;
+        return sift_hip::decode_jpeg(b.data(), b.size(), r.w, r.h, r.bands, r.px, msg);
+    }
+    msg = "did not find a matching codec for the given file (PGM, PPM, PNG and JPEG are read)";
     return false;
 }
 

@@ -30,7 +30,13 @@ namespace sift_hip {
 
 class PhaseGate {
 public:
-    enum Phase { kP = 0, kE = 1, kD = 2 };
+    enum Phase { kP = 0, kE = 1, kD = 2, kC = 3 };
+    // 0: the schedule above.  1 (option "gate_schedule"): the cleanup chain C(g) runs under the next pyramid P(g+1) and the
+    // descriptors D(g) under the next extrema / gradient pass E(g+1):  ... | P(g+1) || C(g) | E(g+1) || D(g) | P(g+2) || C(g+1) | ...
+    void set_schedule(int m) {
+        std::lock_guard<std::mutex> lk(m_);
+        schedule_ = m;
+    }
 
     PhaseGate() {
         for (auto& sl : ring_)
@@ -51,12 +57,12 @@ public:
         // the slot's previous user (g - kRing) finished long ago: every batch is waited for by its owner before the
         // owner submits again, and at most kRing / 2 contexts share a gate
         me.g = g;
-        me.rec[0] = me.rec[1] = me.rec[2] = false;
-        me.entered_c = false;
+        me.rec[0] = me.rec[1] = me.rec[2] = me.rec[3] = false;
+        me.entered_c = me.entered_d = false;
         cv_.notify_all();
         if (g >= 1 && slot(g - 1).g == g - 1) {
             Slot& pred = slot(g - 1);
-            if (pred.entered_c) {
+            if (schedule_ == 1 ? pred.entered_d : pred.entered_c) {
                 cv_.wait(lk, [&] { return pred.rec[kD]; });
                 (void)hipStreamWaitEvent(s, pred.ev[kD], 0);
             } else {
@@ -87,6 +93,11 @@ public:
         std::unique_lock<std::mutex> lk(m_);
         Slot& me = slot(g);
         if (me.g != g) return;
+        if (schedule_ == 1) {   // the chain starts at once, beside the successor's pyramid
+            me.entered_c = true;
+            cv_.notify_all();
+            return;
+        }
         // The host runs far ahead of the device, so "is there a successor" is asked at DEVICE time: the question stays
         // open until the device has finished E(g).  A successor announced by then gets its pyramid in first; after
         // that point waiting could only leave the chip idle.
@@ -101,17 +112,39 @@ public:
         cv_.notify_all();
     }
 
+    // Schedule 1: batch g is about to queue its descriptor stage on `s`, after its cleanup chain.  A successor announced by
+    // the time the device finishes the chain gets its pyramid in first (the descriptors then share the chip with its
+    // extrema / gradient pass: issue-bound beside bandwidth-bound); otherwise the descriptors start at once and the next
+    // pyramid waits for them.
+    void before_descriptors(long long g, hipStream_t s) {
+        std::unique_lock<std::mutex> lk(m_);
+        Slot& me = slot(g);
+        if (me.g != g || schedule_ != 1) return;
+        if (!me.rec[kC]) {
+            (void)hipEventRecord(me.ev[kC], s);
+            me.rec[kC] = true;
+        }
+        while (next_ <= g + 1 && hipEventQuery(me.ev[kC]) == hipErrorNotReady) cv_.wait_for(lk, std::chrono::microseconds(20));
+        if (next_ > g + 1) {
+            Slot& succ = slot(g + 1);
+            cv_.wait(lk, [&] { return succ.g == g + 1 && succ.rec[kP]; });
+            (void)hipStreamWaitEvent(s, succ.ev[kP], 0);
+        }
+        me.entered_d = true;
+        cv_.notify_all();
+    }
+
     // Whatever batch g has not marked yet is marked now (normal end, early return or exception).
     void finish(long long g, hipStream_t s) {
         std::lock_guard<std::mutex> lk(m_);
         Slot& me = slot(g);
         if (me.g != g) return;
-        for (int ph = 0; ph < 3; ++ph)
+        for (int ph = 0; ph < 4; ++ph)
             if (!me.rec[ph]) {
                 (void)hipEventRecord(me.ev[ph], s);
                 me.rec[ph] = true;
             }
-        me.entered_c = true;
+        me.entered_c = me.entered_d = true;
         cv_.notify_all();
     }
 
@@ -123,14 +156,15 @@ public:
 private:
     struct Slot {
         long long g = -1;
-        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-        bool rec[3] = {false, false, false};
-        bool entered_c = false;
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        bool rec[4] = {false, false, false, false};
+        bool entered_c = false, entered_d = false;
     };
     Slot& slot(long long g) { return ring_[g % kRing]; }
     std::mutex m_;
     std::condition_variable cv_;
     long long next_ = 0;
+    int schedule_ = 0;
     Slot ring_[kRing];
 };
 

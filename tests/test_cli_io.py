@@ -59,6 +59,46 @@ def test_image_reader(name):
     assert (h, w) == band0.shape and bands in (1, 2, 3, 4) and bits in (8, 16)
 
 
+@pytest.mark.parametrize("name", sorted({k.split("/")[0] for k in np.load(os.path.join(IMG, "expected_jpeg.npz")).files}))
+def test_jpeg_reader(name):
+    """JPEG without libjpeg (sift_amd/csrc/jpeg_decode.cpp): pixel for pixel what libjpeg-turbo's default decode returns
+    (tests/golden/make_jpeg_fixtures.py): baseline and progressive files, 4:4:4 / 4:2:2 / 4:2:0, restart intervals, custom
+    Huffman tables, greyscale, RGB colour space, sizes that are not whole MCUs, chroma planes too narrow for the triangle filter."""
+    exp = np.load(os.path.join(IMG, "expected_jpeg.npz"))
+    path = os.path.join(IMG, name)
+    band0 = cli.read_image(path)
+    assert band0.dtype == np.float32 and np.array_equal(band0, exp[name + "/band0"])
+    assert np.array_equal(cli.read_image_bgr(path), exp[name + "/bgr"])
+    w, h, bands, bits = cli.image_info(path)
+    assert (h, w) == band0.shape and bands == (1 if name.startswith("grey") else 3) and bits == 8
+
+
+def test_jpeg_reader_against_pil_large(tmp_path):
+    """Files of the size the command line program is fed, encoded here: every MCU geometry again at 1080p / odd sizes."""
+    Image = pytest.importorskip("PIL.Image")
+    from sift_amd.synthetic import synth_frame
+    g = [synth_frame(1920, 1080, s).astype(np.uint8) for s in (1, 2, 3)]
+    cases = [("a.jpg", np.stack(g, 2), dict(quality=90, subsampling=2)),
+             ("b.jpg", np.stack(g, 2)[:1079, :1913], dict(quality=75, subsampling=1, progressive=True)),
+             ("c.jpg", np.stack(g, 2)[:517, :1001], dict(quality=95, subsampling=0, optimize=True, restart_marker_rows=2)),
+             ("d.jpg", g[0][:1001, :777], dict(quality=85, progressive=True))]
+    for name, arr, opts in cases:
+        Image.fromarray(arr).save(tmp_path / name, "JPEG", **opts)
+        ref = np.asarray(Image.open(tmp_path / name).convert("RGB"))
+        assert np.array_equal(cli.read_image_bgr(str(tmp_path / name))[:, :, ::-1], ref), name
+        assert np.array_equal(cli.read_image(str(tmp_path / name)), ref[:, :, 0].astype(np.float32)), name
+
+
+def test_jpeg_reader_on_the_reference_example():
+    """The reference's own example input (example/parrot.jpg, where the reference tree is present): its red band is the PGM the
+    config 1 tests run on (tests/golden/parrot_r.pgm, written with PIL's libjpeg-turbo in round 1)."""
+    path = "/root/reference/example/parrot.jpg"
+    if not os.path.exists(path):
+        pytest.skip("reference tree absent")
+    assert np.array_equal(cli.read_image(path), read_pgm(os.path.join(GOLDEN, "parrot_r.pgm")))
+    assert cli.image_info(path) == (488, 600, 3, 8)
+
+
 def test_rgb_file_takes_band_zero():
     exp = np.load(os.path.join(IMG, "expected.npz"))
     bgr = exp["rgb8.png/bgr"]
@@ -80,6 +120,17 @@ def test_image_reader_errors(tmp_path):
     (tmp_path / "x.jpg").write_bytes(b"\xff\xd8\xff\xe0" + bytes(32))
     with pytest.raises(OSError, match="JPEG"):
         cli.read_image(str(tmp_path / "x.jpg"))
+    whole = open(os.path.join(IMG, "rgb_420.jpg"), "rb").read()
+    (tmp_path / "cut.jpg").write_bytes(whole[:300])          # header only: no scan
+    with pytest.raises(OSError, match="JPEG"):
+        cli.read_image(str(tmp_path / "cut.jpg"))
+    sof = whole.index(b"\xff\xc0")
+    (tmp_path / "p12.jpg").write_bytes(whole[:sof + 4] + b"\x0c" + whole[sof + 5:])   # 12-bit samples
+    with pytest.raises(OSError, match="8-bit"):
+        cli.read_image(str(tmp_path / "p12.jpg"))
+    (tmp_path / "arith.jpg").write_bytes(whole[:sof + 1] + b"\xc9" + whole[sof + 2:])   # SOF9: arithmetic coding
+    with pytest.raises(OSError, match="not decoded"):
+        cli.read_image(str(tmp_path / "arith.jpg"))
     (tmp_path / "bad.png").write_bytes(open(os.path.join(IMG, "rgb8.png"), "rb").read()[:200])
     with pytest.raises(OSError):
         cli.read_image(str(tmp_path / "bad.png"))

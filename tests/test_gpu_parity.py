@@ -631,6 +631,21 @@ def test_cli_result_file(ctx, tmp_path, monkeypatch):
     assert cli.main(["parrot_r.pgm", "--no-overlay"]) == 0 and not os.path.exists(tmp_path / "interstpoints.txt")
 
 
+def test_cli_reads_a_jpeg(ctx, tmp_path, monkeypatch):
+    """The reference's example input is a JPEG (example/parrot.jpg): the command line program decodes one itself
+    (sift_amd/csrc/jpeg_decode.cpp, no libjpeg, no PIL), takes its red band (App. B-15) and draws on its B,G,R pixels."""
+    from sift_amd import cli
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.chdir(tmp_path)
+    import shutil
+    shutil.copy(os.path.join(root, "tests", "golden", "img", "scene_420.jpg"), tmp_path / "scene.jpg")
+    exp = np.load(os.path.join(root, "tests", "golden", "img", "expected_jpeg.npz"))
+    assert cli.main(["-i", "scene.jpg", "-o", "4", "-d", "3", "-r", "1"]) == 0
+    want, run = expected_result_file(tmp_path, exp["scene_420.jpg/band0"], 3, 4)
+    assert open(tmp_path / "interstpoints.txt", "rb").read() == want and len(want) > 10000
+    check_overlay(tmp_path / "scene.jpg_orientation.png", exp["scene_420.jpg/bgr"], run, False)
+
+
 def test_config3_exception_and_nearest_runnable(ctx, report_dir):
     """BASELINE config 3: 1920x1080, subpixel, 4 oct x 5 DoG throws in the reference (App. B-13);
     the nearest runnable setting (subpixel, 4 x 3) is compared in full."""
