@@ -162,6 +162,9 @@ def main():
                          "2 (default): consecutive steps overlap under the phase gate - the next step's extrema / gradient pass\n"
                          "fills the chip while this step's cleanup (one workgroup per image) cannot, and no pyramid shares\n"
                          "the chip, so the per-launch roofline figure is that of the kernel alone.  1: one step at a time")
+    ap.add_argument("--rccl-loopback", action="store_true",
+                    help="N = 1 only: every step's keypoint lists also travel through RCCL point-to-point to this same rank "
+                         "(KeypointGather(loopback=True)): the N > 1 gather path, messages and sizes, on a one-GPU box")
     ap.add_argument("--pipeline-gate", type=int, default=1, choices=[0, 1],
                     help="pipeline depth > 1: 1 (default) joins the contexts with a phase gate (no pyramid shares the chip); 0 leaves the interleaving to the GPU's queues")
     args = ap.parse_args()
@@ -187,7 +190,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    loopback = bool(args.rccl_loopback) and world == 1
+    if loopback:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+    if world > 1 or loopback:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -204,7 +211,10 @@ def main():
     from sift_amd.pipeline import BatchPipeline
 
     depth = max(1, args.pipeline_depth)
-    pipe = BatchPipeline(local_rank, depth, dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in args.set), gated=bool(args.pipeline_gate))
+    options = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in args.set)
+    if (world > 1 or loopback) and args.wire == "sparse":
+        options.setdefault("wire_count", 1)   # the descriptor kernel also counts what the sparse wire format will carry
+    pipe = BatchPipeline(local_rank, depth, options, gated=bool(args.pipeline_gate))
     ctxs = pipe.contexts
     ctx = ctxs[0]
     params = _lib.Params(DOGS, OCTAVES, SIGMA, K_SQRT2, SUBPIXEL)
@@ -215,7 +225,7 @@ def main():
     # N > 1: the gather of step k (keypoint records + descriptors to rank 0 over RCCL point-to-point, never images) rides
     # behind the header of step k+1 and overlaps the kernels of the following steps, which run on the library's own
     # streams (sift_amd/gather.py: KeypointGather, no per-step collective); every transfer completes inside the timed region.
-    gatherer = KeypointGather(nf, comm_dev, dst=0) if world > 1 else None
+    gatherer = KeypointGather(nf, comm_dev, dst=0, loopback=loopback) if (world > 1 or loopback) else None
     gathered = [0, 0]       # steps and keypoints that have arrived on rank 0
     keep = []               # tensors of the last pushes (the gather reads them until two pushes later)
     tickets = []            # submitted steps whose results have not been collected yet (at most depth - 1 between steps)
@@ -229,9 +239,12 @@ def main():
         """Finish one step: wait for its batch, hand its keypoint lists to the gather (N > 1), free its slot."""
         c = ticket.result()
         total = c.total()
-        if world > 1:
+        if gatherer is not None:
             # wire format (lossless, sift_amd/gather.py): sparse = 34-byte records (20 + 112 presence bits) + the floats that are set
-            kp, desc = device_results(c, total, dev, wire=args.wire)
+            rec_out = None
+            if args.wire == "sparse" and comm_dev.type != "cpu" and gatherer.rank != gatherer.dst or (loopback and args.wire == "sparse"):
+                rec_out = gatherer.records_buffer(total * 34)   # the records are packed straight into their message buffer
+            kp, desc = device_results(c, total, dev, wire=args.wire, rec_out=rec_out)
             counts = c.counts()
             if comm_dev.type == "cpu":     # test backend: stage through host memory
                 kp, desc = kp.cpu(), desc.cpu()
@@ -257,7 +270,7 @@ def main():
     drain()
     if gatherer is not None:     # the warm-up steps' lists are gathered too, before the clock starts
         note(gatherer.flush())
-        gatherer = KeypointGather(nf, comm_dev, dst=0)
+        gatherer = KeypointGather(nf, comm_dev, dst=0, loopback=loopback)
         gatherer_t0 = (gathered[0], gathered[1])
     for c in ctxs:
         c.set_option("profile", PROFILE_EVERY)   # every 4th batch of a context carries the per-launch timing events
@@ -307,14 +320,15 @@ def main():
             "config": {"workload": label.format(n=nf),
                        "frames_per_gpu": nf, "frames_total": nf * world, "pipeline_depth": depth, "pipeline_gate": bool(args.pipeline_gate) and depth > 1, "keypoints_per_step": kps // max(args.steps, 1),
                        "frames_per_s": nf * world * args.steps / dt,
-                       "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0,
-                       "gather_steps_on_rank0": (gathered[0] - gatherer_t0[0]) if world > 1 else None,
-                       "gather_keypoints_on_rank0": (gathered[1] - gatherer_t0[1]) if world > 1 else None,
-                       "gather_ms_per_step": (gatherer.wait_s / args.steps * 1e3) if world > 1 else None,
-                       "wire_bytes_per_step": (gatherer.wire_bytes / args.steps) if world > 1 else None,
+                       "rccl_ranks": world if ((world > 1 or loopback) and args.backend == "nccl") else 0,
+                       "rccl_loopback": loopback,   # N = 1 with the N > 1 gather messages sent through RCCL to this same rank
+                       "gather_steps_on_rank0": (gathered[0] - gatherer_t0[0]) if gatherer is not None else None,
+                       "gather_keypoints_on_rank0": (gathered[1] - gatherer_t0[1]) if gatherer is not None else None,
+                       "gather_ms_per_step": (gatherer.wait_s / args.steps * 1e3) if gatherer is not None else None,
+                       "wire_bytes_per_step": (gatherer.wire_bytes / args.steps) if gatherer is not None else None,
                        "gather": ("RCCL p2p of keypoint records + descriptors to rank 0, no per-step collective (sizes ride one step ahead), overlapped with the following steps; "
                                   + {"full": "128 floats per descriptor", "packed": "descriptors on the wire as 112 of 128 floats (bin 7 of each cell is structurally +0.0f; lossless)",
-                                     "sparse": "descriptors on the wire as 112 presence bits + the floats that are not +0.0f (about a third; lossless)"}[args.wire]) if world > 1 else "none (1 GPU)"},
+                                     "sparse": "descriptors on the wire as 112 presence bits + the floats that are not +0.0f (about a third; lossless)"}[args.wire]) if gatherer is not None else "none (1 GPU)"},
             "roofline": {"kernel": "blur_stream_kernel / blur_fused_kernel (separable Gaussian + DoG; every launch of the pyramid)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
@@ -376,7 +390,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(frames[:CPU_SAMPLE_FRAMES])
         print(json.dumps(out), flush=True)
     pipe.close()
-    if world > 1:
+    if world > 1 or loopback:
         dist.destroy_process_group()
 
 

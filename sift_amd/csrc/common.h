@@ -164,11 +164,11 @@ void launch_desc_grid(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan,
                       sift_hip_keypoint* d_kp_out, float* d_desc_out, long long out_cap);
 void launch_descriptors_wave(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level, const int* d_cell_off,
                              const FinalKp* d_pool, int pool_cap, const long long* d_out_base, sift_hip_keypoint* d_kp_out,
-                             float* d_desc_out, long long out_cap, int dbg = 0);
+                             float* d_desc_out, long long out_cap, int dbg = 0, int* d_wire_sums = nullptr);
 
 // wire format of the keypoint gather (kernels_wire.hip)
 size_t wire_blocks(long long total);
-void launch_wire_count(hipStream_t s, const float* d_desc, long long total, int* d_block_sums, long long* d_block_off);
+void launch_wire_count(hipStream_t s, const float* d_desc, long long total, int* d_sums, long long* d_block_off, bool counted);
 void launch_wire_emit(hipStream_t s, const sift_hip_keypoint* d_kp, const float* d_desc, long long total,
                       const long long* d_block_off, uint8_t* d_records, float* d_values);
 

@@ -138,6 +138,8 @@ struct sift_hip_ctx {
     DevBuf d_wire_sums, d_wire_off;   // sparse wire format: floats per block of keypoints, their exclusive scan
     HostBuf h_wire;
     long long wire_values = -1, wire_for_total = -1;
+    bool wire_count = false;          // option "wire_count": the descriptor kernel also counts the floats of the sparse wire format
+    bool wire_counted = false;        // ... and has done so for the current batch
     DevBuf d_lrank, d_ochunk, d_ocnt, d_recs;   // list position -> orientation result; kept counts per 1024 candidates; early/late counts
     HostBuf h_flags, h_orient, h_peaks, h_status;
     hipEvent_t ev_sync = nullptr;
@@ -715,11 +717,22 @@ void launch_descriptor_stage(sift_hip_ctx* c) {
         launch_desc_grid(c->stream, c->d_plan.as<DevPlan>(), dv, c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(), kListCap,
                          c->d_cell_cnt.as<int>(), c->d_cell_off.as<int>(), c->d_pool.as<FinalKp>(), kPoolCap, c->d_out_base.as<long long>(),
                          c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->out_cap);
+        int* wire_sums = nullptr;
+        c->wire_counted = false;
+        if (c->wire_count) {   // multi-GPU jobs: the counting pass of the wire format rides in the descriptor kernel
+            const size_t nb = wire_blocks(c->out_cap);
+            c->d_wire_sums.ensure((nb + 2) * sizeof(int));
+            SIFT_HIP_CHECK(hipMemsetAsync(c->d_wire_sums.p, 0, (nb + 2) * sizeof(int), c->stream));
+            wire_sums = c->d_wire_sums.as<int>();
+            c->wire_counted = true;
+        }
         for (int lvl : P.grad_levels)
             launch_descriptors_wave(c->stream, c->d_plan.as<DevPlan>(), dv, lvl, c->d_cell_off.as<int>(), c->d_pool.as<FinalKp>(), kPoolCap,
-                                    c->d_out_base.as<long long>(), c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->out_cap, c->desc_dbg);
+                                    c->d_out_base.as<long long>(), c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->out_cap, c->desc_dbg,
+                                    wire_sums);
         return;
     }
+    c->wire_counted = false;
     const size_t nt = (size_t)dv.desc_tiles_per_image * (size_t)P.n;
     int* t_cnt = c->d_tile.as<int>();
     int* t_off = t_cnt + nt;
@@ -981,6 +994,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     c->binned = false;
     c->described = false;
     c->wire_values = c->wire_for_total = -1;
+    c->wire_counted = false;
     c->profile = c->profile_every > 0 && (c->profile_batches++ % c->profile_every) == 0;
 
     // Batches of several contexts in flight on this GPU: the gate orders their phases (phase_gate.h).  Whatever
@@ -1229,6 +1243,7 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     if (!std::strcmp(name, "desc_dbg")) { c->desc_dbg = value; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "desc_kernel")) { c->desc_wave = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "gate_early_chain")) { c->gate_early_chain = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "wire_count")) { c->wire_count = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "gate_schedule")) {
         if (value < 0 || value > 1) return SIFT_HIP_EINVAL;
         c->gate_schedule = value;
@@ -1326,12 +1341,13 @@ int sift_hip_result_sparse_size(sift_hip_ctx* c, int64_t* n_values, int* lossles
     return guarded(err, sizeof(err), [&]() {
         SIFT_HIP_CHECK(hipSetDevice(c->device));
         const size_t nb = wire_blocks(c->total);
-        c->d_wire_sums.ensure((nb + 1) * sizeof(int));
+        const bool counted = c->wire_counted;   // by the last descriptor stage of this batch (launch_descriptor_stage)
+        if (!counted) c->d_wire_sums.ensure((nb + 2) * sizeof(int));
         c->d_wire_off.ensure((nb + 1) * sizeof(long long));
         c->h_wire.ensure(2 * sizeof(long long));
-        launch_wire_count(c->stream, c->d_desc.as<float>(), c->total, c->d_wire_sums.as<int>(), c->d_wire_off.as<long long>());
+        launch_wire_count(c->stream, c->d_desc.as<float>(), c->total, c->d_wire_sums.as<int>(), c->d_wire_off.as<long long>(), counted);
         SIFT_HIP_CHECK(hipMemcpyAsync(c->h_wire.p, c->d_wire_off.as<long long>() + nb, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
-        SIFT_HIP_CHECK(hipMemcpyAsync(c->h_wire.as<long long>() + 1, c->d_wire_sums.as<int>() + nb, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        SIFT_HIP_CHECK(hipMemcpyAsync(c->h_wire.as<long long>() + 1, c->d_wire_sums.as<int>(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
         wait_stream(c, c->stream);
         c->wire_values = *c->h_wire.as<long long>();
         if (lossless) *lossless = *reinterpret_cast<const int*>(c->h_wire.as<long long>() + 1) ? 0 : 1;

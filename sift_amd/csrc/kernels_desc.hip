@@ -543,6 +543,7 @@ struct DescGridLevel {
     const float* ori;
     const float* gauss;
     const float* w16;
+    int* wire_sums;   // multi-GPU jobs (option "wire_count"): [0] flag, [1 + slot / 64] floats the block puts on the wire (kernels_wire.hip); or null
 };
 
 // cell of a keypoint, or -1 if the descriptor stage's own bounds test fails (sift.cpp:65-70)
@@ -907,6 +908,18 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
         const long long ok = obase + (long long)myk;
         if (ok < out_cap && !((dbg & 16) && h0 == 12345.0f)) {   // (the output arrays are sized before the final counts reach the host: see run_batch)
             *reinterpret_cast<float2*>(desc_out + (size_t)ok * 128 + (size_t)(2 * lane)) = make_float2(h0, h1);
+            if (lv.wire_sums != nullptr) {
+                // the counting pass of the sparse wire format (kernels_wire.hip: wire_count_kernel) while the 128 floats are
+                // still in registers: floats that are not +0.0f outside bin 7, per block of 64 output slots
+                const bool b0 = __float_as_uint(h0) != 0u, odd7 = (lane & 3) == 3;
+                const bool b1 = !odd7 && __float_as_uint(h1) != 0u;
+                const int nset = __popcll(__ballot(b0)) + __popcll(__ballot(b1));
+                const unsigned long long bin7 = __ballot(odd7 && __float_as_uint(h1) != 0u);
+                if (lane == 0) {
+                    atomicAdd(&lv.wire_sums[1 + (ok >> 6)], nset);
+                    if (bin7 != 0ull) atomicOr(&lv.wire_sums[0], 1);
+                }
+            }
             if (lane == 0) {
                 sift_hip_keypoint r;
                 r.scale = plan->dog_scale[(myoi & 0xffffu) * (unsigned)D + (myoi >> 16)];
@@ -1002,13 +1015,14 @@ void launch_desc_grid(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan,
 
 void launch_descriptors_wave(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level, const int* d_cell_off,
                              const FinalKp* d_pool, int pool_cap, const long long* d_out_base, sift_hip_keypoint* d_kp_out,
-                             float* d_desc_out, long long out_cap, int dbg) {
+                             float* d_desc_out, long long out_cap, int dbg, int* d_wire_sums) {
     DescGridLevel lv;
     const int oct = level / (plan.dogs + 1);
     lv.w = plan.w[oct]; lv.h = plan.h[oct]; lv.dogs = plan.dogs;
     lv.cw = plan.desc_cw[level]; lv.ch = plan.desc_ch[level]; lv.cell_base = plan.desc_cell_base[level];
     lv.cells_per_image = plan.desc_cells_per_image;
     lv.mag = plan.mag[level]; lv.ori = plan.ori[level]; lv.gauss = plan.gauss[level]; lv.w16 = plan.w16[level];
+    lv.wire_sums = d_wire_sums;
     // 2048 workgroups of four waves (8 per CU); whole images per XCD when there are at least 8, eighths of an image otherwise
     const int chunks = plan.n_images >= 8 ? 1 : 8;
     const unsigned nwg = (dbg & 64) ? 512u : ((dbg & 32) ? 1024u : 2048u);   // timing only: fewer resident waves

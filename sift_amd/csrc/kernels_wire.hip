@@ -9,7 +9,7 @@
 //
 // Two passes over the result arrays (the per-keypoint offsets need a scan): counts per block of 64 keypoints, a
 // one-workgroup scan of the block sums, then the emit pass.  A wave reads one descriptor as 64 float2: 512
-// contiguous bytes.
+// contiguous bytes.  Both passes run on every rank of a multi-GPU job once per batch, beside the next batch's kernels.
 #include "common.h"
 
 namespace sift_hip {
@@ -23,26 +23,35 @@ __device__ __forceinline__ void wire_presence(const float2 v, int lane, bool& b0
     b1 = (((2 * lane + 1) & 7) != 7) && __float_as_uint(v.y) != 0u;
 }
 
-// block_sums[gridDim.x] (cleared by the launcher) is raised when some descriptor carries anything but +0.0f in bin 7 of a
+// A wave takes kWirePerWave consecutive descriptors: all their loads are issued before the first is looked at (16 x 512 B
+// in flight per wave), the presence bits come from two wavefront ballots per descriptor (even / odd positions).
+
+// *flag (cleared by the launcher) is raised when some descriptor carries anything but +0.0f in bin 7 of a
 // cell: normalizeVector divides every bin by the cell's sum (algorithms.cpp:210-223), so a negative or NaN sum (negative
 // pixels, inf * 0 after the cumulative `magnitudes += weighting`) turns the never-written bin into -0.0f or NaN, which
 // this format cannot carry
 __global__ __launch_bounds__(256) void wire_count_kernel(const float* __restrict__ desc, long long total,
-                                                        int* __restrict__ block_sums) {
+                                                        int* __restrict__ block_sums, int* __restrict__ flag) {
     __shared__ int s_sum[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int sum = 0;
-#pragma unroll 4
+    const long long k0 = (long long)blockIdx.x * kWireBlock + wave * kWirePerWave;
+    float2 v[kWirePerWave];
+#pragma unroll
     for (int i = 0; i < kWirePerWave; ++i) {
-        const long long k = (long long)blockIdx.x * kWireBlock + wave * kWirePerWave + i;
-        if (k < total) {
-            const float2 v = reinterpret_cast<const float2*>(desc + k * 128)[lane];
-            bool b0, b1;
-            wire_presence(v, lane, b0, b1);
-            sum += __popcll(__ballot(b0)) + __popcll(__ballot(b1));
-            if (__ballot((lane & 3) == 3 && __float_as_uint(v.y) != 0u) != 0ull && lane == 0) atomicOr(&block_sums[gridDim.x], 1);
-        }
+        const long long k = min(k0 + i, total - 1);   // past the end: the last descriptor again (not counted)
+        v[i] = reinterpret_cast<const float2*>(desc + k * 128)[lane];
     }
+    int sum = 0;
+    unsigned long long bin7 = 0ull;
+#pragma unroll
+    for (int i = 0; i < kWirePerWave; ++i) {
+        bool b0, b1;
+        wire_presence(v[i], lane, b0, b1);
+        const int n = __popcll(__ballot(b0)) + __popcll(__ballot(b1));
+        sum += (k0 + i < total) ? n : 0;
+        bin7 |= __ballot((lane & 3) == 3 && __float_as_uint(v[i].y) != 0u);
+    }
+    if (bin7 != 0ull && lane == 0) atomicOr(flag, 1);
     if (lane == 0) s_sum[wave] = sum;
     __syncthreads();
     if (threadIdx.x == 0) block_sums[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
@@ -51,26 +60,36 @@ __global__ __launch_bounds__(256) void wire_count_kernel(const float* __restrict
 // exclusive scan of the block sums (one workgroup); block_off[nb] = total number of floats
 __global__ __launch_bounds__(1024) void wire_scan_kernel(const int* __restrict__ block_sums, int nb,
                                                          long long* __restrict__ block_off) {
-    __shared__ long long s_part[1024];
-    const int tid = threadIdx.x;
+    __shared__ long long s_wave[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = (nb + 1023) / 1024;
     const int lo = tid * per, hi = min(lo + per, nb);
     long long sum = 0;
     for (int i = lo; i < hi; ++i) sum += block_sums[i];
-    s_part[tid] = sum;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const long long v = tid >= o ? s_part[tid - o] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
+    // inclusive scan inside the wave (shuffles), then over the 16 wave totals
+    long long inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
     }
-    long long run = s_part[tid] - sum;
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    long long before = 0;
+    for (int w = 0; w < wave; ++w) before += s_wave[w];
+    long long run = before + inc - sum;
     for (int i = lo; i < hi; ++i) {
         block_off[i] = run;
         run += block_sums[i];
     }
-    if (tid == 1023) block_off[nb] = s_part[1023];
+    if (tid == 1023) block_off[nb] = before + inc;
+}
+
+// Presence bit j = cell * 7 + bin of a descriptor whose even / odd positions are set in `even` / `odd` (bit L <-> positions
+// 2L / 2L + 1): position p = cell * 8 + bin.
+__device__ __forceinline__ bool wire_bit(int j, unsigned long long even, unsigned long long odd) {
+    const int p = (j / 7) * 8 + (j % 7);
+    return (((p & 1) ? odd : even) >> (p >> 1)) & 1ull;
 }
 
 __global__ __launch_bounds__(256) void wire_emit_kernel(const sift_hip_keypoint* __restrict__ kp,
@@ -80,66 +99,73 @@ __global__ __launch_bounds__(256) void wire_emit_kernel(const sift_hip_keypoint*
     __shared__ int s_sum[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
+    const long long k0 = (long long)blockIdx.x * kWireBlock + wave * kWirePerWave;
     float2 v[kWirePerWave];
+#pragma unroll
+    for (int i = 0; i < kWirePerWave; ++i) {
+        const long long k = min(k0 + i, total - 1);
+        v[i] = reinterpret_cast<const float2*>(desc + k * 128)[lane];
+    }
+    // the keypoint records of this wave's descriptors as 16-bit words (a wire record is 34 bytes: only 2-byte aligned):
+    // lane (i, s) = descriptor i / 4 + 4 * round, word s < 10  -> four loads cover the 16 records
+    const unsigned short* __restrict__ kps = reinterpret_cast<const unsigned short*>(kp);
+    unsigned short rw[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * r + (lane >> 4), sidx = lane & 15;
+        const long long k = min(k0 + i, total - 1);
+        rw[r] = sidx < 10 ? kps[k * 10 + sidx] : (unsigned short)0;
+    }
     unsigned long long even[kWirePerWave], odd[kWirePerWave];
     int sum = 0;
 #pragma unroll
     for (int i = 0; i < kWirePerWave; ++i) {
-        const long long k = (long long)blockIdx.x * kWireBlock + wave * kWirePerWave + i;
-        even[i] = odd[i] = 0ull;
-        v[i] = make_float2(0.0f, 0.0f);
-        if (k < total) {
-            v[i] = reinterpret_cast<const float2*>(desc + k * 128)[lane];
-            bool b0, b1;
-            wire_presence(v[i], lane, b0, b1);
-            even[i] = __ballot(b0);
-            odd[i] = __ballot(b1);
-            sum += __popcll(even[i]) + __popcll(odd[i]);
-        }
+        bool b0, b1;
+        wire_presence(v[i], lane, b0, b1);
+        even[i] = __ballot(b0);
+        odd[i] = __ballot(b1);
+        sum += (k0 + i < total) ? __popcll(even[i]) + __popcll(odd[i]) : 0;
     }
     if (lane == 0) s_sum[wave] = sum;
     __syncthreads();
     long long base = block_off[blockIdx.x];
     for (int w = 0; w < wave; ++w) base += s_sum[w];
-    const uint8_t* __restrict__ kpb = reinterpret_cast<const uint8_t*>(kp);
+    unsigned short* __restrict__ rec16 = reinterpret_cast<unsigned short*>(records);
+    // presence bits of this lane's two positions j = lane and lane + 64 in the 112-bit mask: constant per lane
 #pragma unroll
     for (int i = 0; i < kWirePerWave; ++i) {
-        const long long k = (long long)blockIdx.x * kWireBlock + wave * kWirePerWave + i;
-        if (k < total) {
-            // values, ascending position: lane's even element, then its odd one
-            const int r = __popcll(even[i] & below) + __popcll(odd[i] & below);
-            const bool b0 = (even[i] >> lane) & 1ull, b1 = (odd[i] >> lane) & 1ull;
-            if (b0) values[base + r] = v[i].x;
-            if (b1) values[base + r + (b0 ? 1 : 0)] = v[i].y;
-            base += __popcll(even[i]) + __popcll(odd[i]);
-            // record: 20 bytes of the keypoint, 14 bytes of presence bits
-            if (lane < 34) {
-                unsigned byte;
-                if (lane < 20) {
-                    byte = kpb[k * 20 + lane];
-                } else {
-                    byte = 0u;
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        const int j = 8 * (lane - 20) + t;          // < 112
-                        const int p = (j / 7) * 8 + (j % 7);        // position among the 128 floats
-                        const unsigned long long m = (p & 1) ? odd[i] : even[i];
-                        byte |= (unsigned)((m >> (p >> 1)) & 1ull) << t;
-                    }
-                }
-                records[k * 34 + lane] = (uint8_t)byte;
-            }
+        if (k0 + i >= total) break;   // wave-uniform
+        // values, ascending position: lane's even element, then its odd one
+        const int r = __popcll(even[i] & below) + __popcll(odd[i] & below);
+        const bool b0 = (even[i] >> lane) & 1ull, b1 = (odd[i] >> lane) & 1ull;
+        if (b0) values[base + r] = v[i].x;
+        if (b1) values[base + r + (b0 ? 1 : 0)] = v[i].y;
+        base += __popcll(even[i]) + __popcll(odd[i]);
+        // mask words: bit j of the 112 from two ballots
+        const unsigned long long m0 = __ballot(wire_bit(lane, even[i], odd[i]));
+        const unsigned long long m1 = __ballot(lane < 48 && wire_bit(lane + 64, even[i], odd[i]));
+        // 17 words of the record: 10 of the keypoint (held by lane 16 * (i % 4) + s of load round i / 4), 7 of the mask
+        const unsigned short kw = (unsigned short)__shfl((int)rw[i >> 2], 16 * (i & 3) + (lane & 15));
+        unsigned short word = kw;
+        if (lane >= 10) {
+            const int t = lane - 10;   // 0..6: mask bits 16 t .. 16 t + 15
+            word = (unsigned short)((t < 4 ? (m0 >> (16 * t)) : (m1 >> (16 * (t - 4)))) & 0xffffull);
         }
+        if (lane < 17) rec16[(k0 + i) * 17 + lane] = word;
     }
 }
 
 size_t wire_blocks(long long total) { return (size_t)((total + kWireBlock - 1) / kWireBlock); }
 
-void launch_wire_count(hipStream_t s, const float* d_desc, long long total, int* d_block_sums, long long* d_block_off) {
+// d_sums: [0] the "bin 7 is not +0.0f somewhere" flag, [1 + b] floats on the wire of block b (64 output slots).  counted: the
+// descriptor kernel has already filled it for this batch (option "wire_count": kernels_desc.hip), only the scan remains.
+void launch_wire_count(hipStream_t s, const float* d_desc, long long total, int* d_sums, long long* d_block_off, bool counted) {
     const size_t nb = wire_blocks(total);
-    (void)hipMemsetAsync(d_block_sums + nb, 0, sizeof(int), s);   // "bin 7 is not +0.0f somewhere"
-    if (nb) hipLaunchKernelGGL(wire_count_kernel, dim3((unsigned)nb), dim3(256), 0, s, d_desc, total, d_block_sums);
-    hipLaunchKernelGGL(wire_scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)d_block_sums, (int)nb, d_block_off);
+    if (!counted) {
+        (void)hipMemsetAsync(d_sums, 0, sizeof(int), s);
+        if (nb) hipLaunchKernelGGL(wire_count_kernel, dim3((unsigned)nb), dim3(256), 0, s, d_desc, total, d_sums + 1, d_sums);
+    }
+    hipLaunchKernelGGL(wire_scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)(d_sums + 1), (int)nb, d_block_off);
 }
 
 void launch_wire_emit(hipStream_t s, const sift_hip_keypoint* d_kp, const float* d_desc, long long total,

@@ -104,7 +104,7 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
-def device_results(ctx, total: int, device, packed: bool = True, wire: str | None = None):
+def device_results(ctx, total: int, device, packed: bool = True, wire: str | None = None, rec_out: torch.Tensor | None = None):
     """The context's current results as torch tensors on `device`, in a wire format:
         "full"    (records uint8 [total*20], descriptors float32 [total*128])
         "packed"  (records uint8 [total*20], descriptors float32 [total*112])            see pack_descriptors
@@ -115,13 +115,16 @@ def device_results(ctx, total: int, device, packed: bool = True, wire: str | Non
     done.  On return the tensors own their data and the context's slot may be released."""
     wire = wire or ("packed" if packed else "full")
     if total == 0:
-        return (torch.empty(0, dtype=torch.uint8, device=device), torch.empty(0, dtype=torch.float32, device=device))
+        return (rec_out if rec_out is not None and rec_out.numel() == 0 else torch.empty(0, dtype=torch.uint8, device=device),
+                torch.empty(0, dtype=torch.float32, device=device))
     kp_ptr, desc_ptr = ctx.result_device_ptrs()
     kp = torch.as_tensor(_DevArray(kp_ptr, total * 20), device=device)
     d = torch.as_tensor(_DevArray(desc_ptr, total * 512), device=device).view(torch.float32)
     if wire == "sparse":   # packed by the library's own kernels (kernels_wire.hip), straight into torch's memory
         nnz = ctx.sparse_size()
-        rec = torch.empty(total * (20 + SPARSE_MASK_BYTES), dtype=torch.uint8, device=device)
+        # rec_out: where the records go (KeypointGather.records_buffer: the message buffer itself, no copy later)
+        rec = rec_out if rec_out is not None else torch.empty(total * (20 + SPARSE_MASK_BYTES), dtype=torch.uint8, device=device)
+        assert rec.numel() == total * (20 + SPARSE_MASK_BYTES) and rec.dtype == torch.uint8
         values = torch.empty(nnz, dtype=torch.float32, device=device)
         torch.cuda.current_stream(device).synchronize()   # the allocator may hand out memory still in use on torch's stream
         ctx.sparse_pack(rec.data_ptr(), values.data_ptr())
@@ -144,15 +147,26 @@ class KeypointGather:
     construction (images per rank).  All ranks must call `push` the same number of times, then `flush` once.
     """
 
-    def __init__(self, n_images_local: int, device, dst: int = 0):
+    def __init__(self, n_images_local: int, device, dst: int = 0, loopback: bool = False):
+        """loopback (a world of ONE process, testing the transport itself on a one-GPU box): the process plays two ranks of the
+        protocol — rank 0, the receiver, with no images of its own, and rank 1, the sender of its lists — and every message
+        really goes through the backend's point-to-point path, to itself (sends and receives of a round in one group, as RCCL
+        requires of a send to oneself)."""
         self.world, self.rank, self.dst, self.dev = dist.get_world_size(), dist.get_rank(), dst, device
+        self.loopback = bool(loopback)
         t = torch.tensor([n_images_local], dtype=torch.int64, device=device)
         allt = [torch.empty_like(t) for _ in range(self.world)]
         dist.all_gather(allt, t)                       # once, at construction
         self.n_img = [int(v.item()) for v in allt]
+        if self.loopback:
+            if self.world != 1:
+                raise ValueError("loopback is a single-process mode")
+            self.world, self.rank, self.dst, self.n_img = 2, 0, 0, [0, self.n_img[0]]
+            self._lb_keep = []
         self.hdr_words = 3 + max(self.n_img)
         self.hdr_bytes = 8 * self.hdr_words
         self.step = 0
+        self._rec_bufs = {}            # records_buffer: data_ptr of a records view -> the allocation with header room in front
         self.wire_bytes = 0            # received (dst) or sent (others), payload and headers
         self.wait_s = 0.0              # host time spent waiting for transfers / reading headers
         # sender side
@@ -179,23 +193,47 @@ class KeypointGather:
             w.wait()
         self.wait_s += time.perf_counter() - t0
 
-    def _send(self, total, records, values, counts):
-        """non-dst: message = [header of this step | records of the previous step], then the previous step's values"""
-        self._timed_wait([w for w, _ in self._sends])
-        self._sends = []
+    def _peer(self, r):
+        return 0 if self.loopback else r
+
+    def records_buffer(self, nbytes: int) -> torch.Tensor:
+        """A records tensor of `nbytes` bytes with room for a header in front of it in the same allocation: pushed later, it
+        is sent as it stands (the next step's header is written into that room) instead of being copied behind a header."""
+        if nbytes <= 0:
+            return torch.empty(0, dtype=torch.uint8, device=self.dev)
+        buf = torch.empty(self.hdr_bytes + nbytes, dtype=torch.uint8, device=self.dev)
+        view = buf[self.hdr_bytes:]
+        self._rec_bufs[view.data_ptr()] = buf
+        return view
+
+    def _send_ops(self, total, records, values, counts):
+        """message = [header of this step | records of the previous step], then the previous step's values"""
         prev_rec, prev_val = self._prev if self._prev is not None else (torch.empty(0, dtype=torch.uint8, device=self.dev), torch.empty(0, dtype=torch.float32, device=self.dev))
-        a = torch.cat([self._header(total, 0 if records is None else records.numel(), 0 if values is None else values.numel(), counts), prev_rec])
-        ops = [dist.P2POp(dist.isend, a, self.dst)]
+        head = self._header(total, 0 if records is None else records.numel(), 0 if values is None else values.numel(), counts)
+        a = self._rec_bufs.pop(prev_rec.data_ptr(), None) if prev_rec.numel() else None
+        if a is not None and a.numel() == self.hdr_bytes + prev_rec.numel():
+            a[:self.hdr_bytes].copy_(head)           # the message buffer was laid out by records_buffer
+        else:
+            a = torch.cat([head, prev_rec])
+        ops = [dist.P2POp(dist.isend, a, self._peer(self.dst))]
         keep = [a]
         if prev_val.numel():
-            ops.append(dist.P2POp(dist.isend, prev_val, self.dst))
+            ops.append(dist.P2POp(dist.isend, prev_val, self._peer(self.dst)))
             keep.append(prev_val)
+        if not self.loopback:              # (the receiving side counts the same bytes)
+            self.wire_bytes += a.numel() + 4 * prev_val.numel()
+        self._prev = (records, values) if records is not None else None
+        return ops, keep
+
+    def _send(self, total, records, values, counts):
+        """non-dst ranks"""
+        self._timed_wait([w for w, _ in self._sends])
+        self._sends = []
+        ops, keep = self._send_ops(total, records, values, counts)
         for w in dist.batch_isend_irecv(ops):
             self._sends.append((w, keep))
-        self.wire_bytes += a.numel() + 4 * prev_val.numel()
-        self._prev = (records, values) if records is not None else None
 
-    def _receive_round(self, k, have_own):
+    def _receive_round(self, k, have_own, extra_ops=()):
         """dst, at push k (or the flush rounds): finish the messages of round k-1 (headers of step k-1, payload of step k-2),
         emit step k-2, post the receives of round k (headers of step k, payload of step k-1)."""
         import time
@@ -215,7 +253,7 @@ class KeypointGather:
         prev = self._sizes.get(k - 1)
         rec_sizes = {r: (prev[r][0] if prev else 0) for r in others}
         bufs = {r: torch.empty(self.hdr_bytes + rec_sizes[r], dtype=torch.uint8, device=self.dev) for r in others}
-        ops = [dist.P2POp(dist.irecv, bufs[r], r) for r in others]
+        ops = list(extra_ops) + [dist.P2POp(dist.irecv, bufs[r], self._peer(r)) for r in others]
         if prev:
             own_rec, own_val, own_cnt = self._own[k - 1]
             n_val = {r: prev[r][1] for r in others}
@@ -228,7 +266,7 @@ class KeypointGather:
             vals[offs[self.dst]:offs[self.dst] + n_val[self.dst]].copy_(own_val)
             for r in others:
                 if n_val[r]:
-                    ops.append(dist.P2POp(dist.irecv, vals[offs[r]:offs[r] + n_val[r]], r))
+                    ops.append(dist.P2POp(dist.irecv, vals[offs[r]:offs[r] + n_val[r]], self._peer(r)))
             self._assembled[k - 1] = vals
             self.wire_bytes += sum(rec_sizes.values()) + 4 * sum(n_val[r] for r in others)
         self.wire_bytes += self.hdr_bytes * len(others)
@@ -259,6 +297,11 @@ class KeypointGather:
         k = self.step
         self.step += 1
         total = int(sum(int(c) for c in counts))
+        if self.loopback:
+            ops, keep = self._send_ops(total, records, values, counts)          # the sender's half of round k ...
+            self._lb_keep = self._lb_keep[-1:] + [keep]                         # (alive until the round after is posted)
+            self._own[k] = (torch.empty(0, dtype=torch.uint8, device=self.dev), torch.empty(0, dtype=torch.float32, device=self.dev), [])
+            return self._receive_round(k, True, extra_ops=ops)                  # ... in one group with the receiver's
         if self.world == 1:
             return [(records, values, torch.as_tensor(counts, dtype=torch.int32))]
         if self.rank != self.dst:
@@ -272,12 +315,16 @@ class KeypointGather:
         if self.world == 1:
             return []
         k = self.step
-        if self.rank != self.dst:
+        extra = ()
+        if self.loopback:
+            extra, keep = self._send_ops(-1, None, None, None)
+            self._lb_keep = self._lb_keep[-1:] + [keep]
+        elif self.rank != self.dst:
             self._send(-1, None, None, None)      # an end header carrying the last step's payload
             self._timed_wait([w for w, _ in self._sends])
             self._sends = []
             return []
-        out = self._receive_round(k, False)        # finishes round k-1, posts round k (payload of step k-1)
+        out = self._receive_round(k, False, extra_ops=extra)        # finishes round k-1, posts round k (payload of step k-1)
         if self._msgs is not None:
             hk, works, bufs, rec_sizes = self._msgs
             self._timed_wait(works)

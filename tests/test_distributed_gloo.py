@@ -195,3 +195,50 @@ def test_keypoint_gather_without_per_step_collectives_two_ranks():
 
 def test_keypoint_gather_three_ranks_single_step():
     _run_kg(3, 1)
+
+
+class _DoneWork:
+    def wait(self):
+        return True
+
+
+def _fake_self_transport(ops):
+    """what a backend does with one group of sends and receives to oneself: the i-th send lands in the i-th receive"""
+    sends = [o.tensor for o in ops if o.op is dist.isend]
+    recvs = [o.tensor for o in ops if o.op is dist.irecv]
+    assert len(sends) == len(recvs), (len(sends), len(recvs))
+    for a, b in zip(sends, recvs):
+        assert a.numel() == b.numel() and a.dtype == b.dtype, (a.shape, b.shape)   # every receive was posted with its exact size
+        b.copy_(a)
+    return [_DoneWork()]
+
+
+def test_keypoint_gather_loopback_protocol(monkeypatch):
+    """KeypointGather(loopback=True): one process plays sender and receiver and every message goes through the backend's
+    point-to-point path to itself (the form tests/test_gpu_parity.py runs over RCCL on the one-GPU box; gloo cannot send to
+    itself, so the transport is a stand-in here and only the protocol — sizes one step ahead, one group per round — is checked)."""
+    from sift_amd.gather import KeypointGather
+    import sift_amd.gather as G
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(s.getsockname()[1])
+    s.close()
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        monkeypatch.setattr(G.dist, "batch_isend_irecv", _fake_self_transport)
+        g = KeypointGather(3, torch.device("cpu"), loopback=True)
+        rng = np.random.default_rng(3)
+        data, done = [], []
+        for step in range(5):
+            c = rng.integers(0, 6, 3) if step != 2 else np.zeros(3, np.int64)     # one step without a keypoint
+            r = rng.integers(0, 256, int(c.sum()) * 34).astype(np.uint8)
+            v = rng.random(int(c.sum()) * 9).astype(np.float32)
+            data.append((c, r, v))
+            done += g.push(torch.from_numpy(r), torch.from_numpy(v), c)
+        done += g.flush()
+        assert len(done) == 5
+        for (c, r, v), (R, V, C) in zip(data, done):
+            assert C.tolist() == c.tolist() and R.numpy().tobytes() == r.tobytes() and V.numpy().tobytes() == v.tobytes()
+        assert g.wire_bytes == sum(r.size + 4 * v.size for _, r, v in data) + 8 * (3 + 3) * 6
+    finally:
+        dist.destroy_process_group()

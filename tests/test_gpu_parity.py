@@ -733,6 +733,68 @@ def test_gather_of_device_results_two_ranks_sharing_the_gpu(ctx):
     assert desc_all.tobytes() == desc.tobytes()
 
 
+def _rccl_loopback_worker(port, q):
+    """One process, one GPU, a real RCCL communicator: the gather's messages (header | records, values; device memory,
+    sparse wire format packed by the library) go through RCCL's point-to-point path to this same rank."""
+    import torch
+    import torch.distributed as dist
+    from sift_amd.gather import KeypointGather, device_results, split_records, unpack_sparse
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    c = Context(0)
+    c.set_option("wire_count", 1)       # as bench.py does for N > 1: the descriptor kernel counts the wire floats itself
+    g = KeypointGather(2, dev, loopback=True)
+    batches = [np.stack([synth_frame(320, 240, 31), synth_frame(320, 240, 32)]),
+               np.stack([np.full((240, 320), 7.0, np.float32)] * 2),                       # a step without a single keypoint
+               np.stack([synth_frame(320, 240, 33), np.full((240, 320), 9.0, np.float32)]),
+               np.stack([synth_frame(320, 240, 34), synth_frame(320, 240, 35)])]
+    want, done = [], []
+    for b in batches:
+        c.calculate_batch(b, _lib.Params(3, 3, 1.6, O.K_SQRT2, 0))
+        kp, desc = c.results()
+        want.append((c.counts().copy(), kp.copy(), desc.copy()))
+        rec, val = device_results(c, c.total(), dev, wire="sparse", rec_out=g.records_buffer(c.total() * 34))
+        done += g.push(rec, val, c.counts())
+    done += g.flush()
+    dist.barrier()
+    torch.cuda.synchronize()
+    out = []
+    for rec_all, val_all, counts in done:
+        recs, masks = split_records(rec_all.cpu())
+        out.append((counts.cpu().numpy().copy(), recs.numpy().copy(), unpack_sparse(masks, val_all.cpu()).numpy().copy()))
+    q.put((want, out, g.wire_bytes))
+    dist.destroy_process_group()
+
+
+def test_keypoint_gather_over_rccl_on_one_gpu(ctx):
+    """RCCL itself, on the one GPU this box has: the lagged-header gather of bench.py's N > 1 path with every message sent through
+    RCCL point-to-point to the same rank (world of one process, KeypointGather(loopback=True)) — device tensors, the exact
+    message shapes and sizes of the multi-GPU run, zero-keypoint steps included; what arrives equals what the context returned."""
+    import socket
+    import torch.multiprocessing as mp
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    p = mpc.Process(target=_rccl_loopback_worker, args=(port, q))
+    p.start()
+    want, out, wire = q.get(timeout=300)
+    p.join(120)
+    assert p.exitcode == 0
+    assert len(out) == len(want) == 4
+    total = 0
+    for (wc, wk, wd), (gc, gk, gd) in zip(want, out):
+        assert gc.tolist() == wc.tolist()
+        assert gk.tobytes() == wk.tobytes() and gd.tobytes() == wd.tobytes()
+        total += int(wc.sum())
+    assert total > 500 and wire > 34 * total
+
+
 def test_batch_pipeline_matches_single_context(ctx):
     """Batches in flight on a ring of contexts (sift_amd/pipeline.py) give, batch for batch, the single context's results."""
     from sift_amd.pipeline import BatchPipeline
@@ -854,6 +916,15 @@ def test_sparse_wire_kernels_match_the_reference_packing(ctx):
     assert recs.numpy().tobytes() == kp.tobytes()
     assert unpack_sparse(masks, values.cpu()).numpy().tobytes() == desc.tobytes()
     assert 0.2 < values.numel() / (total * 112) < 0.6   # the saving the format exists for
+    # option wire_count: the counting pass rides in the descriptor kernel (what bench.py uses for N > 1); same wire bytes
+    ctx.set_option("wire_count", 1)
+    try:
+        ctx.calculate_batch(frames, _lib.Params(3, 3, 1.6, O.K_SQRT2, 0))
+        assert ctx.sparse_size() == values_ref.numel()
+        rec2, values2 = device_results(ctx, total, torch.device("cuda", 0), wire="sparse")
+        assert rec2.cpu().numpy().tobytes() == rec_ref.numpy().tobytes() and values2.cpu().numpy().tobytes() == values_ref.numpy().tobytes()
+    finally:
+        ctx.set_option("wire_count", 0)
 
 
 # ------------------------------------------------------------------------------------------------
