@@ -530,9 +530,13 @@ __global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __res
 // the descriptor, 512 contiguous bytes per wave.
 // =====================================================================================================
 constexpr int kCellShift = 4;            // 16 px grid cells
-constexpr int kW16Stride = 20;           // weighting table, x-major with padded columns: conflict-free for a half-wave
-constexpr int kW16Bias = 16 * kW16Stride;   // window-local coordinates of a neighbour's window run from -15 to 30
-constexpr int kW16Size = kW16Bias + 31 * kW16Stride + 32;
+// Weighting table in LDS, x-major: column x holds [15 zeros][weighting(x, 0..15)][zeros], and 15 all-zero columns stand on
+// either side, so that EVERY window-local coordinate a neighbour's window can put a pixel at (-15 .. 30 in x and y) reads a
+// real +0.0f outside the 16x16 window: adding it changes nothing (a magnitude is never -0.0f), which spares the walk over the
+// neighbours a select per pixel.  Stride 52: the four column groups of a wave (x = 0, 4, 8, 12) start 16 banks apart.
+constexpr int kW16Stride = 52;
+constexpr int kW16Bias = 15 * kW16Stride + 15;
+constexpr int kW16Size = 46 * kW16Stride;
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at a 4-byte aligned address
 
@@ -669,7 +673,8 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
                                                                  float* __restrict__ desc_out, long long out_cap, int n_images,
                                                                  int chunks, int dbg) {
     __shared__ float s_w16t[kW16Size];
-    __shared__ uint2 s_list[4][64];   // per wave: preceding neighbours (x | y << 16, orientation bits) in vector order
+    __shared__ uint4 s_list[4][64];   // per wave: preceding neighbours in vector order (orientation bits, table offset, dx, dy)
+    __shared__ __attribute__((aligned(16))) unsigned s_keys[4][68];   // per wave: their vector indices, compacted (+ sentinels)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w = lv.w, h = lv.h, D = lv.dogs;
@@ -790,26 +795,27 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
         // one preceding neighbour q: the lane's pixels that q's window covers receive q's additions (sift.cpp:80-92).
         // The four weighting values are fetched by `weights_of` (which can run one neighbour ahead) and consumed by `apply`.
         struct Wq { float v[4]; };
-        auto weights_of = [&](unsigned qxy) {
-            const int dx = px - (int)(qxy & 0xffffu), dy = py - (int)(qxy >> 16);   // window-local offset: p's (x, y) is q's (x + dx, y + dy)
-            const int tq = tbase + dx * kW16Stride + dy;
+        // dx, dy: p's window-local (x, y) is q's (x + dx, y + dy); toff = dx * kW16Stride + dy
+        auto weights_at = [&](int toff) {
             Wq r;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) r.v[i] = s_w16t[tq + i * kW16Stride];
+            for (int i = 0; i < 4; ++i) r.v[i] = s_w16t[tbase + toff + i * kW16Stride];
             return r;
         };
-        auto apply_w = [&](unsigned qxy, float qtheta, const Wq& wq) {
-            const int dx = px - (int)(qxy & 0xffffu), dy = py - (int)(qxy >> 16);
+        auto apply_w = [&](int dx, int dy, float qtheta, const Wq& wq) {
             const bool row_in = (unsigned)(ly + dy) < 16u;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool in = row_in && (unsigned)(lx0 + i + dx) < 16u;
-                const float no = vo[i] + qtheta, nm = vm[i] + wq.v[i];
+                const float no = vo[i] + qtheta;
                 vo[i] = in ? no : vo[i];
-                vm[i] = in ? nm : vm[i];
+                vm[i] = vm[i] + wq.v[i];   // +0.0f from the table's padding where q's window does not cover the pixel
             }
         };
-        auto apply = [&](unsigned qxy, float qtheta) { apply_w(qxy, qtheta, weights_of(qxy)); };
+        auto apply = [&](unsigned qxy, float qtheta) {
+            const int dx = px - (int)(qxy & 0xffffu), dy = py - (int)(qxy >> 16);
+            apply_w(dx, dy, qtheta, weights_at(dx * kW16Stride + dy));
+        };
 
         // ---- neighbours: the 3x3 cells around p's --------------------------------------------------------------------
         if (!(dbg & 1)) {
@@ -818,27 +824,44 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
                 return (int)c.x < myk && (unsigned)(qx - px + 15) < 31u && (unsigned)(qy - py + 15) < 31u;
             };
             if (T <= 64) {
-                // One record per lane.  The preceding neighbours are ranked by vector index (every lane counts the smaller
-                // indices among them: one readlane + compare + add per neighbour), dropped into this wave's LDS list at their
-                // rank and then simply walked: the loop body has no wave-wide minimum and no lane search, only a broadcast LDS
-                // read of the next neighbour.  (Measured alternatives, no faster: a wave minimum per neighbour; finding the lane
-                // of rank r by ballot with the weighting values fetched one neighbour ahead.)
+                // One record per lane.  The preceding neighbours are ranked by vector index: their indices are compacted into
+                // this wave's LDS key list (position = number of passing lanes below), and every lane counts the keys smaller
+                // than its own with broadcast 16-byte reads — a compare and an add per key instead of a trip of a scalar loop
+                // (find the next set bit, readlane, compare, add) per neighbour.  The neighbours are then dropped into the LDS
+                // list at their rank and simply walked.  (Measured alternatives, no faster: a wave minimum per neighbour;
+                // finding the lane of rank r by ballot with the weighting values fetched one neighbour ahead.)
                 const bool pass = lane < T && precedes(c);
-                unsigned long long todo = __ballot(pass);
+                const unsigned long long todo = __ballot(pass);
                 const int n_prev = __popcll(todo);
                 if (n_prev) {
-                    int rank = 0;
-                    while (todo) {
-                        const int j = (int)__builtin_ctzll(todo);
-                        todo &= todo - 1;
-                        rank += (unsigned)__builtin_amdgcn_readlane((int)c.x, j) < c.x ? 1 : 0;
-                    }
-                    uint2* list = s_list[wave];
-                    if (pass) list[rank] = make_uint2(c.z, c.y);
+                    unsigned* keys = s_keys[wave];
+                    const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(todo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)todo, 0u));
+                    if (pass) keys[pos] = c.x;
+                    if (lane < 4) keys[n_prev + lane] = 0xffffffffu;   // the last 16-byte read may run past the keys: never smaller
                     __builtin_amdgcn_wave_barrier();
-                    for (int r = 0; r < n_prev; ++r) {
-                        const uint2 q = list[r];
-                        apply(q.x, __uint_as_float(q.y));
+                    int rank = 0;
+                    for (int ch = 0; ch < n_prev; ch += 4) {
+                        const uint4 k4 = *reinterpret_cast<const uint4*>(keys + ch);
+                        rank += (k4.x < c.x ? 1 : 0) + (k4.y < c.x ? 1 : 0) + (k4.z < c.x ? 1 : 0) + (k4.w < c.x ? 1 : 0);
+                    }
+                    // each lane works out what the walk needs of ITS neighbour once (offsets, table address), so the walk's body
+                    // is a broadcast read and the additions, two neighbours per trip
+                    uint4* list = s_list[wave];
+                    if (pass) {
+                        const int dx = px - (int)(c.z & 0xffffu), dy = py - (int)(c.z >> 16);
+                        list[rank] = make_uint4(c.y, (unsigned)(dx * kW16Stride + dy), (unsigned)dx, (unsigned)dy);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    int r = 0;
+                    for (; r + 1 < n_prev; r += 2) {
+                        const uint4 q0 = list[r], q1 = list[r + 1];
+                        const Wq wq0 = weights_at((int)q0.y), wq1 = weights_at((int)q1.y);
+                        apply_w((int)q0.z, (int)q0.w, __uint_as_float(q0.x), wq0);
+                        apply_w((int)q1.z, (int)q1.w, __uint_as_float(q1.x), wq1);
+                    }
+                    if (r < n_prev) {
+                        const uint4 q0 = list[r];
+                        apply_w((int)q0.z, (int)q0.w, __uint_as_float(q0.x), weights_at((int)q0.y));
                     }
                     __builtin_amdgcn_wave_barrier();   // the list is rewritten for the wave's next keypoint
                 }
