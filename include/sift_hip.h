@@ -76,11 +76,14 @@ void sift_hip_destroy(sift_hip_ctx* ctx);
  * is why a measurement run samples, e.g. N = 4; 0: off), "stream_min_waves" (process-wide; smallest launch, in waves, that takes the streaming blur instead of
  * the LDS-tiled one; default 1024, <= 0 restores it; the parity tests set 1 to run the streaming form on small
  * inputs), "orient_general" (0 default; 1: orientationHistogram36 reads every sample's bin even when the gradient pass
- * found all bins of the frame to be 0, which is what the reference's radians-as-degrees maps always give); measurement
+ * found all bins of the frame to be 0, which is what the reference's radians-as-degrees maps always give), "wire_count"
+ * (0 default; 1: the descriptor kernel also counts the floats the sparse wire format will carry, so that
+ * sift_hip_result_sparse_size needs no pass of its own over the descriptors: for hosts that gather every batch); measurement
  * aids, results unchanged unless stated: "stream_waves" (process-wide; waves a streaming blur launch is cut into, default
  * 2048, 0 = tile kernel only), "desc_kernel" (1 default: one wave per keypoint over a grid of 16 px cells; 0: one workgroup
  * per 48 px tile walking the ordered keypoint list), "desc_dbg" / "orient_dbg" (phases switched off: timing only, WRONG results),
- * "diag_pyramid_span", "diag_serial_gradient", "diag_cleanup_stamps" (print to stderr).  The library reads no
+ * "gate_early_chain" / "gate_schedule" (other orders of the phases of batches joined by a gate, sift_amd/csrc/phase_gate.h:
+ * measured, slower, off), "diag_pyramid_span", "diag_serial_gradient", "diag_cleanup_stamps" (print to stderr).  The library reads no
  * environment variable. */
 int sift_hip_set_option(sift_hip_ctx* ctx, const char* name, int value);
 

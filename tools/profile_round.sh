@@ -25,6 +25,7 @@ timeout 900 python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> /dev/null
 timeout 600 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --pipeline-depth 1 > $O/bench_depth1.json 2> /dev/null
 timeout 600 python3 bench.py --workload config3 --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_config3.json 2> /dev/null
 timeout 600 python3 bench.py --workload config5 --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_config5.json 2> /dev/null
+timeout 600 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --rccl-loopback > $O/bench_rccl_loopback.json 2> /dev/null
 # 4. counters
 bash tools/pmc_kernel.sh > $O/pmc_hbm_traffic.txt 2>&1
 DBGS="" bash tools/desc_probe.sh 2>&1 | grep -vE "^dbg" > $O/pmc_sq_counters.txt
