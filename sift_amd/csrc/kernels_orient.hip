@@ -198,68 +198,69 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
         const int grp = s_grp;
         if (grp * kOrientGroup >= cnt) break;
         // ---- phase 1 --------------------------------------------------------------------------
+        // Bookkeeping of the wave's 32 keypoints with one keypoint per lane (records fetched coalesced, level looked up,
+        // border and dead-blur tests, state and survivor position stored, address of the window's first pixel formed): what the
+        // load loop below needs of keypoint i is then two or three lane reads, not a chain of scalar loads and tests per keypoint.
+        const int slot_w = wv * (kOrientGroup / 4);          // first slot of this wave
+        const int j_lane = grp * kOrientGroup + slot_w + lane;
+        const bool have = lane < kOrientGroup / 4 && j_lane < cnt;
+        unsigned long long org_prod = 0ull, org_bin = 0ull;  // byte address of the window's first sample in the weight / bin maps
+        int pitch = 0;                                       // row pitch of that level (pixels)
+        bool run_l = false;
+        if (have) {
+            const OrientIn rec = oin[lbase + j_lane];
+            const int x = rec.x, y = rec.y;
+            const int l = (int)rec.octave * D + (int)rec.index;
+            const LevelInfo li = s_lvl[l];
+            const int w = li.wh & 0xffff, h = (int)((unsigned)li.wh >> 16);
+            const bool border = (x < kRegion || x >= w - kRegion) || (y < kRegion || y >= h - kRegion);  // sift.cpp:173-174
+            const int throws = border ? 0 : li.dead;  // sift.cpp:184 (0 ok, else error code)
+            run_l = !border && throws == 0 && !(dbg & 4);
+            s_kp[slot_w + lane] = (unsigned short)rec.kp;
+            s_state[slot_w + lane] = (unsigned char)((border ? 1 : 0) | (throws << 1) | ((!border && throws == 0) ? 0x80 : 0));
+            const size_t o = (size_t)img * (size_t)w * (size_t)h + (size_t)(y - kRegion) * (size_t)w + (size_t)(x - kRegion);
+            org_prod = (unsigned long long)(uintptr_t)(li.prod + o);
+            org_bin = (unsigned long long)(uintptr_t)(li.obin + o);
+            pitch = w;
+        }
+        const unsigned runmask32 = (unsigned)__ballot(run_l);   // bit i: keypoint slot_w + i runs
         for (int sb = 0; sb < kOrientGroup / 4 / kOrientSub; ++sb) {
-            const int slot0 = wv * (kOrientGroup / 4) + sb * kOrientSub;
+            const int slot0 = slot_w + sb * kOrientSub;
             if (grp * kOrientGroup + slot0 >= cnt) break;  // wave-uniform
-            unsigned runmask = 0, unimask = 0;             // wave-uniform bit per staged keypoint
-            // all window loads of the 8 keypoints are issued before any of them is consumed
+            const unsigned runmask = (runmask32 >> (sb * kOrientSub)) & ((1u << kOrientSub) - 1u);   // wave-uniform bit per staged keypoint
+            unsigned unimask = 0;
+            // all window loads of the staged keypoints are issued before any of them is consumed
             float pp[kOrientSub][4];
             unsigned pb[kOrientSub][4];
-            // one coalesced fetch brings the 8 keypoint records; fields are then wave-uniform
-            // scalars (readfirstlane) so the plan lookups become scalar loads
-            OrientIn rec;
-            rec.x = rec.y = rec.octave = rec.index = 0;
-            rec.kp = 0;
-            {
-                const int j = grp * kOrientGroup + slot0 + (lane & (kOrientSub - 1));
-                if (j < cnt) rec = oin[lbase + j];
-            }
 #pragma unroll
             for (int k = 0; k < kOrientSub; ++k) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) { pp[k][it] = 0.0f; pb[k][it] = 0u; }
-                const int slot = slot0 + k;
-                const int j = grp * kOrientGroup + slot;   // processing position (spatial order)
-                if (j < cnt) {  // wave-uniform
-                    const unsigned xy = __builtin_amdgcn_readfirstlane(__shfl((unsigned)rec.x | ((unsigned)rec.y << 16), k));
-                    const unsigned oi = __builtin_amdgcn_readfirstlane(__shfl((unsigned)rec.octave | ((unsigned)rec.index << 16), k));
-                    const int kp = (int)__builtin_amdgcn_readfirstlane(__shfl(rec.kp, k));  // survivor-list position
-                    if (lane == 0) s_kp[slot] = (unsigned short)kp;
-                    const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
-                    const int l = (int)(oi & 0xffffu) * D + (int)(oi >> 16);
-                    const LevelInfo li = s_lvl[l];
-                    const int wh = __builtin_amdgcn_readfirstlane(li.wh);
-                    const int w = wh & 0xffff, h = (int)((unsigned)wh >> 16);
-                    const bool border = (x < kRegion || x >= w - kRegion) || (y < kRegion || y >= h - kRegion);  // sift.cpp:173-174
-                    const int throws = border ? 0 : __builtin_amdgcn_readfirstlane(li.dead);  // sift.cpp:184 (0 ok, else error code)
-                    const bool run = !border && throws == 0;
-                    if (lane == 0) s_state[slot] = (unsigned char)((border ? 1 : 0) | (throws << 1) | (run ? 0x80 : 0));
-                    if (run && !(dbg & 4)) {
-                        runmask |= 1u << k;
-                        const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
-                        const unsigned long long pp64 = (unsigned long long)(uintptr_t)li.prod, pb64 = (unsigned long long)(uintptr_t)li.obin;
-                        const float* __restrict__ gp = reinterpret_cast<const float*>((uintptr_t)(
-                            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)pp64) |
-                            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(pp64 >> 32)) << 32))) + img_off;
-                        const uint8_t* __restrict__ gb = reinterpret_cast<const uint8_t*>((uintptr_t)(
-                            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)pb64) |
-                            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(pb64 >> 32)) << 32))) + img_off;
-                        const int x0 = x - kRegion, y0 = y - kRegion;
-                        if (bins_zero) {
-                            // one 16-byte load per lane covers the whole window: lane = (row, 4-column group)
-                            const size_t o = (size_t)(y0 + (lane >> 2)) * (size_t)w + (size_t)(x0 + 4 * (lane & 3));
-                            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-                            const f4u v4 = *reinterpret_cast<const f4u*>(gp + o);
-                            pp[k][0] = v4.x; pp[k][1] = v4.y; pp[k][2] = v4.z; pp[k][3] = v4.w;
-                        } else {
+                if ((runmask >> k) & 1u) {  // wave-uniform
+                    const int src = sb * kOrientSub + k;   // the lane that holds this keypoint's bookkeeping
+                    const unsigned long long a64 =
+                        (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)org_prod, src) |
+                        ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(org_prod >> 32), src) << 32);
+                    const float* __restrict__ gp = reinterpret_cast<const float*>((uintptr_t)a64);
+                    const int w = __builtin_amdgcn_readlane(pitch, src);
+                    if (bins_zero) {
+                        // one 16-byte load per lane covers the whole window: lane = (row, 4-column group)
+                        const size_t o = (size_t)(lane >> 2) * (size_t)w + (size_t)(4 * (lane & 3));
+                        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                        const f4u v4 = *reinterpret_cast<const f4u*>(gp + o);
+                        pp[k][0] = v4.x; pp[k][1] = v4.y; pp[k][2] = v4.z; pp[k][3] = v4.w;
+                    } else {
+                        const unsigned long long b64 =
+                            (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)org_bin, src) |
+                            ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(org_bin >> 32), src) << 32);
+                        const uint8_t* __restrict__ gb = reinterpret_cast<const uint8_t*>((uintptr_t)b64);
 #pragma unroll
-                            for (int it = 0; it < 4; ++it) {
-                                const int ly = it * 4 + (lane >> 4);
-                                const int lx = lane & 15;
-                                const size_t o = (size_t)(y0 + ly) * (size_t)w + (size_t)(x0 + lx);
-                                pp[k][it] = gp[o];
-                                pb[k][it] = gb[o];
-                            }
+                        for (int it = 0; it < 4; ++it) {
+                            const int ly = it * 4 + (lane >> 4);
+                            const int lx = lane & 15;
+                            const size_t o = (size_t)ly * (size_t)w + (size_t)lx;
+                            pp[k][it] = gp[o];
+                            pb[k][it] = gb[o];
                         }
                     }
                 }
