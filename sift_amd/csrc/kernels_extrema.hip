@@ -297,6 +297,7 @@ __device__ __forceinline__ void fx_lds_barrier() { asm volatile("s_waitcnt lgkmc
 // bodies of the previous tile (barriers wait for LDS only: the fetch stays in flight).  Workgroups with equal
 // blockIdx % 8 (observed to share an XCD) own a contiguous run of tiles, whose one-pixel halos then meet in that L2.
 constexpr int kFxLoads = (kFxRows * kFxRow4 + 255) / 256;   // float4 per thread, level and tile
+constexpr int kFxQ2 = 1024;   // second-stage list (a tile's 2048 pixels can all be candidates: the overflow runs its QR body in place)
 
 __global__ __launch_bounds__(256) void extrema_edge_kernel(const float* __restrict__ d0, const float* __restrict__ d1,
                                                            const float* __restrict__ d2, int w, int h, int nyb,
@@ -305,10 +306,12 @@ __global__ __launch_bounds__(256) void extrema_edge_kernel(const float* __restri
                                                            unsigned long long* __restrict__ fmasks,
                                                            int* __restrict__ counts) {
     __shared__ __attribute__((aligned(16))) float s_t[3][kFxRows * kFxPitch];
-    __shared__ unsigned short s_q[4][16 * kFxCols];
-    __shared__ unsigned long long s_cm[4][kFxCols];
-    __shared__ unsigned long long s_fm[kFxCols];
+    __shared__ unsigned short s_q[4][16 * kFxCols];    // per wave: its candidates (column | row << 5)
+    __shared__ unsigned short s_q2[kFxQ2];             // candidates the curvature tests let through: the QR bodies' work list
+    __shared__ unsigned long long s_cm[kFxCols];       // candidate bits per column
+    __shared__ unsigned long long s_fm[kFxCols];       // filtered bits per column
     __shared__ int s_qn[4];
+    __shared__ int s_n2;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int t, t_end, t_step;
     if ((gridDim.x & 7u) == 0) {
@@ -363,61 +366,80 @@ __global__ __launch_bounds__(256) void extrema_edge_kernel(const float* __restri
         const int img = t / tiles_img, rem = t - img * tiles_img;
         const int yb = rem / tiles_x, x0 = (rem - yb * tiles_x) * kFxCols, ya = yb * 64;
         SIFT_FX_STORE(0, pa0, pb0, pc0) SIFT_FX_STORE(1, pa1, pb1, pc1) SIFT_FX_STORE(2, pa2, pb2, pc2)
-        if (tid < kFxCols) s_fm[tid] = 0ull;
+        if (tid < kFxCols) { s_fm[tid] = 0ull; s_cm[tid] = 0ull; }
+        if (tid < 4) s_qn[tid] = 0;
+        if (tid == 4) s_n2 = 0;
         fx_lds_barrier();
         const int tn = t + t_step;
         if (tn < t_end) SIFT_FX_LOAD_TILE(tn)   // stays in flight through the scan and the QR bodies
 
-    const int col = lane & 31, sub = lane >> 5;
-    const int x = x0 + col;
-    const bool x_ok = x >= 1 && x <= w - 2;
-    unsigned long long mask = 0ull, fmask = 0ull;
-    int qn = 0;   // wave-uniform
-    unsigned short* q = s_q[wv];
-#pragma unroll 2
-    for (int st = 0; st < 8; ++st) {
-        const int row = 16 * wv + 2 * st + sub;   // tile-local output row; LDS row index = row + 1
-        const int y = ya + row;
-        const int at = (row + 1) * kFxPitch + (col + kFxLead);
-        const float c = s_t[1][at];
-        // "no neighbour greater" == "max of the neighbours <= centre" (and likewise for smaller): 3-input max / min
-        // instead of 22 compares; DoG samples are finite, so no NaN ordering question arises
-        float nmax, nmin;
-        {
-            const float a0 = s_t[0][at - kFxPitch - 1], b0 = s_t[0][at - kFxPitch], d0 = s_t[0][at - 1], e0 = s_t[0][at];
-            const float a1 = s_t[1][at - kFxPitch - 1], b1 = s_t[1][at - kFxPitch], d1 = s_t[1][at - 1];
-            const float a2 = s_t[2][at - kFxPitch - 1], b2 = s_t[2][at - kFxPitch], d2 = s_t[2][at - 1], e2 = s_t[2][at];
-            nmax = fmaxf(fmaxf(fmaxf(a0, b0), fmaxf(d0, e0)), fmaxf(fmaxf(fmaxf(a1, b1), d1), fmaxf(fmaxf(a2, b2), fmaxf(d2, e2))));
-            nmin = fminf(fminf(fminf(a0, b0), fminf(d0, e0)), fminf(fminf(fminf(a1, b1), d1), fminf(fminf(a2, b2), fminf(d2, e2))));
+    // ---- scan: lane = 4 consecutive columns x 2 consecutive rows; wave v owns rows 16v .. 16v+15 -----------------------------
+    // All 18 LDS reads of a lane (three tile rows of the three levels: a 16-byte group and the sample left of it) are issued
+    // together; the 12-neighbour extremum test of the 8 pixels then runs on registers: pairwise max / min over {x-1, x} per
+    // level and row once, three-input max / min over the rest ("no neighbour greater" == "max of the neighbours <= centre";
+    // DoG samples are finite, so no NaN ordering question arises).
+    {
+        const int cg = lane & 7, rs = lane >> 3;
+        const int row0 = 16 * wv + 2 * rs;                     // first of the lane's two output rows (tile-local)
+        const int at0 = row0 * kFxPitch + kFxLead + 4 * cg;    // LDS index of (row0 - 1, first column): LDS row = tile row + 1
+        float v[3][3][5];                                      // [level][LDS row row0 + R][column -1 .. 3]
+#pragma unroll
+        for (int L = 0; L < 3; ++L)
+#pragma unroll
+            for (int R = 0; R < 3; ++R) {
+                const float4 q4 = *reinterpret_cast<const float4*>(&s_t[L][at0 + R * kFxPitch]);
+                v[L][R][0] = s_t[L][at0 + R * kFxPitch - 1];
+                v[L][R][1] = q4.x; v[L][R][2] = q4.y; v[L][R][3] = q4.z; v[L][R][4] = q4.w;
+            }
+        float pmx[3][3][4], pmn[3][3][4];
+#pragma unroll
+        for (int L = 0; L < 3; ++L)
+#pragma unroll
+            for (int R = 0; R < 3; ++R)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    pmx[L][R][i] = fmaxf(v[L][R][i], v[L][R][i + 1]);
+                    pmn[L][R][i] = fminf(v[L][R][i], v[L][R][i + 1]);
+                }
+        unsigned bits = 0u;   // bit a * 4 + i: pixel (row0 + a, 4 cg + i) is a candidate
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int y = ya + row0 + a;
+            const bool y_ok = y >= 1 && y <= h - 2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int x = x0 + 4 * cg + i;
+                const float c = v[1][a + 1][i + 1];
+                const float nmax = fmaxf(fmaxf(fmaxf(pmx[0][a][i], pmx[0][a + 1][i]), fmaxf(pmx[2][a][i], pmx[2][a + 1][i])),
+                                         fmaxf(pmx[1][a][i], v[1][a + 1][i]));
+                const float nmin = fminf(fminf(fminf(pmn[0][a][i], pmn[0][a + 1][i]), fminf(pmn[2][a][i], pmn[2][a + 1][i])),
+                                         fminf(pmn[1][a][i], v[1][a + 1][i]));
+                const bool cand = y_ok && x >= 1 && x <= w - 2 && (!(nmax > c) || !(nmin < c));
+                bits |= (cand ? 1u : 0u) << (a * 4 + i);
+            }
         }
-        const bool any_gt = nmax > c, any_lt = nmin < c;
-        const bool cand = x_ok && y >= 1 && y <= h - 2 && (!any_gt || !any_lt);
-        mask |= (unsigned long long)(cand ? 1u : 0u) << row;
-        // the curvature tests of the edge filter right here (most candidates fail them): only the others queue for the QR body
-        bool curved = false;
-        if (cand)
-            curved = edge_curvature_filtered(c, s_t[1][at - 1], s_t[1][at + 1], s_t[1][at - kFxPitch], s_t[1][at + kFxPitch],
-                                             s_t[1][at - kFxPitch - 1], s_t[1][at - kFxPitch + 1], s_t[1][at + kFxPitch - 1],
-                                             s_t[1][at + kFxPitch + 1]);
-        fmask |= (unsigned long long)(curved ? 1u : 0u) << row;
-        const bool need_qr = cand && !curved;
-        const unsigned long long bal = __ballot(need_qr);
-        if (need_qr) q[qn + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(col | (row << 5));
-        qn += __popcll(bal);
+        if (bits) {
+            // candidate bits of the lane's four columns into the columns' 64-row words
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned two = ((bits >> i) & 1u) | (((bits >> (4 + i)) & 1u) << 1);
+                if (two) atomicOr(&s_cm[4 * cg + i], (unsigned long long)two << row0);
+            }
+            // and the candidates themselves into the wave's queue
+            int at = atomicAdd(&s_qn[wv], __popc(bits));
+            unsigned rest = bits;
+            while (rest) {
+                const int b = __ffs((int)rest) - 1;
+                rest &= rest - 1u;
+                s_q[wv][at++] = (unsigned short)((4 * cg + (b & 3)) | ((row0 + (b >> 2)) << 5));
+            }
+        }
     }
-    mask |= __shfl_xor(mask, 32);   // the two half-waves hold alternate rows of the same column
-    fmask |= __shfl_xor(fmask, 32);
-    if (lane < kFxCols) s_cm[wv][lane] = mask;
-    if (lane < kFxCols && fmask) atomicOr(&s_fm[lane], fmask);
-    if (lane == 0) s_qn[wv] = qn;
     fx_lds_barrier();
-    // the four queues are walked as one list so that the 3x3 QR body runs on (nearly) full waves
+    // ---- first stage over the candidates (the four queues walked as one list): the two curvature tests of the edge filter,
+    // which most candidates fail; the others are compacted into the second list so that the 3x3 QR bodies run on full waves
     const int n0 = s_qn[0], n1 = n0 + s_qn[1], n2 = n1 + s_qn[2], n3 = n2 + s_qn[3];
-    for (int g = tid; g < n3; g += 256) {
-        const int qi = g < n0 ? 0 : g < n1 ? 1 : g < n2 ? 2 : 3;
-        const int off = qi == 0 ? 0 : qi == 1 ? n0 : qi == 2 ? n1 : n2;
-        const unsigned e = s_q[qi][g - off];
-        const int qc = (int)(e & 31u), qr = (int)(e >> 5);
+    auto qr_body = [&](int qc, int qr) {
         const int at = (qr + 1) * kFxPitch + (qc + kFxLead);
         const int up = at - kFxPitch, dn = at + kFxPitch;
         EdgeTaps tp;
@@ -426,10 +448,43 @@ __global__ __launch_bounds__(256) void extrema_edge_kernel(const float* __restri
         tp.i0c = s_t[0][at]; tp.i0l = s_t[0][at - 1]; tp.i0r = s_t[0][at + 1]; tp.i0u = s_t[0][up]; tp.i0d = s_t[0][dn];
         tp.i2c = s_t[2][at]; tp.i2l = s_t[2][at - 1]; tp.i2r = s_t[2][at + 1]; tp.i2d = s_t[2][dn];
         if (edge_response_core(tp)) atomicOr(&s_fm[qc], 1ull << qr);
+    };
+    for (int gb = 0; gb < n3; gb += 256) {   // block-uniform trip count: every lane takes part in the ballots
+        const int g = gb + tid;
+        bool keep = false;
+        unsigned e = 0u;
+        if (g < n3) {
+            const int qi = g < n0 ? 0 : g < n1 ? 1 : g < n2 ? 2 : 3;
+            const int off = qi == 0 ? 0 : qi == 1 ? n0 : qi == 2 ? n1 : n2;
+            e = s_q[qi][g - off];
+            const int qc = (int)(e & 31u), qr = (int)(e >> 5);
+            const int at = (qr + 1) * kFxPitch + (qc + kFxLead);
+            const bool curved = edge_curvature_filtered(s_t[1][at], s_t[1][at - 1], s_t[1][at + 1], s_t[1][at - kFxPitch], s_t[1][at + kFxPitch],
+                                                        s_t[1][at - kFxPitch - 1], s_t[1][at - kFxPitch + 1], s_t[1][at + kFxPitch - 1],
+                                                        s_t[1][at + kFxPitch + 1]);
+            if (curved) atomicOr(&s_fm[qc], 1ull << qr);
+            keep = !curved;
+        }
+        const unsigned long long bal = __ballot(keep);
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&s_n2, __popcll(bal));
+        base = __shfl(base, 0);
+        if (keep) {
+            const int pos = base + (int)__popcll(bal & ((1ull << lane) - 1ull));
+            if (pos < kFxQ2) s_q2[pos] = (unsigned short)e;
+            else qr_body((int)(e & 31u), (int)(e >> 5));   // list full (a tile of ties): in place
+        }
+    }
+    fx_lds_barrier();
+    // ---- second stage: the 3x3 QR bodies -------------------------------------------------------------------------------
+    const int m2 = min(s_n2, kFxQ2);
+    for (int g = tid; g < m2; g += 256) {
+        const unsigned e = s_q2[g];
+        qr_body((int)(e & 31u), (int)(e >> 5));
     }
     fx_lds_barrier();
     if (tid < kFxCols && x0 + tid < w) {
-        const unsigned long long m = s_cm[0][tid] | s_cm[1][tid] | s_cm[2][tid] | s_cm[3][tid];
+        const unsigned long long m = s_cm[tid];
         const size_t wi = (size_t)img * (size_t)words_per_image + (size_t)word_base + (size_t)(x0 + tid) * (size_t)nyb +
                           (size_t)yb;
         masks[wi] = m;
