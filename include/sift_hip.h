@@ -143,6 +143,12 @@ int sift_hip_result_device(sift_hip_ctx* ctx, const void** dev_keypoints, const 
  * the current results hold such a value: send the plain arrays of sift_hip_result_device instead. */
 int sift_hip_result_sparse_size(sift_hip_ctx* ctx, int64_t* n_values, int* lossless);
 int sift_hip_result_sparse_pack(sift_hip_ctx* ctx, void* dev_records, void* dev_values);
+/* The receiving side, on ctx's GPU: n_keypoints records of 34 bytes + their floats (both in DEVICE memory, as _pack wrote them
+ * on any GPU) -> n_keypoints sift_hip_keypoint records and n_keypoints * 128 descriptor floats in DEVICE memory, bit for bit
+ * what the sending context's sift_hip_result_device arrays held.  Independent of ctx's own results; returns when the device is
+ * done. */
+int sift_hip_sparse_unpack(sift_hip_ctx* ctx, const void* dev_records, const void* dev_values, int64_t n_keypoints,
+                           void* dev_keypoints, void* dev_descriptors);
 /* The image calculate() leaves in the caller's MultiArray: when params.subpixel it is the
  * sigma=1 blurred, 2x nearest-upsampled frame (sift.cpp:20-21); dims of it, then the pixels. */
 int sift_hip_image_dims(sift_hip_ctx* ctx, int* w, int* h);
@@ -203,7 +209,9 @@ typedef struct sift_hip_group sift_hip_group;
 int sift_hip_group_create(const int* devices, int n_devices, sift_hip_group** out, char* err, int errlen);
 void sift_hip_group_destroy(sift_hip_group* group);
 int sift_hip_group_shards(sift_hip_group* group);
-int sift_hip_group_set_option(sift_hip_group* group, const char* name, int value);   /* sift_hip_set_option on every shard */
+/* sift_hip_set_option on every shard; and "gather_wire": 1 (default) lists of shards on other GPUs cross in the sparse wire
+ * format and are unpacked on devices[0], 0 plain arrays, 2 the sparse format for every shard (tests on a one-GPU box) */
+int sift_hip_group_set_option(sift_hip_group* group, const char* name, int value);
 int sift_hip_group_calculate(sift_hip_group* group, const float* host_imgs, int n, int w, int h, const sift_hip_params* params,
                              char* err, int errlen);
 int sift_hip_group_result_images(sift_hip_group* group);

@@ -24,7 +24,7 @@ SYMBOLS = [
     "sift_hip_reduce_to_next_level", "sift_hip_increase_to_next_level", "sift_hip_dog", "sift_hip_gradient",
     "sift_hip_edge_responses", "sift_hip_vertex_parabola", "sift_hip_sort_by_filter", "sift_hip_cleanup_survivors", "sift_hip_profile_get",
     "sift_hip_profile_reset", "sift_hip_version", "sift_hip_gate_create", "sift_hip_gate_destroy", "sift_hip_set_gate",
-    "sift_hip_result_sparse_size", "sift_hip_result_sparse_pack",
+    "sift_hip_result_sparse_size", "sift_hip_result_sparse_pack", "sift_hip_sparse_unpack",
     "sift_hip_host_alloc", "sift_hip_host_free",
     "sift_hip_group_create", "sift_hip_group_destroy", "sift_hip_group_shards", "sift_hip_group_set_option", "sift_hip_group_calculate",
     "sift_hip_group_result_images", "sift_hip_group_result_status", "sift_hip_group_result_counts", "sift_hip_group_result_total",
@@ -90,6 +90,7 @@ def load():
     L.sift_hip_set_gate.argtypes = [vp, vp]
     L.sift_hip_result_sparse_size.argtypes = [vp, C.POINTER(C.c_int64), ip]
     L.sift_hip_result_sparse_pack.argtypes = [vp, vp, vp]
+    L.sift_hip_sparse_unpack.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
     L.sift_hip_set_option.argtypes = [vp, cs, ci]
     L.sift_hip_calculate_batch.argtypes = [vp, fp, ci, ci, ci, C.POINTER(Params), cs, ci]
     L.sift_hip_calculate_batch_device.argtypes = [vp, vp, ci, ci, ci, C.POINTER(Params), cs, ci]

@@ -168,6 +168,8 @@ void launch_descriptors_wave(hipStream_t s, const DevPlan* d_plan, const DevPlan
 
 // wire format of the keypoint gather (kernels_wire.hip)
 size_t wire_blocks(long long total);
+void launch_wire_unpack(hipStream_t s, const uint8_t* d_records, const float* d_values, long long total, int* d_sums,
+                        long long* d_block_off, sift_hip_keypoint* d_kp, float* d_desc);
 void launch_wire_count(hipStream_t s, const float* d_desc, long long total, int* d_sums, long long* d_block_off, bool counted);
 void launch_wire_emit(hipStream_t s, const sift_hip_keypoint* d_kp, const float* d_desc, long long total,
                       const long long* d_block_off, uint8_t* d_records, float* d_values);

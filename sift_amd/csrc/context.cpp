@@ -136,6 +136,7 @@ struct sift_hip_ctx {
     int gate_schedule = 0;           // option "gate_schedule" (phase_gate.h): applies to the gate this context is joined to
     DevBuf d_list, d_list_cnt, d_orient, d_peaks, d_final, d_final_cnt, d_out_base, d_kp, d_desc;
     DevBuf d_wire_sums, d_wire_off;   // sparse wire format: floats per block of keypoints, their exclusive scan
+    DevBuf d_unpack_sums, d_unpack_off;   // the same for sift_hip_sparse_unpack (lists that arrive from other GPUs)
     HostBuf h_wire;
     long long wire_values = -1, wire_for_total = -1;
     bool wire_count = false;          // option "wire_count": the descriptor kernel also counts the floats of the sparse wire format
@@ -1173,7 +1174,7 @@ void sift_hip_destroy(sift_hip_ctx* c) {
     (void)sift_hip_set_gate(c, nullptr);
     for (DevBuf* b : {&c->arena, &c->d_plan, &c->d_taps, &c->d_luts, &c->d_taps16, &c->d_input, &c->d_base, &c->d_tmp, &c->d_tmp2,
                       &c->d_wk, &c->d_wi, &c->d_wi2, &c->d_wp, &c->d_status, &c->d_tile, &c->d_pool, &c->d_order, &c->d_masks, &c->d_fmasks, &c->d_counts, &c->d_totals, &c->d_cands, &c->d_flags, &c->d_list, &c->d_list_cnt, &c->d_orient,
-                      &c->d_peaks, &c->d_final, &c->d_final_cnt, &c->d_out_base, &c->d_kp, &c->d_desc, &c->d_lrank, &c->d_ochunk, &c->d_ocnt, &c->d_recs, &c->d_wire_sums, &c->d_wire_off, &c->d_cell_cnt, &c->d_cell_off})
+                      &c->d_peaks, &c->d_final, &c->d_final_cnt, &c->d_out_base, &c->d_kp, &c->d_desc, &c->d_lrank, &c->d_ochunk, &c->d_ocnt, &c->d_recs, &c->d_wire_sums, &c->d_wire_off, &c->d_unpack_sums, &c->d_unpack_off, &c->d_cell_cnt, &c->d_cell_off})
         b->release();
     for (HostBuf* b : {&c->h_flags, &c->h_orient, &c->h_peaks, &c->h_status, &c->h_wire, &c->h_stage[0], &c->h_stage[1]}) b->release();
     for (auto& e : c->ev_stage) if (e) (void)hipEventDestroy(e);
@@ -1365,6 +1366,25 @@ int sift_hip_result_sparse_pack(sift_hip_ctx* c, void* d_records, void* d_values
         SIFT_HIP_CHECK(hipSetDevice(c->device));
         launch_wire_emit(c->stream, c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->total, c->d_wire_off.as<long long>(),
                          static_cast<uint8_t*>(d_records), static_cast<float*>(d_values));
+        wait_stream(c, c->stream);
+        return SIFT_HIP_OK;
+    });
+}
+
+int sift_hip_sparse_unpack(sift_hip_ctx* c, const void* d_records, const void* d_values, int64_t n_keypoints, void* d_keypoints,
+                           void* d_descriptors) {
+    if (!c || n_keypoints < 0 || (n_keypoints > 0 && (!d_records || !d_keypoints || !d_descriptors))) return SIFT_HIP_EINVAL;
+    if (n_keypoints == 0) return SIFT_HIP_OK;
+    char err[256];
+    return guarded(err, sizeof(err), [&]() {
+        SIFT_HIP_CHECK(hipSetDevice(c->device));
+        const size_t nb = wire_blocks(n_keypoints);
+        c->d_unpack_sums.ensure((nb + 1) * sizeof(int));
+        c->d_unpack_off.ensure((nb + 1) * sizeof(long long));
+        launch_wire_unpack(c->stream, static_cast<const uint8_t*>(d_records), static_cast<const float*>(d_values), n_keypoints,
+                           c->d_unpack_sums.as<int>(), c->d_unpack_off.as<long long>(), static_cast<sift_hip_keypoint*>(d_keypoints),
+                           static_cast<float*>(d_descriptors));
+        SIFT_HIP_CHECK(hipGetLastError());
         wait_stream(c, c->stream);
         return SIFT_HIP_OK;
     });

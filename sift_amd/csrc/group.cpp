@@ -34,6 +34,16 @@ struct sift_hip_group {
     hipStream_t copy_stream = nullptr;       // on devices[0]
     double gather_ms = 0, compute_ms = 0;
     long long gather_bytes = 0;
+    // option "gather_wire": 1 (default) lists of other GPUs cross in the sparse wire format (34-byte records + the descriptor
+    // floats that are set: ~200 instead of 532 bytes per keypoint over the link) and are unpacked on devices[0]; 0 plain arrays;
+    // 2 the sparse format for every shard, also those on devices[0] itself (tests on a one-GPU box)
+    int gather_wire = 1;
+    std::vector<void*> s_rec, s_val;         // per shard, on the shard's device: packed records / values
+    std::vector<long long> s_rec_cap, s_val_cap, s_nnz;
+    std::vector<int> s_packed;               // this batch: the shard's lists are packed (lossless and wanted)
+    void* d_in_rec = nullptr;                // on devices[0]: where packed lists arrive
+    void* d_in_val = nullptr;
+    long long in_rec_cap = 0, in_val_cap = 0;
 };
 
 namespace {
@@ -92,6 +102,13 @@ void sift_hip_group_destroy(sift_hip_group* g) {
     }
     if (g->d_kp) (void)hipFree(g->d_kp);
     if (g->d_desc) (void)hipFree(g->d_desc);
+    if (g->d_in_rec) (void)hipFree(g->d_in_rec);
+    if (g->d_in_val) (void)hipFree(g->d_in_val);
+    for (size_t s = 0; s < g->s_rec.size(); ++s) {
+        (void)hipSetDevice(g->devices[s]);
+        if (g->s_rec[s]) (void)hipFree(g->s_rec[s]);
+        if (g->s_val[s]) (void)hipFree(g->s_val[s]);
+    }
     for (auto* c : g->ctx) sift_hip_destroy(c);
     delete g;
 }
@@ -99,7 +116,12 @@ void sift_hip_group_destroy(sift_hip_group* g) {
 int sift_hip_group_shards(sift_hip_group* g) { return g ? (int)g->ctx.size() : -1; }
 
 int sift_hip_group_set_option(sift_hip_group* g, const char* name, int value) {
-    if (!g) return SIFT_HIP_EINVAL;
+    if (!g || !name) return SIFT_HIP_EINVAL;
+    if (!std::strcmp(name, "gather_wire")) {
+        if (value < 0 || value > 2) return SIFT_HIP_EINVAL;
+        g->gather_wire = value;
+        return SIFT_HIP_OK;
+    }
     int rc = SIFT_HIP_OK;
     for (auto* c : g->ctx) rc = std::max(rc, sift_hip_set_option(c, name, value));
     return rc;
@@ -126,6 +148,10 @@ static int group_calculate(sift_hip_group* g, const float* host_imgs, int n, int
     g->count.assign((size_t)S, 0);
     g->rc.assign((size_t)S, SIFT_HIP_OK);
     g->msg.assign((size_t)S, std::string());
+    g->s_rec.resize((size_t)S, nullptr); g->s_val.resize((size_t)S, nullptr);
+    g->s_rec_cap.resize((size_t)S, 0); g->s_val_cap.resize((size_t)S, 0);
+    g->s_nnz.assign((size_t)S, 0); g->s_packed.assign((size_t)S, 0);
+    if (g->gather_wire) sift_hip_group_set_option(g, "wire_count", 1);   // the descriptor kernels count what the wire will carry
     const int per = (n + S - 1) / S;   // contiguous blocks: shard s holds images s*per .. (256 -> 32 each on 8 GPUs)
     for (int s = 0; s < S; ++s) {
         g->first[(size_t)s] = std::min(n, s * per);
@@ -145,6 +171,31 @@ static int group_calculate(sift_hip_group* g, const float* host_imgs, int n, int
             g->rc[(size_t)s] = sift_hip_calculate_batch(g->ctx[(size_t)s], host_imgs + (size_t)g->first[(size_t)s] * frame, g->count[(size_t)s], w, h,
                                                        params, e, sizeof(e));
             g->msg[(size_t)s] = e;
+            // lists that will cross to another GPU are packed here, on the shard's own GPU and thread
+            g->s_packed[(size_t)s] = 0;
+            const bool remote = g->devices[(size_t)s] != g->devices[0];
+            if ((g->gather_wire == 2 || (g->gather_wire == 1 && remote)) && sift_hip_result_images(g->ctx[(size_t)s]) == g->count[(size_t)s]) {
+                const long long t = sift_hip_result_total(g->ctx[(size_t)s]);
+                int64_t nnz = 0;
+                int lossless = 0;
+                if (t > 0 && sift_hip_result_sparse_size(g->ctx[(size_t)s], &nnz, &lossless) == SIFT_HIP_OK && lossless &&
+                    hipSetDevice(g->devices[(size_t)s]) == hipSuccess) {
+                    auto fit = [](void*& p, long long& cap, long long want) {
+                        if (want <= cap) return true;
+                        if (p) (void)hipFree(p);
+                        p = nullptr; cap = 0;
+                        if (hipMalloc(&p, (size_t)(want + want / 4)) != hipSuccess) { p = nullptr; return false; }
+                        cap = want + want / 4;
+                        return true;
+                    };
+                    if (fit(g->s_rec[(size_t)s], g->s_rec_cap[(size_t)s], t * 34) &&
+                        fit(g->s_val[(size_t)s], g->s_val_cap[(size_t)s], std::max<long long>(nnz, 1) * 4) &&
+                        sift_hip_result_sparse_pack(g->ctx[(size_t)s], g->s_rec[(size_t)s], g->s_val[(size_t)s]) == SIFT_HIP_OK) {
+                        g->s_nnz[(size_t)s] = nnz;
+                        g->s_packed[(size_t)s] = 1;
+                    }
+                }
+            }
         });
     }
     for (auto& t : th) t.join();
@@ -192,9 +243,60 @@ static int group_calculate(sift_hip_group* g, const float* host_imgs, int n, int
         g->cap = want;
     }
     g->gather_bytes = 0;
+    // packed lists first: all of them into one staging area on devices[0] (each over its own link), then unpacked there
+    {
+        long long need_rec = 0, need_val = 0;
+        for (int s = 0; s < S; ++s)
+            if (g->s_packed[(size_t)s] && shard_total[(size_t)s] > 0) { need_rec += shard_total[(size_t)s] * 34; need_val += g->s_nnz[(size_t)s] * 4; }
+        auto fit0 = [](void*& p, long long& cap, long long want) {
+            if (want <= cap) return true;
+            if (p) (void)hipFree(p);
+            p = nullptr; cap = 0;
+            if (hipMalloc(&p, (size_t)(want + want / 4)) != hipSuccess) { p = nullptr; return false; }
+            cap = want + want / 4;
+            return true;
+        };
+        if (need_rec > 0 && (!fit0(g->d_in_rec, g->in_rec_cap, need_rec) || !fit0(g->d_in_val, g->in_val_cap, std::max<long long>(need_val, 4)))) {
+            set_err(err, errlen, "sift_hip_group_calculate: out of device memory for the arriving lists");
+            return SIFT_HIP_EHIP;
+        }
+        long long ro = 0, vo = 0;
+        std::vector<long long> rec_at((size_t)S, 0), val_at((size_t)S, 0);
+        for (int s = 0; s < S; ++s) {
+            if (!g->s_packed[(size_t)s] || shard_total[(size_t)s] <= 0) continue;
+            const size_t br = (size_t)shard_total[(size_t)s] * 34, bv = (size_t)g->s_nnz[(size_t)s] * 4;
+            char* dr = static_cast<char*>(g->d_in_rec) + ro;
+            char* dv = static_cast<char*>(g->d_in_val) + vo;
+            rec_at[(size_t)s] = ro; val_at[(size_t)s] = vo;
+            ro += (long long)br; vo += (long long)bv;
+            hipError_t e1 = hipSuccess, e2 = hipSuccess;
+            if (g->devices[(size_t)s] == g->devices[0]) {
+                e1 = hipMemcpyAsync(dr, g->s_rec[(size_t)s], br, hipMemcpyDeviceToDevice, g->copy_stream);
+                if (bv) e2 = hipMemcpyAsync(dv, g->s_val[(size_t)s], bv, hipMemcpyDeviceToDevice, g->copy_stream);
+            } else {
+                e1 = hipMemcpyPeerAsync(dr, g->devices[0], g->s_rec[(size_t)s], g->devices[(size_t)s], br, g->copy_stream);
+                if (bv) e2 = hipMemcpyPeerAsync(dv, g->devices[0], g->s_val[(size_t)s], g->devices[(size_t)s], bv, g->copy_stream);
+                g->gather_bytes += (long long)(br + bv);
+            }
+            if (e1 != hipSuccess || e2 != hipSuccess) { set_err(err, errlen, "sift_hip_group_calculate: peer copy failed"); return SIFT_HIP_EHIP; }
+        }
+        if (need_rec > 0) {
+            if (hipStreamSynchronize(g->copy_stream) != hipSuccess) { set_err(err, errlen, "sift_hip_group_calculate: gather failed"); return SIFT_HIP_EHIP; }
+            for (int s = 0; s < S; ++s) {
+                if (!g->s_packed[(size_t)s] || shard_total[(size_t)s] <= 0) continue;
+                char* dk = static_cast<char*>(g->d_kp) + (size_t)shard_off[(size_t)s] * sizeof(sift_hip_keypoint);
+                char* dd = static_cast<char*>(g->d_desc) + (size_t)shard_off[(size_t)s] * 128 * sizeof(float);
+                if (sift_hip_sparse_unpack(g->ctx[0], static_cast<char*>(g->d_in_rec) + rec_at[(size_t)s], static_cast<char*>(g->d_in_val) + val_at[(size_t)s],
+                                           shard_total[(size_t)s], dk, dd) != SIFT_HIP_OK) {
+                    set_err(err, errlen, "sift_hip_group_calculate: unpacking the arriving lists failed");
+                    return SIFT_HIP_EHIP;
+                }
+            }
+        }
+    }
     for (int s = 0; s < S; ++s) {
         const long long t = shard_total[(size_t)s];
-        if (t <= 0) continue;
+        if (t <= 0 || g->s_packed[(size_t)s]) continue;
         const void *kp = nullptr, *desc = nullptr;
         if (sift_hip_result_device(g->ctx[(size_t)s], &kp, &desc) != SIFT_HIP_OK) { set_err(err, errlen, "no device results"); return SIFT_HIP_EHIP; }
         char* dk = static_cast<char*>(g->d_kp) + (size_t)shard_off[(size_t)s] * sizeof(sift_hip_keypoint);

@@ -155,7 +155,97 @@ __global__ __launch_bounds__(256) void wire_emit_kernel(const sift_hip_keypoint*
     }
 }
 
+// ---- the receiving side: 34-byte records + set floats -> sift_hip_keypoint records + 128-float descriptors ----------------
+// floats per block of 64 records, from the presence bits alone
+__global__ __launch_bounds__(256) void wire_mask_count_kernel(const uint8_t* __restrict__ records, long long total,
+                                                             int* __restrict__ block_sums) {
+    __shared__ int s_sum[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long k = (long long)blockIdx.x * kWireBlock + threadIdx.x / 4;   // four lanes per record
+    const unsigned short* __restrict__ r16 = reinterpret_cast<const unsigned short*>(records);
+    int n = 0;
+    if (k < total) {
+        // mask = words 10..16 of the record: lane q of the four takes words 10 + q and 14 + q (q < 3)
+        const int q = lane & 3;
+        n = __popc((unsigned)r16[k * 17 + 10 + q]) + (q < 3 ? __popc((unsigned)r16[k * 17 + 14 + q]) : 0);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o);
+    if (lane == 0) s_sum[wave] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+}
+
+__global__ __launch_bounds__(256) void wire_unpack_kernel(const uint8_t* __restrict__ records, const float* __restrict__ values,
+                                                         long long total, const long long* __restrict__ block_off,
+                                                         sift_hip_keypoint* __restrict__ kp, float* __restrict__ desc) {
+    __shared__ int s_sum[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long k0 = (long long)blockIdx.x * kWireBlock + wave * kWirePerWave;
+    const unsigned short* __restrict__ r16 = reinterpret_cast<const unsigned short*>(records);
+    // the wave's 16 records, 17 words each, as 16-bit loads: lane (i, s) = record i of four per round, word s
+    // round r covers records 4r .. 4r+3: lane 16 * (record in round) + s holds word s < 16, every lane of the 16 word 16
+    unsigned short w16[4], wlast[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long long k = min(k0 + 4 * r + (lane >> 4), total - 1);
+        w16[r] = r16[k * 17 + (lane & 15)];
+        wlast[r] = r16[k * 17 + 16];
+    }
+    unsigned long long m0[kWirePerWave], m1[kWirePerWave];
+    int sum = 0;
+#pragma unroll
+    for (int i = 0; i < kWirePerWave; ++i) {
+        const int src = 16 * (i & 3);
+        unsigned long long a = 0ull, b = 0ull;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a |= (unsigned long long)(unsigned short)__shfl((int)w16[i >> 2], src + 10 + t) << (16 * t);
+        b = (unsigned long long)(unsigned short)__shfl((int)w16[i >> 2], src + 14) |
+            ((unsigned long long)(unsigned short)__shfl((int)w16[i >> 2], src + 15) << 16) |
+            ((unsigned long long)(unsigned short)__shfl((int)wlast[i >> 2], src) << 32);
+        m0[i] = a; m1[i] = b;
+        sum += (k0 + i < total) ? __popcll(a) + __popcll(b) : 0;
+    }
+    if (lane == 0) s_sum[wave] = sum;
+    __syncthreads();
+    long long base = block_off[blockIdx.x];
+    for (int w = 0; w < wave; ++w) base += s_sum[w];
+    unsigned short* __restrict__ kp16 = reinterpret_cast<unsigned short*>(kp);
+    // this lane's positions 2 * lane and 2 * lane + 1: cell = position / 8, bin = position % 8; presence bit j = cell * 7 + bin
+    const int p0 = 2 * lane, p1 = 2 * lane + 1;
+    const int j0 = (p0 >> 3) * 7 + (p0 & 7), j1 = (p1 >> 3) * 7 + (p1 & 7);
+    const bool odd7 = (p1 & 7) == 7;   // bin 7 is never on the wire: +0.0f
+    auto below = [](unsigned long long a, unsigned long long b, int j) {   // set bits among presence bits 0 .. j-1
+        return j < 64 ? __popcll(a & ((1ull << j) - 1ull)) : __popcll(a) + __popcll(b & ((1ull << (j - 64)) - 1ull));
+    };
+    auto bit = [](unsigned long long a, unsigned long long b, int j) { return (int)(((j < 64 ? a >> j : b >> (j - 64))) & 1ull); };
+#pragma unroll
+    for (int i = 0; i < kWirePerWave; ++i) {
+        if (k0 + i >= total) break;   // wave-uniform
+        const int has0 = bit(m0[i], m1[i], j0), has1 = odd7 ? 0 : bit(m0[i], m1[i], j1);
+        const int r0 = below(m0[i], m1[i], j0);
+        float2 out;
+        out.x = has0 ? values[base + r0] : 0.0f;
+        out.y = has1 ? values[base + r0 + has0] : 0.0f;
+        reinterpret_cast<float2*>(desc + (k0 + i) * 128)[lane] = out;
+        const unsigned short kw = (unsigned short)__shfl((int)w16[i >> 2], 16 * (i & 3) + (lane & 15));
+        if (lane < 10) kp16[(k0 + i) * 10 + lane] = kw;
+        base += __popcll(m0[i]) + __popcll(m1[i]);
+    }
+}
+
 size_t wire_blocks(long long total) { return (size_t)((total + kWireBlock - 1) / kWireBlock); }
+
+// d_sums: nb + 1 ints of scratch, d_block_off: nb + 1 long longs of scratch
+void launch_wire_unpack(hipStream_t s, const uint8_t* d_records, const float* d_values, long long total, int* d_sums,
+                        long long* d_block_off, sift_hip_keypoint* d_kp, float* d_desc) {
+    const size_t nb = wire_blocks(total);
+    if (!nb) return;
+    hipLaunchKernelGGL(wire_mask_count_kernel, dim3((unsigned)nb), dim3(256), 0, s, d_records, total, d_sums);
+    hipLaunchKernelGGL(wire_scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)d_sums, (int)nb, d_block_off);
+    hipLaunchKernelGGL(wire_unpack_kernel, dim3((unsigned)nb), dim3(256), 0, s, d_records, d_values, total, (const long long*)d_block_off,
+                       d_kp, d_desc);
+}
 
 // d_sums: [0] the "bin 7 is not +0.0f somewhere" flag, [1 + b] floats on the wire of block b (64 output slots).  counted: the
 // descriptor kernel has already filled it for this batch (option "wire_count": kernels_desc.hip), only the scan remains.

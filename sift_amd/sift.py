@@ -193,6 +193,13 @@ class Context:
         if self._L.sift_hip_result_sparse_pack(self._h, C.c_void_p(dev_records), C.c_void_p(dev_values)):
             raise HipError("sift_hip_result_sparse_pack failed")
 
+    def sparse_unpack(self, dev_records: int, dev_values: int, n_keypoints: int, dev_keypoints: int, dev_descriptors: int):
+        """34-byte records + set floats (device addresses, from any context's sparse_pack) -> n_keypoints 20-byte keypoint
+        records and n_keypoints * 128 floats at the device addresses given, on this context's GPU."""
+        if self._L.sift_hip_sparse_unpack(self._h, C.c_void_p(dev_records), C.c_void_p(dev_values), int(n_keypoints),
+                                          C.c_void_p(dev_keypoints), C.c_void_p(dev_descriptors)):
+            raise HipError("sift_hip_sparse_unpack failed")
+
     def image(self, image: int = 0):
         w, h = C.c_int(), C.c_int()
         self._L.sift_hip_image_dims(self._h, C.byref(w), C.byref(h))

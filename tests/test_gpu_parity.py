@@ -594,6 +594,17 @@ def test_group_of_shards_matches_single_context(ctx):
         g.calculate_batch(frames[:2], params)                              # fewer frames than shards
         ctx.calculate_batch(frames[:2], params)
         assert g.results()[1].tobytes() == ctx.results()[1].tobytes()
+        # what shards on other GPUs do (forced here for the shards of this one GPU): every shard packs its lists into the sparse
+        # wire format on its own device, the packed lists are collected and unpacked on the first device
+        g.set_option("gather_wire", 2)
+        mixed = np.concatenate([frames, np.full((1, 240, 320), 3.0, np.float32)])   # the last shard's last frame has no keypoint
+        g.calculate_batch(mixed, params)
+        ctx.calculate_batch(mixed, params)
+        assert g.counts().tolist() == ctx.counts().tolist() and g.total() == ctx.total()
+        kp, desc = g.results()
+        wkp, wdesc = ctx.results()
+        assert kp.tobytes() == wkp.tobytes() and desc.tobytes() == wdesc.tobytes()
+        g.set_option("gather_wire", 1)
         with pytest.raises(PreconditionViolation) as e:                    # 160x120 cannot carry 4 octaves
             g.calculate_batch(np.stack([synth_frame(160, 120, 1)] * 4), _lib.Params(3, 4, 1.6, O.K_SQRT2, 0))
         assert "kernel longer than line" in str(e.value)
@@ -915,6 +926,12 @@ def test_sparse_wire_kernels_match_the_reference_packing(ctx):
     recs, masks = split_records(rec.cpu())
     assert recs.numpy().tobytes() == kp.tobytes()
     assert unpack_sparse(masks, values.cpu()).numpy().tobytes() == desc.tobytes()
+    # the receiving side on the GPU (sift_hip_sparse_unpack): the same records and descriptors, bit for bit
+    kp_dev = torch.full((total * 20,), 0xAB, dtype=torch.uint8, device="cuda:0")
+    desc_dev = torch.full((total * 128,), float("nan"), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    ctx.sparse_unpack(rec.data_ptr(), values.data_ptr(), total, kp_dev.data_ptr(), desc_dev.data_ptr())
+    assert kp_dev.cpu().numpy().tobytes() == kp.tobytes() and desc_dev.cpu().numpy().tobytes() == desc.tobytes()
     assert 0.2 < values.numel() / (total * 112) < 0.6   # the saving the format exists for
     # option wire_count: the counting pass rides in the descriptor kernel (what bench.py uses for N > 1); same wire bytes
     ctx.set_option("wire_count", 1)
