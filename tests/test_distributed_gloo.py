@@ -151,7 +151,12 @@ def _kg_worker(rank, world, port, q, steps):
     done = []
     for step in range(steps):
         c, r, v = _step_data(rank, step)
-        done += g.push(torch.from_numpy(r), torch.from_numpy(v), c)
+        rt = torch.from_numpy(r)
+        if step % 2 == 1:        # every other step: the records sit in a message buffer with header room (no copy at send time)
+            rb = g.records_buffer(rt.numel())
+            rb.copy_(rt)
+            rt = rb
+        done += g.push(rt, torch.from_numpy(v), c)
     done += g.flush()
     if rank == 0:
         q.put([(a.numpy().copy(), b.numpy().copy(), cc.numpy().copy()) for a, b, cc in done] + [g.wire_bytes])

@@ -642,6 +642,30 @@ def test_cli_result_file(ctx, tmp_path, monkeypatch):
     assert cli.main(["parrot_r.pgm", "--no-overlay"]) == 0 and not os.path.exists(tmp_path / "interstpoints.txt")
 
 
+@pytest.mark.parametrize("option", ["gate_schedule", "gate_early_chain"])
+def test_other_gate_schedules_leave_the_results_alone(ctx, option):
+    """The measured-and-rejected orders of the phase gate (sift_amd/csrc/phase_gate.h) are options: same results."""
+    from sift_amd.pipeline import BatchPipeline
+    params = _lib.Params(3, 3, 1.6, O.K_SQRT2, 0)
+    batches = [np.stack([synth_frame(480, 360, 200 + 3 * b + i) for i in range(3)]) for b in range(5)]
+    got = []
+    with BatchPipeline(0, depth=2, options={option: 1}) as pipe:
+        tickets = []
+        for b in batches + [None, None]:
+            if b is not None:
+                tickets.append(pipe.submit(b, params))
+            if len(tickets) == 2 or (b is None and tickets):
+                t = tickets.pop(0)
+                c = t.result()
+                got.append((c.counts().copy(),) + tuple(a.copy() for a in c.results()))
+                t.release()
+    assert len(got) == len(batches)
+    for b, (counts, kp, desc) in zip(batches, got):
+        ctx.calculate_batch(b, params)
+        wkp, wdesc = ctx.results()
+        assert counts.tolist() == ctx.counts().tolist() and kp.tobytes() == wkp.tobytes() and desc.tobytes() == wdesc.tobytes()
+
+
 def test_cli_reads_a_jpeg(ctx, tmp_path, monkeypatch):
     """The reference's example input is a JPEG (example/parrot.jpg): the command line program decodes one itself
     (sift_amd/csrc/jpeg_decode.cpp, no libjpeg, no PIL), takes its red band (App. B-15) and draws on its B,G,R pixels."""
