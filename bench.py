@@ -304,6 +304,7 @@ def main():
         prof = [c.profile(0) for c in ctxs]
         ms, launches, nbytes = (sum(p[i] for p in prof) for i in range(3))
         achieved = (nbytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+        busy_ms = sum(c.profile_busy_ms(0) for c in ctxs)   # launches that overlap (option pyramid_side) counted once
         out = {
             "metric": "keypoints/sec, 1920x1080 4oct/3DoG" if args.workload == "config4" else f"keypoints/sec, {args.workload} (not the headline metric)",
             "value": kps / dt,
@@ -335,7 +336,10 @@ def main():
                          "timing": "hipEventElapsedTime over start/stop events attached to each blur dispatch (hipExtLaunchKernelGGL) on the library's stream, inside the timed region; "
                                    f"every {PROFILE_EVERY}th batch of a context is instrumented (the events keep consecutive launches ~10 us apart)",
                          "launches": launches, "avg_launch_ms": ms / launches if launches else None,
-                         "algorithmic_bytes_per_launch": nbytes / launches if launches else None},
+                         "algorithmic_bytes_per_launch": nbytes / launches if launches else None,
+                         # the same bytes over the time during which at least one blur launch was running: equal to `frac` while the
+                         # launches follow one another (the default), larger when option pyramid_side lets two of them overlap
+                         "frac_of_busy_time": ((nbytes / 1e9) / (busy_ms / 1e3) / HBM_PEAK_GBS) if busy_ms > 0 else None},
         }
         if world == 1 and not args.no_extras:
             # ---- the boundary as a host caller sees it (main.cpp:56-57 hands over host memory and reads the vector back):

@@ -83,7 +83,9 @@ void sift_hip_destroy(sift_hip_ctx* ctx);
  * 2048, 0 = tile kernel only), "desc_kernel" (1 default: one wave per keypoint over a grid of 16 px cells; 0: one workgroup
  * per 48 px tile walking the ordered keypoint list), "desc_dbg" / "orient_dbg" (phases switched off: timing only, WRONG results),
  * "gate_early_chain" / "gate_schedule" (other orders of the phases of batches joined by a gate, sift_amd/csrc/phase_gate.h:
- * measured, slower, off), "diag_pyramid_span", "diag_serial_gradient", "diag_cleanup_stamps" (print to stderr).  The library reads no
+ * measured, slower, off), "pyramid_side" (0 default; 1: the top Gaussian level of an octave, which only feeds the octave's last
+ * DoG, is formed on the side stream beside the reduction and the next octave's small launches: ~2.5 % more throughput on the
+ * bench workload, at the price that blur launches then overlap and their summed durations no longer equal the pyramid's time), "diag_pyramid_span", "diag_serial_gradient", "diag_cleanup_stamps" (print to stderr).  The library reads no
  * environment variable. */
 int sift_hip_set_option(sift_hip_ctx* ctx, const char* name, int value);
 
@@ -251,6 +253,9 @@ int sift_hip_overlay_draw(uint8_t* bgr, int w, int h, const sift_hip_keypoint* k
  * which: 0 = fused blur(+DoG) kernel, 1 = everything else in the pyramid stage.
  * Returns accumulated milliseconds, launches and ALGORITHMIC bytes since reset. */
 int sift_hip_profile_get(sift_hip_ctx* ctx, int which, double* ms, int64_t* launches, double* bytes);
+/* Milliseconds during which at least one launch of the class was running (the union of the launches' intervals): equal to the
+ * sum above while launches follow one another, smaller when launches of two streams overlap (option "pyramid_side"). */
+int sift_hip_profile_get_busy(sift_hip_ctx* ctx, int which, double* busy_ms);
 int sift_hip_profile_reset(sift_hip_ctx* ctx);
 
 const char* sift_hip_version(void);

@@ -134,6 +134,10 @@ struct sift_hip_ctx {
     bool desc_wave = true;           // option "desc_kernel": 1 wave-per-keypoint kernel (default), 0 tile kernel
     bool gate_early_chain = false;   // option "gate_early_chain" (measured alternative, off)
     int gate_schedule = 0;           // option "gate_schedule" (phase_gate.h): applies to the gate this context is joined to
+    // option "pyramid_side": the top Gaussian level of an octave (it only feeds the octave's last DoG) is formed on a stream of
+    // its own, beside the reduction and the first levels of the next octave, which are too small to fill the chip alone
+    bool pyramid_side = false;
+    hipEvent_t ev_side_fork = nullptr, ev_side_join = nullptr;
     DevBuf d_list, d_list_cnt, d_orient, d_peaks, d_final, d_final_cnt, d_out_base, d_kp, d_desc;
     DevBuf d_wire_sums, d_wire_off;   // sparse wire format: floats per block of keypoints, their exclusive scan
     DevBuf d_unpack_sums, d_unpack_off;   // the same for sift_hip_sparse_unpack (lists that arrive from other GPUs)
@@ -168,6 +172,7 @@ struct sift_hip_ctx {
     double prof_ms[2] = {0, 0};
     long long prof_launches[2] = {0, 0};
     double prof_bytes[2] = {0, 0};
+    double prof_busy_ms[2] = {0, 0};   // time during which at least one launch of the class was running (union of the launches' intervals)
 };
 
 namespace {
@@ -201,13 +206,27 @@ void resolve_events(sift_hip_ctx* c) {
         for (auto& p : c->pending) { float ms = 0; (void)hipEventElapsedTime(&ms, p.a, p.b); sum += ms; }
         std::fprintf(stderr, "pyramid span %.3f ms, sum of blur kernels %.3f ms, launches %zu\n", span, sum, c->pending.size());
     }
+    std::vector<std::pair<float, float>> iv[2];   // launch intervals, milliseconds after the batch's first launch began
     for (auto& p : c->pending) {
-        float ms = 0;
+        float ms = 0, t0 = 0;
         SIFT_HIP_CHECK(hipEventSynchronize(p.b));
         SIFT_HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
         c->prof_ms[p.which] += ms;
         c->prof_launches[p.which] += 1;
         c->prof_bytes[p.which] += p.bytes;
+        if (&p != &c->pending.front()) SIFT_HIP_CHECK(hipEventElapsedTime(&t0, c->pending.front().a, p.a));
+        iv[p.which].emplace_back(t0, t0 + ms);
+    }
+    for (int wch = 0; wch < 2; ++wch) {   // launches on two streams overlap (option "pyramid_side"): count that time once
+        std::sort(iv[wch].begin(), iv[wch].end());
+        float end = -1e30f;
+        for (auto& x : iv[wch]) {
+            if (x.second <= end) continue;
+            c->prof_busy_ms[wch] += x.second - std::max(x.first, end);
+            end = x.second;
+        }
+    }
+    for (auto& p : c->pending) {
         c->event_pool.push_back(p.a);
         c->event_pool.push_back(p.b);
     }
@@ -217,7 +236,7 @@ void resolve_events(sift_hip_ctx* c) {
 // Blur with optional event bracket.  Algorithmic bytes: 4 B read + 4 B written per
 // pixel, + 4 B when the DoG is written too.
 void run_blur(sift_hip_ctx* c, const float* in, float* out, float* dog, int w, int h, int n, size_t tap_off,
-              int radius) {
+              int radius, hipStream_t st = nullptr) {
     const bool is_fused = c->fused && radius >= 1 && radius <= kMaxRadiusFused;
     hipEvent_t a = nullptr, b = nullptr;
     if (c->profile) {
@@ -226,7 +245,7 @@ void run_blur(sift_hip_ctx* c, const float* in, float* out, float* dog, int w, i
     }
     // the events ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL): start/stop are the
     // kernel's begin/end timestamps and back-to-back launches stay back-to-back
-    launch_blur(c->stream, c->fused, in, c->d_tmp.as<float>(), out, dog, w, h, n, c->d_taps.as<float>() + tap_off,
+    launch_blur(st ? st : c->stream, c->fused, in, c->d_tmp.as<float>(), out, dog, w, h, n, c->d_taps.as<float>() + tap_off,
                 radius, a, b);
     if (c->profile) {
         const double px = (double)w * (double)h * (double)n;
@@ -496,6 +515,15 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
     const DevPlan& dv = P.dev;
     const int n = P.n, O = P.O, D = P.D;
     const float* base = d_in;
+    bool side_used = false;
+    struct SideJoin {   // whatever ran on the side stream is part of the pyramid: the main stream goes on after it
+        sift_hip_ctx* c; bool* used;
+        ~SideJoin() {
+            if (!*used) return;
+            (void)hipEventRecord(c->ev_side_join, c->stream2);
+            (void)hipStreamWaitEvent(c->stream, c->ev_side_join, 0);
+        }
+    } side_join{c, &side_used};
     for (size_t k = 0; k < P.ops.size(); ++k) {
         if (k >= P.fail_op) break;
         const BlurOp& op = P.ops[k];
@@ -513,8 +541,20 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
                 break;
             case 2: {
                 const int l = op.octave * (D + 1) + op.j;
-                run_blur(c, dv.gauss[l - 1], dv.gauss[l], dv.dog[op.octave * D + op.j - 1], op.w, op.h, n, op.tap_off, op.radius);
-                early_w16(c, l);
+                // The top level of an octave only feeds the octave's last DoG; the next octave starts from the level below it
+                // (sift.cpp:406-409).  Option "pyramid_side": it is formed on the side stream beside the reduction and the
+                // next octave's levels (fused kernels only: the two-pass fallback shares a scratch image with them).
+                const bool side = c->pyramid_side && c->ev_side_fork && op.j == D && op.octave + 1 < O && c->fused && op.radius >= 1 &&
+                                  op.radius <= kMaxRadiusFused && std::find(P.grad_levels.begin(), P.grad_levels.end(), l) == P.grad_levels.end();
+                if (side) {
+                    SIFT_HIP_CHECK(hipEventRecord(c->ev_side_fork, c->stream));
+                    SIFT_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_side_fork, 0));
+                    run_blur(c, dv.gauss[l - 1], dv.gauss[l], dv.dog[op.octave * D + op.j - 1], op.w, op.h, n, op.tap_off, op.radius, c->stream2);
+                    side_used = true;
+                } else {
+                    run_blur(c, dv.gauss[l - 1], dv.gauss[l], dv.dog[op.octave * D + op.j - 1], op.w, op.h, n, op.tap_off, op.radius);
+                    early_w16(c, l);
+                }
                 break;
             }
             case 3: {  // reduceToNextLevel(g(o, D-1), g(o, D-1).scale)
@@ -1185,6 +1225,8 @@ void sift_hip_destroy(sift_hip_ctx* c) {
     (void)hipEventDestroy(c->ev_fork);
     (void)hipEventDestroy(c->ev_join);
     (void)hipEventDestroy(c->ev_sync);
+    if (c->ev_side_fork) (void)hipEventDestroy(c->ev_side_fork);
+    if (c->ev_side_join) (void)hipEventDestroy(c->ev_side_join);
     (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1245,6 +1287,16 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     if (!std::strcmp(name, "desc_kernel")) { c->desc_wave = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "gate_early_chain")) { c->gate_early_chain = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "wire_count")) { c->wire_count = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "pyramid_side")) {
+        if (value != 0 && !c->ev_side_fork) {
+            if (hipSetDevice(c->device) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_side_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_side_join, hipEventDisableTiming) != hipSuccess)
+                return SIFT_HIP_EHIP;
+        }
+        c->pyramid_side = value != 0;
+        return SIFT_HIP_OK;
+    }
     if (!std::strcmp(name, "gate_schedule")) {
         if (value < 0 || value > 1) return SIFT_HIP_EINVAL;
         c->gate_schedule = value;
@@ -1760,9 +1812,15 @@ int sift_hip_profile_get(sift_hip_ctx* c, int which, double* ms, int64_t* launch
     if (bytes) *bytes = c->prof_bytes[which];
     return SIFT_HIP_OK;
 }
+
+int sift_hip_profile_get_busy(sift_hip_ctx* c, int which, double* busy_ms) {
+    if (!c || which < 0 || which > 1 || !busy_ms) return SIFT_HIP_EINVAL;
+    *busy_ms = c->prof_busy_ms[which];
+    return SIFT_HIP_OK;
+}
 int sift_hip_profile_reset(sift_hip_ctx* c) {
     if (!c) return SIFT_HIP_EINVAL;
-    for (int i = 0; i < 2; ++i) { c->prof_ms[i] = 0; c->prof_launches[i] = 0; c->prof_bytes[i] = 0; }
+    for (int i = 0; i < 2; ++i) { c->prof_ms[i] = 0; c->prof_launches[i] = 0; c->prof_bytes[i] = 0; c->prof_busy_ms[i] = 0; }
     return SIFT_HIP_OK;
 }
 

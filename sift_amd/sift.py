@@ -297,6 +297,12 @@ class Context:
         self._L.sift_hip_profile_get(self._h, which, C.byref(ms), C.byref(n), C.byref(by))
         return ms.value, n.value, by.value
 
+    def profile_busy_ms(self, which: int) -> float:
+        """time during which at least one launch of the class ran (overlapping launches counted once)"""
+        ms = C.c_double()
+        self._L.sift_hip_profile_get_busy(self._h, which, C.byref(ms))
+        return ms.value
+
     def profile_reset(self):
         self._L.sift_hip_profile_reset(self._h)
 

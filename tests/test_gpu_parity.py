@@ -642,9 +642,10 @@ def test_cli_result_file(ctx, tmp_path, monkeypatch):
     assert cli.main(["parrot_r.pgm", "--no-overlay"]) == 0 and not os.path.exists(tmp_path / "interstpoints.txt")
 
 
-@pytest.mark.parametrize("option", ["gate_schedule", "gate_early_chain"])
+@pytest.mark.parametrize("option", ["gate_schedule", "gate_early_chain", "pyramid_side"])
 def test_other_gate_schedules_leave_the_results_alone(ctx, option):
-    """The measured-and-rejected orders of the phase gate (sift_amd/csrc/phase_gate.h) are options: same results."""
+    """The measured-and-rejected orders of the phase gate (sift_amd/csrc/phase_gate.h) and the pyramid's side stream are
+    options: same results."""
     from sift_amd.pipeline import BatchPipeline
     params = _lib.Params(3, 3, 1.6, O.K_SQRT2, 0)
     batches = [np.stack([synth_frame(480, 360, 200 + 3 * b + i) for i in range(3)]) for b in range(5)]
