@@ -97,10 +97,14 @@ __global__ __launch_bounds__(256) void gradient4_kernel(const float* __restrict_
     const size_t base = (size_t)blockIdx.z * (size_t)w * (size_t)h;
     const float* __restrict__ col = g + base + (size_t)x;
     const bool has_l = x >= 1, has_r = x + 4 <= w - 1;
-    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    auto row4 = [&](int y) { return (y >= 0 && y < h) ? *reinterpret_cast<const float4*>(col + (size_t)y * (size_t)w) : z4; };
-    auto left = [&](int y) { return (has_l && y < h) ? col[(size_t)y * (size_t)w - 1] : 0.0f; };
-    auto right = [&](int y) { return (has_r && y < h) ? col[(size_t)y * (size_t)w + 4] : 0.0f; };
+    // Every load is issued with its row and column clamped into the image and nothing is zeroed afterwards: a clamped sample
+    // only ever reaches a border pixel, whose results are discarded (gradient_pixel's `interior`).  No load sits under a branch
+    // or behind a selected pointer (a select between the global row and a zero vector in private memory compiles to a FLAT load).
+    const int lo_off = has_l ? -1 : 0, ro_off = has_r ? 4 : 3;
+    auto rowc = [&](int y) { return (size_t)min(max(y, 0), h - 1) * (size_t)w; };
+    auto row4 = [&](int y) { return *reinterpret_cast<const float4*>(col + rowc(y)); };
+    auto left = [&](int y) { return col[(ptrdiff_t)rowc(y) + lo_off]; };
+    auto right = [&](int y) { return col[(ptrdiff_t)rowc(y) + ro_off]; };
     float4 u4 = row4(y0 - 1), c4 = row4(y0);
     float lf = left(y0), rt = right(y0);
     unsigned any = 0u;
