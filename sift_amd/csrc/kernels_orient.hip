@@ -245,19 +245,24 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
                     const unsigned long long a64 =
                         (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)org_prod, src) |
                         ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(org_prod >> 32), src) << 32);
-                    const float* __restrict__ gp = reinterpret_cast<const float*>((uintptr_t)a64);
+                    // (pointers made from integers are generic: spelled as global ones, or the loads become FLAT loads, which also
+                    // count against the LDS counter the staging below waits on)
+                    typedef const __attribute__((address_space(1))) float* gfloat_p;
+                    typedef const __attribute__((address_space(1))) uint8_t* gbyte_p;
+                    const gfloat_p gp = (gfloat_p)(uintptr_t)a64;
                     const int w = __builtin_amdgcn_readlane(pitch, src);
                     if (bins_zero) {
                         // one 16-byte load per lane covers the whole window: lane = (row, 4-column group)
                         const size_t o = (size_t)(lane >> 2) * (size_t)w + (size_t)(4 * (lane & 3));
                         typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-                        const f4u v4 = *reinterpret_cast<const f4u*>(gp + o);
+                        typedef const __attribute__((address_space(1))) f4u* gf4u_p;
+                        const f4u v4 = *(gf4u_p)(gp + o);
                         pp[k][0] = v4.x; pp[k][1] = v4.y; pp[k][2] = v4.z; pp[k][3] = v4.w;
                     } else {
                         const unsigned long long b64 =
                             (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)org_bin, src) |
                             ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(org_bin >> 32), src) << 32);
-                        const uint8_t* __restrict__ gb = reinterpret_cast<const uint8_t*>((uintptr_t)b64);
+                        const gbyte_p gb = (gbyte_p)(uintptr_t)b64;
 #pragma unroll
                         for (int it = 0; it < 4; ++it) {
                             const int ly = it * 4 + (lane >> 4);
