@@ -61,17 +61,29 @@ def host_cpu():
     return {"host_cores": os.cpu_count(), "host_cpu": model}
 
 
+def _result_digest(pts, desc):
+    """SHA-256 over one image's returned keypoints (x, y, octave, index, scale, orientation) and its 128-float descriptors."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("x", "y", "octave", "index", "scale", "orientation"):
+        h.update(np.ascontiguousarray(pts[f]).tobytes())
+    h.update(np.ascontiguousarray(desc, dtype=np.float32).tobytes())
+    return h.hexdigest()
+
+
 def cpu_baseline(frames, faithful=True):
     """Oracle on a bounded sample of the same workload, 1 thread, on this box's host cores: lean mode (identical results to
     the reference, its redundant copies hoisted) on 8 frames, and faithful mode (the reference's own cost structure: three
     DoG images copied per extremum candidate, sift.cpp:297-298, a level re-blurred per keypoint, sift.cpp:87) on one."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    kps, secs = 0, 0.0
+    kps, secs, per_frame = 0, 0.0, []
     for f in frames:
         run = O.OracleRun(f, DOGS, OCTAVES, SIGMA)
         secs += run.seconds
-        kps += run.points("final")[0].size
+        pts, desc = run.points("final")
+        kps += pts.size
+        per_frame.append((int(pts.size), _result_digest(pts, desc)))
         run.close()
     faith = None
     if faithful:
@@ -96,7 +108,7 @@ def cpu_baseline(frames, faithful=True):
                       "container (not on this box: the reference does not travel); same keypoints and descriptors, bit for bit"}
     except Exception:
         pass
-    return {"reference_binary": ref, "faithful": faith, **host_cpu(), "value": kps / secs, "unit": "keypoints/s", "cores": 1, "kind": "port",
+    return {"per_frame": per_frame, "reference_binary": ref, "faithful": faith, **host_cpu(), "value": kps / secs, "unit": "keypoints/s", "cores": 1, "kind": "port",
             "sample": f"{len(frames)} of the {FRAMES_PER_GPU} synthetic 1920x1080 frames, 4 oct x 3 DoG, oracle in lean mode "
                       f"(reference's per-candidate image copies and per-keypoint re-blur hoisted; same results), "
                       f"{secs:.1f} s CPU, {kps} keypoints"}
@@ -139,6 +151,46 @@ def pmc_traffic_live(extra_args):  # noqa: C901
     return tot["FETCH_SIZE"] * 1024 * 2 + tot["WRITE_SIZE"] * 1024, f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this bench on this box ({launches} blur launches each; FETCH_SIZE x2)"
 
 
+def launch_ranks(n):
+    """Start `n` children of this script, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as
+    torch.distributed.run would), wait for all, return the exit status (non-zero if any rank failed).  Called before anything in
+    this process has initialised the GPU; the children are ordinary subprocesses (no exec of a process that touched HIP).
+    Rank 0 inherits stdout, so its one JSON line is this command's one JSON line; the other ranks' stdout goes to stderr."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    status = 0
+    try:
+        pending = dict(enumerate(procs))
+        while pending:
+            for r, p in list(pending.items()):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                del pending[r]
+                if rc != 0:
+                    print(f"bench.py: rank {r} exited with status {rc}", file=sys.stderr)
+                    status = status or (rc if rc > 0 else 1)
+                    for q in pending.values():     # a dead rank leaves the others waiting in a collective: end them (exact PIDs)
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return status
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,6 +202,9 @@ def main():
                          "configurations at their nearest non-throwing parameters (SURVEY 8(d)), reported as labelled extra lines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the legs beside the headline: host-buffer rate, single-frame latency, live PMC traffic")
+    ap.add_argument("--pmc-traffic", type=int, default=1, choices=[0, 1],
+                    help="1 (default): roofline.traffic is measured live by two child passes of this bench under rocprofv3 --pmc "
+                         "(FETCH_SIZE / WRITE_SIZE, one step each); 0: traffic stays null")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "exercise the N > 1 flow where ranks have to share one GPU: results are staged through host memory)")
     ap.add_argument("--share-device", action="store_true", help="testing: every rank uses GPU 0")
@@ -176,8 +231,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # bare `python bench.py --gpus N`: this process becomes the launcher.  It has not touched the GPU (no torch import,
+        # no HIP call so far) and never will: N fresh children, one rank per GPU, rank 0's JSON line passed through.
+        raise SystemExit(launch_ranks(args.gpus))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, "
+                         f"or bare (no WORLD_SIZE in the environment) to let bench.py start its own ranks")
 
     import torch
     import torch.distributed as dist
@@ -191,6 +251,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
     loopback = bool(args.rccl_loopback) and world == 1
+    rccl_ranks = 0
     if loopback:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
@@ -198,6 +259,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)                       # creates the RCCL communicator; every rank contributes 1
+            rccl_ranks = int(probe.item()) if int(probe.item()) == dist.get_world_size() else -1
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
@@ -242,7 +306,7 @@ def main():
         if gatherer is not None:
             # wire format (lossless, sift_amd/gather.py): sparse = 34-byte records (20 + 112 presence bits) + the floats that are set
             rec_out = None
-            if args.wire == "sparse" and comm_dev.type != "cpu" and gatherer.rank != gatherer.dst or (loopback and args.wire == "sparse"):
+            if args.wire == "sparse" and ((comm_dev.type != "cpu" and gatherer.rank != gatherer.dst) or loopback):
                 rec_out = gatherer.records_buffer(total * 34)   # the records are packed straight into their message buffer
             kp, desc = device_results(c, total, dev, wire=args.wire, rec_out=rec_out)
             counts = c.counts()
@@ -321,7 +385,7 @@ def main():
             "config": {"workload": label.format(n=nf),
                        "frames_per_gpu": nf, "frames_total": nf * world, "pipeline_depth": depth, "pipeline_gate": bool(args.pipeline_gate) and depth > 1, "keypoints_per_step": kps // max(args.steps, 1),
                        "frames_per_s": nf * world * args.steps / dt,
-                       "rccl_ranks": world if ((world > 1 or loopback) and args.backend == "nccl") else 0,
+                       "rccl_ranks": rccl_ranks,   # as the RCCL communicator reports it (0: no RCCL communicator in this run)
                        "rccl_loopback": loopback,   # N = 1 with the N > 1 gather messages sent through RCCL to this same rank
                        "gather_steps_on_rank0": (gathered[0] - gatherer_t0[0]) if gatherer is not None else None,
                        "gather_keypoints_on_rank0": (gathered[1] - gatherer_t0[1]) if gatherer is not None else None,
@@ -385,13 +449,29 @@ def main():
                 ctx.results(pin_out[0][0], pin_out[0][1])
                 lat.append(time.perf_counter() - t_0)
             out["single_frame_ms"] = float(np.median(lat[2:]) * 1e3)
-            if args.workload == "config4" or True:
+            if args.pmc_traffic:
                 extra = ["--workload", args.workload, "--frames", str(nf)] + [a for kv in args.set for a in ("--set", kv)]
                 traffic, src = pmc_traffic_live(extra)
                 out["roofline"]["traffic"] = traffic
                 out["roofline"]["traffic_source"] = src
         if world == 1 and not args.no_cpu_baseline and args.workload == "config4":
             out["cpu_baseline"] = cpu_baseline(frames[:CPU_SAMPLE_FRAMES])
+            # ---- result check of this very run, outside the timed region: one more step of the batch through the same pipeline,
+            # its first CPU_SAMPLE_FRAMES images' keypoints and descriptors against what the oracle just computed for those frames
+            per_frame = out["cpu_baseline"].pop("per_frame")
+            tk = pipe.submit_device(d_frames.data_ptr(), nf, W, H, params)
+            c = tk.result()
+            cnt = c.counts().copy()
+            kp_h, de_h = c.results()
+            ok, base = True, 0
+            for i, (n_want, digest) in enumerate(per_frame):
+                n = int(cnt[i])
+                ok = ok and n == n_want and _result_digest(kp_h[base:base + n], de_h[base:base + n]) == digest
+                base += n
+            tk.release()
+            out["parity_spot_check"] = bool(ok)
+            out["parity_spot_check_what"] = (f"frames 1..{len(per_frame)} of one more step of this batch: per-image keypoint count and SHA-256 over "
+                                            "(x, y, octave, index, scale, orientation, 128-float descriptors) equal the oracle's")
         print(json.dumps(out), flush=True)
     pipe.close()
     if world > 1 or loopback:

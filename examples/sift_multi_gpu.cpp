@@ -15,6 +15,7 @@
 extern "C" int hipGetDeviceCount(int*);
 
 int main(int argc, char** argv) {
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);   // before the first HIP call: contexts side by side want hardware queues of their own
     if (argc < 2) {
         std::cerr << "usage: " << argv[0] << " image.{pgm,ppm,png} [frames] [shards]\n";
         return 1;

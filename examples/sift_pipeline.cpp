@@ -37,6 +37,7 @@ static bool same(const std::vector<sift::InterestPoint>& a, const std::vector<si
 }
 
 int main(int argc, char** argv) {
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);   // before the first HIP call: contexts side by side want hardware queues of their own
     if (argc < 2) {
         std::cerr << "usage: " << argv[0] << " image.pgm [frames]\n";
         return 1;

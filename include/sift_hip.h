@@ -98,13 +98,15 @@ int sift_hip_set_option(sift_hip_ctx* ctx, const char* name, int value);
  * order in which their calculate calls begin. */
 typedef struct sift_hip_gate sift_hip_gate;
 int sift_hip_gate_create(int device, sift_hip_gate** out);
-void sift_hip_gate_destroy(sift_hip_gate* gate);              /* after the contexts using it are detached or destroyed */
+/* The host's handle goes at once; the gate itself lives until the last context joined by it has left (sift_hip_set_gate(ctx,
+ * NULL) or sift_hip_destroy), so contexts and gate may be destroyed in either order.  No context can join a gate after this. */
+void sift_hip_gate_destroy(sift_hip_gate* gate);
 /* NULL detaches; not while a batch is running.  SIFT_HIP_EINVAL for a gate of another device and for the fifth
  * context on one gate (a gate tells at most four batches in flight apart). */
 int sift_hip_set_gate(sift_hip_ctx* ctx, sift_hip_gate* gate);
-/* Contexts that run side by side need hardware queues of their own: sift_hip_create / sift_hip_gate_create put
- * GPU_MAX_HW_QUEUES=8 into the environment unless the host has set it, which the HIP runtime honours if it has not
- * been initialised yet (i.e. when one of these is the process's first HIP call); otherwise export it yourself. */
+/* Contexts that run side by side need hardware queues of their own: the HOST exports GPU_MAX_HW_QUEUES=8 (the HIP runtime's
+ * default is 4) before its first HIP call - the library never writes the environment (setenv beside a host's other threads
+ * is not safe).  sift_amd/_lib.py does it at import, the example programs at the top of main(). */
 
 /* ---- host memory the copy engines can reach directly ------------------------------------------------------
  * calculate / result_copy accept any host pointer.  Memory from sift_hip_host_alloc (page-locked) moves at the PCIe rate

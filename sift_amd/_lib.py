@@ -73,6 +73,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the HIP path)")
+    # contexts that run side by side (BatchPipeline) need hardware queues of their own; the HIP runtime reads this when it
+    # initialises, the library itself never writes the environment
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     _preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")

@@ -1175,7 +1175,9 @@ int guarded(char* err, int errlen, F&& f) {
 // of different contexts share a queue and inherit each other's ordering (the phase gate then loses what it arranges).
 // The runtime reads GPU_MAX_HW_QUEUES when it initialises, so this only has an effect if it comes before the process's
 // first HIP call; a value the host has set is left alone.
-static void default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// The library does not touch the environment (setenv is not safe beside a host's other threads): the HOST sets
+// GPU_MAX_HW_QUEUES=8 before its first HIP call when it runs several contexts on one GPU (sift_amd/_lib.py does at import,
+// the example programs do at the top of main).
 
 extern "C" {
 
@@ -1184,7 +1186,6 @@ const char* sift_hip_version(void) { return "sift_hip 0.1 (gfx950)"; }
 int sift_hip_create(int device, sift_hip_ctx** out, char* err, int errlen) {
     if (!out) return SIFT_HIP_EINVAL;
     *out = nullptr;
-    default_hw_queues();
     return guarded(err, errlen, [&]() {
         int count = 0;
         SIFT_HIP_CHECK(hipGetDeviceCount(&count));
@@ -1237,12 +1238,12 @@ struct sift_hip_gate {
     sift_hip::PhaseGate gate;
     std::mutex m;
     int attached = 0;     // contexts joined by this gate (at most PhaseGate::kMaxContexts: its slot ring)
+    bool released = false;   // sift_hip_gate_destroy has been called: the last context to leave frees the gate
 };
 
 
 int sift_hip_gate_create(int device, sift_hip_gate** out) {
     if (!out) return SIFT_HIP_EINVAL;
-    default_hw_queues();
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return SIFT_HIP_EINVAL;
     if (hipSetDevice(device) != hipSuccess) return SIFT_HIP_EHIP;
@@ -1254,6 +1255,13 @@ int sift_hip_gate_create(int device, sift_hip_gate** out) {
 
 void sift_hip_gate_destroy(sift_hip_gate* g) {
     if (!g) return;
+    // contexts still joined by the gate keep it alive (they reach into it from run_batch and from sift_hip_destroy): the
+    // gate goes when the last of them leaves, whichever order the host destroys things in
+    {
+        std::lock_guard<std::mutex> lk(g->m);
+        g->released = true;
+        if (g->attached > 0) return;
+    }
     (void)hipSetDevice(g->device);
     delete g;
 }
@@ -1263,13 +1271,21 @@ int sift_hip_set_gate(sift_hip_ctx* c, sift_hip_gate* g) {
     if (c->gate_owner == g) return SIFT_HIP_OK;
     if (g) {
         std::lock_guard<std::mutex> lk(g->m);
+        if (g->released) return SIFT_HIP_EINVAL;
         // more contexts than the gate's ring can tell apart would reuse the slot of a batch that is still live
         if (g->attached >= sift_hip::PhaseGate::kMaxContexts) return SIFT_HIP_EINVAL;
         g->attached++;
     }
     if (c->gate_owner) {
-        std::lock_guard<std::mutex> lk(c->gate_owner->m);
-        c->gate_owner->attached--;
+        bool last;
+        {
+            std::lock_guard<std::mutex> lk(c->gate_owner->m);
+            last = --c->gate_owner->attached == 0 && c->gate_owner->released;
+        }
+        if (last) {
+            (void)hipSetDevice(c->device);
+            delete c->gate_owner;
+        }
     }
     c->gate_owner = g;
     c->gate = g ? &g->gate : nullptr;

@@ -30,6 +30,10 @@ bool decode_jpeg(const uint8_t* data, size_t n, int& w, int& h, int& bands, std:
 
 namespace {
 
+// Largest image a file may announce (2^26 pixels = 8192 x 8192; BASELINE's largest input is 3840 x 2160): a header is
+// untrusted, and every decoder also checks that the file is long enough for its header BEFORE allocating for it.
+constexpr long long kMaxPixels = 1LL << 26;
+
 struct Raster {          // decoded file: interleaved samples, 8 or 16 bit per sample, as stored
     int w = 0, h = 0, bands = 0, bits = 8;
     std::vector<uint16_t> px;   // w * h * bands
@@ -56,7 +60,7 @@ bool read_file(const char* path, std::vector<uint8_t>& buf, std::string& msg) {
 struct PnmCursor {
     const std::vector<uint8_t>& b;
     size_t i;
-    bool token(long& v) {   // next unsigned integer, skipping whitespace and # comments
+    bool token(long& v) {   // next unsigned integer (saturating at 2^40: no signed overflow on a damaged file), skipping whitespace and # comments
         for (;;) {
             while (i < b.size() && std::isspace(b[i])) ++i;
             if (i < b.size() && b[i] == '#') { while (i < b.size() && b[i] != '\n') ++i; continue; }
@@ -64,7 +68,10 @@ struct PnmCursor {
         }
         if (i >= b.size() || !std::isdigit(b[i])) return false;
         v = 0;
-        while (i < b.size() && std::isdigit(b[i])) v = v * 10 + (b[i++] - '0');
+        while (i < b.size() && std::isdigit(b[i])) {
+            const long d = b[i++] - '0';
+            v = v > (1L << 40) ? v : v * 10 + d;
+        }
         return true;
     }
 };
@@ -73,9 +80,13 @@ bool decode_pnm(const std::vector<uint8_t>& b, Raster& r, std::string& msg) {
     const int kind = b[1] - '0';   // 2 grey ascii, 3 rgb ascii, 5 grey raw, 6 rgb raw
     PnmCursor c{b, 2};
     long w, h, maxv;
-    if (!c.token(w) || !c.token(h) || !c.token(maxv) || w <= 0 || h <= 0 || w > (1L << 20) || h > (1L << 20) || maxv <= 0 || maxv > 65535) { msg = "bad PNM header"; return false; }
+    if (!c.token(w) || !c.token(h) || !c.token(maxv) || w <= 0 || h <= 0 || w > (1L << 20) || h > (1L << 20) || w * h > kMaxPixels || maxv <= 0 || maxv > 65535) { msg = "bad PNM header"; return false; }
     r.w = (int)w; r.h = (int)h; r.bands = (kind == 3 || kind == 6) ? 3 : 1; r.bits = maxv < 256 ? 8 : 16;
     const size_t n = (size_t)w * (size_t)h * (size_t)r.bands;
+    // the file must be able to hold what its header announces before anything is allocated: a raw sample takes 1 or 2 bytes,
+    // an ASCII sample at least 2 (a digit and a separator; the last one may lack it)
+    const size_t need = (kind == 2 || kind == 3) ? 2 * n - 1 : n * (maxv < 256 ? 1 : 2);
+    if (c.i >= b.size() || b.size() - c.i < need) { msg = "truncated PNM"; return false; }
     r.px.resize(n);
     if (kind == 2 || kind == 3) {
         for (size_t k = 0; k < n; ++k) { long v; if (!c.token(v)) { msg = "truncated PNM"; return false; } r.px[k] = (uint16_t)v; }
@@ -145,7 +156,7 @@ bool decode_png(const std::vector<uint8_t>& b, Raster& r, bool expand_low_grey, 
         }
         i += 12 + len;
     }
-    if (!have_hdr || w <= 0 || h <= 0 || (long long)w * (long long)h > (1LL << 31)) { msg = "bad PNG header"; return false; }
+    if (!have_hdr || w <= 0 || h <= 0 || (long long)w * (long long)h > kMaxPixels) { msg = "bad PNG header"; return false; }
     const int chans = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     const bool depth_ok = (ctype == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) ||
                           (ctype == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) ||
@@ -167,6 +178,8 @@ bool decode_png(const std::vector<uint8_t>& b, Raster& r, bool expand_low_grey, 
         total += (size_t)q.ph * (q.stride + 1);
         passes.push_back(q);
     }
+    // deflate cannot expand by more than 1032 : 1: a short IDAT stream cannot justify the buffers its header asks for
+    if (idat.empty() || (unsigned long long)idat.size() * 1032ull < (unsigned long long)total) { msg = "PNG inflate failed"; return false; }
     std::vector<uint8_t> raw(total);
     uLongf out_len = (uLongf)total;
     const int zr = uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size());

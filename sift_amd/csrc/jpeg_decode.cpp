@@ -56,40 +56,47 @@ struct BitReader {
     const uint8_t* end;
     uint64_t acc = 0;
     int n = 0;
-    int marker = 0;   // marker met inside the entropy-coded data (reading then continues with zero bits, as libjpeg does)
+    int marker = 0;   // marker met inside the entropy-coded data: no byte is read past it
+    // jdhuff.c jpeg_fill_bit_buffer: a code or a value that needs more bits than the segment holds gets zero bits and sets
+    // `insufficient_data`; the MCU in progress is finished with those zeros, the following ones up to the next restart are
+    // left as they are (zero coefficients: uniform grey)
+    bool insufficient = false;
     void fill() {
-        while (n <= 56) {
+        while (n <= 56 && !marker) {
             unsigned byte = 0;
-            if (!marker && p < end) {
+            if (p < end) {
                 byte = *p++;
                 if (byte == 0xff) {
                     while (p < end && *p == 0xff) ++p;   // fill bytes
                     if (p < end && *p == 0) ++p;         // stuffed zero: a data byte 0xff
-                    else { marker = p < end ? *p++ : 0xd9; byte = 0; }
+                    else { marker = p < end ? *p++ : 0xd9; break; }
                 }
-            } else if (!marker) {
+            } else {
                 marker = 0xd9;
+                break;
             }
             acc |= (uint64_t)byte << (56 - n);
             n += 8;
         }
     }
+    void starve() { insufficient = true; n = 57; }   // the accumulator's bits below the valid ones are zero already
     unsigned peek16() { if (n < 16) fill(); return (unsigned)(acc >> 48); }
     void skip(int k) { acc <<= k; n -= k; }
     unsigned receive(int k) {   // k <= 16
         if (k == 0) return 0;
-        if (n < k) fill();
+        if (n < k) { fill(); if (n < k) starve(); }
         const unsigned v = (unsigned)(acc >> (64 - k));
         skip(k);
         return v;
     }
     int decode(const HuffTable& t, bool& ok) {
         const unsigned e = t.look[peek16()];
-        if (!e) { ok = false; return 0; }
+        if (!e) { if (n < 16 && marker) { starve(); return 0; } ok = false; return 0; }
+        if ((int)(e >> 8) > n) starve();
         skip((int)(e >> 8));
         return (int)(e & 0xff);
     }
-    void restart() { acc = 0; n = 0; marker = 0; }
+    void restart() { acc = 0; n = 0; marker = 0; insufficient = false; }
 };
 
 inline int extend(unsigned v, int s) { return v < (1u << (s - 1)) ? (int)v - (1 << s) + 1 : (int)v; }
@@ -118,18 +125,18 @@ void idct_islow(const int16_t* in, const int* q, uint8_t* out, int pitch) {
         const int* qp = q + c;
         int* wp = ws + c;
         if (!(ip[8] | ip[16] | ip[24] | ip[32] | ip[40] | ip[48] | ip[56])) {
-            const int dc = (ip[0] * qp[0]) * (1 << P1);
+            const int dc = (int)(((unsigned)ip[0] * (unsigned)qp[0]) << P1);   // same bits as the signed product; no overflow on a damaged file
             for (int r = 0; r < 8; ++r) wp[8 * r] = dc;
             continue;
         }
-        long z2 = ip[16] * qp[16], z3 = ip[48] * qp[48];
+        long z2 = (long)ip[16] * qp[16], z3 = (long)ip[48] * qp[48];
         long z1 = (z2 + z3) * F0541;
         long tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
-        z2 = ip[0] * qp[0];
-        z3 = ip[32] * qp[32];
+        z2 = (long)ip[0] * qp[0];
+        z3 = (long)ip[32] * qp[32];
         long tmp0 = (z2 + z3) * (1L << CB), tmp1 = (z2 - z3) * (1L << CB);
         const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
-        tmp0 = ip[56] * qp[56]; tmp1 = ip[40] * qp[40]; tmp2 = ip[24] * qp[24]; tmp3 = ip[8] * qp[8];
+        tmp0 = (long)ip[56] * qp[56]; tmp1 = (long)ip[40] * qp[40]; tmp2 = (long)ip[24] * qp[24]; tmp3 = (long)ip[8] * qp[8];
         z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
         long z4 = tmp1 + tmp3;
         const long z5 = (z3 + z4) * F1175;
@@ -304,7 +311,7 @@ struct Decoder {
         W = p[3] << 8 | p[4];
         ncomp = p[5];
         if (W <= 0 || H <= 0) return fail("bad JPEG size");
-        if ((long long)W * (long long)H > (1LL << 28)) return fail("JPEG image too large");
+        if ((long long)W * (long long)H > (1LL << 26)) return fail("JPEG image too large");   // a header is untrusted (image_io.cpp kMaxPixels)
         if (ncomp != 1 && ncomp != 3) return fail("only greyscale and three-component JPEG files are decoded");
         if (len < 6 + 3 * (size_t)ncomp) return fail("truncated JPEG frame header");
         for (int c = 0; c < ncomp; ++c) {
@@ -325,8 +332,7 @@ struct Decoder {
             k.dw = (W * k.h + hmax - 1) / hmax;
             k.dh = (H * k.v + vmax - 1) / vmax;
             k.bw = mcux * k.h;
-            k.bh = mcuy * k.v;
-            k.coef.assign((size_t)k.bw * (size_t)k.bh * 64, 0);
+            k.bh = mcuy * k.v;   // the coefficient arrays are allocated by the first scan, once entropy-coded data is seen to exist
         }
         have_sof = true;
         return true;
@@ -337,7 +343,7 @@ struct Decoder {
         bool ok = true;
         int s = br.decode(dc[k.td], ok);
         if (!ok || s > 16) return fail("corrupt JPEG data");
-        if (s) k.pred += extend(br.receive(s), s);
+        if (s) k.pred = (int)((unsigned)k.pred + (unsigned)extend(br.receive(s), s));   // wraps on a damaged file, never overflows
         blk[0] = (int16_t)k.pred;
         for (int i = 1; i < 64; ++i) {
             const int rs = br.decode(ac[k.ta], ok);
@@ -359,8 +365,8 @@ struct Decoder {
         bool ok = true;
         const int s = br.decode(dc[k.td], ok);
         if (!ok || s > 16) return fail("corrupt JPEG data");
-        if (s) k.pred += extend(br.receive(s), s);
-        blk[0] = (int16_t)(k.pred * (1 << al));
+        if (s) k.pred = (int)((unsigned)k.pred + (unsigned)extend(br.receive(s), s));
+        blk[0] = (int16_t)((unsigned)k.pred << al);
         return true;
     }
 
@@ -461,6 +467,15 @@ struct Decoder {
             if (need_ac && !ac[sc[i]->ta].defined) return fail("JPEG Huffman table missing");
         }
 
+        // Nothing is allocated for a header alone: a block takes at least one bit of entropy-coded data in a scan, so a file
+        // shorter than that cannot hold the image its frame header announces.
+        {
+            unsigned long long blocks = 0;
+            for (int i = 0; i < ns; ++i) blocks += (unsigned long long)sc[i]->bw * (unsigned long long)sc[i]->bh;
+            if ((unsigned long long)(data_end - (p + len)) * 8ull < blocks / 2) return fail("truncated JPEG data");
+            for (int c = 0; c < ncomp; ++c)
+                if (comp[c].coef.empty()) comp[c].coef.assign((size_t)comp[c].bw * (size_t)comp[c].bh * 64, 0);
+        }
         BitReader br{p + len, data_end};
         for (int c = 0; c < ncomp; ++c) comp[c].pred = 0;
         eobrun = 0;
@@ -486,19 +501,48 @@ struct Decoder {
         for (int y = 0; y < my; ++y)
             for (int x = 0; x < mx; ++x) {
                 if (restart_interval && until_restart == 0) {
-                    // byte-align, expect RSTn; a missing marker is tolerated the way libjpeg's default resync does for the common case
-                    br.fill();
-                    if (br.marker >= 0xd0 && br.marker <= 0xd7) {
-                        const uint8_t* resume = br.p;
-                        br.restart();
-                        br.p = resume;
-                    } else {
-                        return fail("JPEG restart marker missing");
+                    // jdhuff.c process_restart + jdmarker.c read_restart_marker: drop the bits left, take the marker the reader ran
+                    // into (or the next one in the stream); the expected RSTn is swallowed, anything else goes through libjpeg's
+                    // default jpeg_resync_to_restart.  A damaged file is decoded, not refused (libjpeg only warns).
+                    int m = br.marker;
+                    const uint8_t* q = br.p;
+                    auto next_marker = [&]() -> int {   // jdmarker.c next_marker: the next 0xff that is followed by neither 0x00 nor 0xff
+                        for (;;) {
+                            while (q < data_end && *q != 0xff) ++q;
+                            while (q < data_end && *q == 0xff) ++q;
+                            if (q >= data_end) return 0xd9;
+                            if (*q != 0) return *q++;
+                            ++q;
+                        }
+                    };
+                    if (!m) m = next_marker();
+                    bool starved = false;   // the marker stays unread: the segment up to the next restart has no data (zero blocks)
+                    if (m != 0xd0 + next_rst) {
+                        for (;;) {
+                            int action;
+                            if (m < 0xc0) action = 2;                                   // not a marker libjpeg knows: skip it
+                            else if (m < 0xd0 || m > 0xd7) action = 3;                  // a real non-restart marker: stop in front of it
+                            else if (m == 0xd0 + ((next_rst + 1) & 7) || m == 0xd0 + ((next_rst + 2) & 7)) action = 3;   // one of the next two restarts
+                            else if (m == 0xd0 + ((next_rst - 1) & 7) || m == 0xd0 + ((next_rst - 2) & 7)) action = 2;   // an earlier restart: advance
+                            else action = 1;                                            // the expected one, or too far away: resume after it
+                            if (action == 2) { m = next_marker(); continue; }
+                            starved = action == 3;
+                            break;
+                        }
                     }
+                    br.restart();
+                    br.p = q;
+                    // jdhuff.c process_restart: with the marker left unread the segment is empty - its first MCU is decoded from
+                    // zero bits (which sets insufficient_data), the rest is skipped
+                    if (starved) br.marker = m;
                     next_rst = (next_rst + 1) & 7;
                     for (int c = 0; c < ncomp; ++c) comp[c].pred = 0;
                     eobrun = 0;
                     until_restart = restart_interval;
+                }
+                if (br.insufficient) {          // jdhuff.c: "if (!entropy->pub.insufficient_data)" - the MCU's blocks keep their zeros
+                    --until_restart;
+                    continue;
                 }
                 if (ns == 1) {
                     if (!one_block(*sc[0], x, y)) return false;

@@ -112,6 +112,7 @@ class Context:
             pass
 
     def set_gate(self, gate: "Gate | None"):
+        self._gate = gate    # keeps the Gate object alive as long as this context points at it
         if self._L.sift_hip_set_gate(self._h, gate._h if gate is not None else None):
             raise ValueError("gate and context are on different devices, or the gate already joins its maximum of four contexts")
 

@@ -89,6 +89,58 @@ def test_jpeg_reader_against_pil_large(tmp_path):
         assert np.array_equal(cli.read_image(str(tmp_path / name)), ref[:, :, 0].astype(np.float32)), name
 
 
+def test_jpeg_reader_resyncs_like_libjpeg(tmp_path):
+    """Damaged restart markers (a marker missing, renumbered, a whole segment missing, garbage in front of one): libjpeg only warns
+    and resynchronises (jdmarker.c jpeg_resync_to_restart, jdhuff.c insufficient_data), so the reference's ingest still returns an
+    image; so does this reader, pixel for pixel what libjpeg-turbo returns (through PIL)."""
+    import io
+    import re
+    Image = pytest.importorskip("PIL.Image")
+    from sift_amd.synthetic import synth_frame
+    img = synth_frame(320, 240, 3).astype(np.uint8)
+    rgb = np.stack([img, np.roll(img, 5, 1), np.roll(img, 9, 0)], -1)
+    for k, opts in enumerate((dict(restart_marker_rows=1), dict(restart_marker_blocks=3), dict(restart_marker_rows=1, progressive=True),
+                              dict(restart_marker_blocks=5, subsampling=0))):
+        buf = io.BytesIO()
+        Image.fromarray(rgb).save(buf, "JPEG", quality=85, **opts)
+        b = buf.getvalue()
+        pos = [m.start() for m in re.finditer(b"\xff[\xd0-\xd7]", b)]
+        assert len(pos) > 8
+        renum = lambda d: b[:pos[3] + 1] + bytes([0xd0 + ((b[pos[3] + 1] - 0xd0 + d) & 7)]) + b[pos[3] + 2:]   # noqa: E731
+        cases = {"intact": b, "marker removed": b[:pos[3]] + b[pos[3] + 2:], "next number": renum(1), "previous number": renum(-1),
+                 "far number": renum(4), "segment dropped": b[:pos[3]] + b[pos[4]:], "garbage before a marker": b[:pos[5]] + b"\x12\x34\x56" + b[pos[5]:]}
+        for name, data in cases.items():
+            path = tmp_path / f"r{k}.jpg"
+            path.write_bytes(data)
+            ref = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+            assert np.array_equal(cli.read_image_bgr(str(path))[:, :, ::-1], ref), (opts, name)
+
+
+def test_headers_cannot_make_the_readers_allocate(tmp_path):
+    """A header is untrusted: a file of a few hundred bytes that announces 2^30 pixels (or 2^26, the largest accepted, without
+    the data for them) is refused before any buffer of that size exists (no std::bad_alloc, no OOM kill)."""
+    import struct
+    import zlib
+
+    def png(w, h, idat):
+        def chunk(t, d):
+            return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+        return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) + chunk(b"IDAT", idat) + chunk(b"IEND", b"")
+    whole = open(os.path.join(IMG, "rgb_420.jpg"), "rb").read()
+    sof = whole.index(b"\xff\xc0")
+    files = {"huge.png": png(32768, 32768, zlib.compress(bytes(64))), "big.png": png(8192, 8192, zlib.compress(bytes(64))),
+             "huge.pgm": b"P5 1000000 1000000 255\n" + bytes(64), "big.pgm": b"P5 8192 8192 255\n" + bytes(64),
+             "big.ppm": b"P3 8192 8192 255\n1 2 3\n", "overflow.pgm": b"P5 99999999999999999999999999 1 255\n" + bytes(8),
+             "huge.jpg": whole[:sof + 5] + b"\xff\xff\xff\xff" + whole[sof + 9:], "big.jpg": whole[:sof + 5] + b"\x20\x00\x20\x00" + whole[sof + 9:1200]}
+    for name, data in files.items():
+        (tmp_path / name).write_bytes(data)
+    for name in files:
+        with pytest.raises(OSError):
+            cli.read_image(str(tmp_path / name))
+        with pytest.raises(OSError):
+            cli.read_image_bgr(str(tmp_path / name))
+
+
 def test_jpeg_reader_on_the_reference_example():
     """The reference's own example input (example/parrot.jpg, where the reference tree is present): its red band is the PGM the
     config 1 tests run on (tests/golden/parrot_r.pgm, written with PIL's libjpeg-turbo in round 1)."""

@@ -311,6 +311,97 @@ def test_pipeline_parity_bench_workload(ctx, report_dir):
     assert rep["final"] > 0
 
 
+def test_pipeline_parity_bench_frames(ctx, report_dir):
+    """The bench's own CONTENT: synth_frame(1920, 1080, s) for s = 1..32 (what bench.py's rank 0 runs), 32 distinct frames in
+    ONE batch, so every image of the launch has its own candidate count, cleanup rounds, list offsets and output offset
+    (sift.cpp:37-54 per image).  Every frame: every stage list (coordinates, octave / index, scale, flags, orientations),
+    the per-image counts, the keypoint records and all descriptors, bit for bit against the oracle; three frames also every
+    Gaussian and DoG level; frame 1 also against what the reference's own binary returned for it."""
+    import hashlib
+    dogs, octaves = 3, 4
+    frames = np.stack([synth_frame(1920, 1080, s) for s in range(1, 33)])
+    ctx.calculate_batch(frames, _lib.Params(dogs, octaves, 1.6, O.K_SQRT2, 0))
+    counts = ctx.counts().copy()
+    kp, desc = ctx.results()
+    kp, desc = kp.copy(), desc.copy()
+    assert len(set(counts.tolist())) > 16, "the frames should differ in their keypoint counts"
+    base, rep = 0, {"case": "bench frames 1..32 in one batch", "counts": counts.tolist()}
+    for i in range(32):
+        run = O.OracleRun(frames[i], dogs, octaves)
+        assert run.status == 0, run.error
+        for stage in ("candidates", "after_sort1", "after_orient", "after_sort2", "final"):
+            got = ctx.stage(stage, i)
+            want, wdesc = run.points(stage)
+            assert got.size == want.size, f"frame {i + 1}: {stage}: {got.size} points vs oracle {want.size}"
+            for f in ("x", "y", "octave", "index"):
+                assert (got[f] == want[f]).all(), f"frame {i + 1}: {stage}: field {f}"
+            assert got["scale"].tobytes() == want["scale"].tobytes(), f"frame {i + 1}: {stage}: scale"
+            if stage != "after_sort1":
+                assert (got["filtered"].astype(bool) == want["filtered"].astype(bool)).all(), f"frame {i + 1}: {stage}: filtered"
+            if stage in ("after_orient", "after_sort2", "final"):
+                m = ~want["filtered"].astype(bool)
+                assert_bits_equal(got["orientation"][m], want["orientation"][m], f"frame {i + 1}: {stage}: orientation")
+        want, wdesc = run.points("final")
+        assert counts[i] == want.size, f"frame {i + 1}: count"
+        k = kp[base:base + want.size]
+        for f in ("x", "y", "octave", "index"):
+            assert (k[f] == want[f]).all(), f"frame {i + 1}: result field {f}"
+        assert k["scale"].tobytes() == want["scale"].tobytes() and k["orientation"].tobytes() == want["orientation"].tobytes()
+        assert (k["has_descriptor"] == (want["n_desc"] == 128)).all()
+        assert desc[base:base + want.size].tobytes() == wdesc.tobytes(), f"frame {i + 1}: descriptors"
+        if i in (0, 13, 31):
+            for o in range(octaves):
+                for j in range(dogs + 1):
+                    assert_bits_equal(ctx.level("gaussian", o, j, i), run.level("gaussian", o, j), f"frame {i + 1}: gaussian({o},{j})")
+                for j in range(dogs):
+                    assert_bits_equal(ctx.level("dog", o, j, i), run.level("dog", o, j), f"frame {i + 1}: dog({o},{j})")
+        if i == 0:
+            pin_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refpin_bench_frame.npz")
+            if os.path.exists(pin_path):     # the reference binary's own answer for frame 1
+                pin = np.load(pin_path)
+                ref = pin["points"]
+                assert k.size == ref.size
+                for f in ("x", "y", "octave", "index"):
+                    assert (k[f] == ref[f]).all(), f
+                assert k["scale"].tobytes() == ref["scale"].tobytes() and k["orientation"].tobytes() == ref["orientation"].tobytes()
+                d0 = desc[base:base + want.size]
+                assert hashlib.sha256(d0[k["has_descriptor"].astype(bool)].tobytes()).hexdigest() == str(pin["desc_sha"])
+                rep["frame1_equals_reference_binary"] = True
+        run.close()
+        base += want.size
+    assert base == kp.size
+    with open(os.path.join(report_dir, "pipeline.jsonl"), "a") as f:
+        f.write(json.dumps(rep) + "\n")
+
+
+def test_bench_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` as a BARE command (no torch.distributed.run, no WORLD_SIZE): the parent starts two fresh
+    rank processes before touching the GPU and passes rank 0's one JSON line through.  Both ranks share this box's one GPU, so the
+    transport is gloo; the flow (block-sharded seeds, per-step gather of the keypoint lists on rank 0, barrier + max-over-ranks
+    timing) is the N > 1 flow."""
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo",
+                        "--steps", "2", "--warmup", "1", "--frames", "4", "--no-cpu-baseline", "--no-extras"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["config"]["frames_total"] == 8
+    assert out["config"]["gather_steps_on_rank0"] == 2
+    assert out["config"]["gather_keypoints_on_rank0"] == out["config"]["keypoints_per_step"] * 2
+    assert out["config"]["rccl_ranks"] == 0      # gloo: no RCCL communicator in this run, and the line says so
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0
+    # a failing rank makes the command fail (here: a library option that does not exist)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo",
+                        "--steps", "1", "--warmup", "0", "--frames", "2", "--no-cpu-baseline", "--no-extras", "--set", "no_such_option=1"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0
+
+
 def test_pipeline_parity_256_frame_batch(ctx, report_dir):
     """BASELINE.json configs[3]'s whole 256-frame batch on one GPU: every level buffer is larger than 2^31 bytes, so
     any 32-bit byte offset would show in the last frame."""
