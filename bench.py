@@ -367,8 +367,13 @@ def main():
     if rank == 0:
         prof = [c.profile(0) for c in ctxs]
         ms, launches, nbytes = (sum(p[i] for p in prof) for i in range(3))
-        achieved = (nbytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0
-        busy_ms = sum(c.profile_busy_ms(0) for c in ctxs)   # launches that overlap (option pyramid_side) counted once
+        # The top Gaussian level of an octave runs on the side stream beside the next octave's first launches (option
+        # pyramid_side, default): launches overlap, so the family's rate is its bytes over the time during which at least one
+        # blur launch was running (union of the launches' [start, stop] intervals, from the same events), not over the sum of
+        # the durations, which counts the overlapped time twice.
+        busy_ms = sum(c.profile_busy_ms(0) for c in ctxs)
+        achieved = (nbytes / 1e9) / (busy_ms / 1e3) if busy_ms > 0 else 0.0
+        achieved_sum = (nbytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0
         out = {
             "metric": "keypoints/sec, 1920x1080 4oct/3DoG" if args.workload == "config4" else f"keypoints/sec, {args.workload} (not the headline metric)",
             "value": kps / dt,
@@ -397,20 +402,22 @@ def main():
             "roofline": {"kernel": "blur_stream_kernel / blur_fused_kernel (separable Gaussian + DoG; every launch of the pyramid)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
-                         "timing": "hipEventElapsedTime over start/stop events attached to each blur dispatch (hipExtLaunchKernelGGL) on the library's stream, inside the timed region; "
-                                   f"every {PROFILE_EVERY}th batch of a context is instrumented (the events keep consecutive launches ~10 us apart)",
-                         "launches": launches, "avg_launch_ms": ms / launches if launches else None,
+                         "timing": "hipEventElapsedTime over start/stop events attached to each blur dispatch (hipExtLaunchKernelGGL) on the library's streams, inside the timed region; "
+                                   f"every {PROFILE_EVERY}th batch of a context is instrumented (the events keep consecutive launches ~10 us apart); "
+                                   "achieved = algorithmic bytes of all blur launches / the time during which at least one of them was running (union of the "
+                                   "launches' intervals: an octave's top level overlaps the next octave's first launches on a second stream)",
+                         "launches": launches, "avg_launch_ms": busy_ms / launches if launches else None,
                          "algorithmic_bytes_per_launch": nbytes / launches if launches else None,
-                         # the same bytes over the time during which at least one blur launch was running: equal to `frac` while the
-                         # launches follow one another (the default), larger when option pyramid_side lets two of them overlap
-                         "frac_of_busy_time": ((nbytes / 1e9) / (busy_ms / 1e3) / HBM_PEAK_GBS) if busy_ms > 0 else None},
+                         # the same bytes over the SUM of the launches' durations (overlapped time counted twice)
+                         "achieved_over_sum_of_durations": achieved_sum, "frac_over_sum_of_durations": achieved_sum / HBM_PEAK_GBS,
+                         "sum_of_durations_ms_per_launch": ms / launches if launches else None},
         }
         if world == 1 and not args.no_extras:
             # ---- the boundary as a host caller sees it (main.cpp:56-57 hands over host memory and reads the vector back):
             # frames from host memory in, keypoints + descriptors to host memory out, two batches in flight
             from sift_amd.sift import pinned_array
 
-            def host_loop(src, outs, n_steps):
+            def host_loop(src, fetch, n_steps):
                 pend, total = [], 0
                 t_0 = time.perf_counter()
                 for i in range(n_steps + depth - 1):
@@ -418,28 +425,66 @@ def main():
                         pend.append(pipe.submit(src, params))
                     if len(pend) >= depth or i >= n_steps:
                         tk = pend.pop(0)
-                        c = tk.result()
-                        kp_o, de_o = outs[tk.slot] if outs else (None, None)
-                        total += c.results(kp_o, de_o)[0].size
+                        total += fetch(tk.result(), tk.slot)
                         tk.release()
                 return (time.perf_counter() - t_0) / n_steps, total // n_steps
 
+            from sift_amd.sift import unpack_sparse_host
             cap = int(out["config"]["keypoints_per_step"] * 1.25) + 1024
+            hs = max(2, min(args.steps, 20))
+            # (a) what a host that reads 8-bit files holds (the reference's inputs are 8-bit files, main.cpp:52-54): uint8 frames in
+            # (widened on the GPU), keypoint lists out in the sparse wire format (34-byte records + the descriptor floats that are set)
+            frames_u8 = frames.astype(np.uint8)
+            assert np.array_equal(frames_u8.astype(np.float32), frames)
+            pin_u8 = pinned_array(frames_u8.shape, np.uint8)
+            pin_u8[...] = frames_u8
+            pin_sp = [(pinned_array((cap, 34), np.uint8), pinned_array((cap * 64,), np.float32)) for _ in range(depth)]
+            wire = [0]
+            for c in ctxs:
+                c.set_option("wire_count", 1)     # the descriptor kernel counts the floats the sparse format will carry
+
+            def fetch_sparse(c, slot):
+                rec, val = c.results_sparse(pin_sp[slot][0], pin_sp[slot][1])
+                wire[0] = rec.nbytes + val.nbytes
+                return rec.shape[0]
+
+            dense = [(np.empty(cap, _lib.KEYPOINT_DTYPE), np.empty((cap, 128), np.float32)) for _ in range(depth)]
+
+            def fetch_sparse_unpacked(c, slot):   # ... and expanded again on the host into records + 128-float descriptors
+                rec, val = c.results_sparse(pin_sp[slot][0], pin_sp[slot][1])
+                unpack_sparse_host(rec, val, dense[slot][0], dense[slot][1], threads=min(16, os.cpu_count() or 1))
+                return rec.shape[0]
+
+            host_loop(pin_u8, fetch_sparse, 2)
+            t_sp, k_sp = host_loop(pin_u8, fetch_sparse, hs)
+            host_loop(pin_u8, fetch_sparse_unpacked, 2)
+            t_spu, _ = host_loop(pin_u8, fetch_sparse_unpacked, hs)
+            for c in ctxs:
+                c.set_option("wire_count", int(options.get("wire_count", 0)))
+            # (b) float32 frames in, dense 532-byte records out (round 2's figure)
             pin_frames = pinned_array(frames.shape, np.float32)
             pin_frames[...] = frames
             pin_out = [(pinned_array((cap,), _lib.KEYPOINT_DTYPE), pinned_array((cap, 128), np.float32)) for _ in range(depth)]
-            hs = max(2, min(args.steps, 20))
-            host_loop(pin_frames, pin_out, 2)
-            t_pin, k_pin = host_loop(pin_frames, pin_out, hs)
-            host_loop(frames, None, 1)
-            t_page, _ = host_loop(frames, None, max(2, hs // 4))
+            fetch_dense = lambda c, slot: c.results(pin_out[slot][0], pin_out[slot][1])[0].size   # noqa: E731
+            host_loop(pin_frames, fetch_dense, 2)
+            t_pin, k_pin = host_loop(pin_frames, fetch_dense, hs)
+            fetch_page = lambda c, slot: c.results()[0].size   # noqa: E731
+            host_loop(frames, fetch_page, 1)
+            t_page, _ = host_loop(frames, fetch_page, max(2, hs // 4))
             nbytes_io = frames.nbytes + k_pin * (20 + 512)
-            out["host_inclusive"] = {"ms_per_step": t_pin * 1e3, "keypoints_per_s": k_pin / t_pin,
-                                     "pcie_gbytes_per_step": nbytes_io / 1e9, "pcie_gb_per_s": nbytes_io / 1e9 / t_pin,
-                                     "what": "frames from page-locked host memory (sift_hip_host_alloc) in, keypoints + 128-float descriptors to page-locked host "
-                                             "memory out, per step; two batches in flight, transfers overlapped with the other batch's kernels",
+            nbytes_sp = frames_u8.nbytes + wire[0]
+            out["host_inclusive"] = {"ms_per_step": t_sp * 1e3, "keypoints_per_s": k_sp / t_sp,
+                                     "pcie_gbytes_per_step": nbytes_sp / 1e9, "pcie_gb_per_s": nbytes_sp / 1e9 / t_sp,
+                                     "what": "8-bit frames from page-locked host memory in (sift_hip_calculate_batch_u8: a quarter of the bytes, widened on the GPU to the "
+                                             "floats vigra::importImage yields), keypoint lists to page-locked host memory out in the lossless sparse format "
+                                             "(sift_hip_result_copy_sparse: 34-byte records + the descriptor floats that are not +0.0f), per step; two batches in flight",
+                                     "with_host_unpack_ms_per_step": t_spu * 1e3,
+                                     "with_host_unpack_what": "the same plus sift_hip_sparse_unpack_host on up to 16 host threads: dense 20-byte records + 128-float descriptors in ordinary memory",
+                                     "float_dense_ms_per_step": t_pin * 1e3, "float_dense_keypoints_per_s": k_pin / t_pin,
+                                     "float_dense_pcie_gbytes_per_step": nbytes_io / 1e9, "float_dense_pcie_gb_per_s": nbytes_io / 1e9 / t_pin,
+                                     "float_dense_what": "float32 frames in, 20-byte records + 128-float descriptors out, page-locked memory on both sides (round 2's boundary)",
                                      "pageable_ms_per_step": t_page * 1e3,
-                                     "pageable_what": "the same with ordinary (pageable) numpy arrays on both sides: chunked through the library's pinned staging buffers"}
+                                     "pageable_what": "float32 / dense with ordinary (pageable) numpy arrays on both sides: chunked through the library's pinned staging buffers"}
             one = pinned_array((1,) + frames.shape[1:], np.float32)
             one[...] = frames[:1]
             lat = []

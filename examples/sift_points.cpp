@@ -23,12 +23,20 @@ int main(int argc, char** argv) {
     try {
         char err[512] = "";
         int w = 0, h = 0;
-        if (sift_hip_image_info(img_file.c_str(), &w, &h, nullptr, nullptr, err, sizeof(err)) != SIFT_HIP_OK) throw std::runtime_error(err);
+        int bits = 0;
+        if (sift_hip_image_info(img_file.c_str(), &w, &h, nullptr, &bits, err, sizeof(err)) != SIFT_HIP_OK) throw std::runtime_error(err);
         sift::Image2f img(w, h);
         if (sift_hip_image_read_band0(img_file.c_str(), img.data(), (long long)w * h, err, sizeof(err)) != SIFT_HIP_OK) throw std::runtime_error(err);
 
         sift::Sift sift(dogsPerEpoch, octaves, 1.6f, std::sqrt(2.0f), subpixel);
-        std::vector<sift::InterestPoint> interestPoints = sift.calculate(img);
+        std::vector<sift::InterestPoint> interestPoints;
+        if (bits == 8) {   // an 8-bit file: its samples go to the GPU as bytes and are widened there (same floats, same result)
+            std::vector<unsigned char> px((size_t)w * (size_t)h);
+            for (size_t i = 0; i < px.size(); ++i) px[i] = (unsigned char)img.data()[i];
+            interestPoints = sift.calculate(px.data(), w, h);
+        } else {
+            interestPoints = sift.calculate(img);
+        }
 
         // main.cpp:59-76: boxes on the colour image
         std::vector<uint8_t> image((size_t)w * (size_t)h * 3);

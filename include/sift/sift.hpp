@@ -8,6 +8,7 @@
 #define SIFT_AMD_SIFT_HPP
 #include <cassert>
 #include <cmath>
+#include <cstring>
 #include <exception>
 #include <stdexcept>
 #include <string>
@@ -58,6 +59,16 @@ public:
         return collect();
     }
 
+    // Extension (not in the reference): an 8-bit frame as a host that has just decoded an 8-bit file holds it (the reference's
+    // inputs are such files, main.cpp:52-54).  A quarter of the bytes cross the link; the GPU widens them to the integer-valued
+    // floats vigra::importImage would have produced, so the result equals calculate() on (float)pixel.  The caller's pixels are
+    // never replaced (with subpixel the upsampled image stays in the library: sift_hip_image_copy).
+    std::vector<InterestPoint> calculate(const unsigned char* pixels, int w, int h) {
+        sift_hip_params p = params();
+        raise(sift_hip_calculate_batch_u8(_ctx, pixels, 1, w, h, &p, _err, sizeof(_err)));
+        return collect();
+    }
+
     // Extension (not in the reference): Sift objects on one GPU, one host thread each, can be joined by a gate
     // (sift_hip_gate_create) so that their calculate() calls overlap on the device while no pyramid shares the chip
     // (include/sift_hip.h).  nullptr detaches.
@@ -87,13 +98,17 @@ private:
     sift_hip_ctx* _ctx = nullptr;
     char _err[512] = "";
 
-    int run(const float* data, int w, int h) {
+    sift_hip_params params() const {
         sift_hip_params p{};
         p.dogs_per_epoch = _dogsPerEpoch;
         p.octaves = _octaves;
         p.sigma = _sigma;
         p.k = _k;
         p.subpixel = subpixel ? 1 : 0;
+        return p;
+    }
+    int run(const float* data, int w, int h) {
+        const sift_hip_params p = params();
         return sift_hip_calculate_batch(_ctx, data, 1, w, h, &p, _err, sizeof(_err));
     }
     void raise(int rc) const {
@@ -105,22 +120,48 @@ private:
         }
         throw std::runtime_error(_err);
     }
+    static void fill(InterestPoint& p, const sift_hip_keypoint& k) {
+        p.scale = k.scale;
+        p.octave = k.octave;
+        p.index = k.index;
+        p.filtered = k.filtered != 0;
+        p.loc = Point<u16_t, u16_t>(k.x, k.y);
+        p.orientation = k.orientation;
+    }
+    // The keypoint lists come down in the library's sparse format (34-byte records = the 20-byte keypoint + 112 presence bits,
+    // and only the descriptor floats that are not +0.0f: ~200 instead of 532 bytes per keypoint over the link) and are expanded
+    // straight into the InterestPoints; results the format would lose (a bin 7 that is not +0.0f) take the dense arrays.
     std::vector<InterestPoint> collect() {
         const long long n = sift_hip_result_total(_ctx);
-        std::vector<sift_hip_keypoint> kp((size_t)(n > 0 ? n : 0));
-        std::vector<float> desc((size_t)(n > 0 ? n : 0) * 128);
-        if (n > 0 && sift_hip_result_copy(_ctx, kp.data(), desc.data()) != SIFT_HIP_OK)
-            throw std::runtime_error("sift_hip_result_copy failed");
         std::vector<InterestPoint> out((size_t)(n > 0 ? n : 0));
+        if (n <= 0) return out;
+        int64_t nnz = 0;
+        int lossless = 0;
+        if (sift_hip_result_sparse_size(_ctx, &nnz, &lossless) == SIFT_HIP_OK && lossless) {
+            std::vector<unsigned char> rec((size_t)n * 34);
+            std::vector<float> val((size_t)(nnz > 0 ? nnz : 1));
+            if (sift_hip_result_copy_sparse(_ctx, rec.data(), val.data()) != SIFT_HIP_OK) throw std::runtime_error("sift_hip_result_copy_sparse failed");
+            const float* v = val.data();
+            for (size_t i = 0; i < out.size(); ++i) {
+                sift_hip_keypoint k;
+                std::memcpy(&k, &rec[i * 34], sizeof(k));
+                fill(out[i], k);
+                const unsigned char* m = &rec[i * 34 + 20];
+                if (k.has_descriptor) out[i].descriptors.assign(128, 0.0f);
+                for (int j = 0; j < 112; ++j)      // presence bit j = cell * 7 + bin  <->  descriptor float cell * 8 + bin
+                    if ((m[j >> 3] >> (j & 7)) & 1) {
+                        const float x = *v++;
+                        if (k.has_descriptor) out[i].descriptors[(size_t)(j / 7 * 8 + j % 7)] = x;
+                    }
+            }
+            return out;
+        }
+        std::vector<sift_hip_keypoint> kp((size_t)n);
+        std::vector<float> desc((size_t)n * 128);
+        if (sift_hip_result_copy(_ctx, kp.data(), desc.data()) != SIFT_HIP_OK) throw std::runtime_error("sift_hip_result_copy failed");
         for (size_t i = 0; i < out.size(); ++i) {
-            InterestPoint& p = out[i];
-            p.scale = kp[i].scale;
-            p.octave = kp[i].octave;
-            p.index = kp[i].index;
-            p.filtered = kp[i].filtered != 0;
-            p.loc = Point<u16_t, u16_t>(kp[i].x, kp[i].y);
-            p.orientation = kp[i].orientation;
-            if (kp[i].has_descriptor) p.descriptors.assign(desc.begin() + (std::ptrdiff_t)i * 128, desc.begin() + (std::ptrdiff_t)(i + 1) * 128);
+            fill(out[i], kp[i]);
+            if (kp[i].has_descriptor) out[i].descriptors.assign(desc.begin() + (std::ptrdiff_t)i * 128, desc.begin() + (std::ptrdiff_t)(i + 1) * 128);
         }
         return out;
     }

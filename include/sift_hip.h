@@ -123,6 +123,14 @@ int sift_hip_calculate_batch(sift_hip_ctx* ctx, const float* host_imgs, int n, i
 int sift_hip_calculate_batch_device(sift_hip_ctx* ctx, const void* dev_imgs, int n, int w, int h,
                                     const sift_hip_params* params, char* err, int errlen);
 
+/* 8-bit frames (the reference's inputs are 8-bit files, main.cpp:52-54 vigra::importImage): a quarter of the bytes cross the
+ * link and the GPU widens them to the same integer-valued floats importImage yields, so the results are those of the float
+ * entry points on (float)pixel, bit for bit.  _u8 takes HOST memory, _device_u8 memory of ctx's GPU. */
+int sift_hip_calculate_batch_u8(sift_hip_ctx* ctx, const uint8_t* host_imgs, int n, int w, int h,
+                                const sift_hip_params* params, char* err, int errlen);
+int sift_hip_calculate_batch_device_u8(sift_hip_ctx* ctx, const void* dev_imgs, int n, int w, int h,
+                                       const sift_hip_params* params, char* err, int errlen);
+
 /* Images of the last batch whose results the context holds; -1 when it holds none (no batch yet, or the last calculate
  * call failed before it ran: a failed call never leaves an earlier batch's results readable). */
 int sift_hip_result_images(sift_hip_ctx* ctx);
@@ -147,6 +155,15 @@ int sift_hip_result_device(sift_hip_ctx* ctx, const void** dev_keypoints, const 
  * the current results hold such a value: send the plain arrays of sift_hip_result_device instead. */
 int sift_hip_result_sparse_size(sift_hip_ctx* ctx, int64_t* n_values, int* lossless);
 int sift_hip_result_sparse_pack(sift_hip_ctx* ctx, void* dev_records, void* dev_values);
+/* The same lists to HOST memory (page-locked memory moves at the link's rate): packed on the GPU, so ~200 instead of 532 bytes
+ * per keypoint cross the link.  After sift_hip_result_sparse_size (use sift_hip_result_copy when it reports lossless = 0);
+ * records: sift_hip_result_total() * 34 bytes, values: n_values floats. */
+int sift_hip_result_copy_sparse(sift_hip_ctx* ctx, void* records, float* values);
+/* ... and back, in host memory, no GPU: n_keypoints records + their floats -> sift_hip_keypoint records and n_keypoints * 128
+ * descriptor floats (either may be NULL), bit for bit what sift_hip_result_copy delivers.  `threads` host threads share the
+ * work (<= 1: the calling thread). */
+int sift_hip_sparse_unpack_host(const void* records, const float* values, int64_t n_keypoints, sift_hip_keypoint* keypoints,
+                                float* descriptors, int threads);
 /* The receiving side, on ctx's GPU: n_keypoints records of 34 bytes + their floats (both in DEVICE memory, as _pack wrote them
  * on any GPU) -> n_keypoints sift_hip_keypoint records and n_keypoints * 128 descriptor floats in DEVICE memory, bit for bit
  * what the sending context's sift_hip_result_device arrays held.  Independent of ctx's own results; returns when the device is
@@ -204,28 +221,48 @@ int sift_hip_cleanup_survivors(sift_hip_ctx* ctx, const uint8_t* flags, int n, i
 /* ---- a batch over several GPUs of one node, from one process ----------------------------------
  * The reference runs one calculate() on one image (main.cpp:56-57) and keeps no state between images, so a batch shards
  * by image.  A group holds one context per entry of `devices` (a device may be listed more than once), each driven by a
- * host thread of its own inside sift_hip_group_calculate; frames are dealt in contiguous blocks (frame i to shard
- * i / ceil(n / shards)); afterwards the shards' keypoint lists — records and descriptors, never images — are copied
- * device to device (over xGMI between GPUs) into one array on devices[0], in global image order.  There is no collective
- * and no step in which shards wait for each other except that gather.  Status / error behaviour as sift_hip_calculate_batch:
- * the return value and err are those of the first image (in global order) that "threw". */
+ * persistent host thread of its own; frames are dealt in contiguous blocks (frame i to shard i / ceil(n / shards)).  A shard
+ * packs its keypoint lists - records and descriptors, never images - into the sparse wire format on its own GPU and sends
+ * them to devices[0] at once on a stream of its own; a gather thread receives all shards' lists there (side by side, one
+ * link each) and unpacks them into one array in global image order.  Transport: RCCL point-to-point (ncclSend / ncclRecv over
+ * xGMI, one communicator per GPU; librccl.so.1 is opened at run time) when the devices are all different; device-to-device
+ * copies when a device is listed twice (RCCL takes one rank per GPU) or RCCL is absent.  There is no collective and no step
+ * in which shards wait for each other except that gather.  Status / error behaviour as sift_hip_calculate_batch: the return
+ * value and err are those of the first image (in global order) that "threw". */
 typedef struct sift_hip_group sift_hip_group;
 int sift_hip_group_create(const int* devices, int n_devices, sift_hip_group** out, char* err, int errlen);
-void sift_hip_group_destroy(sift_hip_group* group);
+void sift_hip_group_destroy(sift_hip_group* group);           /* batches still in flight run to their end first */
 int sift_hip_group_shards(sift_hip_group* group);
-/* sift_hip_set_option on every shard; and "gather_wire": 1 (default) lists of shards on other GPUs cross in the sparse wire
- * format and are unpacked on devices[0], 0 plain arrays, 2 the sparse format for every shard (tests on a one-GPU box) */
+/* sift_hip_set_option on every shard; and (with no batch in flight)
+ *   "gather_wire": 1 (default) lists of shards on other GPUs cross in the sparse wire format and are unpacked on devices[0],
+ *                  0 plain arrays, 2 the sparse format for every shard (tests on a one-GPU box);
+ *   "gather_transport" (before the first batch): 0 device-to-device copies, 1 (default) RCCL when the devices allow it,
+ *                  2 RCCL or the batch fails;
+ *   "gather_loopback" (before the first batch; a group of ONE shard): 1 = its lists travel through RCCL to the same rank
+ *                  (ncclSend + ncclRecv in one group): the RCCL path on a box with one GPU. */
 int sift_hip_group_set_option(sift_hip_group* group, const char* name, int value);
+/* 1: the gather runs over RCCL, 0: over copies; `text` (may be NULL) says why.  Makes the communicators if no batch has yet. */
+int sift_hip_group_transport(sift_hip_group* group, char* text, int textlen);
+/* One batch, start to end: submit + collect. */
 int sift_hip_group_calculate(sift_hip_group* group, const float* host_imgs, int n, int w, int h, const sift_hip_params* params,
                              char* err, int errlen);
+/* Two batches in flight: submit returns at once (host_imgs must stay valid until the batch has been collected); collect waits
+ * for the OLDEST submitted batch, whose results the accessors below then return - until the next-but-one submit, which reuses
+ * their buffers.  The gather of batch k runs under the kernels of batch k+1.  A third submit without a collect is refused. */
+int sift_hip_group_submit(sift_hip_group* group, const float* host_imgs, int n, int w, int h, const sift_hip_params* params,
+                          char* err, int errlen);
+int sift_hip_group_collect(sift_hip_group* group, char* err, int errlen);
 int sift_hip_group_result_images(sift_hip_group* group);
 int sift_hip_group_result_status(sift_hip_group* group, int32_t* status, int cap);
 int sift_hip_group_result_counts(sift_hip_group* group, int32_t* counts, int cap);
 int64_t sift_hip_group_result_total(sift_hip_group* group);
 int sift_hip_group_result_copy(sift_hip_group* group, sift_hip_keypoint* keypoints, float* descriptors);   /* to host or device memory */
 int sift_hip_group_result_device(sift_hip_group* group, const void** dev_keypoints, const void** dev_descriptors);   /* on devices[0] */
-/* wall time of the shards' calculate calls and of the gather of the last batch, bytes that crossed devices in it */
+/* Of the batch collected last: the slowest shard's calculate + pack time, the time from the last shard's report to the lists
+ * being in place on devices[0] (transfer + unpack), bytes that crossed devices. */
 int sift_hip_group_timing(sift_hip_group* group, double* compute_ms, double* gather_ms, int64_t* gather_bytes);
+/* ... and how much of that gather time the collect call itself had to wait for (the rest ran under the next batch). */
+int sift_hip_group_gather_exposed(sift_hip_group* group, double* exposed_ms);
 
 /* ---- image files and the result overlay (host code, no GPU) ------------------------------------------
  * What /root/reference/main.cpp does around calculate(): vigra::importImage (main.cpp:52-54), cv::imread (:59), the

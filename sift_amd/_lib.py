@@ -28,7 +28,9 @@ SYMBOLS = [
     "sift_hip_host_alloc", "sift_hip_host_free",
     "sift_hip_group_create", "sift_hip_group_destroy", "sift_hip_group_shards", "sift_hip_group_set_option", "sift_hip_group_calculate",
     "sift_hip_group_result_images", "sift_hip_group_result_status", "sift_hip_group_result_counts", "sift_hip_group_result_total",
-    "sift_hip_group_result_copy", "sift_hip_group_result_device", "sift_hip_group_timing",
+    "sift_hip_group_result_copy", "sift_hip_group_result_device", "sift_hip_group_timing", "sift_hip_group_submit", "sift_hip_group_collect",
+    "sift_hip_group_transport", "sift_hip_group_gather_exposed", "sift_hip_calculate_batch_u8", "sift_hip_calculate_batch_device_u8",
+    "sift_hip_result_copy_sparse", "sift_hip_sparse_unpack_host",
     "sift_hip_image_info", "sift_hip_image_read_band0", "sift_hip_image_read_bgr8", "sift_hip_png_write_bgr8",
     "sift_hip_rotated_rect_points", "sift_hip_overlay_box", "sift_hip_overlay_draw",
 ]
@@ -132,6 +134,14 @@ def load():
     L.sift_hip_group_shards.argtypes = [vp]
     L.sift_hip_group_set_option.argtypes = [vp, cs, ci]
     L.sift_hip_group_calculate.argtypes = [vp, fp, ci, ci, ci, C.POINTER(Params), cs, ci]
+    L.sift_hip_calculate_batch_u8.argtypes = [vp, vp, ci, ci, ci, C.POINTER(Params), cs, ci]
+    L.sift_hip_calculate_batch_device_u8.argtypes = [vp, vp, ci, ci, ci, C.POINTER(Params), cs, ci]
+    L.sift_hip_result_copy_sparse.argtypes = [vp, vp, vp]
+    L.sift_hip_sparse_unpack_host.argtypes = [vp, vp, C.c_int64, vp, vp, ci]
+    L.sift_hip_group_submit.argtypes = [vp, fp, ci, ci, ci, C.POINTER(Params), cs, ci]
+    L.sift_hip_group_collect.argtypes = [vp, cs, ci]
+    L.sift_hip_group_transport.argtypes = [vp, cs, ci]
+    L.sift_hip_group_gather_exposed.argtypes = [vp, C.POINTER(C.c_double)]
     L.sift_hip_group_result_images.argtypes = [vp]
     L.sift_hip_group_result_status.argtypes = [vp, i32p, ci]
     L.sift_hip_group_result_counts.argtypes = [vp, i32p, ci]

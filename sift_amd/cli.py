@@ -120,6 +120,8 @@ def main(argv=None) -> int:
         return 1
     try:
         img = read_image(path)
+        if image_info(path)[3] == 8:
+            img = img.astype(np.uint8)     # an 8-bit file: its samples cross the link as bytes, the GPU widens them to the same floats
         sift = Sift(args.dogsPerEpoch, args.octaves, args.sigma, args.k, bool(args.subpixel))
         points = sift.calculate(img)
         if not args.no_overlay:

@@ -107,6 +107,7 @@ void set_orient_dbg(int v);        // timing ablations of the orientation kernel
 void launch_resample(hipStream_t s, const float* src, float* dst, int ws, int hs, int wd, int hd, int n,
                      const int* d_lutx, const int* d_luty);
 void launch_dog(hipStream_t s, const float* lower, const float* higher, float* out, size_t count);
+void launch_widen_u8(hipStream_t s, const uint8_t* in, float* out, size_t count);
 void launch_extrema_mask(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan,
                          unsigned long long* d_masks, int* d_counts);
 void launch_extrema_scan(hipStream_t s, const DevPlan& plan, int* d_counts, int* d_totals);

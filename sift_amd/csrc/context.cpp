@@ -124,7 +124,8 @@ struct sift_hip_ctx {
     int host_threads = 0;
     int desc_dbg = 0;
     Plan plan;
-    DevBuf arena, d_plan, d_taps, d_luts, d_taps16, d_input, d_base, d_tmp, d_tmp2;
+    DevBuf arena, d_plan, d_taps, d_luts, d_taps16, d_input, d_input_u8, d_base, d_tmp, d_tmp2;
+    DevBuf d_sparse_rec, d_sparse_val;   // sift_hip_result_copy_sparse: the packed lists on their way to the host
     DevBuf d_masks, d_fmasks, d_counts, d_totals, d_cands, d_flags;
     DevBuf d_wk, d_wi, d_wi2, d_wp, d_status, d_tile, d_pool;
     DevBuf d_order;
@@ -134,9 +135,9 @@ struct sift_hip_ctx {
     bool desc_wave = true;           // option "desc_kernel": 1 wave-per-keypoint kernel (default), 0 tile kernel
     bool gate_early_chain = false;   // option "gate_early_chain" (measured alternative, off)
     int gate_schedule = 0;           // option "gate_schedule" (phase_gate.h): applies to the gate this context is joined to
-    // option "pyramid_side": the top Gaussian level of an octave (it only feeds the octave's last DoG) is formed on a stream of
-    // its own, beside the reduction and the first levels of the next octave, which are too small to fill the chip alone
-    bool pyramid_side = false;
+    // option "pyramid_side" (default on): the top Gaussian level of an octave (it only feeds the octave's last DoG) is formed on
+    // the side stream, beside the reduction and the first levels of the next octave, which are too small to fill the chip alone
+    bool pyramid_side = true;
     hipEvent_t ev_side_fork = nullptr, ev_side_join = nullptr;
     DevBuf d_list, d_list_cnt, d_orient, d_peaks, d_final, d_final_cnt, d_out_base, d_kp, d_desc;
     DevBuf d_wire_sums, d_wire_off;   // sparse wire format: floats per block of keypoints, their exclusive scan
@@ -1203,6 +1204,8 @@ int sift_hip_create(int device, sift_hip_ctx** out, char* err, int errlen) {
         SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
         SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_grad, hipEventDisableTiming));
         SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming));
+        SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_side_fork, hipEventDisableTiming));
+        SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_side_join, hipEventDisableTiming));
         *out = c;
         return SIFT_HIP_OK;
     });
@@ -1213,7 +1216,7 @@ void sift_hip_destroy(sift_hip_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)sift_hip_set_gate(c, nullptr);
-    for (DevBuf* b : {&c->arena, &c->d_plan, &c->d_taps, &c->d_luts, &c->d_taps16, &c->d_input, &c->d_base, &c->d_tmp, &c->d_tmp2,
+    for (DevBuf* b : {&c->arena, &c->d_plan, &c->d_taps, &c->d_luts, &c->d_taps16, &c->d_input, &c->d_input_u8, &c->d_sparse_rec, &c->d_sparse_val, &c->d_base, &c->d_tmp, &c->d_tmp2,
                       &c->d_wk, &c->d_wi, &c->d_wi2, &c->d_wp, &c->d_status, &c->d_tile, &c->d_pool, &c->d_order, &c->d_masks, &c->d_fmasks, &c->d_counts, &c->d_totals, &c->d_cands, &c->d_flags, &c->d_list, &c->d_list_cnt, &c->d_orient,
                       &c->d_peaks, &c->d_final, &c->d_final_cnt, &c->d_out_base, &c->d_kp, &c->d_desc, &c->d_lrank, &c->d_ochunk, &c->d_ocnt, &c->d_recs, &c->d_wire_sums, &c->d_wire_off, &c->d_unpack_sums, &c->d_unpack_off, &c->d_cell_cnt, &c->d_cell_off})
         b->release();
@@ -1361,6 +1364,44 @@ int sift_hip_calculate_batch(sift_hip_ctx* c, const float* host_imgs, int n, int
     });
 }
 
+// 8-bit frames: what a host that reads 8-bit files holds (the reference's inputs are such files, main.cpp:52-54).  A quarter
+// of the bytes cross the link; the GPU widens them to the integer-valued floats vigra::importImage would have produced.
+int sift_hip_calculate_batch_u8(sift_hip_ctx* c, const uint8_t* host_imgs, int n, int w, int h,
+                                const sift_hip_params* params, char* err, int errlen) {
+    if (!c || !host_imgs || !params || n <= 0 || w <= 0 || h <= 0) return SIFT_HIP_EINVAL;
+    return guarded(err, errlen, [&]() {
+        SIFT_HIP_CHECK(hipSetDevice(c->device));
+        c->have_result = c->have_pyramid = false;
+        const size_t count = (size_t)n * (size_t)w * (size_t)h;
+        c->d_input.ensure(count * sizeof(float));
+        c->d_input_u8.ensure(count);
+        upload(c, c->d_input_u8.p, host_imgs, count, c->stream);
+        launch_widen_u8(c->stream, c->d_input_u8.as<uint8_t>(), c->d_input.as<float>(), count);
+        SIFT_HIP_CHECK(hipGetLastError());
+        std::string msg;
+        const int rc = build_plan(c, n, w, h, *params, msg);
+        if (rc) { set_err(err, errlen, msg); return rc; }
+        return run_batch(c, c->d_input.as<float>(), err, errlen);
+    });
+}
+
+int sift_hip_calculate_batch_device_u8(sift_hip_ctx* c, const void* dev_imgs, int n, int w, int h,
+                                       const sift_hip_params* params, char* err, int errlen) {
+    if (!c || !dev_imgs || !params || n <= 0 || w <= 0 || h <= 0) return SIFT_HIP_EINVAL;
+    return guarded(err, errlen, [&]() {
+        SIFT_HIP_CHECK(hipSetDevice(c->device));
+        c->have_result = c->have_pyramid = false;
+        const size_t count = (size_t)n * (size_t)w * (size_t)h;
+        c->d_input.ensure(count * sizeof(float));
+        launch_widen_u8(c->stream, static_cast<const uint8_t*>(dev_imgs), c->d_input.as<float>(), count);
+        SIFT_HIP_CHECK(hipGetLastError());
+        std::string msg;
+        const int rc = build_plan(c, n, w, h, *params, msg);
+        if (rc) { set_err(err, errlen, msg); return rc; }
+        return run_batch(c, c->d_input.as<float>(), err, errlen);
+    });
+}
+
 void* sift_hip_host_alloc(size_t bytes) {
     void* p = nullptr;
     if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
@@ -1434,9 +1475,98 @@ int sift_hip_result_sparse_pack(sift_hip_ctx* c, void* d_records, void* d_values
         SIFT_HIP_CHECK(hipSetDevice(c->device));
         launch_wire_emit(c->stream, c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->total, c->d_wire_off.as<long long>(),
                          static_cast<uint8_t*>(d_records), static_cast<float*>(d_values));
+        SIFT_HIP_CHECK(hipGetLastError());
         wait_stream(c, c->stream);
         return SIFT_HIP_OK;
     });
+}
+
+// The same lists to HOST memory: packed on the GPU, then only the 34-byte records and the floats that are set cross the link
+// (~200 instead of 532 bytes per keypoint).  After sift_hip_result_sparse_size; records: total * 34 bytes, values: n_values floats.
+int sift_hip_result_copy_sparse(sift_hip_ctx* c, void* records, float* values) {
+    if (!c || !c->have_result || c->wire_for_total != c->total || c->wire_values < 0) return SIFT_HIP_EINVAL;
+    if (c->total > 0 && (!records || (c->wire_values > 0 && !values))) return SIFT_HIP_EINVAL;
+    if (c->total == 0) return SIFT_HIP_OK;
+    char err[256];
+    return guarded(err, sizeof(err), [&]() {
+        SIFT_HIP_CHECK(hipSetDevice(c->device));
+        c->d_sparse_rec.ensure((size_t)c->total * 34);
+        c->d_sparse_val.ensure((size_t)std::max<long long>(c->wire_values, 1) * sizeof(float));
+        launch_wire_emit(c->stream, c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->total, c->d_wire_off.as<long long>(),
+                         c->d_sparse_rec.as<uint8_t>(), c->d_sparse_val.as<float>());
+        SIFT_HIP_CHECK(hipGetLastError());
+        if (is_pinned(records) && is_pinned(values)) {   // both copies queued behind the kernel, one wait
+            SIFT_HIP_CHECK(hipMemcpyAsync(records, c->d_sparse_rec.p, (size_t)c->total * 34, hipMemcpyDefault, c->stream));
+            if (c->wire_values > 0) SIFT_HIP_CHECK(hipMemcpyAsync(values, c->d_sparse_val.p, (size_t)c->wire_values * sizeof(float), hipMemcpyDefault, c->stream));
+            wait_stream(c, c->stream);
+        } else {
+            download(c, records, c->d_sparse_rec.p, (size_t)c->total * 34, c->stream);
+            if (c->wire_values > 0) download(c, values, c->d_sparse_val.p, (size_t)c->wire_values * sizeof(float), c->stream);
+        }
+        return SIFT_HIP_OK;
+    });
+}
+
+// Host side of the format: n records + their floats -> n sift_hip_keypoint and n x 128 descriptor floats, bit for bit what
+// sift_hip_result_copy would have delivered.  Plain CPU code; `threads` <= 1 runs on the calling thread.
+namespace {
+struct UnpackJob {
+    const uint8_t* rec; const float* val; int64_t n; sift_hip_keypoint* kp; float* desc;
+    std::vector<int64_t> start;   // first value of every chunk
+    int64_t chunk;
+};
+inline int popcount_mask(const uint8_t* m) {
+    uint64_t a, b;
+    std::memcpy(&a, m, 8);
+    std::memcpy(&b, m + 6, 8);   // bytes 6..13: keep the top 6 bytes (8..13)
+    return __builtin_popcountll(a) + __builtin_popcountll(b >> 16);
+}
+void unpack_chunk(int part, void* arg) {
+    const UnpackJob* j = static_cast<const UnpackJob*>(arg);
+    const int64_t i0 = (int64_t)part * j->chunk, i1 = std::min(j->n, i0 + j->chunk);
+    const float* v = j->val + j->start[(size_t)part];
+    for (int64_t i = i0; i < i1; ++i) {
+        const uint8_t* r = j->rec + i * 34;
+        if (j->kp) std::memcpy(&j->kp[i], r, sizeof(sift_hip_keypoint));
+        const uint8_t* m = r + 20;
+        float* d = j->desc ? j->desc + i * 128 : nullptr;
+        for (int cell = 0; cell < 16; ++cell) {
+            // presence bit cell*7+bin <-> descriptor float cell*8+bin; bin 7 is never on the wire (+0.0f)
+            const int bit0 = cell * 7;
+            unsigned bits = (unsigned)((m[bit0 >> 3] | (m[(bit0 >> 3) + 1 < 14 ? (bit0 >> 3) + 1 : 13] << 8)) >> (bit0 & 7)) & 0x7fu;
+            if (d) {
+                float* dc = d + cell * 8;
+                for (int b = 0; b < 7; ++b) { dc[b] = (bits >> b) & 1u ? *v++ : 0.0f; }
+                dc[7] = 0.0f;
+            } else {
+                v += __builtin_popcount(bits);
+            }
+        }
+    }
+}
+}  // namespace
+
+int sift_hip_sparse_unpack_host(const void* records, const float* values, int64_t n_keypoints, sift_hip_keypoint* keypoints,
+                                float* descriptors, int threads) {
+    if (n_keypoints < 0 || (n_keypoints > 0 && !records)) return SIFT_HIP_EINVAL;
+    if (n_keypoints == 0) return SIFT_HIP_OK;
+    try {
+        UnpackJob j{static_cast<const uint8_t*>(records), values, n_keypoints, keypoints, descriptors, {}, 0};
+        const int parts = (int)std::min<int64_t>(std::max(threads, 1), (n_keypoints + 1023) / 1024);
+        j.chunk = (n_keypoints + parts - 1) / parts;
+        j.start.assign((size_t)parts, 0);
+        int64_t at = 0;
+        for (int p = 0; p < parts; ++p) {   // where every chunk's floats begin: one pass over the presence bits
+            j.start[(size_t)p] = at;
+            const int64_t i1 = std::min(n_keypoints, (int64_t)(p + 1) * j.chunk);
+            if (p + 1 < parts)
+                for (int64_t i = (int64_t)p * j.chunk; i < i1; ++i) at += popcount_mask(j.rec + i * 34 + 20);
+        }
+        parallel_for(parts, parts, unpack_chunk, &j);
+        return SIFT_HIP_OK;
+    } catch (const std::exception&) {
+        return SIFT_HIP_EHIP;
+    }
 }
 
 int sift_hip_sparse_unpack(sift_hip_ctx* c, const void* d_records, const void* d_values, int64_t n_keypoints, void* d_keypoints,

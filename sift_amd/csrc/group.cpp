@@ -1,58 +1,470 @@
 // Several GPUs of one node from ONE process, no torch: SURVEY.md 8(e)'s layout as native host code.  A batch of independent
 // frames (sift.cpp keeps no state between images) is block-sharded over the shards of a group; every shard is one
-// sift_hip_ctx driven by its own host thread; nothing but keypoint lists crosses devices: the per-shard result arrays
-// (20-byte records, 128-float descriptors) are copied device-to-device (hipMemcpyPeerAsync: xGMI between GPUs, each shard
-// over its own link to shard 0's GPU) into one array in global image order on shard 0's device.  No collective: shards never
-// wait for each other except at this gather.  Written against the public C ABI only (include/sift_hip.h).
+// sift_hip_ctx driven by its own persistent host thread; nothing but keypoint lists crosses devices.
+//
+//   shard thread s:   calculate its block  ->  pack its lists into the sparse wire format on its own GPU (34-byte records +
+//                     the descriptor floats that are set, ~200 instead of 532 bytes per keypoint)  ->  send them to the first
+//                     GPU on its own stream, at once (RCCL ncclSend over its own xGMI link; or a peer copy)  ->  next batch
+//   gather thread:    (on devices[0]) once every shard of the batch has reported its sizes: ONE RCCL group with all the
+//                     receives (the links run side by side), then unpacks every shard's lists into one array in global image
+//                     order (sift_hip_sparse_unpack on a context of its own)
+//
+// sift_hip_group_submit / _collect keep two batches in flight: the gather of batch k runs under the kernels of batch k+1
+// (pack buffers, arrival areas and result arrays are double-buffered).  There is no collective and no step in which shards
+// wait for each other except that gather.
+//
+// Transport.  RCCL (librccl.so.1, opened at run time so that the library also loads where RCCL is absent; one communicator
+// per GPU from ncclCommInitAll) when the group's devices are all different, which is the multi-GPU case; RCCL refuses two
+// ranks on one GPU, so a group that lists a device twice (tests on a one-GPU box) uses peer / same-device copies, each shard's
+// on a stream of its own.  Option "gather_transport": 0 copies, 1 RCCL if possible (default), 2 RCCL required.  A group of ONE
+// shard with "gather_loopback" = 1 sends its lists through RCCL to itself (ncclSend + ncclRecv to the same rank in one group):
+// the whole RCCL path - communicator, grouped point-to-point, arrival area, unpack - on a box with one GPU.
+// Written against the public C ABI only (include/sift_hip.h).
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <exception>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "../../include/sift_hip.h"
 
-struct sift_hip_group {
-    std::vector<int> devices;
-    std::vector<sift_hip_ctx*> ctx;
-    // last batch
-    int n = 0;
-    std::vector<int> first, count;           // frames of every shard: [first, first + count)
-    std::vector<int> rc;
-    std::vector<std::string> msg;
-    std::vector<int32_t> status, counts;     // per image, global order
-    long long total = 0;
-    bool have_result = false;
-    void* d_kp = nullptr;                    // on devices[0]
-    void* d_desc = nullptr;
-    long long cap = 0;
-    hipStream_t copy_stream = nullptr;       // on devices[0]
-    double gather_ms = 0, compute_ms = 0;
-    long long gather_bytes = 0;
-    // option "gather_wire": 1 (default) lists of other GPUs cross in the sparse wire format (34-byte records + the descriptor
-    // floats that are set: ~200 instead of 532 bytes per keypoint over the link) and are unpacked on devices[0]; 0 plain arrays;
-    // 2 the sparse format for every shard, also those on devices[0] itself (tests on a one-GPU box)
-    int gather_wire = 1;
-    std::vector<void*> s_rec, s_val;         // per shard, on the shard's device: packed records / values
-    std::vector<long long> s_rec_cap, s_val_cap, s_nnz;
-    std::vector<int> s_packed;               // this batch: the shard's lists are packed (lossless and wanted)
-    void* d_in_rec = nullptr;                // on devices[0]: where packed lists arrive
-    void* d_in_val = nullptr;
-    long long in_rec_cap = 0, in_val_cap = 0;
-};
-
 namespace {
+
 void set_err(char* err, int errlen, const std::string& m) {
     if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", m.c_str());
 }
 double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+
+// ---- RCCL, resolved at run time ------------------------------------------------------------------------------------
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        // a copy the process already holds (PyTorch-ROCm ships one) is found by its SONAME; otherwise the system's
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) return;
+        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(r.lib, "ncclCommInitAll"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.lib, "ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.lib, "ncclGroupEnd"));
+        r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(r.lib, "ncclSend"));
+        r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(r.lib, "ncclRecv"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+        r.ok = r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv && r.GetErrorString;
+    });
+    return r;
+}
+
+struct DevMem {   // grow-only device buffer on a fixed device
+    void* p = nullptr;
+    long long cap = 0;
+    bool fit(int device, long long want) {
+        if (want <= cap) return true;
+        if (hipSetDevice(device) != hipSuccess) return false;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const long long take = want + want / 4 + 256;
+        if (hipMalloc(&p, (size_t)take) != hipSuccess) { p = nullptr; (void)hipGetLastError(); return false; }
+        cap = take;
+        return true;
+    }
+    void release(int device) {
+        if (!p) return;
+        (void)hipSetDevice(device);
+        (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+constexpr int kSlots = 2;   // batches in flight
+
+struct ShardBatch {          // what shard s reports for one batch
+    int rc = SIFT_HIP_OK;
+    std::string msg;
+    bool ran = false;        // the context holds results for its whole block
+    bool packed = false;     // its lists travel in the sparse wire format
+    bool sent = false;       // the shard thread has queued its transfer (copies: the data is under way; RCCL: the sends are posted)
+    long long total = 0, nnz = 0;
+    double compute_ms = 0;
+    std::vector<int32_t> status, counts;
+};
+
+struct Batch {
+    long long seq = -1;
+    int n = 0, w = 0, h = 0;
+    const float* imgs = nullptr;
+    sift_hip_params params{};
+    std::vector<int> first, count;
+    std::vector<ShardBatch> shard;
+    int reported = 0;        // shards that have finished computing (and queued their transfer)
+    bool gathered = false;   // the gather thread is done with it
+    int rc = SIFT_HIP_OK;
+    std::string msg;
+    long long total = 0;
+    std::vector<int32_t> status, counts;
+    double t_submit = 0, t_computed = 0, t_gathered = 0;
+    long long wire_bytes = 0;
+};
+
+}  // namespace
+
+struct sift_hip_group {
+    std::vector<int> devices;
+    std::vector<sift_hip_ctx*> ctx;
+    sift_hip_ctx* unpack_ctx = nullptr;       // on devices[0]: the gather thread's own (sift_hip_sparse_unpack beside shard 0's kernels)
+    int S = 0;
+    // options
+    int gather_wire = 1;        // 1 (default): lists of other GPUs cross in the sparse wire format; 0 plain arrays; 2 sparse for every shard
+    int gather_transport = 1;   // 0 copies, 1 RCCL when the devices allow it, 2 RCCL or fail
+    int gather_loopback = 0;    // one shard: its lists go through RCCL to itself
+    // RCCL
+    std::vector<ncclComm_t> comm;
+    bool comm_tried = false, use_rccl = false;
+    std::string rccl_note;
+    // threads
+    std::mutex m;
+    std::condition_variable cv;
+    bool stop = false;
+    std::vector<std::thread> workers;
+    std::thread gatherer;
+    long long submitted = 0, collected = 0;     // batches
+    std::vector<long long> shard_next;          // next batch each shard thread takes
+    long long gather_next = 0;
+    Batch batch[kSlots];
+    // device memory
+    std::vector<hipStream_t> send_stream;       // per shard, on the shard's device
+    std::vector<hipEvent_t> sent_ev[kSlots];    // per shard: its transfer of the slot's batch is complete (source side)
+    std::vector<DevMem> pack_rec[kSlots], pack_val[kSlots];   // per shard, on the shard's device
+    std::vector<DevMem> in_rec[kSlots], in_val[kSlots];       // per shard, on devices[0]: where its lists arrive
+    DevMem out_kp[kSlots], out_desc[kSlots];                  // on devices[0]: gathered lists, global image order
+    hipStream_t recv_stream = nullptr, copy_stream = nullptr;   // on devices[0]
+    // the batch the result accessors read (the last one collected)
+    int cur = -1;
+    double compute_ms = 0, gather_ms = 0, exposed_ms = 0;
+    long long gather_bytes = 0;
+};
+
+namespace {
+
+bool distinct(const std::vector<int>& d) {
+    for (size_t i = 0; i < d.size(); ++i)
+        for (size_t j = i + 1; j < d.size(); ++j)
+            if (d[i] == d[j]) return false;
+    return true;
+}
+
+// RCCL communicators, made on first use (the options are known by then).  Holding g->m.
+void init_transport(sift_hip_group* g) {
+    if (g->comm_tried) return;
+    g->comm_tried = true;
+    g->use_rccl = false;
+    const bool loop = g->S == 1 && g->gather_loopback;
+    if (g->gather_transport == 0) { g->rccl_note = "copies (option gather_transport = 0)"; return; }
+    if (g->S == 1 && !loop) { g->rccl_note = "one shard: nothing to gather"; return; }
+    if (!distinct(g->devices)) { g->rccl_note = "copies: RCCL takes one rank per GPU and the group lists a device twice"; return; }
+    Rccl& r = rccl();
+    if (!r.ok) { g->rccl_note = "copies: librccl.so.1 not found"; return; }
+    g->comm.assign((size_t)g->S, nullptr);
+    const ncclResult_t e = r.CommInitAll(g->comm.data(), g->S, g->devices.data());
+    if (e != ncclSuccess) {
+        g->rccl_note = std::string("copies: ncclCommInitAll failed: ") + r.GetErrorString(e);
+        g->comm.clear();
+        return;
+    }
+    g->use_rccl = true;
+    g->rccl_note = "RCCL point-to-point (ncclSend / ncclRecv), one communicator per GPU";
+}
+
+bool remote(const sift_hip_group* g, int s) { return g->devices[(size_t)s] != g->devices[0]; }
+bool wants_pack(const sift_hip_group* g, int s) {
+    return g->gather_wire == 2 || (g->gather_wire == 1 && (remote(g, s) || (g->S == 1 && g->gather_loopback)));
+}
+
+// ---- shard thread ----------------------------------------------------------------------------------------------------
+void shard_main(sift_hip_group* g, int s) {
+    const int dev = g->devices[(size_t)s];
+    (void)hipSetDevice(dev);
+    for (;;) {
+        long long seq;
+        {
+            std::unique_lock<std::mutex> lk(g->m);
+            g->cv.wait(lk, [&] { return g->stop || g->shard_next[(size_t)s] < g->submitted; });
+            if (g->stop) return;
+            seq = g->shard_next[(size_t)s];
+        }
+        const int slot = (int)(seq % kSlots);
+        Batch& B = g->batch[slot];
+        ShardBatch& R = B.shard[(size_t)s];
+        const int cnt = B.count[(size_t)s];
+        bool wait_for_transfer = false;
+        if (cnt > 0) {
+            try {
+                char e[512] = "";
+                const double t0 = now_ms();
+                const size_t frame = (size_t)B.w * (size_t)B.h;
+                R.rc = sift_hip_calculate_batch(g->ctx[(size_t)s], B.imgs + (size_t)B.first[(size_t)s] * frame, cnt, B.w, B.h, &B.params, e, sizeof(e));
+                R.msg = e;
+                R.ran = sift_hip_result_images(g->ctx[(size_t)s]) == cnt;
+                if (R.ran) {
+                    R.status.assign((size_t)cnt, 0);
+                    R.counts.assign((size_t)cnt, 0);
+                    (void)sift_hip_result_status(g->ctx[(size_t)s], R.status.data(), cnt);
+                    (void)sift_hip_result_counts(g->ctx[(size_t)s], R.counts.data(), cnt);
+                    R.total = sift_hip_result_total(g->ctx[(size_t)s]);
+                }
+                // lists that cross to another GPU are packed here, on the shard's own GPU and thread
+                if (R.ran && R.total > 0 && wants_pack(g, s)) {
+                    int64_t nnz = 0;
+                    int lossless = 0;
+                    if (sift_hip_result_sparse_size(g->ctx[(size_t)s], &nnz, &lossless) == SIFT_HIP_OK && lossless &&
+                        g->pack_rec[slot][(size_t)s].fit(dev, R.total * 34) && g->pack_val[slot][(size_t)s].fit(dev, std::max<long long>(nnz, 1) * 4) &&
+                        sift_hip_result_sparse_pack(g->ctx[(size_t)s], g->pack_rec[slot][(size_t)s].p, g->pack_val[slot][(size_t)s].p) == SIFT_HIP_OK) {
+                        R.nnz = nnz;
+                        R.packed = true;
+                    }
+                }
+                R.compute_ms = now_ms() - t0;
+                // ---- the transfer, queued by the shard itself on its own stream as soon as its lists exist -------------------
+                if (R.ran && R.total > 0) {
+                    (void)hipSetDevice(dev);
+                    const bool loop = g->S == 1 && g->gather_loopback && g->use_rccl;
+                    const void* src_a = nullptr;
+                    const void* src_b = nullptr;
+                    size_t na = 0, nb = 0;
+                    if (R.packed) {
+                        src_a = g->pack_rec[slot][(size_t)s].p; na = (size_t)R.total * 34;
+                        src_b = g->pack_val[slot][(size_t)s].p; nb = (size_t)R.nnz * 4;
+                    } else {
+                        (void)sift_hip_result_device(g->ctx[(size_t)s], &src_a, &src_b);
+                        na = (size_t)R.total * sizeof(sift_hip_keypoint); nb = (size_t)R.total * 128 * sizeof(float);
+                    }
+                    if (loop) {
+                        // one shard, one GPU: the gather thread sends and receives (a communicator serves one thread at a time)
+                    } else if (g->use_rccl && s > 0) {
+                        // RCCL: this GPU's side of the exchange; the gather thread posts the matching receives in one group
+                        Rccl& r = rccl();
+                        ncclResult_t e1 = r.GroupStart();
+                        if (e1 == ncclSuccess) e1 = r.Send(src_a, na, ncclUint8, 0, g->comm[(size_t)s], g->send_stream[(size_t)s]);
+                        if (e1 == ncclSuccess && nb) e1 = r.Send(src_b, nb, ncclUint8, 0, g->comm[(size_t)s], g->send_stream[(size_t)s]);
+                        const ncclResult_t e2 = r.GroupEnd();
+                        if (e1 != ncclSuccess || e2 != ncclSuccess) {
+                            R.rc = SIFT_HIP_EHIP;
+                            R.msg = std::string("sift_hip_group: ncclSend failed: ") + r.GetErrorString(e1 != ncclSuccess ? e1 : e2);
+                        }
+                        R.sent = true;
+                    } else {
+                        // copies: straight into this shard's arrival area on devices[0], over this GPU's own link (a shard on
+                        // devices[0] itself moves its lists aside the same way: its context is then free for the next batch)
+                        DevMem& ia = g->in_rec[slot][(size_t)s];
+                        DevMem& ib = g->in_val[slot][(size_t)s];
+                        const bool ok = ia.fit(g->devices[0], (long long)na) && ib.fit(g->devices[0], (long long)std::max<size_t>(nb, 4));
+                        (void)hipSetDevice(dev);
+                        hipError_t h1 = hipSuccess, h2 = hipSuccess;
+                        if (ok && remote(g, s)) {
+                            h1 = hipMemcpyPeerAsync(ia.p, g->devices[0], src_a, dev, na, g->send_stream[(size_t)s]);
+                            if (nb) h2 = hipMemcpyPeerAsync(ib.p, g->devices[0], src_b, dev, nb, g->send_stream[(size_t)s]);
+                        } else if (ok) {
+                            h1 = hipMemcpyAsync(ia.p, src_a, na, hipMemcpyDeviceToDevice, g->send_stream[(size_t)s]);
+                            if (nb) h2 = hipMemcpyAsync(ib.p, src_b, nb, hipMemcpyDeviceToDevice, g->send_stream[(size_t)s]);
+                        }
+                        if (!ok || h1 != hipSuccess || h2 != hipSuccess) {
+                            R.rc = SIFT_HIP_EHIP;
+                            R.msg = ok ? "sift_hip_group: device-to-device copy failed" : "sift_hip_group: out of device memory for the arriving lists";
+                            (void)hipGetLastError();
+                        } else {
+                            R.sent = true;
+                        }
+                    }
+                    (void)hipEventRecord(g->sent_ev[slot][(size_t)s], g->send_stream[(size_t)s]);
+                    wait_for_transfer = !R.packed && R.sent;
+                }
+            } catch (const std::exception& ex) {
+                R.rc = SIFT_HIP_EHIP;
+                R.msg = std::string("sift_hip_group: ") + ex.what();
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(g->m);
+            if (++B.reported == g->S) B.t_computed = now_ms();
+        }
+        g->cv.notify_all();
+        // Lists that leave from the context's own arrays (not packed) must be gone before the context runs its next batch.  Only
+        // now, after reporting: an RCCL send completes when the gather thread has posted its receive, which waits for the reports.
+        if (wait_for_transfer) (void)hipStreamSynchronize(g->send_stream[(size_t)s]);
+        {
+            std::lock_guard<std::mutex> lk(g->m);
+            g->shard_next[(size_t)s] = seq + 1;
+        }
+        g->cv.notify_all();
+    }
+}
+
+// ---- gather thread: keypoint lists only, device to device, global image order ------------------------------------------
+void gather_batch(sift_hip_group* g, Batch& B, int slot) {
+    const int S = g->S;
+    B.status.assign((size_t)B.n, 0);
+    B.counts.assign((size_t)B.n, 0);
+    B.rc = SIFT_HIP_OK;
+    B.msg.clear();
+    B.total = 0;
+    B.wire_bytes = 0;
+    std::vector<long long> off((size_t)S, 0);
+    for (int s = 0; s < S; ++s) {
+        const ShardBatch& R = B.shard[(size_t)s];
+        const int cnt = B.count[(size_t)s];
+        if (cnt == 0) continue;
+        if (R.rc != SIFT_HIP_OK && B.rc == SIFT_HIP_OK) { B.rc = R.rc; B.msg = R.msg; }
+        if (!R.ran) {   // nothing ran on this shard: the batch has no result
+            if (B.rc == SIFT_HIP_OK) { B.rc = SIFT_HIP_EHIP; B.msg = "sift_hip_group_calculate: a shard returned no results"; }
+            B.total = -1;
+            break;
+        }
+        std::copy(R.status.begin(), R.status.end(), B.status.begin() + B.first[(size_t)s]);
+        std::copy(R.counts.begin(), R.counts.end(), B.counts.begin() + B.first[(size_t)s]);
+        off[(size_t)s] = B.total;
+        B.total += R.total;
+    }
+    auto fail = [&](const std::string& m) {
+        B.rc = SIFT_HIP_EHIP;
+        B.msg = m;
+        B.total = -1;
+    };
+    // Receives must be posted whatever happened above: a shard that has queued ncclSend waits for them.
+    const int dev0 = g->devices[0];
+    (void)hipSetDevice(dev0);
+    Rccl& r = rccl();
+    const bool loop = S == 1 && g->gather_loopback && g->use_rccl;
+    if (g->use_rccl) {
+        bool any = false, ok = true;
+        for (int s = loop ? 0 : 1; s < S; ++s) {
+            const ShardBatch& R = B.shard[(size_t)s];
+            if (!(R.sent || (loop && R.ran && R.total > 0))) continue;
+            const long long na = R.packed ? R.total * 34 : R.total * (long long)sizeof(sift_hip_keypoint);
+            const long long nb = R.packed ? R.nnz * 4 : R.total * 128 * (long long)sizeof(float);
+            ok = g->in_rec[slot][(size_t)s].fit(dev0, na) && g->in_val[slot][(size_t)s].fit(dev0, std::max<long long>(nb, 4)) && ok;
+            any = true;
+        }
+        if (any && ok) {
+            // ONE group: every link carries its shard's lists at the same time
+            ncclResult_t e1 = r.GroupStart();
+            for (int s = loop ? 0 : 1; s < S && e1 == ncclSuccess; ++s) {
+                const ShardBatch& R = B.shard[(size_t)s];
+                if (!(R.sent || (loop && R.ran && R.total > 0))) continue;
+                const size_t na = R.packed ? (size_t)R.total * 34 : (size_t)R.total * sizeof(sift_hip_keypoint);
+                const size_t nb = R.packed ? (size_t)R.nnz * 4 : (size_t)R.total * 128 * sizeof(float);
+                if (loop) {   // one shard, one GPU: the sends are this thread's too (a communicator serves one thread at a time)
+                    const void* src_a = g->pack_rec[slot][0].p;
+                    const void* src_b = g->pack_val[slot][0].p;
+                    if (!R.packed) (void)sift_hip_result_device(g->ctx[0], &src_a, &src_b);
+                    e1 = r.Send(src_a, na, ncclUint8, 0, g->comm[0], g->recv_stream);
+                    if (e1 == ncclSuccess && nb) e1 = r.Send(src_b, nb, ncclUint8, 0, g->comm[0], g->recv_stream);
+                }
+                if (e1 == ncclSuccess) e1 = r.Recv(g->in_rec[slot][(size_t)s].p, na, ncclUint8, s, g->comm[0], g->recv_stream);
+                if (e1 == ncclSuccess && nb) e1 = r.Recv(g->in_val[slot][(size_t)s].p, nb, ncclUint8, s, g->comm[0], g->recv_stream);
+                B.wire_bytes += (long long)(na + nb);
+            }
+            const ncclResult_t e2 = r.GroupEnd();
+            if (e1 != ncclSuccess || e2 != ncclSuccess) fail(std::string("sift_hip_group: ncclRecv failed: ") + r.GetErrorString(e1 != ncclSuccess ? e1 : e2));
+            else if (hipStreamSynchronize(g->recv_stream) != hipSuccess) fail("sift_hip_group: the RCCL gather failed");
+        } else if (any) {
+            fail("sift_hip_group: out of device memory for the arriving lists");
+        }
+    } else {
+        for (int s = 0; s < S; ++s) {   // copies: wait for every shard's own stream
+            const ShardBatch& R = B.shard[(size_t)s];
+            if (!R.sent) continue;
+            if (hipEventSynchronize(g->sent_ev[slot][(size_t)s]) != hipSuccess) fail("sift_hip_group: a device-to-device copy failed");
+            if (remote(g, s)) B.wire_bytes += R.packed ? R.total * 34 + R.nnz * 4 : R.total * (20 + 512);
+        }
+    }
+    if (B.total < 0) return;
+    if (B.total > 0 && (!g->out_kp[slot].fit(dev0, B.total * (long long)sizeof(sift_hip_keypoint)) ||
+                        !g->out_desc[slot].fit(dev0, B.total * 128 * (long long)sizeof(float)))) {
+        fail("sift_hip_group_calculate: out of device memory for the gathered lists");
+        return;
+    }
+    (void)hipSetDevice(dev0);
+    for (int s = 0; s < S; ++s) {
+        const ShardBatch& R = B.shard[(size_t)s];
+        if (R.total <= 0) continue;
+        char* dk = static_cast<char*>(g->out_kp[slot].p) + (size_t)off[(size_t)s] * sizeof(sift_hip_keypoint);
+        char* dd = static_cast<char*>(g->out_desc[slot].p) + (size_t)off[(size_t)s] * 128 * sizeof(float);
+        const bool arrived = R.sent || (loop && s == 0);
+        if (R.packed) {
+            const void* rec = arrived ? g->in_rec[slot][(size_t)s].p : g->pack_rec[slot][(size_t)s].p;
+            const void* val = arrived ? g->in_val[slot][(size_t)s].p : g->pack_val[slot][(size_t)s].p;
+            if (sift_hip_sparse_unpack(g->unpack_ctx, rec, val, R.total, dk, dd) != SIFT_HIP_OK) { fail("sift_hip_group_calculate: unpacking the arriving lists failed"); return; }
+        } else {
+            const void *kp = nullptr, *desc = nullptr;
+            if (arrived) { kp = g->in_rec[slot][(size_t)s].p; desc = g->in_val[slot][(size_t)s].p; }
+            else if (sift_hip_result_device(g->ctx[(size_t)s], &kp, &desc) != SIFT_HIP_OK) { fail("sift_hip_group: no device results"); return; }
+            // (lists still in the shard's own buffers: loopback mode only, which runs one batch at a time)
+            if (hipMemcpyAsync(dk, kp, (size_t)R.total * sizeof(sift_hip_keypoint), hipMemcpyDeviceToDevice, g->copy_stream) != hipSuccess ||
+                hipMemcpyAsync(dd, desc, (size_t)R.total * 128 * sizeof(float), hipMemcpyDeviceToDevice, g->copy_stream) != hipSuccess) {
+                fail("sift_hip_group: device-to-device copy failed");
+                return;
+            }
+        }
+    }
+    if (hipStreamSynchronize(g->copy_stream) != hipSuccess) fail("sift_hip_group_calculate: gather failed");
+}
+
+void gather_main(sift_hip_group* g) {
+    (void)hipSetDevice(g->devices[0]);
+    for (;;) {
+        long long seq;
+        {
+            std::unique_lock<std::mutex> lk(g->m);
+            g->cv.wait(lk, [&] { return g->stop || (g->gather_next < g->submitted && g->batch[g->gather_next % kSlots].reported == g->S); });
+            if (g->stop) return;
+            seq = g->gather_next;
+        }
+        Batch& B = g->batch[seq % kSlots];
+        try {
+            gather_batch(g, B, (int)(seq % kSlots));
+        } catch (const std::exception& ex) {
+            B.rc = SIFT_HIP_EHIP;
+            B.msg = std::string("sift_hip_group: ") + ex.what();
+            B.total = -1;
+        }
+        {
+            std::lock_guard<std::mutex> lk(g->m);
+            B.t_gathered = now_ms();
+            B.gathered = true;
+            g->gather_next = seq + 1;
+        }
+        g->cv.notify_all();
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -62,15 +474,23 @@ int sift_hip_group_create(const int* devices, int n_devices, sift_hip_group** ou
     *out = nullptr;
     auto* g = new sift_hip_group();
     g->devices.assign(devices, devices + n_devices);
+    g->S = n_devices;
+    auto bail = [&](int rc, const char* m) {
+        if (m) set_err(err, errlen, m);
+        for (auto* p : g->ctx) sift_hip_destroy(p);
+        if (g->unpack_ctx) sift_hip_destroy(g->unpack_ctx);
+        delete g;
+        return rc;
+    };
     for (int s = 0; s < n_devices; ++s) {
         sift_hip_ctx* c = nullptr;
         const int rc = sift_hip_create(devices[s], &c, err, errlen);
-        if (rc != SIFT_HIP_OK) {
-            for (auto* p : g->ctx) sift_hip_destroy(p);
-            delete g;
-            return rc;
-        }
+        if (rc != SIFT_HIP_OK) return bail(rc, nullptr);
         g->ctx.push_back(c);
+    }
+    {
+        const int rc = sift_hip_create(devices[0], &g->unpack_ctx, err, errlen);
+        if (rc != SIFT_HIP_OK) return bail(rc, nullptr);
     }
     // direct peer copies into shard 0's device (already-enabled and same-device answers are fine)
     for (int s = 1; s < n_devices; ++s)
@@ -82,12 +502,35 @@ int sift_hip_group_create(const int* devices, int n_devices, sift_hip_group** ou
             }
             (void)hipGetLastError();
         }
+    g->send_stream.assign((size_t)n_devices, nullptr);
+    for (int b = 0; b < kSlots; ++b) {
+        g->sent_ev[b].assign((size_t)n_devices, nullptr);
+        g->pack_rec[b].resize((size_t)n_devices); g->pack_val[b].resize((size_t)n_devices);
+        g->in_rec[b].resize((size_t)n_devices); g->in_val[b].resize((size_t)n_devices);
+    }
+    for (int s = 0; s < n_devices; ++s) {
+        if (hipSetDevice(devices[s]) != hipSuccess || hipStreamCreateWithFlags(&g->send_stream[(size_t)s], hipStreamNonBlocking) != hipSuccess)
+            return bail(SIFT_HIP_EHIP, "sift_hip_group_create: cannot create a shard's transfer stream");
+        for (int b = 0; b < kSlots; ++b)
+            if (hipEventCreateWithFlags(&g->sent_ev[b][(size_t)s], hipEventDisableTiming) != hipSuccess)
+                return bail(SIFT_HIP_EHIP, "sift_hip_group_create: cannot create an event");
+    }
     (void)hipSetDevice(devices[0]);
-    if (hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) != hipSuccess) {
-        set_err(err, errlen, "sift_hip_group_create: cannot create the gather stream");
-        for (auto* p : g->ctx) sift_hip_destroy(p);
-        delete g;
-        return SIFT_HIP_EHIP;
+    if (hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&g->recv_stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(SIFT_HIP_EHIP, "sift_hip_group_create: cannot create the gather streams");
+    g->shard_next.assign((size_t)n_devices, 0);
+    try {
+        for (int s = 0; s < n_devices; ++s) g->workers.emplace_back(shard_main, g, s);
+        g->gatherer = std::thread(gather_main, g);
+    } catch (const std::exception& e) {
+        {
+            std::lock_guard<std::mutex> lk(g->m);
+            g->stop = true;
+        }
+        g->cv.notify_all();
+        for (auto& t : g->workers) if (t.joinable()) t.join();
+        return bail(SIFT_HIP_EHIP, e.what());
     }
     *out = g;
     return SIFT_HIP_OK;
@@ -95,262 +538,197 @@ int sift_hip_group_create(const int* devices, int n_devices, sift_hip_group** ou
 
 void sift_hip_group_destroy(sift_hip_group* g) {
     if (!g) return;
+    {
+        std::unique_lock<std::mutex> lk(g->m);
+        // batches still in flight run to their end first (a shard may be inside an RCCL exchange another thread has to answer)
+        g->cv.wait(lk, [&] { return g->gather_next == g->submitted; });
+        g->stop = true;
+    }
+    g->cv.notify_all();
+    for (auto& t : g->workers) if (t.joinable()) t.join();
+    if (g->gatherer.joinable()) g->gatherer.join();
+    if (!g->comm.empty()) {
+        Rccl& r = rccl();
+        for (auto c : g->comm) if (c) (void)r.CommDestroy(c);
+    }
+    for (int s = 0; s < g->S; ++s) {
+        (void)hipSetDevice(g->devices[(size_t)s]);
+        if (g->send_stream[(size_t)s]) { (void)hipStreamSynchronize(g->send_stream[(size_t)s]); (void)hipStreamDestroy(g->send_stream[(size_t)s]); }
+        for (int b = 0; b < kSlots; ++b) {
+            if (g->sent_ev[b][(size_t)s]) (void)hipEventDestroy(g->sent_ev[b][(size_t)s]);
+            g->pack_rec[b][(size_t)s].release(g->devices[(size_t)s]);
+            g->pack_val[b][(size_t)s].release(g->devices[(size_t)s]);
+            g->in_rec[b][(size_t)s].release(g->devices[0]);
+            g->in_val[b][(size_t)s].release(g->devices[0]);
+        }
+    }
     (void)hipSetDevice(g->devices[0]);
-    if (g->copy_stream) {
-        (void)hipStreamSynchronize(g->copy_stream);
-        (void)hipStreamDestroy(g->copy_stream);
-    }
-    if (g->d_kp) (void)hipFree(g->d_kp);
-    if (g->d_desc) (void)hipFree(g->d_desc);
-    if (g->d_in_rec) (void)hipFree(g->d_in_rec);
-    if (g->d_in_val) (void)hipFree(g->d_in_val);
-    for (size_t s = 0; s < g->s_rec.size(); ++s) {
-        (void)hipSetDevice(g->devices[s]);
-        if (g->s_rec[s]) (void)hipFree(g->s_rec[s]);
-        if (g->s_val[s]) (void)hipFree(g->s_val[s]);
-    }
+    for (int b = 0; b < kSlots; ++b) { g->out_kp[b].release(g->devices[0]); g->out_desc[b].release(g->devices[0]); }
+    if (g->copy_stream) { (void)hipStreamSynchronize(g->copy_stream); (void)hipStreamDestroy(g->copy_stream); }
+    if (g->recv_stream) { (void)hipStreamSynchronize(g->recv_stream); (void)hipStreamDestroy(g->recv_stream); }
     for (auto* c : g->ctx) sift_hip_destroy(c);
+    if (g->unpack_ctx) sift_hip_destroy(g->unpack_ctx);
     delete g;
 }
 
-int sift_hip_group_shards(sift_hip_group* g) { return g ? (int)g->ctx.size() : -1; }
+int sift_hip_group_shards(sift_hip_group* g) { return g ? g->S : -1; }
 
 int sift_hip_group_set_option(sift_hip_group* g, const char* name, int value) {
     if (!g || !name) return SIFT_HIP_EINVAL;
-    if (!std::strcmp(name, "gather_wire")) {
-        if (value < 0 || value > 2) return SIFT_HIP_EINVAL;
-        g->gather_wire = value;
-        return SIFT_HIP_OK;
+    {
+        std::lock_guard<std::mutex> lk(g->m);
+        if (g->collected != g->submitted) return SIFT_HIP_EINVAL;   // not while a batch is in flight
+        if (!std::strcmp(name, "gather_wire")) {
+            if (value < 0 || value > 2) return SIFT_HIP_EINVAL;
+            g->gather_wire = value;
+            return SIFT_HIP_OK;
+        }
+        if (!std::strcmp(name, "gather_transport")) {   // before the first batch: the communicators are made then
+            if (value < 0 || value > 2 || g->comm_tried) return SIFT_HIP_EINVAL;
+            g->gather_transport = value;
+            return SIFT_HIP_OK;
+        }
+        if (!std::strcmp(name, "gather_loopback")) {
+            if (value < 0 || value > 1 || g->comm_tried) return SIFT_HIP_EINVAL;
+            g->gather_loopback = value;
+            return SIFT_HIP_OK;
+        }
     }
     int rc = SIFT_HIP_OK;
     for (auto* c : g->ctx) rc = std::max(rc, sift_hip_set_option(c, name, value));
     return rc;
 }
 
-static int group_calculate(sift_hip_group* g, const float* host_imgs, int n, int w, int h, const sift_hip_params* params, char* err, int errlen);
+int sift_hip_group_transport(sift_hip_group* g, char* text, int textlen) {
+    if (!g) return -1;
+    std::lock_guard<std::mutex> lk(g->m);
+    init_transport(g);
+    set_err(text, textlen, g->rccl_note);
+    return g->use_rccl ? 1 : 0;
+}
+
+int sift_hip_group_submit(sift_hip_group* g, const float* host_imgs, int n, int w, int h, const sift_hip_params* params, char* err, int errlen) {
+    if (!g || !host_imgs || !params || n <= 0 || w <= 0 || h <= 0) return SIFT_HIP_EINVAL;
+    try {
+        std::unique_lock<std::mutex> lk(g->m);
+        if (g->submitted - g->collected >= kSlots) {
+            set_err(err, errlen, "sift_hip_group_submit: two batches are in flight already: collect one first");
+            return SIFT_HIP_EINVAL;
+        }
+        init_transport(g);
+        if (g->gather_transport == 2 && !g->use_rccl && (g->S > 1 || g->gather_loopback)) {
+            set_err(err, errlen, "sift_hip_group_submit: option gather_transport = 2 asks for RCCL: " + g->rccl_note);
+            return SIFT_HIP_EHIP;
+        }
+        if (g->S == 1 && g->gather_loopback)   // test mode: the gather thread reads the shard's own buffers, one batch at a time
+            g->cv.wait(lk, [&] { return g->gather_next == g->submitted; });
+        const long long seq = g->submitted;
+        Batch& B = g->batch[seq % kSlots];
+        B = Batch();
+        B.seq = seq;
+        B.n = n; B.w = w; B.h = h; B.imgs = host_imgs; B.params = *params;
+        const int S = g->S;
+        B.first.assign((size_t)S, 0);
+        B.count.assign((size_t)S, 0);
+        B.shard.assign((size_t)S, ShardBatch());
+        const int per = (n + S - 1) / S;   // contiguous blocks: shard s holds images s*per .. (256 -> 32 each on 8 GPUs)
+        for (int s = 0; s < S; ++s) {
+            B.first[(size_t)s] = std::min(n, s * per);
+            B.count[(size_t)s] = std::min(n, (s + 1) * per) - B.first[(size_t)s];
+        }
+        B.t_submit = now_ms();
+        if (g->cur == (int)(seq % kSlots)) g->cur = -1;   // the results read so far lived in this slot
+        if (g->gather_wire)
+            for (auto* c : g->ctx) (void)sift_hip_set_option(c, "wire_count", 1);   // the descriptor kernels count what the wire will carry
+        g->submitted = seq + 1;
+    } catch (const std::exception& e) {
+        set_err(err, errlen, std::string("sift_hip_group_submit: ") + e.what());
+        return SIFT_HIP_EHIP;
+    }
+    g->cv.notify_all();
+    return SIFT_HIP_OK;
+}
+
+int sift_hip_group_collect(sift_hip_group* g, char* err, int errlen) {
+    if (!g) return SIFT_HIP_EINVAL;
+    std::unique_lock<std::mutex> lk(g->m);
+    if (g->collected == g->submitted) {
+        set_err(err, errlen, "sift_hip_group_collect: no batch in flight");
+        return SIFT_HIP_EINVAL;
+    }
+    const long long seq = g->collected;
+    const double t_wait = now_ms();
+    g->cv.wait(lk, [&] { return g->gather_next > seq; });
+    Batch& B = g->batch[seq % kSlots];
+    g->collected = seq + 1;
+    g->cur = B.total >= 0 ? (int)(seq % kSlots) : -1;
+    double cms = 0;
+    for (const auto& R : B.shard) cms = std::max(cms, R.compute_ms);
+    g->compute_ms = cms;
+    g->gather_ms = B.t_gathered - B.t_computed;                 // last shard done -> lists in place on devices[0]
+    g->exposed_ms = std::max(0.0, B.t_gathered - std::max(t_wait, B.t_computed));   // the part of it this call had to wait for
+    g->gather_bytes = B.wire_bytes;
+    if (B.rc != SIFT_HIP_OK) set_err(err, errlen, B.msg);
+    return B.rc;
+}
 
 int sift_hip_group_calculate(sift_hip_group* g, const float* host_imgs, int n, int w, int h, const sift_hip_params* params,
                              char* err, int errlen) {
-    try {   // no C++ exception (thread creation, allocation) leaves the C ABI
-        return group_calculate(g, host_imgs, n, w, h, params, err, errlen);
-    } catch (const std::exception& e) {
-        set_err(err, errlen, std::string("sift_hip_group_calculate: ") + e.what());
-        return SIFT_HIP_EHIP;
-    }
-}
-
-static int group_calculate(sift_hip_group* g, const float* host_imgs, int n, int w, int h, const sift_hip_params* params, char* err, int errlen) {
-    if (!g || !host_imgs || !params || n <= 0 || w <= 0 || h <= 0) return SIFT_HIP_EINVAL;
-    const int S = (int)g->ctx.size();
-    g->have_result = false;
-    g->n = n;
-    g->first.assign((size_t)S, 0);
-    g->count.assign((size_t)S, 0);
-    g->rc.assign((size_t)S, SIFT_HIP_OK);
-    g->msg.assign((size_t)S, std::string());
-    g->s_rec.resize((size_t)S, nullptr); g->s_val.resize((size_t)S, nullptr);
-    g->s_rec_cap.resize((size_t)S, 0); g->s_val_cap.resize((size_t)S, 0);
-    g->s_nnz.assign((size_t)S, 0); g->s_packed.assign((size_t)S, 0);
-    if (g->gather_wire) sift_hip_group_set_option(g, "wire_count", 1);   // the descriptor kernels count what the wire will carry
-    const int per = (n + S - 1) / S;   // contiguous blocks: shard s holds images s*per .. (256 -> 32 each on 8 GPUs)
-    for (int s = 0; s < S; ++s) {
-        g->first[(size_t)s] = std::min(n, s * per);
-        g->count[(size_t)s] = std::min(n, (s + 1) * per) - g->first[(size_t)s];
-    }
-    const size_t frame = (size_t)w * (size_t)h;
-    const double t0 = now_ms();
-    struct Joiner {
-        std::vector<std::thread> th;
-        ~Joiner() { for (auto& t : th) if (t.joinable()) t.join(); }
-    } threads;
-    std::vector<std::thread>& th = threads.th;
-    for (int s = 0; s < S; ++s) {
-        if (g->count[(size_t)s] == 0) continue;
-        th.emplace_back([g, s, host_imgs, frame, w, h, params]() {
-            char e[512] = "";
-            g->rc[(size_t)s] = sift_hip_calculate_batch(g->ctx[(size_t)s], host_imgs + (size_t)g->first[(size_t)s] * frame, g->count[(size_t)s], w, h,
-                                                       params, e, sizeof(e));
-            g->msg[(size_t)s] = e;
-            // lists that will cross to another GPU are packed here, on the shard's own GPU and thread
-            g->s_packed[(size_t)s] = 0;
-            const bool remote = g->devices[(size_t)s] != g->devices[0];
-            if ((g->gather_wire == 2 || (g->gather_wire == 1 && remote)) && sift_hip_result_images(g->ctx[(size_t)s]) == g->count[(size_t)s]) {
-                const long long t = sift_hip_result_total(g->ctx[(size_t)s]);
-                int64_t nnz = 0;
-                int lossless = 0;
-                if (t > 0 && sift_hip_result_sparse_size(g->ctx[(size_t)s], &nnz, &lossless) == SIFT_HIP_OK && lossless &&
-                    hipSetDevice(g->devices[(size_t)s]) == hipSuccess) {
-                    auto fit = [](void*& p, long long& cap, long long want) {
-                        if (want <= cap) return true;
-                        if (p) (void)hipFree(p);
-                        p = nullptr; cap = 0;
-                        if (hipMalloc(&p, (size_t)(want + want / 4)) != hipSuccess) { p = nullptr; return false; }
-                        cap = want + want / 4;
-                        return true;
-                    };
-                    if (fit(g->s_rec[(size_t)s], g->s_rec_cap[(size_t)s], t * 34) &&
-                        fit(g->s_val[(size_t)s], g->s_val_cap[(size_t)s], std::max<long long>(nnz, 1) * 4) &&
-                        sift_hip_result_sparse_pack(g->ctx[(size_t)s], g->s_rec[(size_t)s], g->s_val[(size_t)s]) == SIFT_HIP_OK) {
-                        g->s_nnz[(size_t)s] = nnz;
-                        g->s_packed[(size_t)s] = 1;
-                    }
-                }
-            }
-        });
-    }
-    for (auto& t : th) t.join();
-    g->compute_ms = now_ms() - t0;
-
-    // per-image status / counts in global order; a shard whose call failed before it ran (bad arguments, HIP error) fails the batch
-    g->status.assign((size_t)n, 0);
-    g->counts.assign((size_t)n, 0);
-    int first_rc = SIFT_HIP_OK;
-    std::string first_msg;
-    std::vector<long long> shard_total((size_t)S, 0), shard_off((size_t)S, 0);
-    long long total = 0;
-    for (int s = 0; s < S; ++s) {
-        const int cnt = g->count[(size_t)s];
-        if (cnt == 0) continue;
-        const int rc = g->rc[(size_t)s];
-        if (rc != SIFT_HIP_OK && first_rc == SIFT_HIP_OK) { first_rc = rc; first_msg = g->msg[(size_t)s]; }
-        if (sift_hip_result_images(g->ctx[(size_t)s]) != cnt) {   // nothing ran on this shard
-            if (rc == SIFT_HIP_OK) { first_rc = SIFT_HIP_EHIP; first_msg = "sift_hip_group_calculate: a shard returned no results"; }
-            set_err(err, errlen, first_msg);
-            return first_rc;
-        }
-        (void)sift_hip_result_status(g->ctx[(size_t)s], g->status.data() + g->first[(size_t)s], cnt);
-        (void)sift_hip_result_counts(g->ctx[(size_t)s], g->counts.data() + g->first[(size_t)s], cnt);
-        shard_total[(size_t)s] = sift_hip_result_total(g->ctx[(size_t)s]);
-        shard_off[(size_t)s] = total;
-        total += shard_total[(size_t)s];
-    }
-    g->total = total;
-
-    // ---- gather: keypoint lists only, device to device, global image order ------------------------------------
-    const double t1 = now_ms();
-    if (hipSetDevice(g->devices[0]) != hipSuccess) { set_err(err, errlen, "hipSetDevice failed"); return SIFT_HIP_EHIP; }
-    if (total > g->cap) {
-        if (g->d_kp) (void)hipFree(g->d_kp);
-        if (g->d_desc) (void)hipFree(g->d_desc);
-        g->d_kp = g->d_desc = nullptr;
-        g->cap = 0;
-        const long long want = total + total / 4;
-        if (hipMalloc(&g->d_kp, (size_t)want * sizeof(sift_hip_keypoint)) != hipSuccess ||
-            hipMalloc(&g->d_desc, (size_t)want * 128 * sizeof(float)) != hipSuccess) {
-            set_err(err, errlen, "sift_hip_group_calculate: out of device memory for the gathered lists");
-            return SIFT_HIP_EHIP;
-        }
-        g->cap = want;
-    }
-    g->gather_bytes = 0;
-    // packed lists first: all of them into one staging area on devices[0] (each over its own link), then unpacked there
+    if (!g) return SIFT_HIP_EINVAL;
     {
-        long long need_rec = 0, need_val = 0;
-        for (int s = 0; s < S; ++s)
-            if (g->s_packed[(size_t)s] && shard_total[(size_t)s] > 0) { need_rec += shard_total[(size_t)s] * 34; need_val += g->s_nnz[(size_t)s] * 4; }
-        auto fit0 = [](void*& p, long long& cap, long long want) {
-            if (want <= cap) return true;
-            if (p) (void)hipFree(p);
-            p = nullptr; cap = 0;
-            if (hipMalloc(&p, (size_t)(want + want / 4)) != hipSuccess) { p = nullptr; return false; }
-            cap = want + want / 4;
-            return true;
-        };
-        if (need_rec > 0 && (!fit0(g->d_in_rec, g->in_rec_cap, need_rec) || !fit0(g->d_in_val, g->in_val_cap, std::max<long long>(need_val, 4)))) {
-            set_err(err, errlen, "sift_hip_group_calculate: out of device memory for the arriving lists");
-            return SIFT_HIP_EHIP;
-        }
-        long long ro = 0, vo = 0;
-        std::vector<long long> rec_at((size_t)S, 0), val_at((size_t)S, 0);
-        for (int s = 0; s < S; ++s) {
-            if (!g->s_packed[(size_t)s] || shard_total[(size_t)s] <= 0) continue;
-            const size_t br = (size_t)shard_total[(size_t)s] * 34, bv = (size_t)g->s_nnz[(size_t)s] * 4;
-            char* dr = static_cast<char*>(g->d_in_rec) + ro;
-            char* dv = static_cast<char*>(g->d_in_val) + vo;
-            rec_at[(size_t)s] = ro; val_at[(size_t)s] = vo;
-            ro += (long long)br; vo += (long long)bv;
-            hipError_t e1 = hipSuccess, e2 = hipSuccess;
-            if (g->devices[(size_t)s] == g->devices[0]) {
-                e1 = hipMemcpyAsync(dr, g->s_rec[(size_t)s], br, hipMemcpyDeviceToDevice, g->copy_stream);
-                if (bv) e2 = hipMemcpyAsync(dv, g->s_val[(size_t)s], bv, hipMemcpyDeviceToDevice, g->copy_stream);
-            } else {
-                e1 = hipMemcpyPeerAsync(dr, g->devices[0], g->s_rec[(size_t)s], g->devices[(size_t)s], br, g->copy_stream);
-                if (bv) e2 = hipMemcpyPeerAsync(dv, g->devices[0], g->s_val[(size_t)s], g->devices[(size_t)s], bv, g->copy_stream);
-                g->gather_bytes += (long long)(br + bv);
-            }
-            if (e1 != hipSuccess || e2 != hipSuccess) { set_err(err, errlen, "sift_hip_group_calculate: peer copy failed"); return SIFT_HIP_EHIP; }
-        }
-        if (need_rec > 0) {
-            if (hipStreamSynchronize(g->copy_stream) != hipSuccess) { set_err(err, errlen, "sift_hip_group_calculate: gather failed"); return SIFT_HIP_EHIP; }
-            for (int s = 0; s < S; ++s) {
-                if (!g->s_packed[(size_t)s] || shard_total[(size_t)s] <= 0) continue;
-                char* dk = static_cast<char*>(g->d_kp) + (size_t)shard_off[(size_t)s] * sizeof(sift_hip_keypoint);
-                char* dd = static_cast<char*>(g->d_desc) + (size_t)shard_off[(size_t)s] * 128 * sizeof(float);
-                if (sift_hip_sparse_unpack(g->ctx[0], static_cast<char*>(g->d_in_rec) + rec_at[(size_t)s], static_cast<char*>(g->d_in_val) + val_at[(size_t)s],
-                                           shard_total[(size_t)s], dk, dd) != SIFT_HIP_OK) {
-                    set_err(err, errlen, "sift_hip_group_calculate: unpacking the arriving lists failed");
-                    return SIFT_HIP_EHIP;
-                }
-            }
+        std::lock_guard<std::mutex> lk(g->m);
+        if (g->collected != g->submitted) {
+            set_err(err, errlen, "sift_hip_group_calculate: batches submitted earlier have not been collected");
+            return SIFT_HIP_EINVAL;
         }
     }
-    for (int s = 0; s < S; ++s) {
-        const long long t = shard_total[(size_t)s];
-        if (t <= 0 || g->s_packed[(size_t)s]) continue;
-        const void *kp = nullptr, *desc = nullptr;
-        if (sift_hip_result_device(g->ctx[(size_t)s], &kp, &desc) != SIFT_HIP_OK) { set_err(err, errlen, "no device results"); return SIFT_HIP_EHIP; }
-        char* dk = static_cast<char*>(g->d_kp) + (size_t)shard_off[(size_t)s] * sizeof(sift_hip_keypoint);
-        char* dd = static_cast<char*>(g->d_desc) + (size_t)shard_off[(size_t)s] * 128 * sizeof(float);
-        const size_t bk = (size_t)t * sizeof(sift_hip_keypoint), bd = (size_t)t * 128 * sizeof(float);
-        hipError_t e1, e2;
-        if (g->devices[(size_t)s] == g->devices[0]) {
-            e1 = hipMemcpyAsync(dk, kp, bk, hipMemcpyDeviceToDevice, g->copy_stream);
-            e2 = hipMemcpyAsync(dd, desc, bd, hipMemcpyDeviceToDevice, g->copy_stream);
-        } else {
-            e1 = hipMemcpyPeerAsync(dk, g->devices[0], kp, g->devices[(size_t)s], bk, g->copy_stream);
-            e2 = hipMemcpyPeerAsync(dd, g->devices[0], desc, g->devices[(size_t)s], bd, g->copy_stream);
-            g->gather_bytes += (long long)(bk + bd);
-        }
-        if (e1 != hipSuccess || e2 != hipSuccess) { set_err(err, errlen, "sift_hip_group_calculate: peer copy failed"); return SIFT_HIP_EHIP; }
+    const int rc = sift_hip_group_submit(g, host_imgs, n, w, h, params, err, errlen);
+    if (rc != SIFT_HIP_OK) {
+        std::lock_guard<std::mutex> lk(g->m);
+        g->cur = -1;
+        return rc;
     }
-    if (hipStreamSynchronize(g->copy_stream) != hipSuccess) { set_err(err, errlen, "sift_hip_group_calculate: gather failed"); return SIFT_HIP_EHIP; }
-    g->gather_ms = now_ms() - t1;
-    g->have_result = true;
-    if (first_rc != SIFT_HIP_OK) set_err(err, errlen, first_msg);
-    return first_rc;
+    return sift_hip_group_collect(g, err, errlen);
 }
 
-int sift_hip_group_result_images(sift_hip_group* g) { return (g && g->have_result) ? g->n : -1; }
-int64_t sift_hip_group_result_total(sift_hip_group* g) { return (g && g->have_result) ? g->total : -1; }
+int sift_hip_group_result_images(sift_hip_group* g) { return (g && g->cur >= 0) ? g->batch[g->cur].n : -1; }
+int64_t sift_hip_group_result_total(sift_hip_group* g) { return (g && g->cur >= 0) ? g->batch[g->cur].total : -1; }
 int sift_hip_group_result_status(sift_hip_group* g, int32_t* status, int cap) {
-    if (!g || !g->have_result || !status || cap < g->n) return SIFT_HIP_EINVAL;
-    std::copy(g->status.begin(), g->status.end(), status);
+    if (!g || g->cur < 0 || !status || cap < g->batch[g->cur].n) return SIFT_HIP_EINVAL;
+    std::copy(g->batch[g->cur].status.begin(), g->batch[g->cur].status.end(), status);
     return SIFT_HIP_OK;
 }
 int sift_hip_group_result_counts(sift_hip_group* g, int32_t* counts, int cap) {
-    if (!g || !g->have_result || !counts || cap < g->n) return SIFT_HIP_EINVAL;
-    std::copy(g->counts.begin(), g->counts.end(), counts);
+    if (!g || g->cur < 0 || !counts || cap < g->batch[g->cur].n) return SIFT_HIP_EINVAL;
+    std::copy(g->batch[g->cur].counts.begin(), g->batch[g->cur].counts.end(), counts);
     return SIFT_HIP_OK;
 }
 int sift_hip_group_result_device(sift_hip_group* g, const void** dev_keypoints, const void** dev_descriptors) {
-    if (!g || !g->have_result) return SIFT_HIP_EINVAL;
-    if (dev_keypoints) *dev_keypoints = g->d_kp;
-    if (dev_descriptors) *dev_descriptors = g->d_desc;
+    if (!g || g->cur < 0) return SIFT_HIP_EINVAL;
+    if (dev_keypoints) *dev_keypoints = g->out_kp[g->cur].p;
+    if (dev_descriptors) *dev_descriptors = g->out_desc[g->cur].p;
     return SIFT_HIP_OK;
 }
 int sift_hip_group_result_copy(sift_hip_group* g, sift_hip_keypoint* kp, float* desc) {
-    if (!g || !g->have_result) return SIFT_HIP_EINVAL;
-    if (g->total <= 0) return SIFT_HIP_OK;
+    if (!g || g->cur < 0) return SIFT_HIP_EINVAL;
+    const long long total = g->batch[g->cur].total;
+    if (total <= 0) return SIFT_HIP_OK;
     if (hipSetDevice(g->devices[0]) != hipSuccess) return SIFT_HIP_EHIP;
-    if (kp && hipMemcpyAsync(kp, g->d_kp, (size_t)g->total * sizeof(sift_hip_keypoint), hipMemcpyDefault, g->copy_stream) != hipSuccess) return SIFT_HIP_EHIP;
-    if (desc && hipMemcpyAsync(desc, g->d_desc, (size_t)g->total * 128 * sizeof(float), hipMemcpyDefault, g->copy_stream) != hipSuccess) return SIFT_HIP_EHIP;
-    return hipStreamSynchronize(g->copy_stream) == hipSuccess ? SIFT_HIP_OK : SIFT_HIP_EHIP;
+    // a copy of its own, not the gather thread's streams: the next batch's gather may be running
+    if (kp && hipMemcpy(kp, g->out_kp[g->cur].p, (size_t)total * sizeof(sift_hip_keypoint), hipMemcpyDefault) != hipSuccess) return SIFT_HIP_EHIP;
+    if (desc && hipMemcpy(desc, g->out_desc[g->cur].p, (size_t)total * 128 * sizeof(float), hipMemcpyDefault) != hipSuccess) return SIFT_HIP_EHIP;
+    return SIFT_HIP_OK;
 }
 int sift_hip_group_timing(sift_hip_group* g, double* compute_ms, double* gather_ms, int64_t* gather_bytes) {
-    if (!g || !g->have_result) return SIFT_HIP_EINVAL;
+    if (!g || g->collected == 0) return SIFT_HIP_EINVAL;
     if (compute_ms) *compute_ms = g->compute_ms;
     if (gather_ms) *gather_ms = g->gather_ms;
     if (gather_bytes) *gather_bytes = g->gather_bytes;
+    return SIFT_HIP_OK;
+}
+int sift_hip_group_gather_exposed(sift_hip_group* g, double* exposed_ms) {
+    if (!g || g->collected == 0 || !exposed_ms) return SIFT_HIP_EINVAL;
+    *exposed_ms = g->exposed_ms;
     return SIFT_HIP_OK;
 }
 

@@ -694,6 +694,27 @@ void launch_resample(hipStream_t s, const float* src, float* dst, int ws, int hs
     hipLaunchKernelGGL(resample_lut_kernel, grid, dim3(256), 0, s, src, dst, ws, hs, wd, hd, d_lutx, d_luty);
 }
 
+// 8-bit samples -> the integer-valued floats vigra::importImage hands to Sift::calculate (/root/reference/main.cpp:52-54):
+// a thread widens 16 consecutive bytes (one 16-byte load, four 16-byte stores)
+__global__ void widen_u8_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, size_t count) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (i + 16 <= count && (((uintptr_t)in | (uintptr_t)out) & 15u) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4*>(in + i);
+        const unsigned wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            *reinterpret_cast<float4*>(out + i + 4 * k) = make_float4((float)(wd[k] & 255u), (float)((wd[k] >> 8) & 255u),
+                                                                      (float)((wd[k] >> 16) & 255u), (float)(wd[k] >> 24));
+    } else {
+        for (size_t k = i; k < count && k < i + 16; ++k) out[k] = (float)in[k];
+    }
+}
+
+void launch_widen_u8(hipStream_t s, const uint8_t* in, float* out, size_t count) {
+    const size_t threads = (count + 15) / 16;
+    hipLaunchKernelGGL(widen_u8_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, in, out, count);
+}
+
 void launch_dog(hipStream_t s, const float* lower, const float* higher, float* out, size_t count) {
     const unsigned grid = (unsigned)((count + 255) / 256);
     hipLaunchKernelGGL(dog_kernel, dim3(grid), dim3(256), 0, s, lower, higher, out, count);

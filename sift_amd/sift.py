@@ -122,12 +122,19 @@ class Context:
 
     # ---- Sift::calculate ---------------------------------------------------------------------
     def calculate_batch(self, imgs, params, raise_on_error=True):
-        imgs = np.ascontiguousarray(imgs, dtype=np.float32)
+        """Frames from host memory.  A uint8 array takes the 8-bit entry point (a quarter of the bytes cross the link, the GPU
+        widens them to the floats vigra::importImage would have produced); anything else is handed over as float32."""
+        imgs = np.asarray(imgs)
+        u8 = imgs.dtype == np.uint8
+        imgs = np.ascontiguousarray(imgs, dtype=np.uint8 if u8 else np.float32)
         if imgs.ndim == 2:
             imgs = imgs[None]
         n, h, w = imgs.shape
         err = C.create_string_buffer(512)
-        rc = self._L.sift_hip_calculate_batch(self._h, imgs.reshape(-1), n, w, h, C.byref(params), err, 512)
+        if u8:
+            rc = self._L.sift_hip_calculate_batch_u8(self._h, imgs.ctypes.data, n, w, h, C.byref(params), err, 512)
+        else:
+            rc = self._L.sift_hip_calculate_batch(self._h, imgs.reshape(-1), n, w, h, C.byref(params), err, 512)
         if rc and raise_on_error:
             _raise(rc, err)
         return rc, err.value.decode(errors="replace")
@@ -172,6 +179,25 @@ class Context:
         if t > 0 and self._L.sift_hip_result_copy(self._h, kp.ctypes.data, desc.ctypes.data):
             raise HipError("sift_hip_result_copy failed")
         return kp, desc
+
+    def results_sparse(self, rec_out=None, val_out=None):
+        """The results in the sparse wire format, in host memory: (records uint8 [total, 34] = 20-byte keypoint record + 112
+        presence bits, values float32 [n] = the descriptor floats that are not +0.0f) - what crosses the link is ~200 instead of
+        532 bytes per keypoint.  `unpack_sparse_host` turns them back into (keypoints, descriptors).  Falls back to None when the
+        results hold a value the format would lose (see sift_hip_result_sparse_size)."""
+        t = max(self.total(), 0)
+        nnz, lossless = C.c_int64(), C.c_int()
+        if self._L.sift_hip_result_sparse_size(self._h, C.byref(nnz), C.byref(lossless)):
+            raise HipError("sift_hip_result_sparse_size failed")
+        if not lossless.value:
+            return None
+        rec = np.zeros((t, 34), np.uint8) if rec_out is None else rec_out.reshape(-1)[:t * 34].reshape(t, 34)
+        val = np.zeros(nnz.value, np.float32) if val_out is None else val_out.reshape(-1)[:nnz.value]
+        if val.size < nnz.value or rec.shape[0] < t:
+            raise ValueError("result arrays too small")
+        if t > 0 and self._L.sift_hip_result_copy_sparse(self._h, rec.ctypes.data, val.ctypes.data):
+            raise HipError("sift_hip_result_copy_sparse failed")
+        return rec, val
 
     def result_device_ptrs(self):
         a, b = C.c_void_p(), C.c_void_p()
@@ -347,6 +373,37 @@ class Group:
             _raise(rc, err)
         return rc, err.value.decode(errors="replace")
 
+    def submit(self, imgs, params):
+        """Start a batch and return at once (at most two in flight); `collect()` waits for the oldest one.  The gather of a batch
+        runs under the kernels of the next."""
+        imgs = np.ascontiguousarray(imgs, dtype=np.float32)
+        n, h, w = imgs.shape
+        err = C.create_string_buffer(512)
+        rc = self._L.sift_hip_group_submit(self._h, imgs.reshape(-1), n, w, h, C.byref(params), err, 512)
+        if rc:
+            _raise(rc, err)
+        self._inflight = getattr(self, "_inflight", []) + [imgs]    # the frames stay alive until their batch is collected
+
+    def collect(self, raise_on_error=True):
+        err = C.create_string_buffer(512)
+        rc = self._L.sift_hip_group_collect(self._h, err, 512)
+        if getattr(self, "_inflight", None):
+            self._inflight.pop(0)
+        if rc and raise_on_error:
+            _raise(rc, err)
+        return rc, err.value.decode(errors="replace")
+
+    def transport(self):
+        """(1 if the gather runs over RCCL else 0, why)"""
+        text = C.create_string_buffer(256)
+        return int(self._L.sift_hip_group_transport(self._h, text, 256)), text.value.decode(errors="replace")
+
+    def gather_exposed_ms(self):
+        v = C.c_double()
+        if self._L.sift_hip_group_gather_exposed(self._h, C.byref(v)):
+            raise HipError("no batch collected")
+        return v.value
+
     def counts(self):
         out = np.zeros(max(self._L.sift_hip_group_result_images(self._h), 0), np.int32)
         if self._L.sift_hip_group_result_counts(self._h, out, out.size):
@@ -378,6 +435,20 @@ class Group:
         return a.value, b.value, n.value
 
 
+def unpack_sparse_host(rec, val, kp_out=None, desc_out=None, threads: int = 8):
+    """Sparse wire format in host memory -> (keypoints, descriptors [n, 128]), bit for bit what Context.results returns
+    (sift_hip_sparse_unpack_host: plain host code, `threads` threads)."""
+    L = _lib.load()
+    rec = np.ascontiguousarray(rec, np.uint8).reshape(-1, 34)
+    val = np.ascontiguousarray(val, np.float32)
+    n = rec.shape[0]
+    kp = np.zeros(n, _lib.KEYPOINT_DTYPE) if kp_out is None else kp_out.reshape(-1)[:n]
+    desc = np.empty((n, 128), np.float32) if desc_out is None else desc_out.reshape(-1, 128)[:n]
+    if L.sift_hip_sparse_unpack_host(rec.ctypes.data, val.ctypes.data, n, kp.ctypes.data, desc.ctypes.data, int(threads)):
+        raise HipError("sift_hip_sparse_unpack_host failed")
+    return kp, desc
+
+
 def gauss_taps(sigma: float):
     L = _lib.load()
     buf = np.zeros(8192, np.float32)
@@ -403,12 +474,14 @@ class Sift:
     def calculate(self, img: np.ndarray):
         """Returns (points, img): the InterestPoint list and the image the reference leaves in the
         caller's array (the 2x upsampled one when subpixel, sift.cpp:20-21)."""
-        img = np.ascontiguousarray(img, np.float32)
+        img = np.asarray(img)
+        img = np.ascontiguousarray(img, np.uint8 if img.dtype == np.uint8 else np.float32)   # uint8: widened on the GPU
         try:
             self.ctx.calculate_batch(img[None], self._params)
         finally:
             self.image = self.ctx.image(0) if self.subpixel else img
-        kp, desc = self.ctx.results()
+        sparse = self.ctx.results_sparse() if self.ctx.total() > 0 else None    # ~200 instead of 532 bytes per keypoint over the link
+        kp, desc = unpack_sparse_host(*sparse, threads=1) if sparse is not None else self.ctx.results()
         pts = [InterestPoint(float(k["scale"]), int(k["octave"]), int(k["index"]), bool(k["filtered"]),
                              (int(k["x"]), int(k["y"])), float(k["orientation"]),
                              desc[i].tolist() if k["has_descriptor"] else [])

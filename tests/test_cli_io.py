@@ -294,6 +294,33 @@ def bresenham_reference(x1, y1, x2, y2):
     return pts
 
 
+def test_overlay_matches_the_independent_renderer_on_random_boxes():
+    """sift_hip_overlay_draw against tests/overlay_ref.py on 150 images of 20 random boxes each, most of which cross the image
+    border (clipped lines walked from the clipped end points), with and without the subpixel divisor: pixel for pixel."""
+    import overlay_ref
+    L = _lib.load()
+    rng = np.random.default_rng(3)
+    w, h = 200, 150
+    clipped = 0
+    for it in range(150):
+        n = 20
+        kps = np.zeros(n, _lib.KEYPOINT_DTYPE)
+        kps["x"] = rng.integers(0, 230, n)
+        kps["y"] = rng.integers(0, 180, n)
+        kps["octave"] = rng.integers(0, 2, n)
+        kps["scale"] = rng.uniform(0, 9, n).astype(np.float32)
+        kps["orientation"] = rng.uniform(-400, 400, n).astype(np.float32)
+        if it % 10 == 0:
+            kps["orientation"][:3] = (np.nan, np.inf, 177.49134826660156)
+        sub = it % 2
+        got = np.full((h, w, 3), 7, np.uint8)
+        assert L.sift_hip_overlay_draw(got.reshape(-1), w, h, kps.ctypes.data, n, sub) == 0
+        want = overlay_ref.draw_overlay(np.full((h, w, 3), 7, np.uint8), kps, bool(sub))
+        assert np.array_equal(got, want), it
+        clipped += int((want[0] != 7).any() or (want[-1] != 7).any() or (want[:, 0] != 7).any() or (want[:, -1] != 7).any())
+    assert clipped > 100
+
+
 def test_overlay_draw_and_png_roundtrip(tmp_path):
     L = _lib.load()
     w, h = 160, 120
@@ -301,24 +328,24 @@ def test_overlay_draw_and_png_roundtrip(tmp_path):
     kps = np.concatenate([kp_record(80, 60, 0, 3.2, 30.0), kp_record(5, 5, 0, 4.0, 177.49134826660156),   # the second box leaves the image
                           kp_record(40, 30, 1, 1.2, float("nan"))])                                          # NaN orientation: nothing drawn
     assert L.sift_hip_overlay_draw(img.reshape(-1), w, h, kps.ctypes.data, kps.size, 0) == 0
-    want = np.full((h, w, 3), 7, np.uint8)
-    for k in range(2):
-        _, _, _, p = cli.overlay_box(kps[k], False)
-        q = [(int(np.rint(x)), int(np.rint(y))) for x, y in p]        # cvRound: nearest, ties to even
-        for a, b in ((0, 1), (0, 3), (2, 3), (1, 2)):
-            for x, y in bresenham_reference(*q[a], *q[b]):
-                if 0 <= x < w and 0 <= y < h:
-                    want[y, x] = (255, 0, 0)
+    # the whole image, boxes that leave it included, against the independent renderer (tests/overlay_ref.py: cv::clipLine, then
+    # LineIterator from the CLIPPED end points) - exact
+    import overlay_ref
+    want = overlay_ref.draw_overlay(np.full((h, w, 3), 7, np.uint8), kps, False)
+    assert np.array_equal(img, want)
+    # ... which inside the image is the plain 8-connected walk between the rounded corners
+    plain = np.full((h, w, 3), 7, np.uint8)
+    _, _, _, p = cli.overlay_box(kps[0], False)
+    q = [(int(np.rint(x)), int(np.rint(y))) for x, y in p]        # cvRound: nearest, ties to even
+    for a, b in ((0, 1), (0, 3), (2, 3), (1, 2)):
+        for x, y in bresenham_reference(*q[a], *q[b]):
+            plain[y, x] = (255, 0, 0)
     inside = np.zeros((h, w), bool)
-    inside[20:100, 40:120] = True        # the first box lies fully inside: compare exactly there
-    assert np.array_equal(img[inside], want[inside])
+    inside[20:100, 40:120] = True        # the first box lies fully inside
+    assert np.array_equal(img[inside], plain[inside])
     drawn = (img != 7).any(axis=2)
     assert drawn[inside].sum() > 100 and drawn[:28, :28].sum() > 40    # the clipped box still leaves its inner parts in the corner
     assert set(map(tuple, img[drawn])) == {(255, 0, 0)}             # B, G, R = Scalar(255, 0, 0)
-    # clipped lines only differ from the unclipped walk at the border crossing: they stay on the same pixels within 1
-    ys, xs = np.nonzero(drawn & ~inside)
-    wy, wx = np.nonzero((want != 7).any(axis=2))
-    assert all(min(abs(wx - x) + abs(wy - y)) <= 1 for x, y in zip(xs, ys))
     # imwrite -> imread round trip through the PNG writer and reader
     path = str(tmp_path / "o.png")
     cli._err_call(L.sift_hip_png_write_bgr8, path.encode(), img.reshape(-1), w, h)

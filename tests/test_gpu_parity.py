@@ -426,6 +426,42 @@ def test_batch_images_independent(ctx, report_dir):
         base += counts[i]
 
 
+def test_u8_frames_in_sparse_lists_out(ctx):
+    """The boundary for a host that holds 8-bit frames (the reference's inputs are 8-bit files, main.cpp:52-54): uint8 in
+    (sift_hip_calculate_batch_u8: widened on the GPU to the floats vigra::importImage yields), sparse lists out
+    (sift_hip_result_copy_sparse + sift_hip_sparse_unpack_host) - bit for bit the float path's keypoints and descriptors, from
+    pageable and from page-locked memory, and for a batch without a keypoint."""
+    from sift_amd.sift import pinned_array, unpack_sparse_host
+    params = _lib.Params(3, 3, 1.6, O.K_SQRT2, 0)
+    frames = np.stack([synth_frame(333, 257, 70 + i) for i in range(5)])          # odd sizes: the scalar tail of the widening kernel
+    u8 = frames.astype(np.uint8)
+    assert np.array_equal(u8.astype(np.float32), frames)                            # the generator's frames are 8-bit valued
+    ctx.calculate_batch(frames, params)
+    wcounts, (wkp, wdesc) = ctx.counts().copy(), tuple(a.copy() for a in ctx.results())
+    assert wkp.size > 500
+    pin = pinned_array(u8.shape, np.uint8)
+    pin[...] = u8
+    for src in (u8, pin):
+        ctx.calculate_batch(src, params)
+        assert ctx.counts().tolist() == wcounts.tolist()
+        kp, desc = ctx.results()
+        assert kp.tobytes() == wkp.tobytes() and desc.tobytes() == wdesc.tobytes()
+        for o in range(3):
+            assert_bits_equal(ctx.level("gaussian", o, 1, 4), O.OracleRun(frames[4], 3, 3).level("gaussian", o, 1), f"g({o},1)")
+        rec, val = ctx.results_sparse()
+        assert rec.shape == (wkp.size, 34) and val.size == int((wdesc.view(np.uint32) != 0).sum())
+        for threads in (1, 5):
+            kp2, desc2 = unpack_sparse_host(rec, val, threads=threads)
+            assert kp2.tobytes() == wkp.tobytes() and desc2.tobytes() == wdesc.tobytes()
+        prec, pval = pinned_array((wkp.size + 7, 34), np.uint8), pinned_array((val.size + 100,), np.float32)
+        rec3, val3 = ctx.results_sparse(prec, pval)
+        assert rec3.tobytes() == rec.tobytes() and val3.tobytes() == val.tobytes()
+    ctx.calculate_batch(np.full((2, 96, 128), 9, np.uint8), params)
+    assert ctx.total() == 0
+    rec, val = ctx.results_sparse()
+    assert rec.shape == (0, 34) and val.size == 0 and unpack_sparse_host(rec, val)[0].size == 0
+
+
 def test_constant_image_has_no_keypoints(ctx):
     """Every interior pixel ties => candidate; H = 0 => inverse fails => all filtered."""
     img = np.full((96, 128), 77.0, np.float32)
@@ -599,15 +635,15 @@ def expected_result_file(tmp_path, img, dogs, octaves, subpixel=False):
 
 
 def check_overlay(png_path, src_bgr, run, subpixel):
-    """<img>_orientation.png = the colour image with the boxes of main.cpp:60-73 for the oracle's points."""
+    """<img>_orientation.png = the colour image with the boxes of main.cpp:60-73 for the oracle's points, drawn by the
+    independent restatement of cv::RotatedRect::points / cv::line in tests/overlay_ref.py."""
     from sift_amd import cli
     pts, desc = run.points("final")
     kp = np.zeros(pts.size, _lib.KEYPOINT_DTYPE)
     for f in ("scale", "orientation", "x", "y", "octave", "index"):
         kp[f] = pts[f]
-    want = src_bgr.copy()
-    h, w, _ = want.shape
-    assert _lib.load().sift_hip_overlay_draw(want.reshape(-1), w, h, kp.ctypes.data, kp.size, int(subpixel)) == 0
+    import overlay_ref
+    want = overlay_ref.draw_overlay(src_bgr, kp, bool(subpixel))   # the independent renderer, not the library's own
     got = cli.read_image_bgr(str(png_path))
     assert np.array_equal(got, want)
     assert (got != src_bgr).any()
@@ -682,6 +718,7 @@ def test_group_of_shards_matches_single_context(ctx):
         assert (g.status() == 0).all()
         cms, gms, nbytes = g.timing()
         assert cms > 0 and gms >= 0 and nbytes == 0                        # same device: nothing crossed a link
+        assert g.gather_exposed_ms() >= 0
         g.calculate_batch(frames[:2], params)                              # fewer frames than shards
         ctx.calculate_batch(frames[:2], params)
         assert g.results()[1].tobytes() == ctx.results()[1].tobytes()
@@ -701,6 +738,79 @@ def test_group_of_shards_matches_single_context(ctx):
         assert "kernel longer than line" in str(e.value)
     finally:
         g.close()
+
+
+def test_group_two_batches_in_flight(ctx):
+    """sift_hip_group_submit / _collect: two batches in flight over three shards, the gather of batch k under the kernels of
+    batch k+1 (pack buffers, arrival areas and result arrays double-buffered); every batch returns the single context's lists;
+    a third submit without a collect is refused."""
+    from sift_amd.sift import Group
+    params = _lib.Params(3, 3, 1.6, O.K_SQRT2, 0)
+    batches = [np.stack([synth_frame(320, 240, 300 + 8 * b + i) for i in range(5 + b % 3)]) for b in range(5)]
+    batches[3] = np.concatenate([batches[3], np.full((1, 240, 320), 5.0, np.float32)])     # a frame without keypoints
+    for wire in (1, 2):
+        g = Group([0, 0, 0])
+        try:
+            g.set_option("gather_wire", wire)
+            got = []
+            g.submit(batches[0], params)
+            for b in range(1, len(batches) + 1):
+                if b < len(batches):
+                    g.submit(batches[b], params)
+                    if b == 1:
+                        with pytest.raises(ValueError):
+                            g.submit(batches[0], params)
+                g.collect()
+                got.append((g.counts().copy(),) + tuple(a.copy() for a in g.results()))
+            assert g.transport()[0] == 0                       # one GPU listed three times: RCCL takes one rank per GPU
+            for b, (counts, kp, desc) in zip(batches, got):
+                ctx.calculate_batch(b, params)
+                wkp, wdesc = ctx.results()
+                assert counts.tolist() == ctx.counts().tolist()
+                assert kp.tobytes() == wkp.tobytes() and desc.tobytes() == wdesc.tobytes()
+        finally:
+            g.close()
+
+
+_GROUP_RCCL_SCRIPT = """
+import sys, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + '/tests')
+from sift_amd import _lib
+from sift_amd.sift import Group, Context, K_SQRT2
+from sift_amd.synthetic import synth_frame
+params = _lib.Params(3, 3, 1.6, K_SQRT2, 0)
+g = Group([0])
+g.set_option('gather_loopback', 1)
+g.set_option('gather_transport', 2)      # RCCL or fail
+used, why = g.transport()
+assert used == 1, why
+c = Context(0)
+batches = [np.stack([synth_frame(320, 240, 500 + 4 * b + i) for i in range(3)]) for b in range(3)]
+batches.append(np.full((2, 240, 320), 9.0, np.float32))        # a batch without a single keypoint
+for wire in (1, 0):
+    g.set_option('gather_wire', wire)
+    for b in batches:
+        g.calculate_batch(b, params)
+        c.calculate_batch(b, params)
+        kp, desc = g.results(); wkp, wdesc = c.results()
+        assert g.counts().tolist() == c.counts().tolist()
+        assert kp.tobytes() == wkp.tobytes() and desc.tobytes() == wdesc.tobytes()
+        cms, gms, nbytes = g.timing()
+        assert nbytes == (34 if wire else 532) * kp.size + (4 * int((desc.view(np.uint32) != 0).sum()) if wire else 0), (nbytes, kp.size)
+g.close(); c.close()
+print('rccl loopback ok:', why)
+"""
+
+
+def test_group_gather_over_rccl_on_one_gpu(ctx):
+    """The native RCCL gather of sift_hip_group on a box with one GPU: a group of one shard with option gather_loopback sends its
+    packed lists (and, with gather_wire = 0, its plain arrays) through ncclSend / ncclRecv to the same rank - communicator from
+    ncclCommInitAll, grouped point-to-point, arrival area, unpack - and returns the single context's results."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _GROUP_RCCL_SCRIPT.format(root=root)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl loopback ok" in r.stdout, r.stdout + r.stderr[-3000:]
 
 
 def test_cpp_multi_gpu_example(ctx, tmp_path):
@@ -733,15 +843,16 @@ def test_cli_result_file(ctx, tmp_path, monkeypatch):
     assert cli.main(["parrot_r.pgm", "--no-overlay"]) == 0 and not os.path.exists(tmp_path / "interstpoints.txt")
 
 
-@pytest.mark.parametrize("option", ["gate_schedule", "gate_early_chain", "pyramid_side"])
+@pytest.mark.parametrize("option", ["gate_schedule=1", "gate_early_chain=1", "pyramid_side=0"])
 def test_other_gate_schedules_leave_the_results_alone(ctx, option):
-    """The measured-and-rejected orders of the phase gate (sift_amd/csrc/phase_gate.h) and the pyramid's side stream are
-    options: same results."""
+    """The measured-and-rejected orders of the phase gate (sift_amd/csrc/phase_gate.h) and the pyramid without its side stream
+    (every launch on one stream) are options: same results."""
+    option, value = option.split("=")
     from sift_amd.pipeline import BatchPipeline
     params = _lib.Params(3, 3, 1.6, O.K_SQRT2, 0)
     batches = [np.stack([synth_frame(480, 360, 200 + 3 * b + i) for i in range(3)]) for b in range(5)]
     got = []
-    with BatchPipeline(0, depth=2, options={option: 1}) as pipe:
+    with BatchPipeline(0, depth=2, options={option: int(value)}) as pipe:
         tickets = []
         for b in batches + [None, None]:
             if b is not None:

@@ -114,19 +114,38 @@ def main():
     elif a.launches:
         rows = [(r["kernel"], int(r["start_ns"]), int(r["end_ns"])) for r in csv.DictReader(open(a.launches))]
     if rows:
-        # Two contexts may interleave their pyramids only at whole-pyramid granularity (the phase gate), so the launches
-        # come in runs of len(ops)
+        # Two contexts interleave their pyramids only at whole-pyramid granularity (the phase gate), so the launches come in
+        # runs of len(ops).  Inside a run the order is not the plan's: an octave's top level runs on the side stream beside the
+        # next octave's first launches (option pyramid_side), so a launch is matched to the plan by (radius, DoG, decimating)
+        # and, among equal signatures, by octave order (the dependency chain keeps those in start order).
         if len(rows) % len(ops):
             print(f"warning: {len(rows)} blur launches is not a multiple of the plan's {len(ops)}", file=sys.stderr)
         acc = [[0.0, 0, 0.0] for _ in ops]
-        for i, (name, t0, t1) in enumerate(rows):
-            op = ops[i % len(ops)]
-            p = parse_name(name)
-            assert p["R"] == op[3], f"launch {i}: {name} has radius {p['R']}, the plan expects {op[3]} for {op[0]}"
-            nbytes = op[5] if (not op[0].startswith("reduce") or p["dec"]) else op[6]
-            acc[i % len(ops)][0] += t1 - t0
-            acc[i % len(ops)][1] += 1
-            acc[i % len(ops)][2] = nbytes
+        spans, busy = [], []
+        for g0 in range(0, len(rows) - len(ops) + 1, len(ops)):
+            grp = rows[g0:g0 + len(ops)]
+            free = list(range(len(ops)))
+            for name, t0, t1 in grp:
+                p = parse_name(name)
+                def fits(op):
+                    has_dog, is_reduce = "dog(" in op[0], op[0].startswith("reduce")
+                    return op[3] == p["R"] and ((p["dog"] and has_dog) or (p["dec"] and is_reduce) or (not p["dog"] and not p["dec"] and not has_dog))
+                k = next((i for i in free if fits(ops[i])), None)
+                assert k is not None, f"{name} matches no launch of the plan that is still open in its pyramid"
+                free.remove(k)
+                op = ops[k]
+                nbytes = op[5] if (not op[0].startswith("reduce") or p["dec"]) else op[6]
+                acc[k][0] += t1 - t0
+                acc[k][1] += 1
+                acc[k][2] = nbytes
+            spans.append(max(r[2] for r in grp) - min(r[1] for r in grp))
+            end, b = -1, 0
+            for _, t0, t1 in sorted(grp, key=lambda r: r[1]):   # union of the launches' intervals
+                if t1 <= end:
+                    continue
+                b += t1 - max(t0, end)
+                end = t1
+            busy.append(b)
         print(f"{'launch':34s} {'octave':>6s} {'R':>3s} {'MB':>8s} {'us':>8s} {'GB/s':>7s} {'frac':>6s}")
         tb = tt = 0.0
         for op, (ns, cnt, nbytes) in zip(ops, acc):
@@ -137,8 +156,15 @@ def main():
             tb += nbytes
             tt += us
         print(f"{'family (sum bytes / sum time)':34s} {'':6s} {'':3s} {tb / 1e6:8.1f} {tt:8.1f} {tb / tt / 1e3:7.0f} {tb / tt / 1e3 / PEAK:6.3f}")
-        span = [rows[i + len(ops) - 1][2] - rows[i][1] for i in range(0, len(rows) - len(ops) + 1, len(ops))]
-        print(f"pyramid span (first blur start to last blur end), median over {len(span)} steps: {np.median(span) / 1e3:.1f} us; sum of its launches {tt:.1f} us")
+        bu = float(np.mean(busy)) / 1e3
+        print(f"{'family (sum bytes / busy time)':34s} {'':6s} {'':3s} {tb / 1e6:8.1f} {bu:8.1f} {tb / bu / 1e3:7.0f} {tb / bu / 1e3 / PEAK:6.3f}"
+              "   <- bench.py's roofline.frac: time during which at least one blur launch runs (launches of two streams overlap)")
+        tail = [(nbytes, ns / cnt / 1e3) for op, (ns, cnt, nbytes) in zip(ops, acc) if cnt and op[1] > 0 or op[0].startswith("reduce")]
+        if tail:
+            b_, t_ = sum(x[0] for x in tail), sum(x[1] for x in tail)
+            print(f"{'launches outside octave 0 (sum time)':34s} {'':5s} {'':3s} {b_ / 1e6:8.1f} {t_:8.1f} {b_ / t_ / 1e3:7.0f} {b_ / t_ / 1e3 / PEAK:6.3f}")
+        print(f"pyramid span (first blur start to last blur end), median over {len(spans)} steps: {np.median(spans) / 1e3:.1f} us; "
+              f"busy time {np.median(busy) / 1e3:.1f} us; sum of its launches {tt:.1f} us")
 
 
 if __name__ == "__main__":
