@@ -91,6 +91,7 @@ struct Plan {
     std::vector<int> luts;            // all index maps back to back
     std::vector<size_t> lut_x_off, lut_y_off;  // per octave transition (index o -> o+1); [O] = subpixel
     std::vector<size_t> inv_x_off, inv_y_off;  // inverse maps (source -> destination or -1) of the decimations
+    std::vector<int> red_sx, red_sy;           // decimation o -> o+1: first destination column / row kept from source index 2 i + 1 (-1: the map has another form)
     int fail_status = 0;              // plan-time precondition failure (depends only on sizes/params)
     size_t fail_op = (size_t)-1;      // first op that cannot run
     std::string fail_msg;
@@ -113,6 +114,7 @@ struct sift_hip_ctx {
     bool fused = true;
     bool fused_edge = true;   // extremum scan and edge filter in one LDS-tiled pass
     bool fused_reduce = true; // reduceToNextLevel: blur and decimation in one pass
+    bool reduce_kept = true;  // ... that evaluates the kept pixels only (option "reduce_kept"; 0: blur_stream_kernel<..., DEC>)
     bool orient_general = false;  // tests: orientation histogram with per-sample bins even when every bin is 0
     bool gpu_cleanup = true;
     bool profile = false;     // this batch's blur launches carry timing events
@@ -332,6 +334,18 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
     P.lut_y_off.assign((size_t)O + 1, 0);
     P.inv_x_off.assign((size_t)O + 1, (size_t)-1);
     P.inv_y_off.assign((size_t)O + 1, (size_t)-1);
+    P.red_sx.assign((size_t)O + 1, -1);
+    P.red_sy.assign((size_t)O + 1, -1);
+    // lut[i] == 2 i for i < split, 2 i + 1 from there on (the form resizeImageNoInterpolation's map takes for a halving): split, or -1
+    auto split_point = [&](size_t map_off, int nd) -> int {
+        int split = nd;
+        for (int i = 0; i < nd; ++i) {
+            const int par = P.luts[map_off + (size_t)i] - 2 * i;
+            if (par == 1 && split == nd) split = i;
+            if (par != (i >= split ? 1 : 0)) return -1;
+        }
+        return split;
+    };
     P.bw = w; P.bh = h;
     bool ok = true;
     if (prm.subpixel) {  // sift.cpp:20-21: increaseToNextLevel(img, 1.0)
@@ -368,6 +382,8 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
             if (ok) {
                 add_inverse(P.lut_x_off[(size_t)o], dv.w[o + 1], dv.w[o], P.inv_x_off[(size_t)o]);
                 add_inverse(P.lut_y_off[(size_t)o], dv.h[o + 1], dv.h[o], P.inv_y_off[(size_t)o]);
+                P.red_sx[(size_t)o] = split_point(P.lut_x_off[(size_t)o], dv.w[o + 1]);
+                P.red_sy[(size_t)o] = split_point(P.lut_y_off[(size_t)o], dv.h[o + 1]);
             }
         }
     }
@@ -447,7 +463,7 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
         poff[g] = carve(px);
         boff[g] = carve((px + 3) / 4);
     }
-    c->arena.ensure(total);
+    c->arena.ensure(total + 256);   // slack: the kept-pixels decimating blur may read the float after a level's last row (kernels_reduce.hip)
     char* base = c->arena.as<char>();
     for (size_t l = 0; l < goff.size(); ++l) dv.gauss[l] = reinterpret_cast<float*>(base + goff[l]);
     for (size_t l = 0; l < doff.size(); ++l) dv.dog[l] = reinterpret_cast<float*>(base + doff[l]);
@@ -567,7 +583,13 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
                     // blur and decimation in one pass: the full-resolution blurred image is never written
                     hipEvent_t a = nullptr, b = nullptr;
                     if (c->profile) { a = get_event(c); b = get_event(c); }
-                    done = launch_blur_reduce(c->stream, src, dst, op.w, op.h, dv.w[o + 1], dv.h[o + 1], n,
+                    // kept pixels only (kernels_reduce.hip) where the index maps and the shape allow it, else the streaming blur
+                    // that stores the kept quarter of a full-resolution result
+                    if (c->reduce_kept && P.red_sx[(size_t)o] >= 0 && P.red_sy[(size_t)o] >= 0)
+                        done = launch_blur_reduce_kept(c->stream, src, dst, op.w, op.h, dv.w[o + 1], dv.h[o + 1], n, c->d_taps.as<float>() + op.tap_off,
+                                                       op.radius, P.red_sx[(size_t)o], P.red_sy[(size_t)o], std::min(stream_min_waves_now(), 256), a, b);
+                    if (!done)
+                        done = launch_blur_reduce(c->stream, src, dst, op.w, op.h, dv.w[o + 1], dv.h[o + 1], n,
                                               c->d_taps.as<float>() + op.tap_off, op.radius, c->d_luts.as<int>() + P.inv_x_off[(size_t)o],
                                               c->d_luts.as<int>() + P.inv_y_off[(size_t)o], c->d_tmp.as<float>(), a, b);
                     if (c->profile) {
@@ -1301,6 +1323,7 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     if (!std::strcmp(name, "fused_blur")) { c->fused = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "fused_edge")) { c->fused_edge = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "fused_reduce")) { c->fused_reduce = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "reduce_kept")) { c->reduce_kept = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "spin_wait")) { c->spin_wait = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "desc_dbg")) { c->desc_dbg = value; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "desc_kernel")) { c->desc_wave = value != 0; return SIFT_HIP_OK; }
@@ -1326,6 +1349,7 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     if (!std::strcmp(name, "profile")) { c->profile_every = value > 0 ? value : 0; c->profile_batches = 0; c->profile = false; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "orient_general")) { c->orient_general = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "stream_min_waves")) { set_stream_min_waves(value); return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "fused_grid")) { set_fused_grid_mode(value); return SIFT_HIP_OK; }
     if (!std::strcmp(name, "stream_waves")) { set_stream_waves(value); return SIFT_HIP_OK; }
     if (!std::strcmp(name, "orient_dbg")) { set_orient_dbg(value); return SIFT_HIP_OK; }
     if (!std::strcmp(name, "diag_pyramid_span")) { c->diag_pyramid_span = value != 0; return SIFT_HIP_OK; }

@@ -379,8 +379,15 @@ __global__ __launch_bounds__(256) void extrema_edge_kernel(const float* __restri
     // level and row once, three-input max / min over the rest ("no neighbour greater" == "max of the neighbours <= centre";
     // DoG samples are finite, so no NaN ordering question arises).
     {
+        // Lane -> (column group cg, row pair): the eight lanes of a column group row share an LDS row (128 contiguous bytes); the
+        // 16 lanes a 16-byte LDS read serves together hold two row pairs, taken FOUR rows apart (row pairs 0,2,1,3,4,6,5,7 over
+        // lane >> 3): 4 rows x 40 floats = 160 floats = 32 banks past the first group's, so the two groups never meet in a bank
+        // (two rows apart they overlap in half of them).  The sample left of a lane's four columns is its left neighbour's last
+        // one: a DPP move, and an LDS read only for the column group at the tile's left edge (with one read per lane all 64
+        // lanes would land in the 16 banks = 3 mod 4, four deep).
         const int cg = lane & 7, rs = lane >> 3;
-        const int row0 = 16 * wv + 2 * rs;                     // first of the lane's two output rows (tile-local)
+        const int rp = (rs & 4) | ((rs & 1) << 1) | ((rs >> 1) & 1);
+        const int row0 = 16 * wv + 2 * rp;                     // first of the lane's two output rows (tile-local)
         const int at0 = row0 * kFxPitch + kFxLead + 4 * cg;    // LDS index of (row0 - 1, first column): LDS row = tile row + 1
         float v[3][3][5];                                      // [level][LDS row row0 + R][column -1 .. 3]
 #pragma unroll
@@ -388,8 +395,16 @@ __global__ __launch_bounds__(256) void extrema_edge_kernel(const float* __restri
 #pragma unroll
             for (int R = 0; R < 3; ++R) {
                 const float4 q4 = *reinterpret_cast<const float4*>(&s_t[L][at0 + R * kFxPitch]);
-                v[L][R][0] = s_t[L][at0 + R * kFxPitch - 1];
                 v[L][R][1] = q4.x; v[L][R][2] = q4.y; v[L][R][3] = q4.z; v[L][R][4] = q4.w;
+            }
+#pragma unroll
+        for (int L = 0; L < 3; ++L)
+#pragma unroll
+            for (int R = 0; R < 3; ++R) {
+                // row_shr:1 within the 16-lane DPP row: lane l receives lane l-1's value (lanes 0 and 8 of a row are column group 0)
+                float left = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[L][R][4]), 0x111, 0xf, 0xf, false));
+                if (cg == 0) left = s_t[L][at0 + R * kFxPitch - 1];
+                v[L][R][0] = left;
             }
         float pmx[3][3][4], pmn[3][3][4];
 #pragma unroll

@@ -539,12 +539,35 @@ static thread_local hipEvent_t t_ev_start = nullptr, t_ev_stop = nullptr;
 
 constexpr long long kSmallTileLaunch = 4096;   // 64x64 tiles: up to 16 per CU
 
+static int g_fused_grid_mode = 1;   // option "fused_grid": 1 = as many persistent workgroups as the chip holds at once; 0 = 1024 (round 2)
+void set_fused_grid_mode(int v) { g_fused_grid_mode = v; }
+
+// Workgroups of `kernel` one launch can have resident at a time on this device (CUs x occupancy), asked once per instantiation.
+template <class K>
+static int resident_workgroups(K kernel) {
+    static thread_local int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (cached[dev] == 0) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        (void)hipGetLastError();
+        cached[dev] = per_cu * cus;
+    }
+    return cached[dev];
+}
+
 template <int R, int TH>
 static void launch_fused_rt(hipStream_t s, const float* in, float* out, float* dog, int w, int h, int n,
                             const float* d_taps) {
     const int tiles_x = (w + 63) / 64, tiles_y = (h + TH - 1) / TH;
     const int total = tiles_x * tiles_y * n;
-    const int cap = 1024;  // persistent workgroups offered per launch
+    // Persistent workgroups: as many as are resident at once, so that every workgroup starts at once and fetches its next
+    // tile under the arithmetic of the current one.  (More than that - 1024 in round 2 - run in a second round that begins
+    // when the first ends: two tile latencies back to back and nothing prefetched.)
+    int cap = 1024;
+    if (g_fused_grid_mode == 1) cap = dog ? resident_workgroups(blur_fused_kernel<R, true, TH>) : resident_workgroups(blur_fused_kernel<R, false, TH>);
     int grid = total < cap ? total : cap;
     if (grid >= 8) grid &= ~7;
     const bool aligned = (((uintptr_t)in | (uintptr_t)out | (uintptr_t)dog) & 15u) == 0;
@@ -577,6 +600,7 @@ constexpr int kMaxRadiusStream = 14;   // beyond: the 2R+1 partial sums per colu
 constexpr int kMinStreamWaves = 1024;  // below one wave per SIMD the tile kernel's finer work units win
 static int g_stream_min_waves = kMinStreamWaves;  // option "stream_min_waves": tests lower it to run the streaming form on small inputs
 void set_stream_min_waves(int v) { g_stream_min_waves = v < 1 ? kMinStreamWaves : v; }
+int stream_min_waves_now() { return g_stream_min_waves; }
 
 template <int R, int CPL>
 static bool launch_stream_rc(hipStream_t s, const float* in, float* out, float* dog, int w, int h, int n,

@@ -294,6 +294,33 @@ def test_pipeline_parity_streaming_blur(ctx, report_dir, case):
         ctx.set_option("stream_min_waves", 0)
 
 
+REDUCE_CASES = [
+    # name, w, h, seed, octaves, frames
+    ("kept-pixels reduce 640x480 (runs of 160: 4 columns per lane)", 640, 480, 31, 4, 2),
+    ("kept-pixels reduce 1000x600 (runs of 250: 2 columns per lane)", 1000, 600, 32, 3, 1),
+    ("kept-pixels reduce 641x479 (odd sizes: no parity split)", 641, 479, 33, 3, 2),
+    ("kept-pixels reduce 1280x360 (several strips per run)", 1280, 360, 34, 3, 1),
+    ("kept-pixels reduce 328x248 (run of 82 then 41/41: falls back where a run is odd)", 328, 248, 35, 3, 3),
+]
+
+
+@pytest.mark.parametrize("case", REDUCE_CASES, ids=[c[0] for c in REDUCE_CASES])
+def test_pipeline_parity_kept_pixels_reduce(ctx, report_dir, case):
+    """reduceToNextLevel as the blur that evaluates only the kept pixels (kernels_reduce.hip: de-interleaved LDS rows, column
+    pass on kept rows), forced onto small inputs: every level of every octave (each next octave is seeded by it), stage lists
+    and descriptors against the oracle; and the same again with the kernel switched off (option reduce_kept = 0)."""
+    name, w, h, seed, octaves, frames = case
+    ctx.set_option("stream_min_waves", 1)
+    try:
+        rep = compare_run(ctx, synth_frame(w, h, seed), 3, octaves, False, name, report_dir, batch_of=frames)
+        assert rep["final"] > 0
+        ctx.set_option("reduce_kept", 0)
+        compare_run(ctx, synth_frame(w, h, seed), 3, octaves, False, name + " [reduce_kept = 0]", report_dir, batch_of=frames)
+    finally:
+        ctx.set_option("reduce_kept", 1)
+        ctx.set_option("stream_min_waves", 0)
+
+
 def test_pipeline_parity_general_orientation_bins(ctx, report_dir):
     """The orientation histogram's per-sample-bin form (never selected by real frames: App. B-9 puts every sample
     in bin 0, which the gradient pass detects) gives the same results as the all-zero-bins fast path."""

@@ -59,6 +59,9 @@ def plan(w, h, n, dogs, octaves, sigma, k, subpixel):
 
 
 def parse_name(name):
+    m = re.search(r"blur_reduce_kernel<(\d+), (\d+)>", name)   # reduceToNextLevel, kept pixels only (kernels_reduce.hip)
+    if m:
+        return {"form": "reduce", "R": int(m.group(1)), "dog": False, "dec": True}
     m = re.search(r"blur_(stream|fused)_kernel<(\d+), (true|false)(?:, (\d+))?(?:, (true|false))?>", name)
     if not m:
         return None
