@@ -417,13 +417,18 @@ def main():
             # frames from host memory in, keypoints + descriptors to host memory out, two batches in flight
             from sift_amd.sift import pinned_array
 
+            # three batches in flight for this leg (upload, kernels and download of different batches side by side): a pipeline of its own
+            hdepth = 3
+            hpipe = BatchPipeline(local_rank, hdepth, options, gated=bool(args.pipeline_gate))
+
             def host_loop(src, fetch, n_steps):
+                """n_steps batches from host memory `src`, `hdepth` in flight; `fetch(context, slot)` brings the oldest batch's lists to the host"""
                 pend, total = [], 0
                 t_0 = time.perf_counter()
-                for i in range(n_steps + depth - 1):
+                for i in range(n_steps + hdepth):
                     if i < n_steps:
-                        pend.append(pipe.submit(src, params))
-                    if len(pend) >= depth or i >= n_steps:
+                        pend.append(hpipe.submit(src, params))
+                    if pend and (len(pend) >= hdepth or i >= n_steps):
                         tk = pend.pop(0)
                         total += fetch(tk.result(), tk.slot)
                         tk.release()
@@ -438,9 +443,9 @@ def main():
             assert np.array_equal(frames_u8.astype(np.float32), frames)
             pin_u8 = pinned_array(frames_u8.shape, np.uint8)
             pin_u8[...] = frames_u8
-            pin_sp = [(pinned_array((cap, 34), np.uint8), pinned_array((cap * 64,), np.float32)) for _ in range(depth)]
+            pin_sp = [(pinned_array((cap, 34), np.uint8), pinned_array((cap * 64,), np.float32)) for _ in range(hdepth)]
             wire = [0]
-            for c in ctxs:
+            for c in hpipe.contexts:
                 c.set_option("wire_count", 1)     # the descriptor kernel counts the floats the sparse format will carry
 
             def fetch_sparse(c, slot):
@@ -448,7 +453,7 @@ def main():
                 wire[0] = rec.nbytes + val.nbytes
                 return rec.shape[0]
 
-            dense = [(np.empty(cap, _lib.KEYPOINT_DTYPE), np.empty((cap, 128), np.float32)) for _ in range(depth)]
+            dense = [(np.empty(cap, _lib.KEYPOINT_DTYPE), np.empty((cap, 128), np.float32)) for _ in range(hdepth)]
 
             def fetch_sparse_unpacked(c, slot):   # ... and expanded again on the host into records + 128-float descriptors
                 rec, val = c.results_sparse(pin_sp[slot][0], pin_sp[slot][1])
@@ -459,12 +464,12 @@ def main():
             t_sp, k_sp = host_loop(pin_u8, fetch_sparse, hs)
             host_loop(pin_u8, fetch_sparse_unpacked, 2)
             t_spu, _ = host_loop(pin_u8, fetch_sparse_unpacked, hs)
-            for c in ctxs:
+            for c in hpipe.contexts:
                 c.set_option("wire_count", int(options.get("wire_count", 0)))
             # (b) float32 frames in, dense 532-byte records out (round 2's figure)
             pin_frames = pinned_array(frames.shape, np.float32)
             pin_frames[...] = frames
-            pin_out = [(pinned_array((cap,), _lib.KEYPOINT_DTYPE), pinned_array((cap, 128), np.float32)) for _ in range(depth)]
+            pin_out = [(pinned_array((cap,), _lib.KEYPOINT_DTYPE), pinned_array((cap, 128), np.float32)) for _ in range(hdepth)]
             fetch_dense = lambda c, slot: c.results(pin_out[slot][0], pin_out[slot][1])[0].size   # noqa: E731
             host_loop(pin_frames, fetch_dense, 2)
             t_pin, k_pin = host_loop(pin_frames, fetch_dense, hs)
@@ -477,7 +482,7 @@ def main():
                                      "pcie_gbytes_per_step": nbytes_sp / 1e9, "pcie_gb_per_s": nbytes_sp / 1e9 / t_sp,
                                      "what": "8-bit frames from page-locked host memory in (sift_hip_calculate_batch_u8: a quarter of the bytes, widened on the GPU to the "
                                              "floats vigra::importImage yields), keypoint lists to page-locked host memory out in the lossless sparse format "
-                                             "(sift_hip_result_copy_sparse: 34-byte records + the descriptor floats that are not +0.0f), per step; two batches in flight",
+                                             "(sift_hip_result_copy_sparse: 34-byte records + the descriptor floats that are not +0.0f), per step; three batches in flight (BatchPipeline depth 3)",
                                      "with_host_unpack_ms_per_step": t_spu * 1e3,
                                      "with_host_unpack_what": "the same plus sift_hip_sparse_unpack_host on up to 16 host threads: dense 20-byte records + 128-float descriptors in ordinary memory",
                                      "float_dense_ms_per_step": t_pin * 1e3, "float_dense_keypoints_per_s": k_pin / t_pin,
@@ -485,6 +490,7 @@ def main():
                                      "float_dense_what": "float32 frames in, 20-byte records + 128-float descriptors out, page-locked memory on both sides (round 2's boundary)",
                                      "pageable_ms_per_step": t_page * 1e3,
                                      "pageable_what": "float32 / dense with ordinary (pageable) numpy arrays on both sides: chunked through the library's pinned staging buffers"}
+            hpipe.close()
             one = pinned_array((1,) + frames.shape[1:], np.float32)
             one[...] = frames[:1]
             lat = []

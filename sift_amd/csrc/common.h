@@ -112,6 +112,8 @@ bool launch_blur_reduce_kept(hipStream_t s, const float* in, float* dst, int w, 
                              int sx, int sy, int min_waves, hipEvent_t ev_start, hipEvent_t ev_stop);
 int stream_min_waves_now();
 void launch_widen_u8(hipStream_t s, const uint8_t* in, float* out, size_t count);
+void launch_io_copy(hipStream_t s, const void* src, void* dst, size_t bytes);      // kernels_io.hip: transfers as small kernels
+void launch_io_widen(hipStream_t s, const void* src, float* dst, size_t count);
 void launch_extrema_mask(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan,
                          unsigned long long* d_masks, int* d_counts);
 void launch_extrema_scan(hipStream_t s, const DevPlan& plan, int* d_counts, int* d_totals);

@@ -114,6 +114,7 @@ struct sift_hip_ctx {
     bool fused = true;
     bool fused_edge = true;   // extremum scan and edge filter in one LDS-tiled pass
     bool fused_reduce = true; // reduceToNextLevel: blur and decimation in one pass
+    bool io_kernels = false;  // option "io_kernels" (measured alternative, off): page-locked host memory is read / written in place by small kernels (kernels_io.hip) instead of hipMemcpyAsync
     bool reduce_kept = true;  // ... that evaluates the kept pixels only (option "reduce_kept"; 0: blur_stream_kernel<..., DEC>)
     bool orient_general = false;  // tests: orientation histogram with per-sample bins even when every bin is 0
     bool gpu_cleanup = true;
@@ -970,6 +971,21 @@ bool is_pinned(const void* p) {
     return a.type == hipMemoryTypeHost || a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
+// Address under which a kernel of this device reaches `p` (page-locked host memory is mapped into the GPU's address space;
+// device memory is its own address), or nullptr: ordinary memory, or memory only a copy engine can reach.
+void* kernel_visible(const void* p) {
+    hipPointerAttribute_t a;
+    std::memset(&a, 0, sizeof(a));
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    if (a.type == hipMemoryTypeDevice) return const_cast<void*>(p);
+    if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
+    // the attributes describe the allocation's base: apply the caller's offset into it
+    return static_cast<char*>(a.devicePointer) + (static_cast<const char*>(p) - static_cast<const char*>(a.hostPointer));
+}
+
 struct CopyJob { char* dst; const char* src; size_t bytes; int parts; };
 void copy_part(int i, void* arg) {
     const CopyJob* j = static_cast<const CopyJob*>(arg);
@@ -994,6 +1010,15 @@ void ensure_staging(sift_hip_ctx* c) {
 // buffer until the batch is done, which calculate only returns after)
 void upload(sift_hip_ctx* c, void* dev, const void* host, size_t bytes, hipStream_t s) {
     if (bytes == 0) return;
+    // option "io_kernels" (off): a kernel of a few workgroups reads page-locked memory in place (kernels_io.hip)
+    if (c->io_kernels) {
+        const void* kv = kernel_visible(host);
+        if (kv && ((reinterpret_cast<uintptr_t>(kv) | reinterpret_cast<uintptr_t>(dev)) & 15u) == 0) {
+            launch_io_copy(s, kv, dev, bytes);
+            SIFT_HIP_CHECK(hipGetLastError());
+            return;
+        }
+    }
     if (is_pinned(host)) {
         SIFT_HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s));
         return;
@@ -1013,6 +1038,15 @@ void upload(sift_hip_ctx* c, void* dev, const void* host, size_t bytes, hipStrea
 // device -> caller memory (host or device), complete on return
 void download(sift_hip_ctx* c, void* dst, const void* dev, size_t bytes, hipStream_t s) {
     if (bytes == 0) return;
+    if (c->io_kernels) {
+        void* kv = kernel_visible(dst);
+        if (kv && ((reinterpret_cast<uintptr_t>(kv) | reinterpret_cast<uintptr_t>(dev)) & 15u) == 0) {
+            launch_io_copy(s, dev, kv, bytes);
+            SIFT_HIP_CHECK(hipGetLastError());
+            wait_stream(c, s);
+            return;
+        }
+    }
     if (is_pinned(dst)) {
         SIFT_HIP_CHECK(hipMemcpyAsync(dst, dev, bytes, hipMemcpyDefault, s));
         wait_stream(c, s);
@@ -1323,6 +1357,7 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     if (!std::strcmp(name, "fused_blur")) { c->fused = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "fused_edge")) { c->fused_edge = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "fused_reduce")) { c->fused_reduce = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "io_kernels")) { c->io_kernels = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "reduce_kept")) { c->reduce_kept = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "spin_wait")) { c->spin_wait = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "desc_dbg")) { c->desc_dbg = value; return SIFT_HIP_OK; }
@@ -1398,9 +1433,15 @@ int sift_hip_calculate_batch_u8(sift_hip_ctx* c, const uint8_t* host_imgs, int n
         c->have_result = c->have_pyramid = false;
         const size_t count = (size_t)n * (size_t)w * (size_t)h;
         c->d_input.ensure(count * sizeof(float));
-        c->d_input_u8.ensure(count);
-        upload(c, c->d_input_u8.p, host_imgs, count, c->stream);
-        launch_widen_u8(c->stream, c->d_input_u8.as<uint8_t>(), c->d_input.as<float>(), count);
+        const void* kv = c->io_kernels ? kernel_visible(host_imgs) : nullptr;
+        if (kv && (reinterpret_cast<uintptr_t>(kv) & 15u) == 0) {
+            // page-locked frames: widened on the way in, by a kernel of a few workgroups that reads the host memory in place
+            launch_io_widen(c->stream, kv, c->d_input.as<float>(), count);
+        } else {
+            c->d_input_u8.ensure(count);
+            upload(c, c->d_input_u8.p, host_imgs, count, c->stream);
+            launch_widen_u8(c->stream, c->d_input_u8.as<uint8_t>(), c->d_input.as<float>(), count);
+        }
         SIFT_HIP_CHECK(hipGetLastError());
         std::string msg;
         const int rc = build_plan(c, n, w, h, *params, msg);
@@ -1519,7 +1560,15 @@ int sift_hip_result_copy_sparse(sift_hip_ctx* c, void* records, float* values) {
         launch_wire_emit(c->stream, c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->total, c->d_wire_off.as<long long>(),
                          c->d_sparse_rec.as<uint8_t>(), c->d_sparse_val.as<float>());
         SIFT_HIP_CHECK(hipGetLastError());
-        if (is_pinned(records) && is_pinned(values)) {   // both copies queued behind the kernel, one wait
+        void* kr = c->io_kernels ? kernel_visible(records) : nullptr;
+        void* kvv = c->io_kernels ? kernel_visible(values) : nullptr;
+        if (kr && kvv && ((reinterpret_cast<uintptr_t>(kr) | reinterpret_cast<uintptr_t>(kvv)) & 15u) == 0) {
+            // page-locked destination: two small kernels behind the pack kernel, one wait
+            launch_io_copy(c->stream, c->d_sparse_rec.p, kr, (size_t)c->total * 34);
+            if (c->wire_values > 0) launch_io_copy(c->stream, c->d_sparse_val.p, kvv, (size_t)c->wire_values * sizeof(float));
+            SIFT_HIP_CHECK(hipGetLastError());
+            wait_stream(c, c->stream);
+        } else if (is_pinned(records) && is_pinned(values)) {   // both copies queued behind the kernel, one wait
             SIFT_HIP_CHECK(hipMemcpyAsync(records, c->d_sparse_rec.p, (size_t)c->total * 34, hipMemcpyDefault, c->stream));
             if (c->wire_values > 0) SIFT_HIP_CHECK(hipMemcpyAsync(values, c->d_sparse_val.p, (size_t)c->wire_values * sizeof(float), hipMemcpyDefault, c->stream));
             wait_stream(c, c->stream);

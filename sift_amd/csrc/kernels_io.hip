@@ -1,0 +1,85 @@
+// Frames in, keypoint lists out, between PAGE-LOCKED host memory and HBM, as kernels of a few workgroups (option "io_kernels",
+// a measured alternative that is OFF by default).
+//
+// The caller of Sift::calculate holds its image in host memory and takes a vector back (/root/reference/main.cpp:52-57).  With
+// batches in flight the transfers of one batch run beside the kernels of the others, and on this platform the runtime moves
+// page-locked memory partly with blit kernels (__amd_rocclr_copyBuffer in the traces) during which a bandwidth-bound launch of
+// another context was measured up to 12x slower (profiles/r03_host_trace.txt).  Page-locked memory is mapped into the GPU's
+// address space, so the transfer can be an ordinary kernel of kIoWorkgroups workgroups instead, every lane keeping kIoUnroll
+// 16-byte accesses in flight; the 8-bit ingest (sift_hip_calculate_batch_u8) then widens on the way in.  Measured (round 3,
+// tools/host_trace.sh): the HBM-bound launches beside such a kernel still slow down (4x instead of 12x: traffic that CUs send
+// over PCIe holds up the memory pipeline whoever issues it), reads over the link reach only ~28 GB/s with this much in
+// flight, and a step of the host loop takes 6.5 - 6.8 ms against 4.5 - 5.5 ms with the runtime's copies.  Kept for the record
+// and for platforms where the runtime's copies behave differently; the default path is hipMemcpyAsync.
+#include "common.h"
+
+namespace sift_hip {
+
+constexpr int kIoWorkgroups = 16;
+constexpr int kIoUnroll = 4;
+
+typedef unsigned u4v __attribute__((ext_vector_type(4)));   // a 16-byte unit the nontemporal builtins accept
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+// 16-byte units [0, n16) of src -> dst (either side may be mapped host memory)
+__global__ __launch_bounds__(256) void io_copy_kernel(const u4v* __restrict__ src, u4v* __restrict__ dst, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (kIoUnroll - 1) * stride < n16; i += kIoUnroll * stride) {
+        u4v v[kIoUnroll];
+#pragma unroll
+        for (int k = 0; k < kIoUnroll; ++k) v[k] = __builtin_nontemporal_load(src + i + k * stride);
+#pragma unroll
+        for (int k = 0; k < kIoUnroll; ++k) __builtin_nontemporal_store(v[k], dst + i + k * stride);
+    }
+    for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
+// 16 samples of 8 bits per unit -> 16 floats
+__global__ __launch_bounds__(256) void io_widen_kernel(const u4v* __restrict__ src, f4v* __restrict__ dst, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    auto put = [&](size_t at, const u4v v) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            dst[4 * at + k] = f4v{(float)(v[k] & 255u), (float)((v[k] >> 8) & 255u), (float)((v[k] >> 16) & 255u), (float)(v[k] >> 24)};
+    };
+    for (; i + (kIoUnroll - 1) * stride < n16; i += kIoUnroll * stride) {
+        u4v v[kIoUnroll];
+#pragma unroll
+        for (int k = 0; k < kIoUnroll; ++k) v[k] = __builtin_nontemporal_load(src + i + k * stride);
+#pragma unroll
+        for (int k = 0; k < kIoUnroll; ++k) put(i + k * stride, v[k]);
+    }
+    for (; i < n16; i += stride) put(i, __builtin_nontemporal_load(src + i));
+}
+
+__global__ void io_tail_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, float* __restrict__ dstf, int n) {
+    const int i = threadIdx.x;
+    if (i < n) {
+        if (dstf) dstf[i] = (float)src[i];
+        else dst[i] = src[i];
+    }
+}
+
+// bytes [0, bytes) of src -> dst; both 16-byte aligned
+void launch_io_copy(hipStream_t s, const void* src, void* dst, size_t bytes) {
+    const size_t n16 = bytes / 16;
+    if (n16) hipLaunchKernelGGL(io_copy_kernel, dim3(kIoWorkgroups), dim3(256), 0, s, static_cast<const u4v*>(src), static_cast<u4v*>(dst), n16);
+    const int tail = (int)(bytes - n16 * 16);
+    if (tail)
+        hipLaunchKernelGGL(io_tail_kernel, dim3(1), dim3(64), 0, s, static_cast<const unsigned char*>(src) + n16 * 16,
+                           static_cast<unsigned char*>(dst) + n16 * 16, (float*)nullptr, tail);
+}
+
+// count 8-bit samples of src -> count floats at dst; src 16-byte aligned, dst 16-byte aligned
+void launch_io_widen(hipStream_t s, const void* src, float* dst, size_t count) {
+    const size_t n16 = count / 16;
+    if (n16) hipLaunchKernelGGL(io_widen_kernel, dim3(kIoWorkgroups), dim3(256), 0, s, static_cast<const u4v*>(src), reinterpret_cast<f4v*>(dst), n16);
+    const int tail = (int)(count - n16 * 16);
+    if (tail)
+        hipLaunchKernelGGL(io_tail_kernel, dim3(1), dim3(64), 0, s, static_cast<const unsigned char*>(src) + n16 * 16, (unsigned char*)nullptr,
+                           dst + n16 * 16, tail);
+}
+
+}  // namespace sift_hip

@@ -60,12 +60,19 @@ class BatchPipeline:
         self._busy: list[Ticket | None] = [None] * depth
         self._next = 0
 
-    def _submit(self, method: str, *args) -> Ticket:
+    def _submit(self, method: str, *args, then=None) -> Ticket:
         slot = self._next
         if self._busy[slot] is not None:
             raise RuntimeError(f"pipeline slot {slot} still holds an unreleased batch: release() it before submitting batch number depth + 1")
         self._next = (slot + 1) % self.depth
-        t = Ticket(self, slot, self._workers[slot].submit(getattr(self.contexts[slot], method), *args))
+        ctx = self.contexts[slot]
+
+        def job():
+            getattr(ctx, method)(*args)
+            if then is not None:       # e.g. the download of the batch's lists: on the slot's own thread, beside the other slots' batches
+                then(ctx, slot)
+
+        t = Ticket(self, slot, self._workers[slot].submit(job))
         self._busy[slot] = t
         return t
 
@@ -74,9 +81,11 @@ class BatchPipeline:
         ticket must have been released (its results are overwritten by this batch)."""
         return self._submit("calculate_batch_device", dev_ptr, n, w, h, params)
 
-    def submit(self, imgs, params) -> Ticket:
-        """Same for a host array [n, h, w] float32 (uploaded by the slot's worker thread)."""
-        return self._submit("calculate_batch", imgs, params)
+    def submit(self, imgs, params, then=None) -> Ticket:
+        """Same for a host array [n, h, w] float32 or uint8 (uploaded by the slot's worker thread).  `then(context, slot)`, if
+        given, runs on that thread right after the batch (e.g. Context.results_sparse into the caller's buffers), so that a
+        host that moves frames in and lists out keeps upload, kernels and download of different batches going side by side."""
+        return self._submit("calculate_batch", imgs, params, then=then)
 
     def close(self) -> None:
         for t in self._busy:
