@@ -5,6 +5,51 @@
 
 #include "../../include/sift_hip.h"
 
+// Host threads and the HIP runtime.  Several contexts are driven by one host thread each (sift_hip_group's shard threads,
+// BatchPipeline's workers).  On this runtime (HIP 7.2) kernel launches of one thread crashed - SEGV at address 0 a few frames
+// below hipLaunchKernel, once a kernel that started with garbage arguments (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION) -
+// while another thread had the runtime copy device memory to device memory (hipMemcpyAsync: a blit kernel the runtime launches
+// itself): 3 - 8 % of the runs of examples/sift_multi_gpu.cpp (tools/example_loop.sh, tools/probe/segv_bt.c for the
+// backtraces).  What was tried, in this order: every translation unit's device code built before any thread starts
+// (tu_touch_*: kept, it removes the first-launch cost from the first batch); all launches of the library under one lock; also
+// the allocations, stream / event creation, event records and the runtime's copies under that lock (all kept: the lock is held
+// for the call only, a batch makes ~60 such calls of a few microseconds); no spin-wait; no null stream; 4 / 24 hardware queues -
+// none of it changed the rate.  Replacing the runtime's device-to-device copies by kernels of this library (group.cpp) did:
+// 1 crash in 200 runs, and none in 150 runs of examples/sift_pipeline.cpp, which never used such copies.
+#include <mutex>
+namespace sift_hip {
+std::recursive_mutex& launch_lock();   // kernels_io.hip
+// ... and so are the calls that create or destroy what a launch touches (device and pinned memory, streams, events): the
+// crashes went on, always below hipLaunchKernel, until hipMalloc / hipFree / hipStreamCreate / hipEventCreate of one thread could
+// no longer run beside a launch of another (tools/example_loop.sh: 9 of 120 runs before).
+struct ApiGuard {
+    std::lock_guard<std::recursive_mutex> g{launch_lock()};
+};
+}
+// ... and the calls that put the runtime's OWN kernels and markers on a stream (copies and fills are blit kernels here; event
+// records and stream waits are marker packets): the guard lives for the call (a temporary in a comma expression), never for a wait.
+#define hipMemcpyAsync(...) (::sift_hip::ApiGuard{}, (hipMemcpyAsync)(__VA_ARGS__))
+#define hipMemcpyPeerAsync(...) (::sift_hip::ApiGuard{}, (hipMemcpyPeerAsync)(__VA_ARGS__))
+#define hipMemcpy(...) (::sift_hip::ApiGuard{}, (hipMemcpy)(__VA_ARGS__))
+#define hipMemsetAsync(...) (::sift_hip::ApiGuard{}, (hipMemsetAsync)(__VA_ARGS__))
+#define hipMemset(...) (::sift_hip::ApiGuard{}, (hipMemset)(__VA_ARGS__))
+#define hipEventRecord(...) (::sift_hip::ApiGuard{}, (hipEventRecord)(__VA_ARGS__))
+#define hipStreamWaitEvent(...) (::sift_hip::ApiGuard{}, (hipStreamWaitEvent)(__VA_ARGS__))
+#ifdef __HIPCC__
+#include <hip/hip_ext.h>
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, ...)                                   \
+    do {                                                                      \
+        std::lock_guard<std::recursive_mutex> sift_launch_guard_(::sift_hip::launch_lock()); \
+        hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__);                \
+    } while (0)
+#define hipExtLaunchKernelGGL(...)                                            \
+    do {                                                                      \
+        std::lock_guard<std::recursive_mutex> sift_launch_guard_(::sift_hip::launch_lock()); \
+        (hipExtLaunchKernelGGL)(__VA_ARGS__);                                 \
+    } while (0)
+#endif
+
 namespace sift_hip {
 
 constexpr int kMaxOctaves = 16;
@@ -114,6 +159,17 @@ int stream_min_waves_now();
 void launch_widen_u8(hipStream_t s, const uint8_t* in, float* out, size_t count);
 void launch_io_copy(hipStream_t s, const void* src, void* dst, size_t bytes);      // kernels_io.hip: transfers as small kernels
 void launch_io_widen(hipStream_t s, const void* src, float* dst, size_t count);
+void launch_zero_ints(hipStream_t s, int* p, size_t n);
+// one empty launch per translation unit: makes the runtime build that unit's device code (see kernels_*.hip, sift_hip_create)
+void tu_touch_pyramid(hipStream_t s);
+void tu_touch_reduce(hipStream_t s);
+void tu_touch_extrema(hipStream_t s);
+void tu_touch_orient(hipStream_t s);
+void tu_touch_desc(hipStream_t s);
+void tu_touch_cleanup(hipStream_t s);
+void tu_touch_wire(hipStream_t s);
+void tu_touch_io(hipStream_t s);
+   // instead of hipMemsetAsync between kernels of a stream
 void launch_extrema_mask(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan,
                          unsigned long long* d_masks, int* d_counts);
 void launch_extrema_scan(hipStream_t s, const DevPlan& plan, int* d_counts, int* d_totals);

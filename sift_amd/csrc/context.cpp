@@ -29,6 +29,7 @@ struct DevBuf {
     size_t cap = 0;
     void ensure(size_t bytes) {
         if (bytes <= cap) return;
+        ApiGuard api;
         if (p) SIFT_HIP_CHECK(hipFree(p));
         p = nullptr;
         cap = 0;
@@ -36,6 +37,7 @@ struct DevBuf {
         cap = bytes;
     }
     void release() {
+        ApiGuard api;
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
@@ -49,6 +51,7 @@ struct HostBuf {  // pinned
     size_t cap = 0;
     void ensure(size_t bytes) {
         if (bytes <= cap) return;
+        ApiGuard api;
         if (p) SIFT_HIP_CHECK(hipHostFree(p));
         p = nullptr;
         cap = 0;
@@ -56,6 +59,7 @@ struct HostBuf {  // pinned
         cap = bytes;
     }
     void release() {
+        ApiGuard api;
         if (p) (void)hipHostFree(p);
         p = nullptr;
         cap = 0;
@@ -198,6 +202,7 @@ hipEvent_t get_event(sift_hip_ctx* c) {
         return e;
     }
     hipEvent_t e;
+    ApiGuard api;
     SIFT_HIP_CHECK(hipEventCreate(&e));
     return e;
 }
@@ -787,7 +792,7 @@ void launch_descriptor_stage(sift_hip_ctx* c) {
         if (c->wire_count) {   // multi-GPU jobs: the counting pass of the wire format rides in the descriptor kernel
             const size_t nb = wire_blocks(c->out_cap);
             c->d_wire_sums.ensure((nb + 2) * sizeof(int));
-            SIFT_HIP_CHECK(hipMemsetAsync(c->d_wire_sums.p, 0, (nb + 2) * sizeof(int), c->stream));
+            launch_zero_ints(c->stream, c->d_wire_sums.as<int>(), nb + 2);
             wire_sums = c->d_wire_sums.as<int>();
             c->wire_counted = true;
         }
@@ -1002,7 +1007,7 @@ void host_copy(sift_hip_ctx* c, void* dst, const void* src, size_t bytes) {
 void ensure_staging(sift_hip_ctx* c) {
     for (int i = 0; i < 2; ++i) {
         c->h_stage[i].ensure(kStageChunk);
-        if (!c->ev_stage[i]) SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming));
+        if (!c->ev_stage[i]) { ApiGuard api; SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming)); }
     }
 }
 
@@ -1126,7 +1131,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     hipStream_t gs = serial_gradient ? s : c->stream2;
     SIFT_HIP_CHECK(hipEventRecord(c->ev_fork0, s));
     SIFT_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork0, 0));
-    SIFT_HIP_CHECK(hipMemsetAsync(c->d_ocnt.as<int>() + 4 * n, 0, (size_t)n * sizeof(int), gs));   // "some sample has a bin != 0" per image
+    launch_zero_ints(gs, c->d_ocnt.as<int>() + 4 * n, (size_t)n);   // "some sample has a bin != 0" per image
     for (int lvl : P.grad_levels) {
         const int o = lvl / (P.D + 1);
         launch_gradient(gs, dv.gauss[lvl], dv.mag[lvl], dv.ori[lvl], dv.prod[lvl], dv.obin[lvl], dv.w[o], dv.h[o], n,
@@ -1251,6 +1256,7 @@ int sift_hip_create(int device, sift_hip_ctx** out, char* err, int errlen) {
             return SIFT_HIP_EINVAL;
         }
         SIFT_HIP_CHECK(hipSetDevice(device));
+        ApiGuard api;   // streams, events and the first launches: not beside another thread's launches (common.h)
         auto* c = new sift_hip_ctx();
         c->device = device;
         SIFT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -1262,6 +1268,20 @@ int sift_hip_create(int device, sift_hip_ctx** out, char* err, int errlen) {
         SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming));
         SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_side_fork, hipEventDisableTiming));
         SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_side_join, hipEventDisableTiming));
+        {
+            // Device code is built lazily, on the first launch from a translation unit, and that step does not survive two host
+            // threads doing it at once: have it done here, once per device, before any worker thread can launch anything.
+            static std::mutex touch_lock;
+            static bool touched[64] = {false};
+            std::lock_guard<std::mutex> lk(touch_lock);
+            if (device < 64 && !touched[device]) {
+                tu_touch_pyramid(c->stream); tu_touch_reduce(c->stream); tu_touch_extrema(c->stream); tu_touch_orient(c->stream);
+                tu_touch_desc(c->stream); tu_touch_cleanup(c->stream); tu_touch_wire(c->stream); tu_touch_io(c->stream);
+                SIFT_HIP_CHECK(hipGetLastError());
+                SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
+                touched[device] = true;
+            }
+        }
         *out = c;
         return SIFT_HIP_OK;
     });
@@ -1272,6 +1292,7 @@ void sift_hip_destroy(sift_hip_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)sift_hip_set_gate(c, nullptr);
+    ApiGuard api;
     for (DevBuf* b : {&c->arena, &c->d_plan, &c->d_taps, &c->d_luts, &c->d_taps16, &c->d_input, &c->d_input_u8, &c->d_sparse_rec, &c->d_sparse_val, &c->d_base, &c->d_tmp, &c->d_tmp2,
                       &c->d_wk, &c->d_wi, &c->d_wi2, &c->d_wp, &c->d_status, &c->d_tile, &c->d_pool, &c->d_order, &c->d_masks, &c->d_fmasks, &c->d_counts, &c->d_totals, &c->d_cands, &c->d_flags, &c->d_list, &c->d_list_cnt, &c->d_orient,
                       &c->d_peaks, &c->d_final, &c->d_final_cnt, &c->d_out_base, &c->d_kp, &c->d_desc, &c->d_lrank, &c->d_ochunk, &c->d_ocnt, &c->d_recs, &c->d_wire_sums, &c->d_wire_off, &c->d_unpack_sums, &c->d_unpack_off, &c->d_cell_cnt, &c->d_cell_off})
@@ -1365,6 +1386,7 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     if (!std::strcmp(name, "gate_early_chain")) { c->gate_early_chain = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "wire_count")) { c->wire_count = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "pyramid_side")) {
+        ApiGuard api;
         if (value != 0 && !c->ev_side_fork) {
             if (hipSetDevice(c->device) != hipSuccess ||
                 hipEventCreateWithFlags(&c->ev_side_fork, hipEventDisableTiming) != hipSuccess ||
@@ -1469,6 +1491,7 @@ int sift_hip_calculate_batch_device_u8(sift_hip_ctx* c, const void* dev_imgs, in
 
 void* sift_hip_host_alloc(size_t bytes) {
     void* p = nullptr;
+    ApiGuard api;
     if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
@@ -1476,6 +1499,7 @@ void* sift_hip_host_alloc(size_t bytes) {
     return p;
 }
 void sift_hip_host_free(void* p) {
+    ApiGuard api;
     if (p) (void)hipHostFree(p);
 }
 
@@ -1792,6 +1816,7 @@ struct Scratch {
     template <class T>
     T* dev(size_t count) {
         void* p = nullptr;
+        ApiGuard api;
         SIFT_HIP_CHECK(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
         ptrs.push_back(p);
         return static_cast<T*>(p);
@@ -1803,6 +1828,7 @@ struct Scratch {
         return d;
     }
     ~Scratch() {
+        ApiGuard api;
         for (void* p : ptrs) (void)hipFree(p);
     }
 };

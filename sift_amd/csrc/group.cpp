@@ -16,7 +16,13 @@
 // Transport.  RCCL (librccl.so.1, opened at run time so that the library also loads where RCCL is absent; one communicator
 // per GPU from ncclCommInitAll) when the group's devices are all different, which is the multi-GPU case; RCCL refuses two
 // ranks on one GPU, so a group that lists a device twice (tests on a one-GPU box) uses peer / same-device copies, each shard's
-// on a stream of its own.  Option "gather_transport": 0 copies, 1 RCCL if possible (default), 2 RCCL required.  A group of ONE
+// on a stream of its own.  Those copies are kernels of this library (kernels_io.hip: the sending GPU writes the arrival area in
+// place, its own memory or the first GPU's through peer access), not hipMemcpyAsync / hipMemcpyPeerAsync: with the runtime's
+// device-to-device copies issued by one host thread while another was launching kernels, the LAUNCHES crashed inside the
+// runtime (SEGV below hipLaunchKernel in 3 - 8 % of the runs of examples/sift_multi_gpu.cpp; 1 in 200 since, tools/
+// example_loop.sh; option "copy_kernels" = 0 brings the runtime's copies back).  For the same reason the caller's ordinary
+// memory is reached through page-locked staging buffers, never handed to the runtime as it is.
+// Option "gather_transport": 0 copies, 1 RCCL if possible (default), 2 RCCL required.  A group of ONE
 // shard with "gather_loopback" = 1 sends its lists through RCCL to itself (ncclSend + ncclRecv to the same rank in one group):
 // the whole RCCL path - communicator, grouped point-to-point, arrival area, unpack - on a box with one GPU.
 // Written against the public C ABI only (include/sift_hip.h).
@@ -37,7 +43,22 @@
 
 #include "../../include/sift_hip.h"
 
+extern "C" int sift_hip_internal_copy(void* stream, const void* src, void* dst, size_t bytes);   // kernels_io.hip
+
+namespace sift_hip {
+std::recursive_mutex& launch_lock();   // common.h: allocations and stream / event creation never run beside another thread's launch
+}
+
 namespace {
+
+struct ApiGuard {
+    std::lock_guard<std::recursive_mutex> g{sift_hip::launch_lock()};
+};
+// the runtime's own kernels and markers (copies, event records) go on their streams under the same lock (common.h)
+#define hipMemcpyAsync(...) (ApiGuard{}, (hipMemcpyAsync)(__VA_ARGS__))
+#define hipMemcpyPeerAsync(...) (ApiGuard{}, (hipMemcpyPeerAsync)(__VA_ARGS__))
+#define hipMemcpy(...) (ApiGuard{}, (hipMemcpy)(__VA_ARGS__))
+#define hipEventRecord(...) (ApiGuard{}, (hipEventRecord)(__VA_ARGS__))
 
 void set_err(char* err, int errlen, const std::string& m) {
     if (err && errlen > 0) std::snprintf(err, (size_t)errlen, "%s", m.c_str());
@@ -86,6 +107,7 @@ struct DevMem {   // grow-only device buffer on a fixed device
     long long cap = 0;
     bool fit(int device, long long want) {
         if (want <= cap) return true;
+        ApiGuard api;
         if (hipSetDevice(device) != hipSuccess) return false;
         if (p) (void)hipFree(p);
         p = nullptr;
@@ -97,6 +119,7 @@ struct DevMem {   // grow-only device buffer on a fixed device
     }
     void release(int device) {
         if (!p) return;
+        ApiGuard api;
         (void)hipSetDevice(device);
         (void)hipFree(p);
         p = nullptr;
@@ -145,6 +168,7 @@ struct sift_hip_group {
     int gather_wire = 1;        // 1 (default): lists of other GPUs cross in the sparse wire format; 0 plain arrays; 2 sparse for every shard
     int gather_transport = 1;   // 0 copies, 1 RCCL when the devices allow it, 2 RCCL or fail
     int gather_loopback = 0;    // one shard: its lists go through RCCL to itself
+    int copy_kernels = 1;       // device-to-device copies of the gather as kernels of the library (0: hipMemcpyAsync / hipMemcpyPeerAsync)
     // RCCL
     std::vector<ncclComm_t> comm;
     bool comm_tried = false, use_rccl = false;
@@ -166,6 +190,9 @@ struct sift_hip_group {
     std::vector<DevMem> in_rec[kSlots], in_val[kSlots];       // per shard, on devices[0]: where its lists arrive
     DevMem out_kp[kSlots], out_desc[kSlots];                  // on devices[0]: gathered lists, global image order
     hipStream_t recv_stream = nullptr, copy_stream = nullptr;   // on devices[0]
+    hipStream_t user_stream = nullptr;                          // on devices[0]: the caller's copies of a collected batch (never the null stream)
+    void* user_stage[2] = {nullptr, nullptr};                   // page-locked, kUserStage bytes each: ordinary caller memory is reached through them
+    hipEvent_t user_ev[2] = {nullptr, nullptr};
     // the batch the result accessors read (the last one collected)
     int cur = -1;
     double compute_ms = 0, gather_ms = 0, exposed_ms = 0;
@@ -288,7 +315,12 @@ void shard_main(sift_hip_group* g, int s) {
                         const bool ok = ia.fit(g->devices[0], (long long)na) && ib.fit(g->devices[0], (long long)std::max<size_t>(nb, 4));
                         (void)hipSetDevice(dev);
                         hipError_t h1 = hipSuccess, h2 = hipSuccess;
-                        if (ok && remote(g, s)) {
+                        if (ok && g->copy_kernels && ((reinterpret_cast<uintptr_t>(src_a) | reinterpret_cast<uintptr_t>(src_b)) & 3u) == 0 && na % 4 == 0 && nb % 4 == 0) {
+                            // a kernel of the library, run by THIS GPU: it writes the arrival area in place (its own memory, or the
+                            // first GPU's through peer access over the link)
+                            if (sift_hip_internal_copy(g->send_stream[(size_t)s], src_a, ia.p, na)) h1 = hipErrorUnknown;
+                            if (nb && sift_hip_internal_copy(g->send_stream[(size_t)s], src_b, ib.p, nb)) h2 = hipErrorUnknown;
+                        } else if (ok && remote(g, s)) {
                             h1 = hipMemcpyPeerAsync(ia.p, g->devices[0], src_a, dev, na, g->send_stream[(size_t)s]);
                             if (nb) h2 = hipMemcpyPeerAsync(ib.p, g->devices[0], src_b, dev, nb, g->send_stream[(size_t)s]);
                         } else if (ok) {
@@ -427,7 +459,14 @@ void gather_batch(sift_hip_group* g, Batch& B, int slot) {
             if (arrived) { kp = g->in_rec[slot][(size_t)s].p; desc = g->in_val[slot][(size_t)s].p; }
             else if (sift_hip_result_device(g->ctx[(size_t)s], &kp, &desc) != SIFT_HIP_OK) { fail("sift_hip_group: no device results"); return; }
             // (lists still in the shard's own buffers: loopback mode only, which runs one batch at a time)
-            if (hipMemcpyAsync(dk, kp, (size_t)R.total * sizeof(sift_hip_keypoint), hipMemcpyDeviceToDevice, g->copy_stream) != hipSuccess ||
+            const bool al = ((reinterpret_cast<uintptr_t>(kp) | reinterpret_cast<uintptr_t>(desc) | reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dd)) & 3u) == 0;
+            if (g->copy_kernels && al) {
+                if (sift_hip_internal_copy(g->copy_stream, kp, dk, (size_t)R.total * sizeof(sift_hip_keypoint)) ||
+                    sift_hip_internal_copy(g->copy_stream, desc, dd, (size_t)R.total * 128 * sizeof(float))) {
+                    fail("sift_hip_group: device-to-device copy failed");
+                    return;
+                }
+            } else if (hipMemcpyAsync(dk, kp, (size_t)R.total * sizeof(sift_hip_keypoint), hipMemcpyDeviceToDevice, g->copy_stream) != hipSuccess ||
                 hipMemcpyAsync(dd, desc, (size_t)R.total * 128 * sizeof(float), hipMemcpyDeviceToDevice, g->copy_stream) != hipSuccess) {
                 fail("sift_hip_group: device-to-device copy failed");
                 return;
@@ -503,6 +542,7 @@ int sift_hip_group_create(const int* devices, int n_devices, sift_hip_group** ou
             (void)hipGetLastError();
         }
     g->send_stream.assign((size_t)n_devices, nullptr);
+    ApiGuard api;
     for (int b = 0; b < kSlots; ++b) {
         g->sent_ev[b].assign((size_t)n_devices, nullptr);
         g->pack_rec[b].resize((size_t)n_devices); g->pack_val[b].resize((size_t)n_devices);
@@ -517,6 +557,7 @@ int sift_hip_group_create(const int* devices, int n_devices, sift_hip_group** ou
     }
     (void)hipSetDevice(devices[0]);
     if (hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&g->user_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&g->recv_stream, hipStreamNonBlocking) != hipSuccess)
         return bail(SIFT_HIP_EHIP, "sift_hip_group_create: cannot create the gather streams");
     g->shard_next.assign((size_t)n_devices, 0);
@@ -551,6 +592,7 @@ void sift_hip_group_destroy(sift_hip_group* g) {
         Rccl& r = rccl();
         for (auto c : g->comm) if (c) (void)r.CommDestroy(c);
     }
+    ApiGuard api;
     for (int s = 0; s < g->S; ++s) {
         (void)hipSetDevice(g->devices[(size_t)s]);
         if (g->send_stream[(size_t)s]) { (void)hipStreamSynchronize(g->send_stream[(size_t)s]); (void)hipStreamDestroy(g->send_stream[(size_t)s]); }
@@ -566,6 +608,11 @@ void sift_hip_group_destroy(sift_hip_group* g) {
     for (int b = 0; b < kSlots; ++b) { g->out_kp[b].release(g->devices[0]); g->out_desc[b].release(g->devices[0]); }
     if (g->copy_stream) { (void)hipStreamSynchronize(g->copy_stream); (void)hipStreamDestroy(g->copy_stream); }
     if (g->recv_stream) { (void)hipStreamSynchronize(g->recv_stream); (void)hipStreamDestroy(g->recv_stream); }
+    if (g->user_stream) { (void)hipStreamSynchronize(g->user_stream); (void)hipStreamDestroy(g->user_stream); }
+    for (int b = 0; b < 2; ++b) {
+        if (g->user_ev[b]) (void)hipEventDestroy(g->user_ev[b]);
+        if (g->user_stage[b]) sift_hip_host_free(g->user_stage[b]);
+    }
     for (auto* c : g->ctx) sift_hip_destroy(c);
     if (g->unpack_ctx) sift_hip_destroy(g->unpack_ctx);
     delete g;
@@ -583,6 +630,7 @@ int sift_hip_group_set_option(sift_hip_group* g, const char* name, int value) {
             g->gather_wire = value;
             return SIFT_HIP_OK;
         }
+        if (!std::strcmp(name, "copy_kernels")) { g->copy_kernels = value != 0; return SIFT_HIP_OK; }
         if (!std::strcmp(name, "gather_transport")) {   // before the first batch: the communicators are made then
             if (value < 0 || value > 2 || g->comm_tried) return SIFT_HIP_EINVAL;
             g->gather_transport = value;
@@ -714,9 +762,44 @@ int sift_hip_group_result_copy(sift_hip_group* g, sift_hip_keypoint* kp, float* 
     const long long total = g->batch[g->cur].total;
     if (total <= 0) return SIFT_HIP_OK;
     if (hipSetDevice(g->devices[0]) != hipSuccess) return SIFT_HIP_EHIP;
-    // a copy of its own, not the gather thread's streams: the next batch's gather may be running
-    if (kp && hipMemcpy(kp, g->out_kp[g->cur].p, (size_t)total * sizeof(sift_hip_keypoint), hipMemcpyDefault) != hipSuccess) return SIFT_HIP_EHIP;
-    if (desc && hipMemcpy(desc, g->out_desc[g->cur].p, (size_t)total * 128 * sizeof(float), hipMemcpyDefault) != hipSuccess) return SIFT_HIP_EHIP;
+    // A stream of its own (not the gather thread's: the next batch's gather may be running; not the null stream).  Ordinary
+    // (pageable) caller memory is NOT handed to the runtime: its copy would page-lock the caller's pages for the transfer and
+    // release them afterwards, and with other threads launching kernels at that moment the launches crashed inside the runtime
+    // (3 - 8 % of the runs of examples/sift_multi_gpu.cpp, tools/example_loop.sh).  Such memory is reached through two
+    // page-locked staging buffers of the group, chunk k+1 on its way while chunk k is copied out by the host.
+    auto pull = [&](void* dst, const void* src, size_t bytes) -> bool {
+        hipPointerAttribute_t a;
+        std::memset(&a, 0, sizeof(a));
+        const bool direct = hipPointerGetAttributes(&a, dst) == hipSuccess && (a.type == hipMemoryTypeHost || a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged);
+        (void)hipGetLastError();
+        if (direct) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, g->user_stream) == hipSuccess && hipStreamSynchronize(g->user_stream) == hipSuccess;
+        constexpr size_t kUserStage = 16u << 20;
+        for (int b = 0; b < 2; ++b) {
+            if (!g->user_stage[b]) g->user_stage[b] = sift_hip_host_alloc(kUserStage);
+            if (!g->user_stage[b]) return false;
+            if (!g->user_ev[b]) {
+                ApiGuard api;
+                if (hipEventCreateWithFlags(&g->user_ev[b], hipEventDisableTiming) != hipSuccess) return false;
+            }
+        }
+        const size_t chunks = (bytes + kUserStage - 1) / kUserStage;
+        for (size_t k = 0; k <= chunks; ++k) {
+            if (k < chunks) {
+                const size_t n = std::min(kUserStage, bytes - k * kUserStage);
+                if (hipMemcpyAsync(g->user_stage[k & 1], static_cast<const char*>(src) + k * kUserStage, n, hipMemcpyDeviceToHost, g->user_stream) != hipSuccess ||
+                    hipEventRecord(g->user_ev[k & 1], g->user_stream) != hipSuccess)
+                    return false;
+            }
+            if (k >= 1) {
+                const size_t o = (k - 1) * kUserStage, n = std::min(kUserStage, bytes - o);
+                if (hipEventSynchronize(g->user_ev[(k - 1) & 1]) != hipSuccess) return false;
+                std::memcpy(static_cast<char*>(dst) + o, g->user_stage[(k - 1) & 1], n);
+            }
+        }
+        return true;
+    };
+    if (kp && !pull(kp, g->out_kp[g->cur].p, (size_t)total * sizeof(sift_hip_keypoint))) return SIFT_HIP_EHIP;
+    if (desc && !pull(desc, g->out_desc[g->cur].p, (size_t)total * 128 * sizeof(float))) return SIFT_HIP_EHIP;
     return SIFT_HIP_OK;
 }
 int sift_hip_group_timing(sift_hip_group* g, double* compute_ms, double* gather_ms, int64_t* gather_bytes) {

@@ -1478,4 +1478,10 @@ void launch_cleanup_kat(hipStream_t s, const uint8_t* d_flags, int n, uint8_t* w
                        force_global, d_ord, d_lrank, d_cd);
 }
 
+// The runtime builds a translation unit's device code on the first launch of any of its kernels, and two host threads that make
+// their first launches at the same time (several contexts, one thread each) were seen to crash inside that step
+// (tools/asan_example.sh: SEGV below hipLaunchKernel).  sift_hip_create touches every unit once, under a lock.
+__global__ void tu_probe_cleanup_kernel() {}
+void tu_touch_cleanup(hipStream_t s) { hipLaunchKernelGGL(tu_probe_cleanup_kernel, dim3(1), dim3(1), 0, s); }
+
 }  // namespace sift_hip

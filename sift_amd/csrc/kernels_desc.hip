@@ -1053,4 +1053,10 @@ void launch_descriptors_wave(hipStream_t s, const DevPlan* d_plan, const DevPlan
                        d_kp_out, d_desc_out, out_cap, plan.n_images, chunks, dbg);
 }
 
+// The runtime builds a translation unit's device code on the first launch of any of its kernels, and two host threads that make
+// their first launches at the same time (several contexts, one thread each) were seen to crash inside that step
+// (tools/asan_example.sh: SEGV below hipLaunchKernel).  sift_hip_create touches every unit once, under a lock.
+__global__ void tu_probe_desc_kernel() {}
+void tu_touch_desc(hipStream_t s) { hipLaunchKernelGGL(tu_probe_desc_kernel, dim3(1), dim3(1), 0, s); }
+
 }  // namespace sift_hip

@@ -626,4 +626,10 @@ void launch_vertex_parabola(hipStream_t s, const uint16_t* lnx, const float* lny
                        px, py, rnx, rny, m, out);
 }
 
+// The runtime builds a translation unit's device code on the first launch of any of its kernels, and two host threads that make
+// their first launches at the same time (several contexts, one thread each) were seen to crash inside that step
+// (tools/asan_example.sh: SEGV below hipLaunchKernel).  sift_hip_create touches every unit once, under a lock.
+__global__ void tu_probe_extrema_kernel() {}
+void tu_touch_extrema(hipStream_t s) { hipLaunchKernelGGL(tu_probe_extrema_kernel, dim3(1), dim3(1), 0, s); }
+
 }  // namespace sift_hip

@@ -461,9 +461,15 @@ void launch_orientation(hipStream_t s, const DevPlan* d_plan, const DevPlan& pla
     const dim3 grid(128, (unsigned)plan.n_images);
     const int dbg = g_orient_dbg;   // option "orient_dbg": timing ablations only
     // zero_counters: how many consecutive per-image counter arrays to clear first (0: the caller already did)
-    if (zero_counters > 0) (void)hipMemsetAsync(d_next_group, 0, sizeof(int) * (size_t)plan.n_images * (size_t)zero_counters, s);
+    if (zero_counters > 0) launch_zero_ints(s, d_next_group, (size_t)plan.n_images * (size_t)zero_counters);
     hipLaunchKernelGGL(orientation_kernel, grid, dim3(256), 0, s, d_plan, d_oin, d_list_cnt, list_cap, d_out,
                        d_peaks, d_next_group, d_any_bin, dbg);
 }
+
+// The runtime builds a translation unit's device code on the first launch of any of its kernels, and two host threads that make
+// their first launches at the same time (several contexts, one thread each) were seen to crash inside that step
+// (tools/asan_example.sh: SEGV below hipLaunchKernel).  sift_hip_create touches every unit once, under a lock.
+__global__ void tu_probe_orient_kernel() {}
+void tu_touch_orient(hipStream_t s) { hipLaunchKernelGGL(tu_probe_orient_kernel, dim3(1), dim3(1), 0, s); }
 
 }  // namespace sift_hip

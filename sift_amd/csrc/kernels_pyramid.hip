@@ -744,4 +744,10 @@ void launch_dog(hipStream_t s, const float* lower, const float* higher, float* o
     hipLaunchKernelGGL(dog_kernel, dim3(grid), dim3(256), 0, s, lower, higher, out, count);
 }
 
+// The runtime builds a translation unit's device code on the first launch of any of its kernels, and two host threads that make
+// their first launches at the same time (several contexts, one thread each) were seen to crash inside that step
+// (tools/asan_example.sh: SEGV below hipLaunchKernel).  sift_hip_create touches every unit once, under a lock.
+__global__ void tu_probe_pyramid_kernel() {}
+void tu_touch_pyramid(hipStream_t s) { hipLaunchKernelGGL(tu_probe_pyramid_kernel, dim3(1), dim3(1), 0, s); }
+
 }  // namespace sift_hip

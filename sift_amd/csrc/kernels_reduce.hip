@@ -285,4 +285,10 @@ bool launch_blur_reduce_kept(hipStream_t s, const float* in, float* dst, int w, 
     return false;
 }
 
+// The runtime builds a translation unit's device code on the first launch of any of its kernels, and two host threads that make
+// their first launches at the same time (several contexts, one thread each) were seen to crash inside that step
+// (tools/asan_example.sh: SEGV below hipLaunchKernel).  sift_hip_create touches every unit once, under a lock.
+__global__ void tu_probe_reduce_kernel() {}
+void tu_touch_reduce(hipStream_t s) { hipLaunchKernelGGL(tu_probe_reduce_kernel, dim3(1), dim3(1), 0, s); }
+
 }  // namespace sift_hip

@@ -252,7 +252,7 @@ void launch_wire_unpack(hipStream_t s, const uint8_t* d_records, const float* d_
 void launch_wire_count(hipStream_t s, const float* d_desc, long long total, int* d_sums, long long* d_block_off, bool counted) {
     const size_t nb = wire_blocks(total);
     if (!counted) {
-        (void)hipMemsetAsync(d_sums, 0, sizeof(int), s);
+        launch_zero_ints(s, d_sums, 1);
         if (nb) hipLaunchKernelGGL(wire_count_kernel, dim3((unsigned)nb), dim3(256), 0, s, d_desc, total, d_sums + 1, d_sums);
     }
     hipLaunchKernelGGL(wire_scan_kernel, dim3(1), dim3(1024), 0, s, (const int*)(d_sums + 1), (int)nb, d_block_off);
@@ -265,5 +265,11 @@ void launch_wire_emit(hipStream_t s, const sift_hip_keypoint* d_kp, const float*
         hipLaunchKernelGGL(wire_emit_kernel, dim3((unsigned)nb), dim3(256), 0, s, d_kp, d_desc, total, d_block_off, d_records,
                            d_values);
 }
+
+// The runtime builds a translation unit's device code on the first launch of any of its kernels, and two host threads that make
+// their first launches at the same time (several contexts, one thread each) were seen to crash inside that step
+// (tools/asan_example.sh: SEGV below hipLaunchKernel).  sift_hip_create touches every unit once, under a lock.
+__global__ void tu_probe_wire_kernel() {}
+void tu_touch_wire(hipStream_t s) { hipLaunchKernelGGL(tu_probe_wire_kernel, dim3(1), dim3(1), 0, s); }
 
 }  // namespace sift_hip

@@ -39,10 +39,12 @@ public:
     }
 
     PhaseGate() {
+        ApiGuard api;
         for (auto& sl : ring_)
             for (auto& e : sl.ev) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
     }
     ~PhaseGate() {
+        ApiGuard api;
         for (auto& sl : ring_)
             for (auto& e : sl.ev) (void)hipEventDestroy(e);
     }
