@@ -118,6 +118,7 @@ struct sift_hip_ctx {
     bool fused = true;
     bool fused_edge = true;   // extremum scan and edge filter in one LDS-tiled pass
     bool fused_reduce = true; // reduceToNextLevel: blur and decimation in one pass
+    bool stage_kernels = false;  // option (off): staged (pageable) transfers move their chunks between staging buffer and HBM by a kernel of the library
     bool io_kernels = false;  // option "io_kernels" (measured alternative, off): page-locked host memory is read / written in place by small kernels (kernels_io.hip) instead of hipMemcpyAsync
     bool reduce_kept = true;  // ... that evaluates the kept pixels only (option "reduce_kept"; 0: blur_stream_kernel<..., DEC>)
     bool orient_general = false;  // tests: orientation histogram with per-sample bins even when every bin is 0
@@ -1013,6 +1014,18 @@ void ensure_staging(sift_hip_ctx* c) {
 
 // host -> device on stream s; returns once `host` may be reused (pageable) or at once (pinned: the caller keeps the
 // buffer until the batch is done, which calculate only returns after)
+// One chunk between the context's page-locked staging buffer and device memory: hipMemcpyAsync, or (option "stage_kernels",
+// off) a kernel of this library reading / writing the mapped staging buffer - tried against the runtime's crashes in
+// multi-threaded hosts (common.h); it did not lower their rate (11 of 200 runs of examples/sift_multi_gpu.cpp).
+void stage_move(sift_hip_ctx* c, void* dst, const void* src, size_t bytes, bool to_device, hipStream_t s) {
+    if (c->stage_kernels && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 3u) == 0 && bytes % 4 == 0) {
+        launch_io_copy(s, src, dst, bytes);
+        SIFT_HIP_CHECK(hipGetLastError());
+        return;
+    }
+    SIFT_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, s));
+}
+
 void upload(sift_hip_ctx* c, void* dev, const void* host, size_t bytes, hipStream_t s) {
     if (bytes == 0) return;
     // option "io_kernels" (off): a kernel of a few workgroups reads page-locked memory in place (kernels_io.hip)
@@ -1035,7 +1048,7 @@ void upload(sift_hip_ctx* c, void* dev, const void* host, size_t bytes, hipStrea
         const size_t n = std::min(kStageChunk, bytes - off);
         if (k >= 2) SIFT_HIP_CHECK(hipEventSynchronize(c->ev_stage[b]));   // the copy engine is done with this buffer
         host_copy(c, c->h_stage[b].p, static_cast<const char*>(host) + off, n);
-        SIFT_HIP_CHECK(hipMemcpyAsync(static_cast<char*>(dev) + off, c->h_stage[b].p, n, hipMemcpyHostToDevice, s));
+        stage_move(c, static_cast<char*>(dev) + off, c->h_stage[b].p, n, true, s);
         SIFT_HIP_CHECK(hipEventRecord(c->ev_stage[b], s));
     }
 }
@@ -1064,7 +1077,7 @@ void download(sift_hip_ctx* c, void* dst, const void* dev, size_t bytes, hipStre
         if (k < chunks) {
             const int b = (int)(k & 1);
             const size_t n = std::min(kStageChunk, bytes - k * kStageChunk);
-            SIFT_HIP_CHECK(hipMemcpyAsync(c->h_stage[b].p, static_cast<const char*>(dev) + k * kStageChunk, n, hipMemcpyDeviceToHost, s));
+            stage_move(c, c->h_stage[b].p, static_cast<const char*>(dev) + k * kStageChunk, n, false, s);
             SIFT_HIP_CHECK(hipEventRecord(c->ev_stage[b], s));
         }
         if (k >= 1) {   // chunk k-1 has landed (or lands now) while chunk k is on its way
@@ -1378,6 +1391,7 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     if (!std::strcmp(name, "fused_blur")) { c->fused = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "fused_edge")) { c->fused_edge = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "fused_reduce")) { c->fused_reduce = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "stage_kernels")) { c->stage_kernels = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "io_kernels")) { c->io_kernels = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "reduce_kept")) { c->reduce_kept = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "spin_wait")) { c->spin_wait = value != 0; return SIFT_HIP_OK; }

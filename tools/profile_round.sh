@@ -3,7 +3,7 @@
 # per-kernel HBM traffic / L2 hit rate, SQ counters of the big non-blur kernels.   bash tools/profile_round.sh r02
 set -u
 export TMPDIR=/tmp
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/$R
 rm -rf $O; mkdir -p $O
 rocminfo 2>/dev/null | grep -m2 -E "gfx|Marketing" > $O/device.txt; lscpu | grep -E "Model name|^CPU\(s\)" >> $O/device.txt
@@ -26,6 +26,11 @@ timeout 600 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras
 timeout 600 python3 bench.py --workload config3 --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_config3.json 2> /dev/null
 timeout 600 python3 bench.py --workload config5 --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_config5.json 2> /dev/null
 timeout 600 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --rccl-loopback > $O/bench_rccl_loopback.json 2> /dev/null
+# 3b. the host-buffer loop: kernels and copies of three batches in flight
+rm -rf gpurun_out/htrace
+timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/htrace -- python3 tools/host_trace.py 3 main > $O/host_trace.txt 2>/dev/null
+python3 tools/host_trace.py --report gpurun_out/htrace >> $O/host_trace.txt 2>&1
+rm -rf gpurun_out/htrace
 # 4. counters
 bash tools/pmc_kernel.sh > $O/pmc_hbm_traffic.txt 2>&1
 DBGS="" bash tools/desc_probe.sh 2>&1 | grep -vE "^dbg" > $O/pmc_sq_counters.txt
