@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void gradient_kernel(const float* __restrict__
 // do not share the neighbouring rows: measured 3.0x before).  16-byte loads and stores, a 4-byte store of the bins.
 constexpr int kGradRows = 16;
 
-__global__ __launch_bounds__(256) void gradient4_kernel(const float* __restrict__ g, float* __restrict__ mag,
+__global__ __launch_bounds__(256, 8) void gradient4_kernel(const float* __restrict__ g, float* __restrict__ mag,
                                                         float* __restrict__ ori, float* __restrict__ prod,
                                                         uint8_t* __restrict__ obin, int w, int h,
                                                         int* __restrict__ any_bin) {

@@ -835,7 +835,8 @@ def test_group_two_batches_in_flight(ctx):
 
 
 _GROUP_RCCL_SCRIPT = """
-import sys, numpy as np
+import os, sys, numpy as np
+os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")      # no network on the test boxes: RCCL's bootstrap stays on the loopback interface
 sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + '/tests')
 from sift_amd import _lib
 from sift_amd.sift import Group, Context, K_SQRT2
