@@ -204,6 +204,8 @@ class KeypointGather:
         buf = torch.empty(self.hdr_bytes + nbytes, dtype=torch.uint8, device=self.dev)
         view = buf[self.hdr_bytes:]
         self._rec_bufs[view.data_ptr()] = buf
+        while len(self._rec_bufs) > 4:     # a view that was staged elsewhere instead of being pushed as it is must not pin its buffer for ever
+            self._rec_bufs.pop(next(iter(self._rec_bufs)))
         return view
 
     def _send_ops(self, total, records, values, counts):
