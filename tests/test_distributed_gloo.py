@@ -247,3 +247,24 @@ def test_keypoint_gather_loopback_protocol(monkeypatch):
         assert g.wire_bytes == sum(r.size + 4 * v.size for _, r, v in data) + 8 * (3 + 3) * 6
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    """`python bench.py --gpus 2` as a bare command starts its own rank processes (bench.py launch_ranks: RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set per child, before the parent has imported torch or touched a GPU) and exits non-zero when a rank
+    fails - here every rank does, on a machine without a GPU, or because the library option does not exist - without printing a
+    result line.  (The passing run is test_bench_starts_its_own_ranks, on the GPU.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo", "--steps", "1",
+                        "--warmup", "0", "--frames", "1", "--no-cpu-baseline", "--no-extras", "--set", "no_such_option=1"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "rank 0 exited with status" in r.stderr or "rank 1 exited with status" in r.stderr
+    # under a launcher that has set WORLD_SIZE the script does not start ranks of its own: a mismatch is refused
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                       cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

@@ -116,3 +116,45 @@ def test_vertex_parabola_kat(hm):
         assert abs(v - 177.4913) < 1e-3
     assert np.isnan(hm.hostmath_vertex_parabola(355, 0.0, 5, 0.0, 15, 0.0))
     assert hm.hostmath_vertex_parabola(355, 0.0, 5, 37.5, 15, 0.0) == np.float32(177.49134826660156)
+
+
+def test_sparse_unpack_host_restores_records_and_descriptors():
+    """sift_hip_sparse_unpack_host (plain host code of the C ABI: the receiving side of sift_hip_result_copy_sparse) against a
+    numpy construction of the wire format: 34-byte records = 20-byte keypoint + 112 presence bits (bit cell*7+bin, LSB first),
+    then the floats whose bit pattern is not +0.0f in ascending position; bin 7 of every cell comes back as +0.0f; any number
+    of threads gives the same bytes; -0.0f and NaN payloads survive."""
+    import ctypes as C
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sift_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(11)
+    n = 5003
+    desc = rng.random((n, 16, 8)).astype(np.float32)
+    desc[rng.random((n, 16, 8)) < 0.62] = 0.0
+    desc[:, :, 7] = 0.0
+    desc[3, 2, 1] = -0.0                       # not +0.0f: travels
+    desc[4, 0, 0] = np.float32("nan")
+    desc[5] = 0.0                              # a keypoint without a single set float
+    kp = np.zeros(n, _lib.KEYPOINT_DTYPE)
+    kp["x"] = rng.integers(0, 1920, n)
+    kp["y"] = rng.integers(0, 1080, n)
+    kp["scale"] = rng.random(n).astype(np.float32)
+    kp["has_descriptor"] = 1
+    d7 = np.ascontiguousarray(desc[:, :, :7]).reshape(n, 112)
+    present = d7.view(np.uint32) != 0
+    rec = np.ascontiguousarray(np.concatenate([kp.view(np.uint8).reshape(n, 20), np.packbits(present, axis=1, bitorder="little")], axis=1))
+    val = np.ascontiguousarray(d7[present])
+    assert rec.shape == (n, 34)
+    want = desc.reshape(n, 128)
+    for threads in (0, 1, 3, 8, 64):
+        k2 = np.zeros(n, _lib.KEYPOINT_DTYPE)
+        d2 = np.full((n, 128), 7.0, np.float32)
+        assert L.sift_hip_sparse_unpack_host(rec.ctypes.data, val.ctypes.data, n, k2.ctypes.data, d2.ctypes.data, threads) == 0
+        assert k2.tobytes() == kp.tobytes() and d2.tobytes() == want.tobytes(), threads
+    # records only / descriptors only / nothing at all
+    k2 = np.zeros(n, _lib.KEYPOINT_DTYPE)
+    assert L.sift_hip_sparse_unpack_host(rec.ctypes.data, val.ctypes.data, n, k2.ctypes.data, None, 2) == 0 and k2.tobytes() == kp.tobytes()
+    d2 = np.empty((n, 128), np.float32)
+    assert L.sift_hip_sparse_unpack_host(rec.ctypes.data, val.ctypes.data, n, None, d2.ctypes.data, 2) == 0 and d2.tobytes() == want.tobytes()
+    assert L.sift_hip_sparse_unpack_host(None, None, 0, None, None, 1) == 0
