@@ -153,6 +153,7 @@ void launch_resample(hipStream_t s, const float* src, float* dst, int ws, int hs
                      const int* d_lutx, const int* d_luty);
 void launch_dog(hipStream_t s, const float* lower, const float* higher, float* out, size_t count);
 void set_fused_grid_mode(int v);
+void set_extrema_stream(int v);
 bool launch_blur_reduce_kept(hipStream_t s, const float* in, float* dst, int w, int h, int wd, int hd, int n, const float* d_taps, int radius,
                              int sx, int sy, int min_waves, hipEvent_t ev_start, hipEvent_t ev_stop);
 int stream_min_waves_now();

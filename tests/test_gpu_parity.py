@@ -321,6 +321,50 @@ def test_pipeline_parity_kept_pixels_reduce(ctx, report_dir, case):
         ctx.set_option("stream_min_waves", 0)
 
 
+SX_CASES = [
+    ("streaming extrema 640x480 4x3 x2", 640, 480, 41, 3, 4, 2),
+    ("streaming extrema 1000x600 (strips of 248 columns: 5th strip 8 columns wide)", 1000, 600, 42, 3, 3, 1),
+    ("streaming extrema 252x130 (one strip and a bit, blocks of 64 rows: 3rd block 2 rows)", 252, 130, 43, 3, 2, 3),
+    ("streaming extrema 768x576 4 dogs (two scanned levels per octave)", 768, 576, 44, 4, 2, 1),
+]
+
+
+@pytest.mark.parametrize("case", SX_CASES, ids=[c[0] for c in SX_CASES])
+def test_pipeline_parity_streaming_extrema(ctx, report_dir, case):
+    """The streaming form of the fused scan + edge filter (extrema_stream_kernel: rows in registers, candidates queued with their
+    18 samples, curvature tests and QR bodies on batches of 64), forced onto small inputs (option extrema_stream = 2): candidate
+    lists, edge-filter flags and everything after them against the oracle."""
+    name, w, h, seed, dogs, octaves, frames = case
+    ctx.set_option("extrema_stream", 2)
+    try:
+        rep = compare_run(ctx, synth_frame(w, h, seed), dogs, octaves, False, name, report_dir, batch_of=frames)
+        assert rep["final"] > 0 and rep["candidates"] > 100
+    finally:
+        ctx.set_option("extrema_stream", 0)
+
+
+def test_streaming_extrema_on_ties(ctx):
+    """A constant image makes EVERY interior pixel a candidate (248 per row and wave: the queue drains a batch at every column
+    position) and every one of them is filtered (H = 0); a checkerboard of two values gives alternating ties."""
+    params = _lib.Params(3, 2, 1.6, O.K_SQRT2, 0)
+    yy, xx = np.mgrid[0:200, 0:512]
+    for img in (np.full((200, 512), 77.0, np.float32), (((xx // 3 + yy // 5) % 2) * 60 + 40).astype(np.float32)):
+        ctx.set_option("extrema_stream", 2)
+        try:
+            ctx.calculate_batch(img[None], params)
+            got = ctx.stage("candidates").copy()
+            counts = ctx.counts().copy()
+        finally:
+            ctx.set_option("extrema_stream", 0)
+        run = O.OracleRun(img, 3, 2)
+        want = run.points("candidates")[0]
+        assert got.size == want.size and got.size > 2000
+        for f in ("x", "y", "octave", "index"):
+            assert (got[f] == want[f]).all(), f
+        assert (got["filtered"].astype(bool) == want["filtered"].astype(bool)).all()
+        assert counts[0] == run.points("final")[0].size
+
+
 def test_pipeline_parity_general_orientation_bins(ctx, report_dir):
     """The orientation histogram's per-sample-bin form (never selected by real frames: App. B-9 puts every sample
     in bin 0, which the gradient pass detects) gives the same results as the all-zero-bins fast path."""
