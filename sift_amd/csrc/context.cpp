@@ -142,7 +142,7 @@ struct sift_hip_ctx {
     DevBuf d_cell_cnt, d_cell_off;   // descriptor grid: keypoints per 16 px cell, exclusive scan (+ total)
     bool desc_wave = true;           // option "desc_kernel": 1 wave-per-keypoint kernel (default), 0 tile kernel
     bool gate_early_chain = false;   // option "gate_early_chain" (measured alternative, off)
-    int gate_schedule = 0;           // option "gate_schedule" (phase_gate.h): applies to the gate this context is joined to
+    int gate_schedule = 1;           // option "gate_schedule" (phase_gate.h; 1 since round 3): applies to the gate this context is joined to
     // option "pyramid_side" (default on): the top Gaussian level of an octave (it only feeds the octave's last DoG) is formed on
     // the side stream, beside the reduction and the first levels of the next octave, which are too small to fill the chip alone
     bool pyramid_side = true;
@@ -1382,7 +1382,7 @@ int sift_hip_set_gate(sift_hip_ctx* c, sift_hip_gate* g) {
     }
     c->gate_owner = g;
     c->gate = g ? &g->gate : nullptr;
-    if (c->gate && c->gate_schedule) c->gate->set_schedule(c->gate_schedule);
+    if (c->gate) c->gate->set_schedule(c->gate_schedule);
     return SIFT_HIP_OK;
 }
 

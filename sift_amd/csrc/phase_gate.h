@@ -5,14 +5,20 @@
 //     E  extrema + edge filter, gradient maps (fill the chip)
 //     C  cleanup -> orientation -> cleanup (one workgroup per image: an eighth of the chip for ~0.6 ms)
 //     D  descriptors (fill the chip)
-// With two contexts taking batches alternately, the gate makes the device run
+// With two contexts taking batches alternately, the gate makes the device run (schedule 1, the default since round 3)
+//     ... | P(g+1) || C(g) | E(g+1) || D(g) | P(g+2) || C(g+1) | E(g+2) || D(g+1) | ...
+// i.e. the cleanup chain, which cannot fill the chip, runs under the next batch's pyramid, and the descriptors (issue-bound)
+// under the next batch's extrema / gradient pass; no two pyramids, and no two descriptor stages, ever share the chip.
+// Schedule 0 (rounds 1 - 2; option "gate_schedule" = 0) keeps the pyramids alone on the chip:
 //     ... | P(g+1) | C(g) || E(g+1), then D(g) | P(g+2) | C(g+1) || E(g+2), then D(g+1) | ...
-// i.e. the next batch's E fills the chip while this batch's C cannot, and a pyramid never shares the chip
-// with anything (its launches keep the bandwidth they have when a batch runs alone).  Everything is expressed
+// The blur launches then run at their stand-alone rate (0.50 of the HBM peak against 0.43 beside the chain), but the chain
+// starves behind the extrema pass's persistent workgroups and the descriptors wait for it: 2.98 against 2.82 - 2.95 ms per step
+// (round 3; in round 2, before the reductions evaluated kept pixels only and the fills left the streams, schedule 1 was the
+// slower one).  Everything is expressed
 // with events between the contexts' streams; the host side only makes sure an event has been RECORDED before
 // another stream is told to wait for it (a wait on an unrecorded event is no wait at all).
 //
-// Rules, g = ticket of a batch in submission order:
+// Rules of schedule 0, g = ticket of a batch in submission order:
 //     P(g)  starts after E(g-1), or after D(g-1) if batch g-1 had already entered C when g was announced;
 //           and after D(g-2).
 //     C(g)  starts after P(g+1) if batch g+1 has been announced by the time the device finishes E(g), else then.
@@ -166,7 +172,7 @@ private:
     std::mutex m_;
     std::condition_variable cv_;
     long long next_ = 0;
-    int schedule_ = 0;
+    int schedule_ = 1;
     Slot ring_[kRing];
 };
 

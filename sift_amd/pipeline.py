@@ -8,10 +8,10 @@ host-side scheduler for that: `depth` contexts, batch k goes to context k % dept
 worker thread of its own (the C ABI blocks until a batch is done and releases the GIL meanwhile).
 
 With `gated=True` (default) the contexts are joined by a phase gate (sift_amd/csrc/phase_gate.h): the device then
-runs  ... | pyramid(k+1) | cleanup(k) || extrema(k+1), descriptors(k) | pyramid(k+2) | ...  — the next batch's
-extrema / gradient pass fills the chip under this batch's cleanup, and no pyramid ever shares the chip, so the
-bandwidth-bound blur launches run exactly as they do alone.  `gated=False` leaves the interleaving to the GPU's
-queues (a little more throughput at depth 3, at the price of pyramids that share the chip).
+runs  ... | pyramid(k+1) || cleanup(k) | extrema(k+1) || descriptors(k) | pyramid(k+2) || cleanup(k+1) | ...  - the cleanup
+chain, which cannot fill the chip, runs under the next batch's pyramid and the descriptors under its extrema / gradient
+pass (library option `gate_schedule` = 0 brings back the order of rounds 1 - 2, in which a pyramid never shares the chip).
+`gated=False` leaves the interleaving to the GPU's queues.
 
 Results are those of the plain context, batch for batch — the contexts share nothing but the GPU.
 """
