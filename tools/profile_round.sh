@@ -14,7 +14,7 @@ f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); cp "$f" $O/kernel
 t=$(find gpurun_out/prof -name "*kernel_trace.csv" | head -1)
 python3 tools/roofline_from_stats.py --stats $O/kernel_stats.csv > $O/roofline.txt
 python3 tools/roofline_from_stats.py --trace "$t" --dump $O/blur_launches.csv >> $O/roofline.txt
-python3 tools/timeline_window.py "$t" 8000 500 > $O/timeline_pipelined.txt 2>&1
+python3 tools/timeline_window.py "$t" 8000 12500 > $O/timeline_pipelined.txt 2>&1   # (the last ~11 ms of the run are the three stand-alone steps)
 # 2. one step at a time: per-kernel timeline
 rm -rf gpurun_out/prof
 timeout 900 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --pipeline-depth 1 > /dev/null 2>&1
