@@ -222,7 +222,7 @@ def main():
                     help="N = 1 only: every step's keypoint lists also travel through RCCL point-to-point to this same rank "
                          "(KeypointGather(loopback=True)): the N > 1 gather path, messages and sizes, on a one-GPU box")
     ap.add_argument("--pipeline-gate", type=int, default=1, choices=[0, 1],
-                    help="pipeline depth > 1: 1 (default) joins the contexts with a phase gate (no pyramid shares the chip); 0 leaves the interleaving to the GPU's queues")
+                    help="pipeline depth > 1: 1 (default) joins the contexts with a phase gate (sift_amd/csrc/phase_gate.h); 0 leaves the interleaving to the GPU's queues")
     args = ap.parse_args()
 
     global W, H, DOGS, OCTAVES, SUBPIXEL

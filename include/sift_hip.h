@@ -82,20 +82,24 @@ void sift_hip_destroy(sift_hip_ctx* ctx);
  * aids, results unchanged unless stated: "stream_waves" (process-wide; waves a streaming blur launch is cut into, default
  * 2048, 0 = tile kernel only), "desc_kernel" (1 default: one wave per keypoint over a grid of 16 px cells; 0: one workgroup
  * per 48 px tile walking the ordered keypoint list), "desc_dbg" / "orient_dbg" (phases switched off: timing only, WRONG results),
- * "gate_early_chain" / "gate_schedule" (other orders of the phases of batches joined by a gate, sift_amd/csrc/phase_gate.h:
- * measured, slower, off), "pyramid_side" (0 default; 1: the top Gaussian level of an octave, which only feeds the octave's last
- * DoG, is formed on the side stream beside the reduction and the next octave's small launches: ~2.5 % more throughput on the
- * bench workload, at the price that blur launches then overlap and their summed durations no longer equal the pyramid's time), "diag_pyramid_span", "diag_serial_gradient", "diag_cleanup_stamps" (print to stderr).  The library reads no
+ * "gate_schedule" (order of the phases of batches joined by a gate, sift_amd/csrc/phase_gate.h: 1 default - the cleanup chain under the
+ * next batch's pyramid, the descriptors under its extrema / gradient pass; 0 - no pyramid shares the chip, the order of rounds 1 - 2),
+ * "gate_early_chain" (measured, slower, off), "pyramid_side" (1 default: the top Gaussian level of an octave, which only feeds the
+ * octave's last DoG, is formed on the side stream beside the reduction and the next octave's small launches; 0: every launch on
+ * one stream), "reduce_kept" (1 default: reduceToNextLevel evaluates the kept pixels only), "extrema_stream" (0 default; 1 / 2: the
+ * strip-walking form of the scan + edge filter for large / all launches), "fused_grid", "stream_min_waves", "io_kernels",
+ * "stage_kernels" (measured alternatives), "diag_pyramid_span", "diag_serial_gradient", "diag_cleanup_stamps" (print to stderr).  The library reads no
  * environment variable. */
 int sift_hip_set_option(sift_hip_ctx* ctx, const char* name, int value);
 
 /* ---- several batches in flight on one GPU --------------------------------------------------------
  * The reference runs one calculate() at a time (main.cpp:56-57).  A host that has the next batch ready can give
  * every batch in flight a context of its own (one host thread each) and join the contexts with a gate: the gate
- * orders the phases of consecutive batches on the device so that the next batch's extrema / gradient pass fills the
- * chip while this batch's cleanup steps (one workgroup per image, sift.cpp:37-54) cannot, and no pyramid shares
- * the chip with anything (sift_amd/csrc/phase_gate.h).  Results are unchanged.  Batches take their place in the
- * order in which their calculate calls begin. */
+ * orders the phases of consecutive batches on the device: this batch's cleanup steps (one workgroup per image,
+ * sift.cpp:37-54), which cannot fill the chip, run under the next batch's pyramid and its descriptors under the next
+ * extrema / gradient pass; no two pyramids and no two descriptor stages share the chip (sift_amd/csrc/phase_gate.h;
+ * option "gate_schedule" = 0: no pyramid shares the chip with anything).  Results are unchanged.  Batches take their
+ * place in the order in which their calculate calls begin. */
 typedef struct sift_hip_gate sift_hip_gate;
 int sift_hip_gate_create(int device, sift_hip_gate** out);
 /* The host's handle goes at once; the gate itself lives until the last context joined by it has left (sift_hip_set_gate(ctx,
