@@ -87,7 +87,10 @@ void sift_hip_destroy(sift_hip_ctx* ctx);
  * "gate_early_chain" (measured, slower, off), "pyramid_side" (1 default: the top Gaussian level of an octave, which only feeds the
  * octave's last DoG, is formed on the side stream beside the reduction and the next octave's small launches; 0: every launch on
  * one stream), "reduce_kept" (1 default: reduceToNextLevel evaluates the kept pixels only), "extrema_stream" (0 default; 1 / 2: the
- * strip-walking form of the scan + edge filter for large / all launches), "fused_grid", "stream_min_waves", "io_kernels",
+ * strip-walking form of the scan + edge filter for large / all launches), "chain_from" (0 default; o > 0: the pyramid's octaves >= o as
+ * ONE launch of per-image work items, sift_amd/csrc/kernels_chain.hip; "chain_mode" 1 / 0 / 2: agent-scope accesses, ordinary accesses +
+ * fences, tiles of an image spread over all XCDs), "gate_mid" (0 default; o > 0: a gated batch's descriptors start when the next batch's
+ * pyramid reaches octave o instead of when it ends), "fused_grid", "stream_min_waves", "io_kernels",
  * "stage_kernels" (measured alternatives), "diag_pyramid_span", "diag_serial_gradient", "diag_cleanup_stamps" (print to stderr).  The library reads no
  * environment variable. */
 int sift_hip_set_option(sift_hip_ctx* ctx, const char* name, int value);

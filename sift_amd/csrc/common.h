@@ -161,6 +161,31 @@ void launch_widen_u8(hipStream_t s, const uint8_t* in, float* out, size_t count)
 void launch_io_copy(hipStream_t s, const void* src, void* dst, size_t bytes);      // kernels_io.hip: transfers as small kernels
 void launch_io_widen(hipStream_t s, const void* src, float* dst, size_t count);
 void launch_zero_ints(hipStream_t s, int* p, size_t n);
+// kernels_chain.hip: the rest of the pyramid from a given octave on as one launch of (stage, image, tile) work items
+constexpr int kChainMaxStages = 16;
+struct ChainStage {
+    const float* src;          // level the blur reads (all images)
+    float* dst;                // blurred level, or the next octave's first level for a reduction
+    float* dog;                // mode 0
+    const int* inv_x;          // mode 1: source column / row -> destination column / row, or -1
+    const int* inv_y;
+    const float* taps;
+    int w, h;                  // size the blur runs on
+    int wd, hd;                // mode 1: destination size
+    int radius, mode;          // mode 0: level blur + DoG; 1: reduction
+    int tiles_x, tiles_y;      // 64 x 48 tiles
+    int dep, dep_tiles;        // stage that must be complete for the image (-1: its source exists before the launch), tiles per image of it
+};
+struct ChainPlan {
+    int n_stages, n_images;
+    int q_off[9];              // items of queue q (images with index mod 8 == q): [q_off[q], q_off[q+1])
+    ChainStage st[kChainMaxStages];
+};
+bool chain_radius_supported(int radius, int mode);
+size_t chain_sync_ints(int n_stages, int n_images);
+int chain_sync_error_index();
+void launch_blur_chain(hipStream_t s, const ChainPlan& cp, const unsigned* d_items, int* d_sync, int mode, hipEvent_t ev_start, hipEvent_t ev_stop);
+void tu_touch_chain(hipStream_t s);
 // one empty launch per translation unit: makes the runtime build that unit's device code (see kernels_*.hip, sift_hip_create)
 void tu_touch_pyramid(hipStream_t s);
 void tu_touch_reduce(hipStream_t s);

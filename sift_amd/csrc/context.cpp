@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -103,6 +104,13 @@ struct Plan {
     std::vector<float> taps16;        // taps of convolveWithGauss(level, 1.6f) (sift.cpp:87)
     int radius16 = 0;
     size_t max_level_floats = 0;      // per image, largest level
+    // level chain (kernels_chain.hip): ops [chain_first_op, end) as one launch
+    int chain_state = 0;              // 0 not decided, 1 usable, -1 not
+    size_t chain_first_op = 0;
+    ChainPlan chain{};
+    std::vector<unsigned> chain_items;
+    std::vector<int> chain_levels;    // Gaussian levels the chain produces (w16 launches follow it)
+    double chain_bytes = 0.0;         // algorithmic bytes of its stages
 };
 
 }  // namespace
@@ -132,7 +140,11 @@ struct sift_hip_ctx {
     int host_threads = 0;
     int desc_dbg = 0;
     Plan plan;
-    DevBuf arena, d_plan, d_taps, d_luts, d_taps16, d_input, d_input_u8, d_base, d_tmp, d_tmp2;
+    DevBuf arena, d_plan, d_taps, d_luts, d_taps16, d_input, d_input_u8, d_base, d_tmp, d_tmp2, d_chain_items, d_chain_sync;
+    bool chain_ran = false;          // this batch's pyramid ended with the chain launch
+    int chain_from = 0;              // option "chain_from" = o > 0: octaves >= o of the pyramid run as ONE launch (kernels_chain.hip); 0 (default): a launch per level
+    int chain_mode = 1;              // option "chain_mode": 1 agent-scope accesses, 0 ordinary accesses + fences per tile, 2 as 1 with every image's tiles spread over all XCDs (tests)
+    int chain_spread = 0;            // option "chain_spread": parts an octave's top level is cut into between the next octave's stages (0: one per stage)
     DevBuf d_sparse_rec, d_sparse_val;   // sift_hip_result_copy_sparse: the packed lists on their way to the host
     DevBuf d_masks, d_fmasks, d_counts, d_totals, d_cands, d_flags;
     DevBuf d_wk, d_wi, d_wi2, d_wp, d_status, d_tile, d_pool;
@@ -142,6 +154,7 @@ struct sift_hip_ctx {
     DevBuf d_cell_cnt, d_cell_off;   // descriptor grid: keypoints per 16 px cell, exclusive scan (+ total)
     bool desc_wave = true;           // option "desc_kernel": 1 wave-per-keypoint kernel (default), 0 tile kernel
     bool gate_early_chain = false;   // option "gate_early_chain" (measured alternative, off)
+    int gate_mid = 0;                // option "gate_mid" = o > 0: the previous batch's descriptors start when this pyramid reaches octave o
     int gate_schedule = 1;           // option "gate_schedule" (phase_gate.h; 1 since round 3): applies to the gate this context is joined to
     // option "pyramid_side" (default on): the top Gaussian level of an octave (it only feeds the octave's last DoG) is formed on
     // the side stream, beside the reduction and the first levels of the next octave, which are too small to fill the chip alone
@@ -533,6 +546,111 @@ void early_w16(sift_hip_ctx* c, int level) {
     launch_w16(c->stream2, P.dev, level, c->d_taps16.as<float>(), P.radius16);
 }
 
+// The ops from the first level blur of octave `chain_from` on as one launch (kernels_chain.hip): stages, their dependencies
+// and the eight item queues.  Decided once per plan; anything the kernel has no body for leaves the per-level launches in place.
+void build_chain(sift_hip_ctx* c) {
+    Plan& P = c->plan;
+    const DevPlan& dv = P.dev;
+    const int n = P.n, O = P.O, D = P.D;
+    P.chain_state = -1;
+    if (c->chain_from <= 0 || c->chain_from >= O || !c->fused || !c->fused_reduce || n > 4096 || P.fail_status) return;
+    size_t k0 = P.ops.size();
+    for (size_t k = 0; k < P.ops.size(); ++k)
+        if (P.ops[k].kind == 2 && P.ops[k].octave == c->chain_from && P.ops[k].j == 1) { k0 = k; break; }
+    if (k0 >= P.ops.size() || P.fail_op != (size_t)-1 || P.ops.size() - k0 > (size_t)kChainMaxStages) return;
+    ChainPlan cp{};
+    cp.n_images = n;
+    std::vector<int> stage_of_level((size_t)O * (size_t)(D + 1), -1);
+    std::vector<int> is_leaf;
+    std::vector<int> levels;
+    double bytes = 0.0;
+    for (size_t k = k0; k < P.ops.size(); ++k) {
+        const BlurOp& op = P.ops[k];
+        ChainStage st{};
+        const int o = op.octave;
+        int src_level, dst_level;
+        if (op.kind == 2) {
+            st.mode = 0;
+            dst_level = o * (D + 1) + op.j;
+            src_level = dst_level - 1;
+            st.dog = dv.dog[o * D + op.j - 1];
+            is_leaf.push_back(op.j == D && o + 1 < O ? 1 : 0);
+            bytes += 12.0 * (double)op.w * (double)op.h * (double)n;
+            levels.push_back(dst_level);
+        } else if (op.kind == 3) {
+            if (P.inv_x_off[(size_t)o] == (size_t)-1 || P.inv_y_off[(size_t)o] == (size_t)-1) return;
+            st.mode = 1;
+            src_level = o * (D + 1) + D - 1;
+            dst_level = (o + 1) * (D + 1);
+            st.inv_x = c->d_luts.as<int>() + P.inv_x_off[(size_t)o];
+            st.inv_y = c->d_luts.as<int>() + P.inv_y_off[(size_t)o];
+            st.wd = dv.w[o + 1];
+            st.hd = dv.h[o + 1];
+            is_leaf.push_back(0);
+            bytes += 4.0 * (double)op.w * (double)op.h * (double)n + 4.0 * (double)st.wd * (double)st.hd * (double)n;
+            levels.push_back(dst_level);
+        } else {
+            return;
+        }
+        if (!chain_radius_supported(op.radius, st.mode) || op.w % 4 != 0) return;
+        st.src = dv.gauss[src_level];
+        st.dst = dv.gauss[dst_level];
+        if ((((uintptr_t)st.src | (uintptr_t)st.dst | (uintptr_t)st.dog) & 15u) != 0) return;
+        st.taps = c->d_taps.as<float>() + op.tap_off;
+        st.w = op.w;
+        st.h = op.h;
+        st.radius = op.radius;
+        st.tiles_x = (op.w + 63) / 64;
+        st.tiles_y = (op.h + 47) / 48;
+        if ((long long)st.tiles_x * st.tiles_y > 65536) return;
+        st.dep = stage_of_level[(size_t)src_level];
+        st.dep_tiles = st.dep >= 0 ? cp.st[st.dep].tiles_x * cp.st[st.dep].tiles_y : 0;
+        stage_of_level[(size_t)dst_level] = cp.n_stages;
+        cp.st[cp.n_stages++] = st;
+    }
+    // the queues: images with index mod 8 == q; within a queue every item after the items it waits for (op order is such an
+    // order); the top level of an octave (a leaf: only its own DoG needs it) is held back and dealt out in parts after the
+    // next stages, where it fills what the smaller next octave leaves idle
+    std::vector<unsigned> items;
+    for (int q = 0; q < 8; ++q) {
+        cp.q_off[q] = (int)items.size();
+        std::vector<unsigned> held;
+        size_t part = 0;
+        auto emit = [&](int sidx, std::vector<unsigned>& to) {
+            const int tiles = cp.st[sidx].tiles_x * cp.st[sidx].tiles_y;
+            for (int img = q; img < n; img += 8)
+                for (int t = 0; t < tiles; ++t) to.push_back(((unsigned)sidx << 28) | ((unsigned)img << 16) | (unsigned)t);
+        };
+        for (int sidx = 0; sidx < cp.n_stages; ++sidx) {
+            if (is_leaf[(size_t)sidx]) {
+                emit(sidx, held);
+                const int parts = c->chain_spread > 0 ? c->chain_spread : D;
+                part = (held.size() + (size_t)parts - 1) / (size_t)parts;
+                continue;
+            }
+            emit(sidx, items);
+            if (cp.st[sidx].mode == 0 && !held.empty()) {
+                const size_t take = std::min(part, held.size());
+                items.insert(items.end(), held.begin(), held.begin() + (long)take);
+                held.erase(held.begin(), held.begin() + (long)take);
+            }
+        }
+        items.insert(items.end(), held.begin(), held.end());
+    }
+    cp.q_off[8] = (int)items.size();
+    if (items.empty()) return;
+    c->d_chain_items.ensure(items.size() * sizeof(unsigned));
+    c->d_chain_sync.ensure(chain_sync_ints(cp.n_stages, n) * sizeof(int));
+    SIFT_HIP_CHECK(hipMemcpyAsync(c->d_chain_items.p, items.data(), items.size() * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+    SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));   // `items` is pageable host memory
+    P.chain = cp;
+    P.chain_items.swap(items);
+    P.chain_levels.swap(levels);
+    P.chain_bytes = bytes;
+    P.chain_first_op = k0;
+    P.chain_state = 1;
+}
+
 // ---- pyramid (Sift::_createDOGs, sift.cpp:381-417) ---------------------------------------------
 void run_pyramid(sift_hip_ctx* c, const float* d_in) {
     Plan& P = c->plan;
@@ -548,8 +666,21 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
             (void)hipStreamWaitEvent(c->stream, c->ev_side_join, 0);
         }
     } side_join{c, &side_used};
+    if (P.chain_state == 0) build_chain(c);
+    c->chain_ran = false;
+    if (P.chain_state == 1)   // tickets and completion counters of the chain launch: cleared long before it runs
+        launch_zero_ints(c->stream, c->d_chain_sync.as<int>(), chain_sync_ints(P.chain.n_stages, n));
     for (size_t k = 0; k < P.ops.size(); ++k) {
         if (k >= P.fail_op) break;
+        if (P.chain_state == 1 && k == P.chain_first_op) {   // the rest of the pyramid in one launch
+            hipEvent_t a = nullptr, b = nullptr;
+            if (c->profile) { a = get_event(c); b = get_event(c); }
+            launch_blur_chain(c->stream, P.chain, c->d_chain_items.as<unsigned>(), c->d_chain_sync.as<int>(), c->chain_mode, a, b);
+            if (c->profile) c->pending.push_back({a, b, 0, P.chain_bytes});
+            c->chain_ran = true;
+            for (int l : P.chain_levels) early_w16(c, l);
+            break;
+        }
         const BlurOp& op = P.ops[k];
         switch (op.kind) {
             case 0: {  // increaseToNextLevel(img, 1.0): blur then 2x nearest upsample
@@ -583,6 +714,7 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
             }
             case 3: {  // reduceToNextLevel(g(o, D-1), g(o, D-1).scale)
                 const int o = op.octave;
+                if (c->gate && c->gate_mid > 0 && o + 1 == c->gate_mid) c->gate->mark(c->gate_ticket, sift_hip::PhaseGate::kM, c->stream);
                 const float* src = dv.gauss[o * (D + 1) + D - 1];
                 float* dst = dv.gauss[(o + 1) * (D + 1)];
                 bool done = false;
@@ -875,9 +1007,12 @@ bool mid_gpu(sift_hip_ctx* c) {
     SIFT_HIP_CHECK(hipGetLastError());
     if (c->gate) c->gate->mark(c->gate_ticket, sift_hip::PhaseGate::kD, s);
     c->described = true;
-    c->h_status.ensure((size_t)n * 5 * sizeof(int));
+    c->h_status.ensure(((size_t)n * 5 + 1) * sizeof(int));
     const int* st = c->h_status.as<int>();   // pinned: the copy is a real asynchronous DMA
     SIFT_HIP_CHECK(hipMemcpyAsync(c->h_status.p, c->d_status.p, (size_t)n * 5 * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (c->chain_ran)   // the chain launch's "gave up waiting" flag
+        SIFT_HIP_CHECK(hipMemcpyAsync(c->h_status.as<int>() + (size_t)n * 5, c->d_chain_sync.as<int>() + chain_sync_error_index(), sizeof(int),
+                                      hipMemcpyDeviceToHost, s));
     resolve_events(c);   // the pyramid's timing events completed long ago: read them while the GPU is still busy
     wait_stream(c, s);
     if (c->diag_cleanup_stamps) {   // diagnostics: phases of the second cleanup (image 0)
@@ -895,6 +1030,7 @@ bool mid_gpu(sift_hip_ctx* c) {
             std::fprintf(stderr, "\n");
         }
     }
+    if (c->chain_ran && st[(size_t)n * 5] != 0) throw std::runtime_error("sift_hip: the pyramid's level chain gave up waiting for a level (kernels_chain.hip)");
     for (int i = 0; i < n; ++i)
         if (st[(size_t)i * 4 + 1] || st[(size_t)n * 4 + (size_t)i]) {
             c->binned = false;   // the host path rebuilds the lists
@@ -1125,7 +1261,10 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     c->gate_ticket = c->gate ? c->gate->begin_batch(s) : -1;
     run_pyramid(c, d_in);
     SIFT_HIP_CHECK(hipGetLastError());   // a rejected launch configuration must not go unnoticed
-    if (c->gate) c->gate->mark(c->gate_ticket, sift_hip::PhaseGate::kP, s);
+    if (c->gate) {
+        c->gate->mark(c->gate_ticket, sift_hip::PhaseGate::kM, s);   // no-op when the pyramid marked it on the way
+        c->gate->mark(c->gate_ticket, sift_hip::PhaseGate::kP, s);
+    }
     c->have_pyramid = true;
     if (P.fail_status) {
         SIFT_HIP_CHECK(hipStreamSynchronize(s));
@@ -1288,7 +1427,7 @@ int sift_hip_create(int device, sift_hip_ctx** out, char* err, int errlen) {
             static bool touched[64] = {false};
             std::lock_guard<std::mutex> lk(touch_lock);
             if (device < 64 && !touched[device]) {
-                tu_touch_pyramid(c->stream); tu_touch_reduce(c->stream); tu_touch_extrema(c->stream); tu_touch_orient(c->stream);
+                tu_touch_pyramid(c->stream); tu_touch_reduce(c->stream); tu_touch_chain(c->stream); tu_touch_extrema(c->stream); tu_touch_orient(c->stream);
                 tu_touch_desc(c->stream); tu_touch_cleanup(c->stream); tu_touch_wire(c->stream); tu_touch_io(c->stream);
                 SIFT_HIP_CHECK(hipGetLastError());
                 SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -1382,7 +1521,7 @@ int sift_hip_set_gate(sift_hip_ctx* c, sift_hip_gate* g) {
     }
     c->gate_owner = g;
     c->gate = g ? &g->gate : nullptr;
-    if (c->gate) c->gate->set_schedule(c->gate_schedule);
+    if (c->gate) { c->gate->set_schedule(c->gate_schedule); c->gate->set_mid(c->gate_mid > 0); }
     return SIFT_HIP_OK;
 }
 
@@ -1408,6 +1547,14 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
                 return SIFT_HIP_EHIP;
         }
         c->pyramid_side = value != 0;
+        return SIFT_HIP_OK;
+    }
+    if (!std::strcmp(name, "chain_from")) { c->chain_from = value; c->plan.chain_state = 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "chain_mode")) { c->chain_mode = value; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "chain_spread")) { c->chain_spread = value; c->plan.chain_state = 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "gate_mid")) {
+        c->gate_mid = value;
+        if (c->gate) c->gate->set_mid(value > 0);
         return SIFT_HIP_OK;
     }
     if (!std::strcmp(name, "gate_schedule")) {

@@ -16,6 +16,7 @@
 #include <hip/hip_ext.h>
 
 #include "common.h"
+#include "lds_tile.h"
 
 #pragma clang fp contract(off)
 
@@ -46,42 +47,7 @@ __device__ __forceinline__ int reflect_clamp(int p, int n) {
 // Tiles that touch the image border, or images whose rows are not 16-byte aligned, take a scalar
 // load / store path with per-element reflection.
 // ---------------------------------------------------------------------------------------------
-constexpr int gcd_ce(int a, int b) { return b == 0 ? a : gcd_ce(b, a % b); }
-
-// 16-byte LDS reads that the optimiser cannot split into narrower (slower, conflicting) reads of just
-// the elements it can prove are used.  Reads and their s_waitcnt live in ONE asm statement, so no
-// output register can be touched before the data has landed.
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
-}
-__device__ __forceinline__ void lds_read_b128x4(const float4* p, float4& a, float4& b, float4& c, float4& d) {
-    asm volatile(
-        "ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
-        "ds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
-        : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
-        : "v"(lds_addr(p))
-        : "memory");
-}
-__device__ __forceinline__ void lds_read_b128x2(const float4* p, float4& a, float4& b) {
-    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(a), "=&v"(b)
-                 : "v"(lds_addr(p))
-                 : "memory");
-}
-__device__ __forceinline__ void lds_read_b128x1(const float4* p, float4& a) {
-    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(a) : "v"(lds_addr(p)) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void lds_read_window(const float4* p, float4 (&f)[N]) {
-    constexpr int N4 = N / 4 * 4;
-#pragma unroll
-    for (int c = 0; c < N4; c += 4) lds_read_b128x4(p + c, f[c], f[c + 1], f[c + 2], f[c + 3]);
-    if constexpr (N - N4 >= 2) lds_read_b128x2(p + N4, f[N4], f[N4 + 1]);
-    if constexpr ((N - N4) & 1) lds_read_b128x1(p + N - 1, f[N - 1]);
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// gcd_ce, lds_read_window<N>, lds_barrier: lds_tile.h
 
 template <int R, bool DOG, int TH = 64>
 __global__ __launch_bounds__(256, (R <= 8 ? 3 : ((R <= 24 || (TH <= 48 && R <= 28)) ? 2 : 1))) void blur_fused_kernel(const float* __restrict__ in,

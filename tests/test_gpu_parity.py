@@ -321,6 +321,76 @@ def test_pipeline_parity_kept_pixels_reduce(ctx, report_dir, case):
         ctx.set_option("stream_min_waves", 0)
 
 
+CHAIN_VARIANTS = [
+    # chain_from, chain_mode, blur launches per batch with 4 octaves x 3 DoGs (16 without the chain)
+    (2, 1, 10),   # octaves 2 - 3 as one launch, agent-scope accesses
+    (2, 2, 10),   # the same with every image's tiles spread over all XCDs (any workgroup reads any workgroup's level)
+    (2, 0, 10),   # ordinary accesses, agent-scope release / acquire fences around every tile
+    (1, 1, 6),    # octaves 1 - 3
+    (3, 1, 14),   # octave 3 only
+]
+
+
+def test_level_chain_on_alternating_batches(ctx):
+    """The rest of the pyramid from an octave on as ONE launch of (stage, image, tile) items that wait for their source level per
+    image (kernels_chain.hip; Sift::_createDOGs, sift.cpp:388-411).  Two batches of 11 DIFFERENT frames alternate on one context -
+    a level read stale would be the other batch's, a wait that lets a tile start early would read a half-written level - in every
+    variant of the kernel: all results against the per-level launches (which the other tests pin to the oracle), and for three
+    frames of each batch every Gaussian and DoG level of every octave against the oracle itself."""
+    dogs, octaves, n = 3, 4, 11
+    params = _lib.Params(dogs, octaves, 1.6, O.K_SQRT2, 0)
+    batches = [np.stack([synth_frame(640, 480, 100 * (b + 1) + s) for s in range(n)]) for b in range(2)]
+    probe = (0, 5, 10)
+    runs = [{i: O.OracleRun(batches[b][i], dogs, octaves) for i in probe} for b in range(2)]
+
+    def run(b):
+        ctx.profile_reset()
+        ctx.calculate_batch(batches[b], params)
+        kp, desc = ctx.results()
+        return ctx.counts().copy(), kp.copy(), desc.copy(), ctx.profile(0)[1]
+
+    try:
+        ctx.set_option("profile", 1)
+        ctx.set_option("chain_from", 0)
+        ref = [run(b) for b in range(2)]
+        assert ref[0][3] == 16 and ref[0][0].tolist() != ref[1][0].tolist()
+        for chain_from, mode, launches in CHAIN_VARIANTS:
+            ctx.set_option("chain_from", chain_from)
+            ctx.set_option("chain_mode", mode)
+            for rep in range(4):
+                b = rep % 2
+                counts, kp, desc, got_launches = run(b)
+                what = f"chain_from {chain_from} chain_mode {mode} pass {rep}"
+                assert got_launches == launches, f"{what}: {got_launches} blur launches - the chain did not run"
+                assert counts.tolist() == ref[b][0].tolist(), f"{what}: counts"
+                assert kp.tobytes() == ref[b][1].tobytes() and desc.tobytes() == ref[b][2].tobytes(), f"{what}: results"
+                if rep < 2:
+                    for i in probe:
+                        for o in range(octaves):
+                            for j in range(dogs + 1):
+                                assert_bits_equal(ctx.level("gaussian", o, j, i), runs[b][i].level("gaussian", o, j), f"{what}: frame {i} gaussian({o},{j})")
+                            for j in range(dogs):
+                                assert_bits_equal(ctx.level("dog", o, j, i), runs[b][i].level("dog", o, j), f"{what}: frame {i} dog({o},{j})")
+    finally:
+        ctx.set_option("profile", 0)
+        ctx.set_option("chain_from", 0)
+        ctx.set_option("chain_mode", 1)
+
+
+def test_level_chain_falls_back(ctx, report_dir):
+    """What the chain kernel has no body for keeps the launch per level: a width that is no multiple of 4 in the octave the chain
+    would start at (1000 -> 500 -> 250)."""
+    ctx.set_option("profile", 1)
+    ctx.set_option("chain_from", 2)
+    try:
+        ctx.profile_reset()
+        compare_run(ctx, synth_frame(1000, 600, 77), 3, 3, False, "chain fallback 1000x600", report_dir, batch_of=2)
+        assert ctx.profile(0)[1] == 12, "one blur launch per level and reduction expected"
+    finally:
+        ctx.set_option("profile", 0)
+        ctx.set_option("chain_from", 0)
+
+
 SX_CASES = [
     ("streaming extrema 640x480 4x3 x2", 640, 480, 41, 3, 4, 2),
     ("streaming extrema 1000x600 (strips of 248 columns: 5th strip 8 columns wide)", 1000, 600, 42, 3, 3, 1),
