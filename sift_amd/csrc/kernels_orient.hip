@@ -169,7 +169,6 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
         const uint8_t* obin;
     };
     __shared__ LevelInfo s_lvl[kMaxLevels];
-    __shared__ int s_grp;
     static_assert(sizeof(float) * 4 * kOrientSub * kOrientStride >= sizeof(float) * 36 * kOrientGroup, "s_set overlay");
     float (*s_set)[kOrientGroup] = reinterpret_cast<float (*)[kOrientGroup]>(s_stage);
 
@@ -194,12 +193,11 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
         li.obin = plan->obin[lvl];
         s_lvl[l] = li;
     }
-    // the survivor count lives on the device: workgroups draw groups of keypoints from a per-image counter
-    while (true) {
+    // The survivor count lives on the device; the groups of an image are dealt round-robin to its workgroups.  (Until round 3
+    // they were drawn from a per-image counter: ~10 k atomics of 4096 workgroups on the ONE cache line that holds the 32
+    // counters - 300 -> 284 us without them, tools/chain_trace.sh with FILTER=orient.)
+    for (int grp = (int)blockIdx.x;; grp += (int)gridDim.x) {
         __syncthreads();
-        if (tid == 0) s_grp = atomicAdd(&next_group[img], 1);
-        __syncthreads();
-        const int grp = s_grp;
         if (grp * kOrientGroup >= cnt) break;
         // ---- phase 1 --------------------------------------------------------------------------
         // Bookkeeping of the wave's 32 keypoints with one keypoint per lane (records fetched coalesced, level looked up,
@@ -461,7 +459,7 @@ void launch_orientation(hipStream_t s, const DevPlan* d_plan, const DevPlan& pla
     const dim3 grid(128, (unsigned)plan.n_images);
     const int dbg = g_orient_dbg;   // option "orient_dbg": timing ablations only
     // zero_counters: how many consecutive per-image counter arrays to clear first (0: the caller already did)
-    if (zero_counters > 0) launch_zero_ints(s, d_next_group, (size_t)plan.n_images * (size_t)zero_counters);
+    (void)zero_counters;   // the groups are dealt statically: no counters to clear
     hipLaunchKernelGGL(orientation_kernel, grid, dim3(256), 0, s, d_plan, d_oin, d_list_cnt, list_cap, d_out,
                        d_peaks, d_next_group, d_any_bin, dbg);
 }

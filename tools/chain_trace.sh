@@ -1,5 +1,6 @@
 #!/bin/bash
-# kernel trace of one context running the bench batch with the level chain from octave $1 (default 2), mode $2 (default 1)
+# kernel trace of one context running the bench batch with the level chain from octave $1 (default 2), mode $2 (default 1);
+# FILTER=<regex> picks the kernels printed (default: the blur family), SIFT_SET="name=value,..." sets library options
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf /tmp/chain_prof
@@ -13,6 +14,7 @@ rows.sort(key=lambda t: t[1])
 idx = [i for i, r in enumerate(rows) if 'blur_stream_kernel<5, false' in r[0]]
 t0 = rows[idx[-1]][1]
 for name, a, b in rows[idx[-1]:]:
-    if 'blur' in name or 'w16' in name:
+    import os, re
+    if re.search(os.environ.get('FILTER', 'blur|w16'), name):
         print(f"{name:62s} {(a - t0) / 1e3:9.1f} {(b - t0) / 1e3:9.1f} {(b - a) / 1e3:8.1f}")
 PY

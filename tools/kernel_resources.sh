@@ -15,6 +15,6 @@ for line in sys.stdin:
     if m and cur: cur[1][m.group(1)] = m.group(2)
 names = subprocess.run(['c++filt'], input='\n'.join(r[0] for r in rows), capture_output=True, text=True).stdout.split('\n')
 for (mangled, vals), name in zip(rows, names):
-    short = re.sub(r'\(.*', '', name).replace('sift_hip::', '').replace('void ', '')
+    short = re.sub(r'\(.*', '', name.replace('(anonymous namespace)::', '')).replace('sift_hip::', '').replace('void ', '')
     print(short, ' '.join(f'{k}: {v}' for k, v in vals.items()))
 "
