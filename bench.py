@@ -202,6 +202,8 @@ def main():
                     help="config4 (default) is the headline workload; config3 / config5 are BASELINE.json's other GPU "
                          "configurations at their nearest non-throwing parameters (SURVEY 8(d)), reported as labelled extra lines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-loop", choices=("stream", "dispatch"), default="stream",
+                    help="N = 1: 'stream' - each context's host thread takes its next step itself; 'dispatch' - one thread submits and collects (rounds 1 - 3)")
     ap.add_argument("--no-extras", action="store_true", help="skip the legs beside the headline: host-buffer rate, single-frame latency, live PMC traffic")
     ap.add_argument("--pmc-traffic", type=int, default=1, choices=[0, 1],
                     help="1 (default): roofline.traffic is measured live by two child passes of this bench under rocprofv3 --pmc "
@@ -345,9 +347,27 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     kps = 0
-    for _ in range(args.steps):
-        kps += step()
-    kps += drain()
+    if gatherer is None and args.host_loop == "stream" and depth > 1:
+        # every context's host thread takes its next step itself (BatchPipeline.run_stream): no dispatching thread between the end
+        # of a context's batch and the start of its next
+        left, per_slot = [args.steps], [0] * depth
+        item = (d_frames.data_ptr(), nf, W, H, params)
+
+        def source():
+            if left[0] <= 0:
+                return None
+            left[0] -= 1
+            return item
+
+        def sink(c, slot, _item):
+            per_slot[slot] += c.total()
+
+        pipe.run_stream(source, sink)
+        kps = sum(per_slot)
+    else:
+        for _ in range(args.steps):
+            kps += step()
+        kps += drain()
     if gatherer is not None:
         note(gatherer.flush())
     torch.cuda.synchronize()
@@ -389,7 +409,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": label.format(n=nf),
-                       "frames_per_gpu": nf, "frames_total": nf * world, "pipeline_depth": depth, "pipeline_gate": bool(args.pipeline_gate) and depth > 1, "keypoints_per_step": kps // max(args.steps, 1),
+                       "frames_per_gpu": nf, "frames_total": nf * world, "pipeline_depth": depth, "host_loop": (args.host_loop if (world == 1 and not loopback and depth > 1) else "dispatch"), "pipeline_gate": bool(args.pipeline_gate) and depth > 1, "keypoints_per_step": kps // max(args.steps, 1),
                        "frames_per_s": nf * world * args.steps / dt,
                        "rccl_ranks": rccl_ranks,   # as the RCCL communicator reports it (0: no RCCL communicator in this run)
                        "rccl_loopback": loopback,   # N = 1 with the N > 1 gather messages sent through RCCL to this same rank
@@ -438,7 +458,10 @@ def main():
             hpipe = BatchPipeline(local_rank, hdepth, options, gated=bool(args.pipeline_gate))
 
             def host_loop(src, fetch, n_steps):
-                """n_steps batches from host memory `src`, `hdepth` in flight; `fetch(context, slot)` brings the oldest batch's lists to the host"""
+                """n_steps batches from host memory `src`, `hdepth` in flight; `fetch(context, slot)` brings the oldest batch's lists to the host.
+                (One dispatching thread: this loop is bound by the link and the copies' interference with the kernels, and letting every
+                context's thread feed itself - BatchPipeline.run_stream, the headline loop - made no difference here: 8.0 against 7.4 - 7.6 ms
+                on the box of that comparison.)"""
                 pend, total = [], 0
                 t_0 = time.perf_counter()
                 for i in range(n_steps + hdepth):

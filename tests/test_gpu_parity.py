@@ -1318,6 +1318,51 @@ def test_batch_pipeline_survives_a_failing_batch(ctx, gated):
     assert isinstance(out[1], PreconditionViolation) and not isinstance(out[0], Exception) and not isinstance(out[5], Exception)
 
 
+def test_batch_pipeline_run_stream(ctx):
+    """BatchPipeline.run_stream: every context's host thread takes its next batch from the source itself and hands its results
+    to the sink before the next one (no dispatching thread in between).  Nine different batches through two gated contexts: each
+    batch's results are those of the single context; a source that raises, or a batch that ends in the reference's exception,
+    ends the stream with that exception after the batches in flight are done."""
+    from sift_amd.pipeline import BatchPipeline
+    prm = _lib.Params(3, 3, 1.6, O.K_SQRT2, 0)
+    batches = [np.stack([synth_frame(320, 240, 300 + 3 * b + i) for i in range(3)]) for b in range(9)]
+    got = {}
+    with BatchPipeline(0, depth=2) as pipe:
+        it = iter(range(len(batches)))
+
+        order = []
+
+        def source_tagged():
+            b = next(it, None)
+            if b is None:
+                return None
+            order.append(b)
+            return (batches[b], prm)
+
+        def sink(c, slot, item):
+            b = next(i for i, a in enumerate(batches) if a is item[0])
+            got[b] = (slot, c.counts().copy()) + tuple(a.copy() for a in c.results())
+
+        pipe.run_stream(source_tagged, sink)
+        assert order == list(range(9)) and sorted(got) == list(range(9))
+        assert {got[b][0] for b in got} == {0, 1}, "both contexts should have taken batches"
+        # a failing batch ends the stream with the reference's exception
+        bad = _lib.Params(3, 4, 1.6, O.K_SQRT2, 0)   # 160x120, 4 octaves: a pyramid level shorter than the blur kernel's radius (App. B-13)
+        small = np.stack([synth_frame(160, 120, 400 + i) for i in range(2)])
+        jobs = iter([(batches[0], prm), (small, bad), (batches[2], prm), (batches[3], prm)])
+        with pytest.raises(PreconditionViolation):
+            pipe.run_stream(lambda: next(jobs, None), None)
+        # ... and the pipeline is usable afterwards
+        t = pipe.submit(batches[4], prm)
+        assert t.result().counts().tolist() == got[4][1].tolist()
+        t.release()
+    for b in range(9):
+        ctx.calculate_batch(batches[b], prm)
+        assert got[b][1].tolist() == ctx.counts().tolist()
+        kp, desc = ctx.results()
+        assert got[b][2].tobytes() == kp.tobytes() and got[b][3].tobytes() == desc.tobytes()
+
+
 def test_sparse_wire_kernels_match_the_reference_packing(ctx):
     """sift_hip_result_sparse_size / _pack (kernels_wire.hip) against the torch restatement of the wire format
     (sift_amd/gather.py:pack_sparse) on real results, and the round trip back to the 128-float descriptors."""
