@@ -12,7 +12,9 @@ kernels of step k+1, all inside the timed region.  Two steps are in flight per G
 contexts joined by a phase gate, sift_amd/csrc/phase_gate.h): step k's cleanup chain, which cannot fill the chip, runs
 under step k+1's pyramid and its descriptors under step k+1's extrema / gradient pass.  `roofline.frac` is measured on
 the blur launches of the timed region, i.e. beside that chain; `roofline.frac_alone` is the same measurement on a few
-steps run one at a time after the timed region (the blur launches alone on the chip).  Every step is complete inside the
+steps run one at a time after the timed region (the blur launches alone on the chip).  At N = 1 each of the two contexts'
+host threads takes its next step itself (--host-loop stream, BatchPipeline.run_stream; `dispatch` is the single submitting
+thread of rounds 1 - 3, which N > 1 still uses because the gather is pushed from that thread).  Every step is complete inside the
 timed region.  Weak scaling: per-GPU work is fixed.  Rank 0 prints ONE JSON line.
 """
 import argparse
