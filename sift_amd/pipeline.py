@@ -102,23 +102,23 @@ class BatchPipeline:
 
         def loop(slot):
             ctx = self.contexts[slot]
-            while True:
-                with lock:
-                    item = None if ended[0] else source()
-                    if item is None:
-                        ended[0] = True
-                        return
-                try:
+            try:
+                while True:
+                    with lock:
+                        item = None if ended[0] else source()
+                        if item is None:
+                            ended[0] = True
+                            return
                     if len(item) == 2:
                         ctx.calculate_batch(*item)
                     else:
                         ctx.calculate_batch_device(*item)
                     if sink is not None:
                         sink(ctx, slot, item)
-                except BaseException:
-                    with lock:          # the other threads finish the batch they are on and take no further one
-                        ended[0] = True
-                    raise
+            except BaseException:
+                with lock:          # the other threads finish the batch they are on and take no further one
+                    ended[0] = True
+                raise
 
         futures = [w.submit(loop, i) for i, w in enumerate(self._workers)]
         first = None
