@@ -204,6 +204,7 @@ def main():
                     help="config4 (default) is the headline workload; config3 / config5 are BASELINE.json's other GPU "
                          "configurations at their nearest non-throwing parameters (SURVEY 8(d)), reported as labelled extra lines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-every", type=int, default=PROFILE_EVERY, help="every N-th batch of a context carries the per-launch timing events of the roofline figure")
     ap.add_argument("--host-loop", choices=("stream", "dispatch"), default="stream",
                     help="N = 1: 'stream' - each context's host thread takes its next step itself; 'dispatch' - one thread submits and collects (rounds 1 - 3)")
     ap.add_argument("--no-extras", action="store_true", help="skip the legs beside the headline: host-buffer rate, single-frame latency, live PMC traffic")
@@ -342,7 +343,7 @@ def main():
         gatherer = KeypointGather(nf, comm_dev, dst=0, loopback=loopback)
         gatherer_t0 = (gathered[0], gathered[1])
     for c in ctxs:
-        c.set_option("profile", PROFILE_EVERY)   # every 4th batch of a context carries the per-launch timing events
+        c.set_option("profile", args.profile_every)   # every N-th batch of a context carries the per-launch timing events
         c.profile_reset()
     torch.cuda.synchronize()
     if world > 1:
@@ -426,7 +427,7 @@ def main():
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                          "timing": "hipEventElapsedTime over start/stop events attached to each blur dispatch (hipExtLaunchKernelGGL) on the library's streams, inside the timed region; "
-                                   f"every {PROFILE_EVERY}th batch of a context is instrumented (the events keep consecutive launches ~10 us apart); "
+                                   f"every {args.profile_every}th batch of a context is instrumented (the events keep consecutive launches ~10 us apart); "
                                    "achieved = algorithmic bytes of all blur launches / the time during which at least one of them was running (union of the "
                                    "launches' intervals: an octave's top level overlaps the next octave's first launches on a second stream); in the timed region "
                                    "the previous step's cleanup chain runs beside the pyramid (see frac_alone for the launches alone on the chip)",
