@@ -91,7 +91,8 @@ void sift_hip_destroy(sift_hip_ctx* ctx);
  * ONE launch of per-image work items, sift_amd/csrc/kernels_chain.hip; "chain_mode" 1 / 0 / 2: agent-scope accesses, ordinary accesses +
  * fences, tiles of an image spread over all XCDs), "gate_mid" (0 default; o > 0: a gated batch's descriptors start when the next batch's
  * pyramid reaches octave o instead of when it ends), "fused_grid", "stream_min_waves", "io_kernels",
- * "stage_kernels" (measured alternatives), "diag_pyramid_span", "diag_serial_gradient", "diag_cleanup_stamps" (print to stderr).  The library reads no
+ * "stage_kernels" (measured alternatives), "diag_pyramid_span", "diag_serial_gradient", "diag_cleanup_stamps" (print to stderr), "diag_repeat" (k > 1: sift_hip_calculate_batch_device runs
+ * its batch k times before it returns; timing only).  The library reads no
  * environment variable. */
 int sift_hip_set_option(sift_hip_ctx* ctx, const char* name, int value);
 

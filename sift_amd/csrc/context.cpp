@@ -154,6 +154,7 @@ struct sift_hip_ctx {
     DevBuf d_cell_cnt, d_cell_off;   // descriptor grid: keypoints per 16 px cell, exclusive scan (+ total)
     bool desc_wave = true;           // option "desc_kernel": 1 wave-per-keypoint kernel (default), 0 tile kernel
     bool gate_early_chain = false;   // option "gate_early_chain" (measured alternative, off)
+    int diag_repeat = 1;             // option "diag_repeat" (diagnostics, sift_hip_calculate_batch_device only)
     int gate_mid = 0;                // option "gate_mid" = o > 0: the previous batch's descriptors start when this pyramid reaches octave o
     int gate_schedule = 1;           // option "gate_schedule" (phase_gate.h; 1 since round 3): applies to the gate this context is joined to
     // option "pyramid_side" (default on): the top Gaussian level of an octave (it only feeds the octave's last DoG) is formed on
@@ -1550,6 +1551,7 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
         return SIFT_HIP_OK;
     }
     if (!std::strcmp(name, "chain_from")) { c->chain_from = value; c->plan.chain_state = 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "diag_repeat")) { c->diag_repeat = value > 1 ? value : 1; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "chain_mode")) { c->chain_mode = value; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "chain_spread")) { c->chain_spread = value; c->plan.chain_state = 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "gate_mid")) {
@@ -1587,6 +1589,12 @@ int sift_hip_calculate_batch_device(sift_hip_ctx* c, const void* dev_imgs, int n
         std::string msg;
         const int rc = build_plan(c, n, w, h, *params, msg);
         if (rc) { set_err(err, errlen, msg); return rc; }
+        // diagnostics (option "diag_repeat" = k > 1): the batch k times over without returning to the caller in between - what a
+        // host with no turnaround between a context's batches would see
+        for (int r = 1; r < c->diag_repeat; ++r) {
+            const int rr = run_batch(c, static_cast<const float*>(dev_imgs), err, errlen);
+            if (rr) return rr;
+        }
         return run_batch(c, static_cast<const float*>(dev_imgs), err, errlen);
     });
 }
