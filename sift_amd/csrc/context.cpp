@@ -1263,7 +1263,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     run_pyramid(c, d_in);
     SIFT_HIP_CHECK(hipGetLastError());   // a rejected launch configuration must not go unnoticed
     if (c->gate) {
-        c->gate->mark(c->gate_ticket, sift_hip::PhaseGate::kM, s);   // no-op when the pyramid marked it on the way
+        if (c->gate_mid > 0) c->gate->mark(c->gate_ticket, sift_hip::PhaseGate::kM, s);   // no-op when the pyramid marked it on the way (unused and left to finish() otherwise)
         c->gate->mark(c->gate_ticket, sift_hip::PhaseGate::kP, s);
     }
     c->have_pyramid = true;
