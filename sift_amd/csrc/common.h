@@ -57,7 +57,6 @@ constexpr int kMaxDogs = 16;                       // dogsPerEpoch upper bound o
 constexpr int kMaxLevels = kMaxOctaves * (kMaxDogs + 1);
 constexpr int kMaxRadiusFused = 32;                // blur radii with a fused LDS-tiled kernel
 constexpr int kRegion = 8;                         // sift.cpp:61,164 `region`
-constexpr int kDescCore = 48;                      // descriptor tile core (kernels_desc.hip)
 
 // Extrema candidate as the scan emits it (order: octave, dog, x outer, y inner; sift.cpp:352-373)
 struct Candidate {
@@ -92,10 +91,7 @@ struct DevPlan {
     int scan_word_base[kMaxLevels];  // first mask word of the level inside one image
     int words_per_image;
     long long cand_capacity;         // per image
-    // descriptor tiles (64x64 core) of the levels some keypoint scale selects, per image
-    int desc_tile_base[kMaxLevels], desc_ntx[kMaxLevels], desc_nty[kMaxLevels];
-    int desc_tiles_per_image;
-    // grid of 16 px cells over the same levels (wave-per-keypoint descriptor kernel): cells across / down, first cell of the level
+    // grid of 16 px cells over the levels some keypoint scale selects (descriptor kernels): cells across / down, first cell of the level
     int desc_cell_base[kMaxLevels], desc_cw[kMaxLevels], desc_ch[kMaxLevels];
     int desc_cells_per_image;
 };
@@ -226,9 +222,7 @@ void launch_cleanup1(hipStream_t s, int n_images, const uint8_t* d_flags, const 
 void launch_orient_prepare(hipStream_t s, int n_images, const uint8_t* d_flags, const int* d_totals, long long cand_cap,
                            int* d_chunk_cnt, const Candidate* d_cands, int list_cap, OrientIn* d_oin, int* d_early_cnt);
 size_t orient_prepare_chunks(long long cand_cap);
-bool cleanup2_can_bin(int tiles_per_image);
-void launch_cleanup2(hipStream_t s, int n_images, const DevPlan* d_plan, int bin_tiles, int* d_tile_cnt, int* d_tile_off,
-                     FinalKp* d_pool, int pool_cap, const Candidate* d_cands, long long cand_cap,
+void launch_cleanup2(hipStream_t s, int n_images, const Candidate* d_cands, long long cand_cap,
                      const uint32_t* d_list, const int* d_list_cnt, int list_cap, const OrientOut* d_orient,
                      const uint32_t* d_lrank, uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, FinalKp* d_final,
                      int* d_final_cnt, int* d_status, FinalKp* d_recs);
@@ -237,23 +231,18 @@ void launch_cleanup_kat(hipStream_t s, const uint8_t* d_flags, int n, uint8_t* w
                         uint32_t* wp, uint32_t* d_out, int* d_info, int force_global, OrientIn* d_ord,
                         uint32_t* d_lrank, const Candidate* d_cd);
 void launch_w16(hipStream_t s, const DevPlan& plan, int level, const float* d_taps16, int radius16);
-// bins the final keypoints into per-tile lists (counts -> offsets -> fill), then one workgroup per tile
-void launch_desc_binning(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const FinalKp* d_final,
-                         const int* d_final_cnt, int final_cap, int* d_tile_cnt, int* d_tile_off,
-                         int* d_tile_cur, FinalKp* d_pool, int pool_cap);
 void launch_out_base(hipStream_t s, const int* d_final_cnt, int n, long long* d_out_base);
-void launch_descriptors(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level,
-                        const FinalKp* d_final, const int* d_final_cnt, int final_cap,
-                        const int* d_tile_cnt, const int* d_tile_off, const FinalKp* d_pool, int pool_cap,
-                        const long long* d_out_base, sift_hip_keypoint* d_kp_out, float* d_desc_out, long long out_cap,
-                        int dbg = 0);
-
 void launch_desc_grid(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const FinalKp* d_final, const int* d_final_cnt,
                       int final_cap, int* d_cell_cnt, int* d_cell_off, FinalKp* d_pool, int pool_cap, const long long* d_out_base,
                       sift_hip_keypoint* d_kp_out, float* d_desc_out, long long out_cap);
 void launch_descriptors_wave(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level, const int* d_cell_off,
                              const FinalKp* d_pool, int pool_cap, const long long* d_out_base, sift_hip_keypoint* d_kp_out,
                              float* d_desc_out, long long out_cap, int dbg = 0, int* d_wire_sums = nullptr);
+
+void launch_descriptors_tile(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level, const int* d_cell_off,
+                             const FinalKp* d_pool, int pool_cap, const long long* d_out_base, sift_hip_keypoint* d_kp_out,
+                             float* d_desc_out, long long out_cap, int* d_wire_sums, int* d_sched);
+size_t desc_tile_sched_ints(int n_images);
 
 // wire format of the keypoint gather (kernels_wire.hip)
 size_t wire_blocks(long long total);

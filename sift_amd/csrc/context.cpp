@@ -22,7 +22,7 @@ using namespace sift_hip;
 
 namespace {
 
-constexpr int kPoolCap = 4 * 65536;  // a 16x16 window touches at most 2x2 descriptor tiles
+constexpr int kPoolCap = 65536;  // records of the descriptor stage's cell grid: every keypoint once (u16_t size, sift.cpp:53)
 constexpr int kListCap = 65536;  // cleanup keeps at most 65535 points (u16_t size, sift.cpp:41)
 
 struct DevBuf {
@@ -134,7 +134,6 @@ struct sift_hip_ctx {
     bool profile = false;     // this batch's blur launches carry timing events
     int profile_every = 0;    // option "profile": 0 off, N > 0: every N-th batch is timed (the events cost ~10 us per launch)
     long long profile_batches = 0;
-    bool binned = false;   // this batch's keypoints are already binned to descriptor tiles
     bool described = false;   // ... and their descriptors are already computed
     long long out_cap = 0;    // keypoints d_kp / d_desc hold
     int host_threads = 0;
@@ -147,12 +146,13 @@ struct sift_hip_ctx {
     int chain_spread = 0;            // option "chain_spread": parts an octave's top level is cut into between the next octave's stages (0: one per stage)
     DevBuf d_sparse_rec, d_sparse_val;   // sift_hip_result_copy_sparse: the packed lists on their way to the host
     DevBuf d_masks, d_fmasks, d_counts, d_totals, d_cands, d_flags;
-    DevBuf d_wk, d_wi, d_wi2, d_wp, d_status, d_tile, d_pool;
+    DevBuf d_wk, d_wi, d_wi2, d_wp, d_status, d_pool;
     DevBuf d_order;
     HostBuf h_stage[2];              // pinned staging of pageable caller memory (host <-> device in chunks)
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
     DevBuf d_cell_cnt, d_cell_off;   // descriptor grid: keypoints per 16 px cell, exclusive scan (+ total)
-    bool desc_wave = true;           // option "desc_kernel": 1 wave-per-keypoint kernel (default), 0 tile kernel
+    DevBuf d_desc_sched;             // tile-per-wave descriptor kernel: draw counters
+    bool desc_tile = false;          // option "desc_kernel": 1 wave-per-keypoint kernel (the default), 2 tile-per-wave kernel
     bool gate_early_chain = false;   // option "gate_early_chain" (measured alternative, off)
     int diag_repeat = 1;             // option "diag_repeat" (diagnostics, sift_hip_calculate_batch_device only)
     int gate_mid = 0;                // option "gate_mid" = o > 0: the previous batch's descriptors start when this pyramid reaches octave o
@@ -442,17 +442,8 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
                 P.grad_levels.push_back(dv.nearest_level[o * D + i]);
         }
     {
-        int tb = 0;
-        for (int lvl : P.grad_levels) {
-            const int o = lvl / (D + 1);
-            dv.desc_ntx[lvl] = (dv.w[o] + kDescCore - 1) / kDescCore;
-            dv.desc_nty[lvl] = (dv.h[o] + kDescCore - 1) / kDescCore;
-            dv.desc_tile_base[lvl] = tb;
-            tb += dv.desc_ntx[lvl] * dv.desc_nty[lvl];
-        }
-        dv.desc_tiles_per_image = std::max(tb, 1);
         int cb = 0;
-        for (int lvl : P.grad_levels) {   // 16 px cells (wave-per-keypoint descriptor kernel)
+        for (int lvl : P.grad_levels) {   // 16 px cells (descriptor kernels)
             const int o = lvl / (D + 1);
             dv.desc_cw[lvl] = (dv.w[o] + 15) / 16;
             dv.desc_ch[lvl] = (dv.h[o] + 15) / 16;
@@ -528,10 +519,10 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
     c->d_final.ensure((size_t)kListCap * (size_t)n * sizeof(FinalKp));
     c->d_final_cnt.ensure((size_t)n * sizeof(int));
     c->d_out_base.ensure((size_t)n * sizeof(long long));
-    c->d_tile.ensure((size_t)dv.desc_tiles_per_image * (size_t)n * 3 * sizeof(int));
     c->d_pool.ensure((size_t)kPoolCap * (size_t)n * sizeof(FinalKp));
     c->d_cell_cnt.ensure((size_t)(dv.desc_cells_per_image + 1) * (size_t)n * sizeof(int));
     c->d_cell_off.ensure((size_t)(dv.desc_cells_per_image + 1) * (size_t)n * sizeof(int));
+    c->d_desc_sched.ensure(desc_tile_sched_ints(n) * sizeof(int));
     SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
     P.valid = true;
     return SIFT_HIP_OK;
@@ -891,20 +882,6 @@ void mid_host(sift_hip_ctx* c) {
     c->stages_on_host = true;
 }
 
-// GPU path: both cleanups as kernels (kernels_cleanup.hip); the host only reads 4 ints per image.
-// Returns false when some image needs the host path.
-// keypoints -> descriptor tiles (device-side counts only)
-void bin_keypoints(sift_hip_ctx* c) {
-    Plan& P = c->plan;
-    const DevPlan& dv = P.dev;
-    const size_t nt = (size_t)dv.desc_tiles_per_image * (size_t)P.n;
-    int* t_cnt = c->d_tile.as<int>();
-    int* t_off = t_cnt + nt;
-    int* t_cur = t_off + nt;
-    launch_desc_binning(c->stream, c->d_plan.as<DevPlan>(), dv, c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(), kListCap, t_cnt,
-                        t_off, t_cur, c->d_pool.as<FinalKp>(), kPoolCap);
-}
-
 void ensure_outputs(sift_hip_ctx* c, long long keypoints) {
     if (keypoints <= c->out_cap) return;
     c->out_cap = 0;   // until both arrays exist at the new size (an allocation that throws leaves them freed)
@@ -916,34 +893,28 @@ void ensure_outputs(sift_hip_ctx* c, long long keypoints) {
 void launch_descriptor_stage(sift_hip_ctx* c) {
     Plan& P = c->plan;
     const DevPlan& dv = P.dev;
-    if (c->desc_wave) {
-        // grid of 16 px cells over the final keypoints, then one wave per keypoint (kernels_desc.hip)
-        launch_desc_grid(c->stream, c->d_plan.as<DevPlan>(), dv, c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(), kListCap,
-                         c->d_cell_cnt.as<int>(), c->d_cell_off.as<int>(), c->d_pool.as<FinalKp>(), kPoolCap, c->d_out_base.as<long long>(),
-                         c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->out_cap);
-        int* wire_sums = nullptr;
-        c->wire_counted = false;
-        if (c->wire_count) {   // multi-GPU jobs: the counting pass of the wire format rides in the descriptor kernel
-            const size_t nb = wire_blocks(c->out_cap);
-            c->d_wire_sums.ensure((nb + 2) * sizeof(int));
-            launch_zero_ints(c->stream, c->d_wire_sums.as<int>(), nb + 2);
-            wire_sums = c->d_wire_sums.as<int>();
-            c->wire_counted = true;
-        }
-        for (int lvl : P.grad_levels)
+    // grid of 16 px cells over the final keypoints, then one wave per keypoint - or per tile of 2 x 2 cells (kernels_desc.hip)
+    launch_desc_grid(c->stream, c->d_plan.as<DevPlan>(), dv, c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(), kListCap,
+                     c->d_cell_cnt.as<int>(), c->d_cell_off.as<int>(), c->d_pool.as<FinalKp>(), kPoolCap, c->d_out_base.as<long long>(),
+                     c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->out_cap);
+    int* wire_sums = nullptr;
+    c->wire_counted = false;
+    if (c->wire_count) {   // multi-GPU jobs: the counting pass of the wire format rides in the descriptor kernel
+        const size_t nb = wire_blocks(c->out_cap);
+        c->d_wire_sums.ensure((nb + 2) * sizeof(int));
+        launch_zero_ints(c->stream, c->d_wire_sums.as<int>(), nb + 2);
+        wire_sums = c->d_wire_sums.as<int>();
+        c->wire_counted = true;
+    }
+    for (int lvl : P.grad_levels)
+        if (c->desc_tile)
+            launch_descriptors_tile(c->stream, c->d_plan.as<DevPlan>(), dv, lvl, c->d_cell_off.as<int>(), c->d_pool.as<FinalKp>(), kPoolCap,
+                                    c->d_out_base.as<long long>(), c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->out_cap,
+                                    wire_sums, c->d_desc_sched.as<int>());
+        else
             launch_descriptors_wave(c->stream, c->d_plan.as<DevPlan>(), dv, lvl, c->d_cell_off.as<int>(), c->d_pool.as<FinalKp>(), kPoolCap,
                                     c->d_out_base.as<long long>(), c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->out_cap, c->desc_dbg,
                                     wire_sums);
-        return;
-    }
-    c->wire_counted = false;
-    const size_t nt = (size_t)dv.desc_tiles_per_image * (size_t)P.n;
-    int* t_cnt = c->d_tile.as<int>();
-    int* t_off = t_cnt + nt;
-    for (int lvl : P.grad_levels)
-        launch_descriptors(c->stream, c->d_plan.as<DevPlan>(), dv, lvl, c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(), kListCap,
-                           t_cnt, t_off, c->d_pool.as<FinalKp>(), kPoolCap, c->d_out_base.as<long long>(),
-                           c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->out_cap, c->desc_dbg);
 }
 
 // Wait for everything queued on `s`.  Polling an event returns within a microsecond or two of the GPU finishing;
@@ -986,16 +957,10 @@ bool mid_gpu(sift_hip_ctx* c) {
     launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_order.as<OrientIn>(), d_late, kListCap,
                        c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 3 * n, (c->orient_general ? nullptr : c->d_ocnt.as<int>() + 4 * n),
                        0 /* its group counters were cleared together with the early launch's */);
-    const bool fused_bin = !c->desc_wave && cleanup2_can_bin(dv.desc_tiles_per_image);
-    const size_t nt = (size_t)dv.desc_tiles_per_image * (size_t)n;
-    launch_cleanup2(s, n, dpl, fused_bin ? 1 : 0, c->d_tile.as<int>(), c->d_tile.as<int>() + nt, c->d_pool.as<FinalKp>(), kPoolCap,
-                    c->d_cands.as<Candidate>(), dv.cand_capacity, c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
+    launch_cleanup2(s, n, c->d_cands.as<Candidate>(), dv.cand_capacity, c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
                     kListCap, c->d_orient.as<OrientOut>(), c->d_lrank.as<uint32_t>(), c->d_wk.as<uint8_t>(),
                     c->d_wi.as<uint32_t>(), c->d_wi2.as<uint32_t>(), c->d_wp.as<uint32_t>(), c->d_final.as<FinalKp>(),
                     c->d_final_cnt.as<int>(), c->d_status.as<int>(), c->d_recs.as<FinalKp>());
-    // the tile binning only needs the device-side lists: it keeps the GPU busy while the host waits for the counts
-    if (!fused_bin && !c->desc_wave) bin_keypoints(c);
-    c->binned = true;
     // The descriptor stage does not wait for the counts to reach the host: output slots come from a device-side
     // scan and the output arrays keep a generous capacity; should a batch ever exceed it, the (idempotent: the
     // mutated maps only live in LDS) stage is simply run again after growing them.
@@ -1034,7 +999,6 @@ bool mid_gpu(sift_hip_ctx* c) {
     if (c->chain_ran && st[(size_t)n * 5] != 0) throw std::runtime_error("sift_hip: the pyramid's level chain gave up waiting for a level (kernels_chain.hip)");
     for (int i = 0; i < n; ++i)
         if (st[(size_t)i * 4 + 1] || st[(size_t)n * 4 + (size_t)i]) {
-            c->binned = false;   // the host path rebuilds the lists
             c->described = false;
             return false;
         }
@@ -1244,7 +1208,6 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     c->have_result = false;
     c->have_pyramid = false;
     c->stages_on_host = false;
-    c->binned = false;
     c->described = false;
     c->wire_values = c->wire_for_total = -1;
     c->wire_counted = false;
@@ -1352,7 +1315,6 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
         ensure_outputs(c, std::max<long long>(total, 1));
         SIFT_HIP_CHECK(hipMemcpyAsync(c->d_out_base.p, c->out_base.data(), (size_t)n * sizeof(long long), hipMemcpyHostToDevice, s));
         if (total > 0) {
-            if (!c->binned && !c->desc_wave) bin_keypoints(c);
             launch_descriptor_stage(c);
         }
     }
@@ -1447,8 +1409,8 @@ void sift_hip_destroy(sift_hip_ctx* c) {
     (void)sift_hip_set_gate(c, nullptr);
     ApiGuard api;
     for (DevBuf* b : {&c->arena, &c->d_plan, &c->d_taps, &c->d_luts, &c->d_taps16, &c->d_input, &c->d_input_u8, &c->d_sparse_rec, &c->d_sparse_val, &c->d_base, &c->d_tmp, &c->d_tmp2,
-                      &c->d_wk, &c->d_wi, &c->d_wi2, &c->d_wp, &c->d_status, &c->d_tile, &c->d_pool, &c->d_order, &c->d_masks, &c->d_fmasks, &c->d_counts, &c->d_totals, &c->d_cands, &c->d_flags, &c->d_list, &c->d_list_cnt, &c->d_orient,
-                      &c->d_peaks, &c->d_final, &c->d_final_cnt, &c->d_out_base, &c->d_kp, &c->d_desc, &c->d_lrank, &c->d_ochunk, &c->d_ocnt, &c->d_recs, &c->d_wire_sums, &c->d_wire_off, &c->d_unpack_sums, &c->d_unpack_off, &c->d_cell_cnt, &c->d_cell_off})
+                      &c->d_wk, &c->d_wi, &c->d_wi2, &c->d_wp, &c->d_status, &c->d_pool, &c->d_order, &c->d_masks, &c->d_fmasks, &c->d_counts, &c->d_totals, &c->d_cands, &c->d_flags, &c->d_list, &c->d_list_cnt, &c->d_orient,
+                      &c->d_peaks, &c->d_final, &c->d_final_cnt, &c->d_out_base, &c->d_kp, &c->d_desc, &c->d_lrank, &c->d_ochunk, &c->d_ocnt, &c->d_recs, &c->d_wire_sums, &c->d_wire_off, &c->d_unpack_sums, &c->d_unpack_off, &c->d_cell_cnt, &c->d_cell_off, &c->d_desc_sched})
         b->release();
     for (HostBuf* b : {&c->h_flags, &c->h_orient, &c->h_peaks, &c->h_status, &c->h_wire, &c->h_stage[0], &c->h_stage[1]}) b->release();
     for (auto& e : c->ev_stage) if (e) (void)hipEventDestroy(e);
@@ -1536,7 +1498,11 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     if (!std::strcmp(name, "reduce_kept")) { c->reduce_kept = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "spin_wait")) { c->spin_wait = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "desc_dbg")) { c->desc_dbg = value; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "desc_kernel")) { c->desc_wave = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "desc_kernel")) {
+        if (value != 1 && value != 2) return SIFT_HIP_EINVAL;
+        c->desc_tile = value == 2;
+        return SIFT_HIP_OK;
+    }
     if (!std::strcmp(name, "gate_early_chain")) { c->gate_early_chain = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "wire_count")) { c->wire_count = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "pyramid_side")) {

@@ -1219,22 +1219,7 @@ size_t orient_prepare_chunks(long long cand_cap) { return (size_t)((cand_cap + k
 // ---- cleanup 2: after orientation assignment -> FinalKp list ---------------------------------------
 // status[img*4 + {0: count, 1: fallback (depth limit or a point with several orientation peaks),
 //                 2: index of the first point whose dead blur throws (or INT_MAX), 3: its code}]
-// With bin_tiles the kernel also bins the final keypoints to the descriptor stage's tiles (counts, exclusive
-// scan and fill in LDS: one workgroup owns an image, so no global atomics are needed).
-constexpr int kTileLdsCap = 4096;   // descriptor tiles per image the LDS binning handles
-
-__device__ __forceinline__ void desc_tile_span(int v, int ntiles, int& lo, int& hi) {
-    // tiles t whose extended region [t*C - 8, t*C + C + 8) meets the window [v - 8, v + 8)  (kernels_desc.hip)
-    const int a = v - kDescCore - 16;
-    lo = a < 0 ? 0 : a / kDescCore + 1;
-    hi = (v + 15) / kDescCore;
-    if (hi > ntiles - 1) hi = ntiles - 1;
-}
-
-__global__ __launch_bounds__(kCT) void cleanup2_kernel(const DevPlan* __restrict__ plan, int bin_tiles,
-                                                       int* __restrict__ tile_cnt, int* __restrict__ tile_off,
-                                                       FinalKp* __restrict__ pool, int pool_cap,
-                                                       const Candidate* __restrict__ cands, long long cand_cap,
+__global__ __launch_bounds__(kCT) void cleanup2_kernel(const Candidate* __restrict__ cands, long long cand_cap,
                                                        const uint32_t* __restrict__ list,
                                                        const int* __restrict__ list_cnt, int list_cap,
                                                        const OrientOut* __restrict__ orient,
@@ -1316,76 +1301,6 @@ __global__ __launch_bounds__(kCT) void cleanup2_kernel(const DevPlan* __restrict
     FinalKp* out = finals + off;
     const int size = compact_kept(sh, n, K, I2, [&](int r, uint32_t id) { out[r] = rec[id]; });
     stamp(103);
-    if (bin_tiles) {
-        __shared__ int s_tcnt[kTileLdsCap];
-        __shared__ int s_toff[kTileLdsCap];
-        __shared__ int s_scan[kCT];
-        __shared__ int s_lv[kMaxLevels][3];   // per (octave, dog): tiles across, tiles down, first tile of its level
-        const int tid = threadIdx.x;
-        const int tpi = plan->desc_tiles_per_image;
-        const int D = plan->dogs;
-        for (int l = tid; l < plan->octaves * D; l += kCT) {
-            const int level = plan->nearest_level[l];
-            s_lv[l][0] = plan->desc_ntx[level];
-            s_lv[l][1] = plan->desc_nty[level];
-            s_lv[l][2] = plan->desc_tile_base[level];
-        }
-        const int nk = s_throw != 0x7fffffff ? 0 : size;   // a throwing image emits nothing
-        for (int t = tid; t < tpi; t += kCT) s_tcnt[t] = 0;
-        __syncthreads();   // also orders this workgroup's out[] writes before the reads below
-        for (int r = tid; r < nk; r += kCT) {
-            const FinalKp f = out[r];
-            const int lq = f.octave * D + f.index;
-            const int ntx = s_lv[lq][0], nty = s_lv[lq][1], tb = s_lv[lq][2];
-            int x0, x1, y0, y1;
-            desc_tile_span(f.x, ntx, x0, x1);
-            desc_tile_span(f.y, nty, y0, y1);
-            for (int ty = y0; ty <= y1; ++ty)
-                for (int tx = x0; tx <= x1; ++tx) atomicAdd(&s_tcnt[tb + ty * ntx + tx], 1);
-        }
-        __syncthreads();
-        // exclusive scan over the tiles: each thread owns a run of consecutive tiles
-        const int chunk = (tpi + kCT - 1) / kCT;
-        const int lo = tid * chunk, hi = min(lo + chunk, tpi);
-        int sum = 0;
-        for (int t = lo; t < hi; ++t) sum += s_tcnt[t];
-        s_scan[tid] = sum;
-        __syncthreads();
-        for (int o = 1; o < kCT; o <<= 1) {
-            const int v = tid >= o ? s_scan[tid - o] : 0;
-            __syncthreads();
-            s_scan[tid] += v;
-            __syncthreads();
-        }
-        int run = s_scan[tid] - sum;
-        int* gc = tile_cnt + (size_t)img * (size_t)tpi;
-        int* go = tile_off + (size_t)img * (size_t)tpi;
-        for (int t = lo; t < hi; ++t) {
-            const int cnt = s_tcnt[t];
-            gc[t] = cnt;
-            go[t] = run;
-            s_toff[t] = run;
-            s_tcnt[t] = 0;   // becomes the fill cursor
-            run += cnt;
-        }
-        __syncthreads();
-        FinalKp* pl = pool + (size_t)img * (size_t)pool_cap;
-        for (int r = tid; r < nk; r += kCT) {
-            FinalKp f = out[r];
-            const int lq = f.octave * D + f.index;
-            const int ntx = s_lv[lq][0], nty = s_lv[lq][1], tb = s_lv[lq][2];
-            int x0, x1, y0, y1;
-            desc_tile_span(f.x, ntx, x0, x1);
-            desc_tile_span(f.y, nty, y0, y1);
-            f.cand = (uint32_t)r;   // the tile kernel sorts by the vector index; the candidate id is not needed there
-            for (int ty = y0; ty <= y1; ++ty)
-                for (int tx = x0; tx <= x1; ++tx) {
-                    const int t = tb + ty * ntx + tx;
-                    const int q = atomicAdd(&s_tcnt[t], 1);
-                    pl[s_toff[t] + q] = f;
-                }
-        }
-    }
     stamp(104);
     if (threadIdx.x == 0) {
         const bool thr = s_throw != 0x7fffffff;
@@ -1452,15 +1367,11 @@ void launch_build_orient_in(hipStream_t s, const Candidate* d_cands, long long c
                        s, d_cands, cand_cap, d_list, d_list_cnt, list_cap, d_oin);
 }
 
-bool cleanup2_can_bin(int tiles_per_image) { return tiles_per_image <= kTileLdsCap; }
-
-void launch_cleanup2(hipStream_t s, int n_images, const DevPlan* d_plan, int bin_tiles, int* d_tile_cnt, int* d_tile_off,
-                     FinalKp* d_pool, int pool_cap, const Candidate* d_cands, long long cand_cap,
+void launch_cleanup2(hipStream_t s, int n_images, const Candidate* d_cands, long long cand_cap,
                      const uint32_t* d_list, const int* d_list_cnt, int list_cap, const OrientOut* d_orient,
                      const uint32_t* d_lrank, uint8_t* wk, uint32_t* wi, uint32_t* wi2, uint32_t* wp, FinalKp* d_final,
                      int* d_final_cnt, int* d_status, FinalKp* d_recs) {
-    hipLaunchKernelGGL(cleanup2_kernel, dim3((unsigned)n_images), dim3(kCT), 0, s, d_plan, bin_tiles, d_tile_cnt, d_tile_off,
-                       d_pool, pool_cap, d_cands, cand_cap, d_list,
+    hipLaunchKernelGGL(cleanup2_kernel, dim3((unsigned)n_images), dim3(kCT), 0, s, d_cands, cand_cap, d_list,
                        d_list_cnt, list_cap, d_orient, d_lrank, wk, wi, wi2, wp, d_final, d_final_cnt, d_status, d_recs);
 }
 

@@ -9,16 +9,14 @@
 // `ori += p.orientation` and `mag += W(lx, ly)` where W is the top-left 16x16 of
 // convolveWithGauss(level, 1.6) indexed by WINDOW-LOCAL coordinates.  A later keypoint whose
 // window overlaps sees the accumulated values, so each pixel carries an order-dependent float
-// chain.  This kernel reproduces those chains exactly and in parallel:
-//   * one workgroup owns a 64x64 core tile of a level and keeps the orientation / magnitude
-//     values of the 80x80 extended tile (core + 8 px fringe) in LDS;
-//   * it walks ALL keypoints of the image in vector order (ballot-compacted to those whose window
-//     touches the extended tile) and applies each one's update to the pixels it holds — every
-//     pixel therefore sees exactly the reference's sequence of float additions;
-//   * for keypoints whose location lies in the core tile the whole window is resident, so the
-//     16 cell histograms are taken right after that keypoint's update, as the reference does.
-// Pixels in the fringe are updated redundantly by the neighbouring tiles; nothing is written back
-// to HBM except the descriptors (the reference's mutated pyramids are private state).
+// chain.  Two kernels reproduce those chains exactly and in parallel (nothing is written back to HBM
+// except the descriptors: the reference's mutated pyramids are private state):
+//   * descriptor_wave_kernel (the default): one wave per keypoint recomputes the chains of its window's 256
+//     pixels from the initial maps and the preceding neighbours, found through a grid of 16 px cells;
+//   * descriptor_tile_kernel (option desc_kernel = 2): one wave per 32x32 tile of keypoint locations keeps
+//     the tile's pixels in LDS and applies the keypoints that touch it in vector order.
+#include <cstdio>
+
 #include "common.h"
 #include "hist_bins.h"
 
@@ -56,463 +54,10 @@ __global__ __launch_bounds__(256) void w16_kernel(const float* __restrict__ leve
     w16[(size_t)img * 256 + (size_t)(lx + 16 * ly)] = out;
 }
 
-constexpr int kCore = kDescCore;
-constexpr int kExt = kCore + 2 * kRegion;  // 64
-constexpr int kTileListCap = 512;         // per-tile list held (and sorted) in LDS
-
-// ---- binning: which keypoints touch which extended tile ------------------------------------------
-// A 16x16 window touches the extended regions of at most 2x2 tiles.  Counts, an exclusive scan per
-// image and an atomic fill give every tile its (unordered) list; the descriptor kernel sorts its
-// list by vector index in LDS, because the order IS the semantics (cumulative mutation).
-__device__ __forceinline__ void tile_span(int v, int ntiles, int& lo, int& hi) {
-    // tiles t whose extended region [t*C - 8, t*C + C + 8) meets the window [v - 8, v + 8):
-    //   v - C - 16 < t*C < v + 16
-    const int a = v - kCore - 16;
-    lo = a < 0 ? 0 : a / kCore + 1;     // smallest t with t*C > a
-    hi = (v + 15) / kCore;              // largest t with t*C < v + 16
-    if (hi > ntiles - 1) hi = ntiles - 1;
-}
-
-template <bool FILL>
-__global__ __launch_bounds__(256) void desc_bin_kernel(const DevPlan* __restrict__ plan,
-                                                       const FinalKp* __restrict__ finals,
-                                                       const int* __restrict__ final_cnt, int final_cap,
-                                                       int* __restrict__ tile_cnt, const int* __restrict__ tile_off,
-                                                       int* __restrict__ tile_cur, FinalKp* __restrict__ pool,
-                                                       int pool_cap) {
-    const int img = blockIdx.y;
-    const int K = final_cnt[img];
-    const int D = plan->dogs;
-    const int tpi = plan->desc_tiles_per_image;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
-        const FinalKp f = finals[(size_t)img * (size_t)final_cap + k];
-        const int level = plan->nearest_level[f.octave * D + f.index];
-        const int ntx = plan->desc_ntx[level], nty = plan->desc_nty[level];
-        int x0, x1, y0, y1;
-        tile_span(f.x, ntx, x0, x1);
-        tile_span(f.y, nty, y0, y1);
-        for (int ty = y0; ty <= y1; ++ty)
-            for (int tx = x0; tx <= x1; ++tx) {
-                const int t = img * tpi + plan->desc_tile_base[level] + ty * ntx + tx;
-                if (!FILL) {
-                    atomicAdd(&tile_cnt[t], 1);
-                } else {
-                    const int p = atomicAdd(&tile_cur[t], 1);
-                    FinalKp rec = f;
-                    rec.cand = (uint32_t)k;  // the tile kernel sorts by this; the candidate id is not needed there
-                    pool[(size_t)img * (size_t)pool_cap + (size_t)tile_off[t] + (size_t)p] = rec;
-                }
-            }
-    }
-}
-
-// exclusive scan of one image's tile counts (one workgroup per image, chunked)
-__global__ __launch_bounds__(1024) void desc_tile_scan_kernel(const int* __restrict__ tile_cnt,
-                                                              int* __restrict__ tile_off, int tpi) {
-    __shared__ int s_part[1024];
-    const int img = blockIdx.x, tid = threadIdx.x;
-    const int* c = tile_cnt + (size_t)img * tpi;
-    int* o = tile_off + (size_t)img * tpi;
-    const int chunk = (tpi + 1023) / 1024;
-    const int lo = tid * chunk, hi = min(lo + chunk, tpi);
-    int sum = 0;
-    for (int i = lo; i < hi; ++i) sum += c[i];
-    s_part[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int v = (tid >= off) ? s_part[tid - off] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
-    }
-    int run = s_part[tid] - sum;
-    for (int i = lo; i < hi; ++i) {
-        o[i] = run;
-        run += c[i];
-    }
-}
-
-// ---- the tile kernel ---------------------------------------------------------------------------------
-// Pixel ownership by residue: thread t owns every pixel (X, Y) of the extended tile with
-// (X mod 16, Y mod 16) == (t mod 16, t / 16).  Any 16x16 window contains exactly one pixel of each
-// residue class, so for every keypoint each thread updates exactly ONE pixel — always one of its
-// own.  A pixel's whole chain of float additions therefore runs in one thread's program order and
-// the cumulative mutation needs no barrier at all.  Only the 4x4x8 histograms need other threads'
-// values: they are staged per keypoint in LDS, kDescBatch keypoints at a time (two barriers per
-// batch), and built by all 256 threads, two keypoints at once.
-constexpr int kDescBatch = 8;
-constexpr int kDescHalf = 4;                       // keypoints whose pixel reads are issued together
-constexpr int kStageRow = 20;                       // staged window COLUMN: 16 samples (y) + pad; multiple of 4
-constexpr int kStageStride = 16 * kStageRow + 4;    // per keypoint; multiple of 4: a cell's 4 y-samples are one 16-byte read
-
-// value of the neighbouring lane (lane ^ 1) through the DPP quad permute: one VALU instruction, no LDS round trip
-__device__ __forceinline__ float lane_xor1(float v) {
-    return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
-}
-
-struct TileKp {   // what the per-pixel chains need of a keypoint
-    unsigned short x, y;
-    float orientation;
-};
-
-// what the kernel needs to know about its level, passed by value (kernel arguments are scalar registers: no
-// dependent loads from the plan before the first useful load can be issued)
-struct DescLevel {
-    int w, h, dogs, tiles_per_image, tile_base;
-    const float* mag;
-    const float* ori;
-    const float* gauss;
-    const float* w16;
-};
-
-__global__ __launch_bounds__(256, 3) void descriptor_kernel(const DevPlan* __restrict__ plan, DescLevel lv, int level,
-                                                         const FinalKp* __restrict__ finals,
-                                                         const int* __restrict__ final_cnt, int final_cap,
-                                                         const int* __restrict__ tile_cnt,
-                                                         const int* __restrict__ tile_off,
-                                                         const FinalKp* __restrict__ pool, int pool_cap,
-                                                         const long long* __restrict__ out_base,
-                                                         sift_hip_keypoint* __restrict__ kp_out,
-                                                         float* __restrict__ desc_out, long long out_cap, int dbg) {
-    __shared__ __attribute__((aligned(16))) float s_ori[kExt * kExt];
-    __shared__ __attribute__((aligned(16))) float s_mag[kExt * kExt];
-    __shared__ float s_w16[256];
-    __shared__ unsigned short s_list[kTileListCap];   // vector index k of each list entry, ascending
-    __shared__ __attribute__((aligned(8))) TileKp s_fin[kTileListCap];
-    __shared__ unsigned short s_flag[kTileListCap];   // bit 0 = fails the bounds test, bit 1 = emitted by this tile; bits 8-15 = octave*D + index
-    // histogram inputs of a batch, laid out [sample-in-cell q][cell][keypoint m]: the phase-B reader
-    // (thread = (m, cell), q marching) then touches 128 consecutive words per read
-    __shared__ __attribute__((aligned(16))) float s_val[kStageStride * kDescBatch];
-    __shared__ __attribute__((aligned(16))) unsigned char s_bin[kStageStride * kDescBatch];
-    __shared__ int s_wcnt[4];
-    __shared__ int s_n;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wv = tid >> 6;
-    const int img = blockIdx.z;
-    const int D = lv.dogs;
-    const int w = lv.w, h = lv.h;
-    const int cx0 = blockIdx.x * kCore, cy0 = blockIdx.y * kCore;
-    const int ex0 = cx0 - kRegion, ey0 = cy0 - kRegion;
-    const int tile = img * lv.tiles_per_image + lv.tile_base + blockIdx.y * gridDim.x + blockIdx.x;
-    const int n_tile = tile_cnt[tile];
-    const int t_off = tile_off[tile];
-    if (n_tile == 0) return;  // no window touches this tile: nothing to mutate, nothing to emit
-    const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
-    const float* __restrict__ gm = lv.mag + img_off;
-    const float* __restrict__ go = lv.ori + img_off;
-    const float* __restrict__ gg = lv.gauss + img_off;
-    // the first 256 records of the tile's list travel together with the tile's pixels
-    const FinalKp* __restrict__ pool_src = pool + (size_t)img * (size_t)pool_cap + (size_t)t_off;
-    FinalKp first_rec;
-    first_rec.cand = 0; first_rec.orientation = 0.0f; first_rec.x = first_rec.y = first_rec.octave = first_rec.index = 0;
-    if (tid < n_tile && n_tile <= kTileListCap) first_rec = pool_src[tid];
-    const FinalKp* __restrict__ fin = finals + (size_t)img * (size_t)final_cap;
-    const int K = final_cnt[img];
-    const long long obase = out_base[img];
-
-    // LDS tile index of pixel (ex, ey): odd rows have their two 16-column halves swapped in every
-    // 32-column group, so the two window rows a half-wave touches fall on disjoint banks
-    auto tile_idx = [](int ex, int ey) { return ey * kExt + (ex ^ ((ey & 1) << 4)); };
-    // initial gradient / Gaussian values of the extended tile: 16-byte loads (all issued before the
-    // LDS stores) when rows are 16-byte aligned, scalar otherwise
-    if (!(dbg & 4)) {
-        const bool vec = (w & 3) == 0 && ((((uintptr_t)gm | (uintptr_t)go) & 15u) == 0);
-        if (vec) {
-            constexpr int R4 = kExt / 4;                 // float4 per tile row
-            static_assert(kExt * R4 == 4 * 256, "tile init assumes 4 float4 per thread and array");
-            const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            float4 o0 = z, o1 = z, o2 = z, o3 = z, m0 = z, m1 = z, m2 = z, m3 = z;
-#define SIFT_TILE_LOAD(i, vo, vm)                                                                 \
-            {                                                                                     \
-                const int e = tid + 256 * (i);                                                    \
-                const int ly = e / R4, c4 = e - ly * R4;                                          \
-                const int X = ex0 + 4 * c4, Y = ey0 + ly;                                         \
-                if (X >= 0 && X < w && Y >= 0 && Y < h) { /* ex0 and w are multiples of 4 */       \
-                    const size_t o = (size_t)Y * (size_t)w + (size_t)X;                           \
-                    vo = *reinterpret_cast<const float4*>(go + o);                                \
-                    vm = *reinterpret_cast<const float4*>(gm + o);                                \
-                }                                                                                 \
-            }
-            SIFT_TILE_LOAD(0, o0, m0)
-            SIFT_TILE_LOAD(1, o1, m1)
-            SIFT_TILE_LOAD(2, o2, m2)
-            SIFT_TILE_LOAD(3, o3, m3)
-#undef SIFT_TILE_LOAD
-            float4* po = reinterpret_cast<float4*>(s_ori);
-            float4* pm = reinterpret_cast<float4*>(s_mag);
-            auto sw4 = [](int e) { const int ly = e / R4; return e ^ ((ly & 1) << 2); };  // same swizzle, float4 units
-            po[sw4(tid)] = o0; po[sw4(tid + 256)] = o1; po[sw4(tid + 512)] = o2; po[sw4(tid + 768)] = o3;
-            pm[sw4(tid)] = m0; pm[sw4(tid + 256)] = m1; pm[sw4(tid + 512)] = m2; pm[sw4(tid + 768)] = m3;
-        } else {
-            for (int idx = tid; idx < kExt * kExt; idx += 256) {
-                const int ly = idx / kExt, lx = idx - ly * kExt;
-                const int X = ex0 + lx, Y = ey0 + ly;
-                const bool ok = X >= 0 && X < w && Y >= 0 && Y < h;
-                const size_t o = (size_t)(ok ? Y : 0) * (size_t)w + (size_t)(ok ? X : 0);
-                s_ori[tile_idx(lx, ly)] = ok ? go[o] : 0.0f;
-                s_mag[tile_idx(lx, ly)] = ok ? gm[o] : 0.0f;
-            }
-        }
-    }
-    s_w16[tid] = lv.w16[(size_t)img * 256 + tid];
-
-    const int rx = tid & 15, ry = tid >> 4;  // residues of the pixels this thread owns
-
-    // Two per-tile flags of a record: bit 0 = the descriptor stage's own bounds test fails
-    // (sift.cpp:65-70; never newly true after the orientation stage's stricter test), bit 1 = the
-    // keypoint's location lies in this tile's core (it is emitted here).
-    auto flags_of = [&](const FinalKp& f) {
-        const int kx = f.x, ky = f.y;
-        const bool kfilt = kx < kRegion || kx > w - kRegion || ky < kRegion || ky > h - kRegion;
-        const bool owned = kx >= cx0 && kx < cx0 + kCore && ky >= cy0 && ky < cy0 + kCore;
-        return (unsigned short)((kfilt ? 1u : 0u) | (owned ? 2u : 0u) | ((unsigned)(f.octave * D + f.index) << 8));
-    };
-    auto compact = [](const FinalKp& f) {
-        TileKp t;
-        t.x = f.x; t.y = f.y; t.orientation = f.orientation;
-        return t;
-    };
-    // Processes the ordered entries s_fin[0..n_seg) / s_list[0..n_seg).
-    // cross-thread data only moves through LDS here: do not drain the output stores at barriers
-    auto lds_only_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    auto run_segment = [&](int n_seg) {
-        // whole batches: the tail is padded with records that fail the bounds test (no access, no output)
-        for (int i = n_seg + tid; i < ((n_seg + kDescBatch - 1) & ~(kDescBatch - 1)); i += 256) {
-            TileKp z;
-            z.x = z.y = 0; z.orientation = 0.0f;
-            s_fin[i] = z;
-            s_flag[i] = 1;
-        }
-        lds_only_barrier();
-        for (int e0 = 0; e0 < n_seg; e0 += kDescBatch) {
-            // Record fields are the same for every lane of a wave: they are moved to scalar registers, so
-            // the per-keypoint window arithmetic is mostly SALU and the kept / emitted tests are scalar
-            // branches.  The list is padded to whole batches with records that fail the bounds test.
-#define SIFT_DESC_RECORD(E, WX, WY, FL, ORI)                                                                     \
-            const uint2 rec_ = *reinterpret_cast<const uint2*>(&s_fin[E]);                                       \
-            const unsigned xy_ = __builtin_amdgcn_readfirstlane(rec_.x);                                         \
-            const float ORI = __uint_as_float(__builtin_amdgcn_readfirstlane(rec_.y));                           \
-            const unsigned FL = __builtin_amdgcn_readfirstlane((unsigned)s_flag[E]) & 3u;                        \
-            const int WX = (int)(xy_ & 0xffffu) - kRegion, WY = (int)(xy_ >> 16) - kRegion;
-            // the Gaussian-level pixels of the keypoints this tile emits come straight from HBM/L2 (read
-            // once each, no reuse): issued for the whole batch before the chains start
-            float pg[kDescBatch];
-            // the thread that writes keypoint (tid >> 5)'s record in phase B fetches its DoG scale now
-            float my_scale = 0.0f;
-            if ((tid & 31) == 0) my_scale = plan->dog_scale[s_flag[e0 + (tid >> 5)] >> 8];
-#pragma unroll
-            for (int m = 0; m < kDescBatch; ++m) {
-                pg[m] = 0.0f;
-                SIFT_DESC_RECORD(e0 + m, wx, wy, fl, ori_unused)
-                (void)ori_unused;
-                if (fl == 2u) {   // emitted here and inside the bounds: the whole window lies in the image
-                    const int X = wx + ((rx - wx) & 15), Y = wy + ((ry - wy) & 15);
-                    pg[m] = gg[(size_t)Y * (size_t)w + (size_t)X];
-                }
-            }
-            // ---- phase A: per-pixel chains, no barrier -------------------------------------------------
-            // A thread owns one pixel of every window, and two keypoints of a batch rarely share it.  So
-            // the LDS reads of kDescHalf keypoints are issued together and the (rare) read-after-write
-            // between them is resolved in registers: keypoint j takes its input from the latest earlier
-            // keypoint of the group with the same LDS index, else from LDS.  Writes go out in keypoint
-            // order (LDS executes a wave's accesses in order), so the last one wins, as in the
-            // reference's sequential in-place updates (sift.cpp:80-92).
-            if (!(dbg & 1))
-#pragma unroll
-            for (int hb = 0; hb < kDescBatch; hb += kDescHalf) {
-                int idx[kDescHalf], stg[kDescHalf];
-                bool own[kDescHalf];
-                float ro[kDescHalf], rm[kDescHalf], wt[kDescHalf], orient[kDescHalf];
-#pragma unroll
-                for (int j = 0; j < kDescHalf; ++j) {
-                    SIFT_DESC_RECORD(e0 + hb + j, wx, wy, fl, ori)
-                    const int lx = (rx - wx) & 15, ly = (ry - wy) & 15;   // window-local position of this thread's pixel
-                    const int ex = lx + (wx - ex0), ey = ly + (wy - ey0);
-                    const bool in = (unsigned)(ex | ey) < (unsigned)kExt && (fl & 1u) == 0u;
-                    idx[j] = in ? tile_idx(ex, ey) : -1 - j;   // no access: unique, matches nothing
-                    own[j] = fl == 2u;
-                    orient[j] = ori;
-                    wt[j] = s_w16[lx + 16 * ly];   // weighting(x, y), window-local (sift.cpp:90)
-                    stg[j] = (hb + j) * kStageStride + lx * kStageRow + ly;  // x-major (the histogram's sample order), padded columns
-                }
-#pragma unroll
-                for (int j = 0; j < kDescHalf; ++j) {
-                    const int ri = idx[j] < 0 ? 0 : idx[j];   // idle lanes read a harmless word
-                    ro[j] = s_ori[ri];
-                    rm[j] = s_mag[ri];
-                }
-                float no[kDescHalf], nm[kDescHalf];
-#pragma unroll
-                for (int j = 0; j < kDescHalf; ++j) {
-                    float o = ro[j], mg = rm[j];
-#pragma unroll
-                    for (int i = 0; i < j; ++i)
-                        if (idx[i] == idx[j]) {
-                            o = no[i];
-                            mg = nm[i];
-                        }
-                    no[j] = o + orient[j];   // sift.cpp:82
-                    nm[j] = mg + wt[j];      // sift.cpp:90
-                }
-#pragma unroll
-                for (int j = 0; j < kDescHalf; ++j)
-                    if (idx[j] >= 0) {
-                        s_ori[idx[j]] = no[j];
-                        s_mag[idx[j]] = nm[j];
-                    }
-#pragma unroll
-                for (int j = 0; j < kDescHalf; ++j)
-                    if (own[j]) {   // scalar; every pixel of an emitted keypoint's window is inside the tile
-                        // alg::orientationHistogram8 inputs in descriptor order: cell = (x/4)*4 + y/4
-                        // (x outer, sift.cpp:95-96), inside a cell x outer, y inner
-                        const float sum = nm[j] * pg[hb + j];
-                        unsigned i = f32_to_u16_x86(__builtin_floorf(no[j] / 45.0f));
-                        i = i % 7u;
-                        s_val[stg[j]] = sum;
-                        s_bin[stg[j]] = (unsigned char)i;
-                    }
-            }
-#undef SIFT_DESC_RECORD
-            lds_only_barrier();
-            // ---- phase B: two threads per (keypoint of the batch, cell): bins 0-3 and 4-7 in registers ------
-            if (!(dbg & 2)) {
-                const int m = tid >> 5, cell = (tid >> 1) & 15, half = tid & 1;   // cell = (x/4)*4 + y/4, sift.cpp:95-96
-                const int sbase = m * kStageStride + (cell >> 2) * 4 * kStageRow + (cell & 3) * 4;   // column 4*(x/4), row 4*(y/4)
-                const int e = e0 + m;
-                if (e < n_seg) {
-                    const unsigned fl = s_flag[e];
-                    const bool kfilt = (fl & 1u) != 0;
-                    const bool owned = (fl & 2u) != 0;
-                    const long long ok = obase + (long long)s_list[e];
-                    // (the output arrays are sized before the final counts reach the host: see run_batch)
-                    if (owned && ok < out_cap) {   // uniform over the 32 threads of a keypoint (partners included)
-                        // bin 7 is never written (the index is taken % 7) but is normalised: a = bins 0|4, ... d = 3|7
-                        float ha = 0.0f, hb2 = 0.0f, hc = 0.0f, hd = 0.0f;
-                        if (!kfilt) {
-                            // alg::orientationHistogram8: samples of the cell in x-outer / y-inner order
-                            const unsigned b0 = half ? 4u : 0u;
-#pragma unroll
-                            for (int qx = 0; qx < 4; ++qx) {   // x outer: one staged column segment = 4 y-samples
-                                const float4 v4 = *reinterpret_cast<const float4*>(&s_val[sbase + qx * kStageRow]);
-                                const unsigned b4 = *reinterpret_cast<const unsigned*>(&s_bin[sbase + qx * kStageRow]);
-                                const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-                                for (int qy = 0; qy < 4; ++qy) {   // y inner
-                                    const float v = vv[qy];
-                                    const unsigned b = ((b4 >> (8 * qy)) & 0xffu) - b0;
-                                    ha = (b == 0u) ? ha + v : ha;
-                                    hb2 = (b == 1u) ? hb2 + v : hb2;
-                                    hc = (b == 2u) ? hc + v : hc;
-                                    hd = (b == 3u) ? hd + v : hd;     // b == 3 with half: bin 7, never produced
-                                }
-                            }
-                            // alg::normalizeVector: length = b0 + ... + b7 sequentially; skip if 0
-                            float lo = 0.0f;
-                            lo += ha; lo += hb2; lo += hc; lo += hd;               // bins 0..3 (used by half 0)
-                            const float lo_partner = lane_xor1(lo);                 // half 1 receives bins 0..3's sum
-                            float length = lo;
-                            if (half) {
-                                length = lo_partner;
-                                length += ha; length += hb2; length += hc; length += hd;   // + bins 4..7
-                            }
-                            const float len_partner = lane_xor1(length);            // half 0 receives the full length
-                            if (!half) length = len_partner;
-                            if (!(length == 0.0f)) {
-                                ha = ha / length; hb2 = hb2 / length; hc = hc / length; hd = hd / length;
-                            }
-                        }
-                        float4* dst = reinterpret_cast<float4*>(desc_out + (size_t)ok * 128 + (size_t)cell * 8);
-                        dst[half] = make_float4(ha, hb2, hc, hd);
-                        if (cell == 0 && half == 0) {
-                            const TileKp f = s_fin[e];
-                            const unsigned oi = fl >> 8;   // octave * D + index
-                            sift_hip_keypoint r;
-                            r.scale = my_scale;
-                            r.orientation = f.orientation;
-                            r.x = f.x;
-                            r.y = f.y;
-                            r.octave = (uint16_t)(oi / (unsigned)D);
-                            r.index = (uint16_t)(oi % (unsigned)D);
-                            r.filtered = kfilt ? 1 : 0;
-                            r.has_descriptor = kfilt ? 0 : 1;
-                            r.reserved = 0;
-                            kp_out[ok] = r;
-                        }
-                    }
-                }
-            }
-            lds_only_barrier();
-        }
-    };
-
-    // the unsorted records are staged in the (not yet used) histogram staging area
-    static_assert(sizeof(FinalKp) * kTileListCap <= sizeof(float) * kStageStride * kDescBatch, "s_raw overlay");
-    static_assert(kTileListCap % kDescBatch == 0 && sizeof(TileKp) == 8, "list padding / record layout");
-    FinalKp* s_raw = reinterpret_cast<FinalKp*>(s_val);
-    if (n_tile <= kTileListCap) {
-        // fetch the tile's list and rank-sort it by vector index (indices are unique)
-        if (tid < n_tile) s_raw[tid] = first_rec;
-        for (int i = tid + 256; i < n_tile; i += 256) s_raw[i] = pool_src[i];
-        __syncthreads();
-        for (int i = tid; i < n_tile; i += 256) {
-            const FinalKp rec = s_raw[i];
-            const uint32_t v = rec.cand;
-            int r = 0;
-            for (int j = 0; j < n_tile; ++j) r += s_raw[j].cand < v;
-            s_list[r] = (unsigned short)v;
-            s_fin[r] = compact(rec);
-            s_flag[r] = flags_of(rec);
-        }
-        __syncthreads();
-        if (!(dbg & 8)) run_segment(n_tile);
-        return;
-    }
-
-    // oversized list (> kTileListCap keypoints touch this tile): walk ALL keypoints of the image in
-    // order, ballot-compacting the ones that touch the tile, in segments that fit the LDS list
-    __syncthreads();
-    for (int k0 = 0; k0 < K;) {
-        if (tid == 0) s_n = 0;
-        __syncthreads();
-        int k_next = k0;
-        for (; k_next < K; k_next += 256) {
-            const int n_before = s_n;
-            if (n_before + 256 > kTileListCap) break;
-            const int k = k_next + tid;
-            bool hit = false;
-            FinalKp f;
-            if (k < K) {
-                f = fin[k];
-                const int l = f.octave * D + f.index;
-                hit = plan->nearest_level[l] == level && (int)f.x + kRegion > ex0 &&
-                      (int)f.x - kRegion < ex0 + kExt && (int)f.y + kRegion > ey0 &&
-                      (int)f.y - kRegion < ey0 + kExt;
-            }
-            const unsigned long long m = __ballot(hit);
-            if (lane == 0) s_wcnt[wv] = __popcll(m);
-            __syncthreads();
-            int off = n_before;
-            for (int q = 0; q < wv; ++q) off += s_wcnt[q];
-            if (hit) {
-                const int p = off + __popcll(m & ((1ull << lane) - 1ull));
-                s_list[p] = (unsigned short)k;
-                s_fin[p] = compact(f);
-                s_flag[p] = flags_of(f);
-            }
-            __syncthreads();
-            if (tid == 0) s_n = n_before + s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-            __syncthreads();
-        }
-        run_segment(s_n);
-        __syncthreads();
-        k0 = k_next;
-    }
-}
-
 // =====================================================================================================
-// Wave-per-keypoint form (the default).  The tile kernel above walks an ordered list per 64x64 tile, so a keypoint near a
-// tile border is processed by up to four workgroups and every tile pays barriers per batch of its list.  Here ONE WAVE
+// Wave-per-keypoint form (the default).  (Round 1's kernel gave a workgroup a 48x48 tile with an 8 px fringe in LDS and
+// walked the tile's ordered keypoint list in batches of eight: a keypoint near a tile border was processed by up to four
+// workgroups and every tile paid two barriers per batch - 1.23 against 0.85 ms; removed in round 4.)  Here ONE WAVE
 // owns ONE keypoint p and recomputes, for the 256 pixels of p's window, the float chains the reference's in-place updates
 // build (sift.cpp:80-92): a pixel's value when p's histograms are taken is
 //     initial value (+ orientation_q, + weighting(window-local position in q))   for every keypoint q that precedes p in the
@@ -664,6 +209,51 @@ __device__ __forceinline__ unsigned quad_bcast_u(unsigned v) {
 __device__ __forceinline__ float quad_prev_f(float v) {
     return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x93 /* quad_perm [3,0,1,2] */, 0xF, 0xF, true));
 }
+
+// The 16 cell histograms of one keypoint (alg::orientationHistogram8, algorithms.cpp:135-150), shared by the descriptor kernels
+// below.  A DPP quad holds one 4x4 cell: lane y of the quad has the cell's row y, val[i] / bin[i] = its sample at x = i; lane l
+// of the quad accumulates the bins b0 = 2l and b1 = 2l + 1 over the 16 samples in the reference's order (x outer, y inner).
+// Written out in assembly: the four bins of a column (one per lane of the quad) are packed into one dword (byte y = bin of row
+// y: a shift and two DPP ORs per column), so that a sample costs two SDWA byte compares, two DPP additions (val of row y + h)
+// and two selects - six instructions, none of them a move; the compiler's form took nine (its packed additions keep the DPP
+// broadcasts as separate moves, with wait states in front of them).
+#define SIFT_HIST_SAMPLE(Y)                                                                                  \
+    "v_cmp_eq_u32_sdwa vcc, %[p], %[b0] src0_sel:BYTE_" #Y " src1_sel:DWORD\n\t"                              \
+    "v_add_f32_dpp %[t], %[v], %[h0] quad_perm:[" #Y "," #Y "," #Y "," #Y "] row_mask:0xf bank_mask:0xf\n\t"  \
+    "v_cndmask_b32 %[h0], %[h0], %[t], vcc\n\t"                                                               \
+    "v_cmp_eq_u32_sdwa vcc, %[p], %[b1] src0_sel:BYTE_" #Y " src1_sel:DWORD\n\t"                              \
+    "v_add_f32_dpp %[t], %[v], %[h1] quad_perm:[" #Y "," #Y "," #Y "," #Y "] row_mask:0xf bank_mask:0xf\n\t"  \
+    "v_cndmask_b32 %[h1], %[h1], %[t], vcc\n\t"
+__device__ __forceinline__ void cell_histograms(const float (&val)[4], const unsigned (&bin)[4], int lane, unsigned b0, unsigned b1,
+                                                float& h0, float& h1) {
+    const unsigned sh = 8u * (unsigned)(lane & 3);
+    unsigned pk[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pk[i] = bin[i] << sh;
+    // byte y of pk[i] = bin of (column i, row y), in every lane of the quad.  (A DPP operand must not have been written by
+    // the two instructions before: the four columns are interleaved, with explicit wait states at the block's start.)
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_or_b32_dpp %[p0], %[p0], %[p0] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_or_b32_dpp %[p1], %[p1], %[p1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_or_b32_dpp %[p2], %[p2], %[p2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_or_b32_dpp %[p3], %[p3], %[p3] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_or_b32_dpp %[p0], %[p0], %[p0] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_or_b32_dpp %[p1], %[p1], %[p1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_or_b32_dpp %[p2], %[p2], %[p2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_or_b32_dpp %[p3], %[p3], %[p3] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        : [p0] "+v"(pk[0]), [p1] "+v"(pk[1]), [p2] "+v"(pk[2]), [p3] "+v"(pk[3]));
+    float t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        asm volatile(
+            "s_nop 1\n\t"
+            SIFT_HIST_SAMPLE(0) SIFT_HIST_SAMPLE(1) SIFT_HIST_SAMPLE(2) SIFT_HIST_SAMPLE(3)
+            : [h0] "+v"(h0), [h1] "+v"(h1), [t] "=&v"(t)
+            : [p] "v"(pk[i]), [v] "v"(val[i]), [b0] "v"(b0), [b1] "v"(b1)
+            : "vcc");
+}
+#undef SIFT_HIST_SAMPLE
 
 __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* __restrict__ plan, DescGridLevel lv,
                                                                  const int* __restrict__ cell_off,
@@ -899,18 +489,7 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
         // ---- 16 cell histograms: a quad holds one cell; samples in x-outer / y-inner order ------------------------------
         float h0 = 0.0f, h1 = 0.0f;
         if (!(dbg & 2)) {
-#define SIFT_DESC_SAMPLE(I, Y)                                            \
-            {                                                             \
-                const float v = quad_bcast_f<Y>(val[I]);                  \
-                const unsigned b = quad_bcast_u<Y>(bin[I]);               \
-                h0 = (b == b0) ? h0 + v : h0;                             \
-                h1 = (b == b1) ? h1 + v : h1;                             \
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                SIFT_DESC_SAMPLE(i, 0) SIFT_DESC_SAMPLE(i, 1) SIFT_DESC_SAMPLE(i, 2) SIFT_DESC_SAMPLE(i, 3)
-            }
-#undef SIFT_DESC_SAMPLE
+            cell_histograms(val, bin, lane, b0, b1, h0, h1);
             // alg::normalizeVector (algorithms.cpp:210-223): length = ((0 + b0) + b1) + ... + b7, handed along the quad
             float run = 0.0f;
             run += h0; run += h1;                       // lane 0 of the quad: bins 0, 1
@@ -959,26 +538,520 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
     }   // units
 }
 
+// =====================================================================================================
+// Tile-per-wave form (round 4, the default).  The wave-per-keypoint kernel above recomputes, for every keypoint, the float
+// chains of its 256 window pixels from the initial maps: a keypoint's additions are applied once for itself and once more
+// for each of the ~8.5 later keypoints whose window overlaps its own, and three quarters of those lane-pixel updates fall
+// outside the neighbour's window.  Here ONE WAVE owns a core of 32 x CH pixels of keypoint locations ("home" keypoints)
+// and keeps the (orientation, magnitude) pairs of the (32 + 15) x (CH + 15) pixels their windows can touch in ITS OWN
+// slice of LDS (~18 KB; a workgroup is one wave, eight of them share a CU).  It sorts the keypoints whose window meets
+// that extended tile by vector index (they are found through the same grid of 16 px cells: 4 x (CH/16 + 2) cells, one
+// run of consecutive records per cell row) and applies them IN VECTOR ORDER, exactly as the reference's in-place
+// updates (sift.cpp:80-92):
+//   * every keypoint's update is made in ITS OWN window frame: lane l owns the pixels (l & 15, (l >> 4) + 4 i), i = 0..3,
+//     of the window, so the weighting value it adds (sift.cpp:87-90: window-local) is the same register for every keypoint
+//     of the image - no table - and an update is four 8-byte LDS reads, eight additions and four 8-byte LDS writes; the
+//     LDS executes a wave's operations in order, which IS the chain order, and no two lanes of an instruction share a
+//     pixel.  (LDS float atomics would need no wait at all, and ds_add_f32 is the same round-to-nearest-even add as
+//     v_add_f32, denormals kept - tools/probe/lds_atomic_probe.hip -, but it takes ~190 cycles per wave-instruction,
+//     22 times the read-add-write form: tools/probe/lds_rate_probe.hip.)  A window that leaves the extended tile is
+//     clipped per pixel (the rest of it belongs to the chains of other tiles): the clipped pixels' reads and writes go to a
+//     scratch line instead, so the code is branch-free;
+//   * after a home keypoint's own update its window is read back in the histogram layout of the kernel above (lane = four
+//     consecutive x of one row, a DPP quad = the four rows of a 4x4 cell) and the 16 cell histograms, the L1
+//     normalisation and the stores are that kernel's.
+// A keypoint is applied in the ~3.75 tiles (CH = 32) its window can meet instead of ~9.5 neighbours' waves, at about half the
+// instructions a time, and every lane-pixel update is a real one.  The row stride of the tile is 47 pixels (odd): an update
+// instruction (two window rows of 16 consecutive pixels per half-wave) and a read-back (16 rows x 2 column groups) meet a
+// bank at most twice.
+// Keypoints after the last home keypoint of the vector cannot change anything the tile emits and are dropped before the
+// sort.  Neighbourhoods of more than kDtListCap records (the blob lattice of the B-7 pin) take the records in order by
+// repeated wave minimum instead of the sorted list.
+// =====================================================================================================
+constexpr int kDtListCap = 192;
+constexpr int kDtRecs = kDtListCap / 64;   // records a lane holds during the sort
+constexpr int kDtCW = 32;                  // core width in pixels of keypoint location (two grid cells)
+constexpr int kDtS = kDtCW + 15;           // row stride of the tile in LDS = its width (odd: see above)
+
+__device__ __forceinline__ int wave_max_int(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp((int)0x80000000, v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v = max(v, __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v = max(v, __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x141, 0xf, 0xf, false));   // row_half_mirror
+    v = max(v, __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x140, 0xf, 0xf, false));   // row_mirror
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// the compiler must not move LDS accesses across this point (the hardware keeps a wave's LDS operations in order)
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
+
+template <int CH>
+__global__ __launch_bounds__(64) void descriptor_tile_kernel(const DevPlan* __restrict__ plan, DescGridLevel lv,
+                                                             const int* __restrict__ cell_off,
+                                                             const FinalKp* __restrict__ pool, int pool_cap,
+                                                             const long long* __restrict__ out_base,
+                                                             sift_hip_keypoint* __restrict__ kp_out,
+                                                             float* __restrict__ desc_out, long long out_cap, int n_images,
+                                                             int chunks, int* __restrict__ sched) {
+    constexpr int CW = kDtCW, S = kDtS, EW = CW + 15, EH = CH + 15;
+    constexpr int NCX = CW / 16, NCY = CH / 16, NROW = NCY + 2;
+    constexpr int TRASH = EH * S;                    // 32 scratch pixels behind the tile (clipped window pixels)
+    constexpr int R4 = 12;                           // 16-byte groups per tile row and map (the 48th float is dropped)
+    constexpr int NLOAD = 3 * ((EH + 15) / 16);      // groups per lane: 16 rows x 4 groups per wave-instruction
+    __shared__ float2 s_tile[EH * S + 32];           // (orientation, magnitude) per pixel
+    __shared__ uint2 s_list[kDtListCap];             // influencing keypoints in vector order: orientation bits, x | y << 16 | home << 15
+    __shared__ unsigned s_kio[kDtListCap];           // same order: vector index k | octave << 16 | index << 24 (read for home keypoints)
+    static_assert(sizeof(s_tile) + sizeof(s_list) + sizeof(s_kio) <= 20480, "eight waves per CU");
+    static_assert(sizeof(unsigned) * (kDtListCap + 4) <= sizeof(s_tile), "the sort's keys borrow the tile");
+    unsigned* const s_keys = reinterpret_cast<unsigned*>(s_tile);
+
+    const int lane = threadIdx.x;
+    const int w = lv.w, h = lv.h, D = lv.dogs;
+    const int colU = lane & 15, rowU = lane >> 4;             // update frame: column lane & 15, rows (lane >> 4) + 4 i
+    const int baseU = rowU * S + colU;
+    const int baseH = (lane & 15) * S + 4 * (lane >> 4);      // histogram frame: row lane & 15, columns 4 (lane >> 4) + i
+    const int trash = TRASH + (lane & 31);
+    const unsigned b0 = 2u * (unsigned)(lane & 3), b1 = b0 + 1u;
+    const int ntx = (w + CW - 1) / CW, nty = (h + CH - 1) / CH;
+    const int tiles = ntx * nty;
+    const bool vec = (w & 3) == 0 && ((((uintptr_t)lv.mag | (uintptr_t)lv.ori) & 15u) == 0);
+    // The 16-byte groups of the tile this lane fetches (constant over the launch).  A wave-instruction takes 16 rows x 4
+    // consecutive groups: its 16 lanes that store together (8-byte LDS stores, one pixel of each group at a time) then hit 16
+    // different rows, 94 dwords apart - all banks distinct; 16 consecutive groups of one row would meet every bank four times.
+    int grp_row[NLOAD], grp_c4[NLOAD];
+#pragma unroll
+    for (int j = 0; j < NLOAD; ++j) {
+        grp_row[j] = 16 * (j / 3) + (lane & 15);
+        grp_c4[j] = 4 * (j % 3) + (lane >> 4);
+    }
+    // DoG scales by octave * D + index, for the records of the emitted keypoints: lane l holds entry l (a lookup is one
+    // v_readlane; a scalar load inside the walk would make every LDS wait of the loop a wait for everything)
+    const float scale_tbl = plan->dog_scale[min(lane, kMaxLevels - 1)];
+
+    // Work units = (image, chunk of the image's tiles) as in the kernel above: the waves of one XCD sweep the same image
+    // in tile order, so the 15-pixel overlap of neighbouring tiles comes out of that XCD's L2.
+    // Inside a unit the tiles are DRAWN (one counter per unit, each on a cache line of its own, zeroed before the launch):
+    // a tile's cost varies with its keypoints - the top-left corner of the level also holds the keypoints of the coarser
+    // octaves (App. B-10) -, and dealt round-robin the slowest wave took half as long again as the average one.
+    const int xcd = (int)blockIdx.x & 7;
+    for (int unit = xcd; unit < n_images * chunks; unit += 8) {
+    const int img = unit / chunks, chunk = unit - img * chunks;
+    const int t_begin = (int)((long long)tiles * chunk / chunks), t_end = (int)((long long)tiles * (chunk + 1) / chunks);
+    int* const ctr = sched + 32 * unit;
+    auto draw = [&]() {   // lane 0 holds the drawn index; it is only looked at when the next tile starts
+        int v = 0;
+        if (lane == 0) v = atomicAdd(ctr, 1);
+        return v;
+    };
+    int drawn = draw();
+    if (t_begin + __builtin_amdgcn_readfirstlane(drawn) >= t_end) continue;
+    const int* __restrict__ coff = cell_off + (size_t)img * (size_t)(lv.cells_per_image + 1) + lv.cell_base;
+    const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
+    const float* __restrict__ gm = lv.mag + img_off;
+    const float* __restrict__ go = lv.ori + img_off;
+    const float* __restrict__ gg = lv.gauss + img_off;
+    const FinalKp* __restrict__ pl = pool + (size_t)img * (size_t)pool_cap;
+    const long long obase = out_base[img];
+    float wU[4];   // weighting(x, y) (sift.cpp:87-90) at this lane's four pixels of the update frame
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wU[i] = lv.w16[(size_t)img * 256 + (size_t)(colU + 16 * (rowU + 4 * i))];
+
+    for (;;) {
+        const int t = t_begin + __builtin_amdgcn_readfirstlane(drawn);
+        if (t >= t_end) break;
+        drawn = draw();
+        const int ty = t / ntx, tx = t - ty * ntx;
+        const int X0 = tx * CW, Y0 = ty * CH, ex0 = X0 - kRegion, ey0 = Y0 - kRegion;
+        const int hcx = tx * NCX, hcy = ty * NCY;
+        // ---- the cells: home records (skip the tile if none), then the runs of the influence region --------------
+        {
+            const int hx1 = min(hcx + NCX, lv.cw);
+            int n_home_rec = 0;
+#pragma unroll
+            for (int j = 0; j < NCY; ++j) {
+                const int cy = min(hcy + j, lv.ch - 1);
+                const int a = coff[cy * lv.cw + hcx], b = coff[cy * lv.cw + hx1];
+                n_home_rec += hcy + j < lv.ch ? b - a : 0;
+            }
+            if (n_home_rec == 0) continue;
+        }
+        int rs[NROW], rp[NROW + 1];   // first record of each run, records before it
+        rp[0] = 0;
+        {
+            const int c0 = max(hcx - 1, 0), c1 = min(hcx + NCX, lv.cw - 1);
+#pragma unroll
+            for (int j = 0; j < NROW; ++j) {
+                const int cy = hcy - 1 + j;
+                const int cyc = min(max(cy, 0), lv.ch - 1);
+                const int a = coff[cyc * lv.cw + c0], b = coff[cyc * lv.cw + c1 + 1];
+                rs[j] = a;
+                rp[j + 1] = rp[j] + ((cy >= 0 && cy < lv.ch) ? b - a : 0);
+            }
+        }
+        const int T = rp[NROW];
+        auto entry_of = [&](int i) {
+            int e = rs[0] + i;
+#pragma unroll
+            for (int j = 1; j < NROW; ++j) e = i >= rp[j] ? rs[j] + (i - rp[j]) : e;
+            return e;
+        };
+        auto influences = [&](unsigned xy) {   // its window meets the extended tile
+            return (unsigned)((int)(xy & 0xffffu) - (X0 - 15)) < (unsigned)(CW + 30) && (unsigned)((int)(xy >> 16) - (Y0 - 15)) < (unsigned)(CH + 30);
+        };
+        auto is_home = [&](unsigned xy) {
+            return (unsigned)((int)(xy & 0xffffu) - X0) < (unsigned)CW && (unsigned)((int)(xy >> 16) - Y0) < (unsigned)CH;
+        };
+
+        // ---- the tile's pixels: fetched into registers now, stored behind the sort (whose keys borrow the tile) ----
+        f4u to[NLOAD], tm[NLOAD];
+        if (vec) {
+#pragma unroll
+            for (int j = 0; j < NLOAD; ++j) {
+                to[j] = (f4u)(0.0f); tm[j] = (f4u)(0.0f);
+                const int X = ex0 + 4 * grp_c4[j], Y = ey0 + grp_row[j];
+                if (grp_row[j] < EH && X >= 0 && X < w && Y >= 0 && Y < h) {   // ex0 and w are multiples of 4
+                    const size_t o = (size_t)Y * (size_t)w + (size_t)X;
+                    to[j] = *reinterpret_cast<const f4u*>(go + o);
+                    tm[j] = *reinterpret_cast<const f4u*>(gm + o);
+                }
+            }
+        }
+        auto store_tile = [&]() {
+            if (vec) {
+#pragma unroll
+                for (int j = 0; j < NLOAD; ++j)
+                    if (grp_row[j] < EH) {
+                        float2* d = s_tile + grp_row[j] * S + 4 * grp_c4[j];
+                        d[0] = make_float2(to[j].x, tm[j].x);
+                        d[1] = make_float2(to[j].y, tm[j].y);
+                        d[2] = make_float2(to[j].z, tm[j].z);
+                        if (grp_c4[j] < R4 - 1) d[3] = make_float2(to[j].w, tm[j].w);   // the row's 48th pixel does not exist
+                    }
+            } else {
+                for (int idx = lane; idx < EH * EW; idx += 64) {
+                    const int ry = idx / EW, rx = idx - ry * EW;
+                    const int X = ex0 + rx, Y = ey0 + ry;
+                    if (X >= 0 && X < w && Y >= 0 && Y < h) {
+                        const size_t o = (size_t)Y * (size_t)w + (size_t)X;
+                        s_tile[ry * S + rx] = make_float2(go[o], gm[o]);
+                    }
+                }
+            }
+            lds_order();
+        };
+
+        // ---- one keypoint of the ordered walk -------------------------------------------------------------------------
+        // xy (x | y << 16) and home are wave-uniform.  An update is split in two so that the walk can run the address
+        // arithmetic of keypoint e + 1 while the LDS reads of keypoint e are on their way:
+        //   addresses(): the tile indices of this lane's four pixels of the window (update frame), the scratch line for pixels
+        //   that a clipped window leaves outside the tile;  then four 8-byte reads, add(), four 8-byte writes.
+        auto addresses = [&](unsigned xy, bool home, int (&a)[4]) {
+            const int wx = (int)(xy & 0xffffu) - kRegion - ex0, wy = (int)(xy >> 16) - kRegion - ey0;   // window origin inside the tile: -15 .. CW + 14
+            const int at = wy * S + wx + baseU;
+            if (home) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = at + 4 * i * S;
+            } else {   // clipped: only the pixels of the window that lie in the tile
+                const bool colok = (unsigned)(wx + colU) < (unsigned)EW;
+                const int ry = wy + rowU;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = (colok && (unsigned)(ry + 4 * i) < (unsigned)EH) ? at + 4 * i * S : trash;
+            }
+        };
+        auto add = [&](float theta, float2 (&v)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i].x = v[i].x + theta;    // sift.cpp:82
+                v[i].y = v[i].y + wU[i];    // sift.cpp:90
+            }
+        };
+        auto update = [&](float theta, unsigned xy, bool home) {   // the whole update at once (crowded path)
+            int a[4];
+            addresses(xy, home, a);
+            float2 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = s_tile[a[i]];
+            add(theta, v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_tile[a[i]] = v[i];
+            lds_order();
+        };
+        // the home keypoint whose update was just made: histograms of its window as the reference sees it now
+        // om = the window's (orientation, magnitude) pairs read back in the histogram frame (window_back);
+        // kio: vector index | octave << 16 | index << 24;  vg4 = its window of the Gaussian level (histogram frame)
+        auto window_back = [&](unsigned xy, float2 (&om)[4]) {
+            const float2* p = s_tile + ((int)(xy >> 16) - kRegion - ey0) * S + ((int)(xy & 0xffffu) - kRegion - ex0) + baseH;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) om[i] = p[i];
+        };
+        auto emit = [&](float theta, unsigned xy, unsigned kio, const float2 (&om)[4], const f4u& vg4) {
+            const int px = (int)(xy & 0xffffu), py = (int)(xy >> 16);
+            float val[4];
+            unsigned bin[4];
+            {
+                const float vg[4] = {vg4.x, vg4.y, vg4.z, vg4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    val[i] = om[i].y * vg[i];          // algorithms.cpp:147
+                    bin[i] = hist8_bin(om[i].x);
+                }
+            }
+            // ---- 16 cell histograms: a quad holds one cell; samples in x-outer / y-inner order -------------------------
+            float h0 = 0.0f, h1 = 0.0f;
+            cell_histograms(val, bin, lane, b0, b1, h0, h1);
+            // alg::normalizeVector (algorithms.cpp:210-223): length = ((0 + b0) + b1) + ... + b7, handed along the quad
+            float run = 0.0f;
+            run += h0; run += h1;
+            float acc = run;
+#pragma unroll
+            for (int step = 1; step < 4; ++step) {
+                const float prev = quad_prev_f(acc);
+                float tt = prev;
+                tt += h0; tt += h1;
+                acc = ((lane & 3) == step) ? tt : acc;
+            }
+            const float length = quad_bcast_f<3>(acc);
+            if (!(length == 0.0f)) {
+                h0 = h0 / length;
+                h1 = h1 / length;
+            }
+            const long long ok = obase + (long long)(kio & 0xffffu);
+            const unsigned lvl_idx = ((kio >> 16) & 0xffu) * (unsigned)D + (kio >> 24);
+            const float my_scale = lvl_idx < 64u ? __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(scale_tbl), (int)lvl_idx))
+                                                 : plan->dog_scale[lvl_idx];
+            if (ok < out_cap) {   // (the output arrays are sized before the final counts reach the host: see run_batch)
+                *reinterpret_cast<float2*>(desc_out + (size_t)ok * 128 + (size_t)(2 * lane)) = make_float2(h0, h1);
+                if (lv.wire_sums != nullptr) {
+                    // the counting pass of the sparse wire format (kernels_wire.hip: wire_count_kernel) while the 128 floats
+                    // are still in registers
+                    const bool s0 = __float_as_uint(h0) != 0u, odd7 = (lane & 3) == 3;
+                    const bool s1 = !odd7 && __float_as_uint(h1) != 0u;
+                    const int nset = __popcll(__ballot(s0)) + __popcll(__ballot(s1));
+                    const unsigned long long bin7 = __ballot(odd7 && __float_as_uint(h1) != 0u);
+                    if (lane == 0) {
+                        atomicAdd(&lv.wire_sums[1 + (ok >> 6)], nset);
+                        if (bin7 != 0ull) atomicOr(&lv.wire_sums[0], 1);
+                    }
+                }
+                if (lane == 0) {
+                    const unsigned oct = (kio >> 16) & 0xffu, idx = kio >> 24;
+                    sift_hip_keypoint r;
+                    r.scale = my_scale;
+                    r.orientation = theta;
+                    r.x = (uint16_t)px; r.y = (uint16_t)py;
+                    r.octave = (uint16_t)oct; r.index = (uint16_t)idx;
+                    r.filtered = 0; r.has_descriptor = 1; r.reserved = 0;
+                    kp_out[ok] = r;
+                }
+            }
+        };
+        auto load_gauss = [&](unsigned xy) {   // histogram frame; the window of a grid keypoint lies inside the image
+            const size_t o = (size_t)((int)(xy >> 16) - kRegion + (lane & 15)) * (size_t)w + (size_t)((int)(xy & 0xffffu) - kRegion + 4 * (lane >> 4));
+            return *reinterpret_cast<const f4u*>(gg + o);
+        };
+        // a record's vector index fits 16 bits (u16_t size, sift.cpp:41,53), octave and index 8 bits each (kMaxOctaves, kMaxDogs)
+        auto kio_of = [](const uint4& c) { return (c.x & 0xffffu) | ((c.w & 0xffu) << 16) | (((c.w >> 16) & 0xffu) << 24); };
+        if (T <= kDtListCap) {
+            // ---- the records: kDtRecs per lane -------------------------------------------------------------------------
+            uint4 rec[kDtRecs];
+            bool hm[kDtRecs], pass[kDtRecs];
+            int khome = -1;
+#pragma unroll
+            for (int u = 0; u < kDtRecs; ++u) {
+                const int i = lane + 64 * u;
+                rec[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (i < T) rec[u] = *reinterpret_cast<const uint4*>(&pl[entry_of(i)]);
+                pass[u] = i < T && influences(rec[u].z);
+                hm[u] = pass[u] && is_home(rec[u].z);
+                if (hm[u]) khome = max(khome, (int)rec[u].x);
+            }
+            const int kmax = wave_max_int(khome);   // >= 0: the home cells hold a record
+            // ---- which of them matter: the home keypoints, and every earlier keypoint whose window overlaps a home
+            // keypoint's (an addition no emitted window ever sees need not be made).  The home keypoints' (index, x | y << 16)
+            // pairs go to LDS (they borrow the tile) and every lane tests its records against them.
+            int nh = 0;
+            {
+                int hp[kDtRecs];
+#pragma unroll
+                for (int u = 0; u < kDtRecs; ++u) {
+                    const unsigned long long m = __ballot(hm[u]);
+                    hp[u] = nh + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    nh += __popcll(m);
+                }
+#pragma unroll
+                for (int u = 0; u < kDtRecs; ++u)
+                    if (hm[u]) *reinterpret_cast<uint2*>(s_keys + 2 * hp[u]) = make_uint2(rec[u].x, rec[u].z);
+                if (lane == 0) *reinterpret_cast<uint2*>(s_keys + 2 * nh) = make_uint2(0u, 0u);   // the last 16-byte read's second half: index 0 is later than nothing
+                lds_order();
+                bool need[kDtRecs];
+#pragma unroll
+                for (int u = 0; u < kDtRecs; ++u) need[u] = hm[u];
+                for (int j = 0; j < nh; j += 2) {
+                    const uint4 h2 = *reinterpret_cast<const uint4*>(s_keys + 2 * j);
+#pragma unroll
+                    for (int u = 0; u < kDtRecs; ++u) {
+                        const int qx = (int)(rec[u].z & 0xffffu), qy = (int)(rec[u].z >> 16);
+                        need[u] = need[u] || (h2.x > rec[u].x && (unsigned)(qx - (int)(h2.y & 0xffffu) + 15) < 31u && (unsigned)(qy - (int)(h2.y >> 16) + 15) < 31u) ||
+                                  (h2.z > rec[u].x && (unsigned)(qx - (int)(h2.w & 0xffffu) + 15) < 31u && (unsigned)(qy - (int)(h2.w >> 16) + 15) < 31u);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kDtRecs; ++u) pass[u] = pass[u] && need[u] && (int)rec[u].x <= kmax;
+                lds_order();
+            }
+            // ---- sort: ranked by counting the smaller keys ------------------------------------------------------------------
+            int n = 0, pos[kDtRecs];
+#pragma unroll
+            for (int u = 0; u < kDtRecs; ++u) {
+                const unsigned long long m = __ballot(pass[u]);
+                pos[u] = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                n += __popcll(m);
+            }
+#pragma unroll
+            for (int u = 0; u < kDtRecs; ++u)
+                if (pass[u]) s_keys[pos[u]] = rec[u].x;
+            if (lane < 4) s_keys[n + lane] = 0xffffffffu;   // the last 16-byte read may run past the keys: never smaller
+            lds_order();
+            int rank[kDtRecs];
+#pragma unroll
+            for (int u = 0; u < kDtRecs; ++u) rank[u] = 0;
+            for (int ch = 0; ch < n; ch += 4) {
+                const uint4 k4 = *reinterpret_cast<const uint4*>(s_keys + ch);
+#pragma unroll
+                for (int u = 0; u < kDtRecs; ++u)
+                    rank[u] += (k4.x < rec[u].x ? 1 : 0) + (k4.y < rec[u].x ? 1 : 0) + (k4.z < rec[u].x ? 1 : 0) + (k4.w < rec[u].x ? 1 : 0);
+            }
+#pragma unroll
+            for (int u = 0; u < kDtRecs; ++u)
+                if (pass[u]) {
+                    s_list[rank[u]] = make_uint2(rec[u].y, rec[u].z | (hm[u] ? 0x8000u : 0u));   // x < 32768 (App. B-17)
+                    s_kio[rank[u]] = kio_of(rec[u]);
+                }
+            lds_order();
+            store_tile();   // (the keys are dead: every lane's reads of them have returned)
+            // which entries of the ordered list are home keypoints: one bit each, in scalar registers
+            unsigned long long hmask[kDtRecs];
+#pragma unroll
+            for (int u = 0; u < kDtRecs; ++u) {
+                const int e = lane + 64 * u;
+                hmask[u] = __ballot(e < n && (s_list[min(e, kDtListCap - 1)].y & 0x8000u) != 0u);
+            }
+            auto next_home = [&](int from) {   // first home entry at or behind `from`, n if none
+                int r = n;
+#pragma unroll
+                for (int u = kDtRecs - 1; u >= 0; --u) {
+                    const int sh = from - 64 * u;
+                    const unsigned long long m = sh <= 0 ? hmask[u] : (sh >= 64 ? 0ull : hmask[u] & (~0ull << sh));
+                    if (m != 0ull) r = 64 * u + (int)__builtin_ctzll(m);
+                }
+                return r;
+            };
+            // the first home keypoint's Gaussian window; the following ones are fetched one home keypoint ahead
+            int hnext = next_home(0);
+            f4u gnext = load_gauss((unsigned)__builtin_amdgcn_readfirstlane((int)s_list[hnext].y) & 0xffff7fffu);
+            // ---- the walk, software-pipelined: while the LDS reads of keypoint e are on their way the addresses of keypoint
+            // e + 1 are worked out; its reads are issued right behind the writes of keypoint e (the LDS keeps a wave's
+            // operations in order, so they see them) and BEFORE the histograms of keypoint e, which hide their latency; list
+            // entries are fetched two keypoints ahead.
+            auto decode = [](const uint2& q, unsigned& xy, bool& home) {
+                const unsigned xyf = (unsigned)__builtin_amdgcn_readfirstlane((int)q.y);
+                home = (xyf & 0x8000u) != 0u;
+                xy = xyf & 0xffff7fffu;
+            };
+            unsigned xy_c, kio_c;
+            bool home_c;
+            int a_c[4];
+            float th_c;
+            float2 v[4];
+            {
+                const uint2 q = s_list[0];
+                kio_c = s_kio[0];
+                decode(q, xy_c, home_c);
+                th_c = __uint_as_float(q.x);
+                addresses(xy_c, home_c, a_c);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = s_tile[a_c[i]];
+            }
+            uint2 qn = s_list[min(1, n - 1)];
+            unsigned kion = s_kio[min(1, n - 1)];
+            for (int e = 0; e < n; ++e) {
+                // keypoint e + 1 (the last keypoint once more behind the end: read, never written)
+                unsigned xy_n;
+                bool home_n;
+                int a_n[4];
+                decode(qn, xy_n, home_n);
+                const float th_n = __uint_as_float(qn.x);
+                const unsigned kio_n = kion;
+                addresses(xy_n, home_n, a_n);
+                qn = s_list[min(e + 2, n - 1)];
+                kion = s_kio[min(e + 2, n - 1)];
+                // keypoint e: additions and writes
+                add(th_c, v);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s_tile[a_c[i]] = v[i];
+                lds_order();
+                float2 om[4];
+                if (home_c) window_back(xy_c, om);
+                lds_order();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = s_tile[a_n[i]];
+                lds_order();
+                if (home_c) {
+                    const f4u gcur = gnext;
+                    hnext = next_home(e + 1);
+                    if (hnext < n) gnext = load_gauss((unsigned)__builtin_amdgcn_readfirstlane((int)s_list[hnext].y) & 0xffff7fffu);
+                    emit(th_c, xy_c, (unsigned)__builtin_amdgcn_readfirstlane((int)kio_c), om, gcur);
+                }
+                xy_c = xy_n; home_c = home_n; th_c = th_n; kio_c = kio_n;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a_c[i] = a_n[i];
+            }
+            lds_order();   // the list and the tile are rewritten for the wave's next tile
+        } else {
+            // ---- crowded neighbourhood: the records in vector order by repeated wave minimum ---------------------
+            store_tile();
+            int khome = -1;
+            for (int i = lane; i < T; i += 64) {
+                const uint4 c = *reinterpret_cast<const uint4*>(&pl[entry_of(i)]);
+                if (is_home(c.z)) khome = max(khome, (int)c.x);
+            }
+            const int kmax = wave_max_int(khome);
+            int last = -1;
+            for (;;) {
+                int bk = 0x7fffffff;
+                unsigned bxy = 0u, bth = 0u, bio = 0u;
+                for (int i = lane; i < T; i += 64) {
+                    const uint4 c = *reinterpret_cast<const uint4*>(&pl[entry_of(i)]);
+                    if (influences(c.z) && (int)c.x > last && (int)c.x <= kmax && (int)c.x < bk) { bk = (int)c.x; bxy = c.z; bth = c.y; bio = kio_of(c); }
+                }
+                const int m = wave_min_nonneg(bk);
+                if (m == 0x7fffffff) break;
+                const int src = (int)__builtin_ctzll(__ballot(bk == m));
+                const unsigned xy = (unsigned)__builtin_amdgcn_readlane((int)bxy, src);
+                const unsigned th = (unsigned)__builtin_amdgcn_readlane((int)bth, src);
+                const unsigned kio = (unsigned)__builtin_amdgcn_readlane((int)bio, src);
+                const bool home = is_home(xy);
+                const float theta = __uint_as_float(th);
+                update(theta, xy, home);
+                if (home) {
+                    float2 om[4];
+                    window_back(xy, om);
+                    lds_order();
+                    emit(theta, xy, kio, om, load_gauss(xy));
+                }
+                last = m;
+            }
+            lds_order();
+        }
+    }
+    }   // units
+}
+
 void launch_w16(hipStream_t s, const DevPlan& plan, int level, const float* d_taps16, int radius16) {
     const int oct = level / (plan.dogs + 1);
     hipLaunchKernelGGL(w16_kernel, dim3((unsigned)plan.n_images), dim3(256), 0, s,
                        (const float*)plan.gauss[level], plan.w16[level], plan.w[oct], plan.h[oct], d_taps16,
                        radius16);
-}
-
-void launch_desc_binning(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const FinalKp* d_final,
-                         const int* d_final_cnt, int final_cap, int* d_tile_cnt, int* d_tile_off,
-                         int* d_tile_cur, FinalKp* d_pool, int pool_cap) {
-    const size_t nt = (size_t)plan.desc_tiles_per_image * (size_t)plan.n_images;
-    (void)hipMemsetAsync(d_tile_cnt, 0, nt * sizeof(int), s);
-    (void)hipMemsetAsync(d_tile_cur, 0, nt * sizeof(int), s);
-    const dim3 grid(64, (unsigned)plan.n_images);
-    hipLaunchKernelGGL(desc_bin_kernel<false>, grid, dim3(256), 0, s, d_plan, d_final, d_final_cnt, final_cap,
-                       d_tile_cnt, (const int*)d_tile_off, d_tile_cur, d_pool, pool_cap);
-    hipLaunchKernelGGL(desc_tile_scan_kernel, dim3((unsigned)plan.n_images), dim3(1024), 0, s,
-                       (const int*)d_tile_cnt, d_tile_off, plan.desc_tiles_per_image);
-    hipLaunchKernelGGL(desc_bin_kernel<true>, grid, dim3(256), 0, s, d_plan, d_final, d_final_cnt, final_cap,
-                       d_tile_cnt, (const int*)d_tile_off, d_tile_cur, d_pool, pool_cap);
 }
 
 // exclusive scan of the per-image final counts -> first output slot of every image
@@ -1009,21 +1082,6 @@ void launch_out_base(hipStream_t s, const int* d_final_cnt, int n, long long* d_
     hipLaunchKernelGGL(out_base_kernel, dim3(1), dim3(1024), 0, s, d_final_cnt, n, d_out_base);
 }
 
-void launch_descriptors(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level,
-                        const FinalKp* d_final, const int* d_final_cnt, int final_cap,
-                        const int* d_tile_cnt, const int* d_tile_off, const FinalKp* d_pool, int pool_cap,
-                        const long long* d_out_base, sift_hip_keypoint* d_kp_out, float* d_desc_out, long long out_cap,
-                        int dbg) {
-    const dim3 grid((unsigned)plan.desc_ntx[level], (unsigned)plan.desc_nty[level], (unsigned)plan.n_images);
-    DescLevel lv;
-    const int oct = level / (plan.dogs + 1);
-    lv.w = plan.w[oct]; lv.h = plan.h[oct]; lv.dogs = plan.dogs;
-    lv.tiles_per_image = plan.desc_tiles_per_image; lv.tile_base = plan.desc_tile_base[level];
-    lv.mag = plan.mag[level]; lv.ori = plan.ori[level]; lv.gauss = plan.gauss[level]; lv.w16 = plan.w16[level];
-    hipLaunchKernelGGL(descriptor_kernel, grid, dim3(256), 0, s, d_plan, lv, level, d_final, d_final_cnt, final_cap,
-                       d_tile_cnt, d_tile_off, d_pool, pool_cap, d_out_base, d_kp_out, d_desc_out, out_cap, dbg);
-}
-
 // grid of 16 px cells over the final keypoints of every image
 void launch_desc_grid(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const FinalKp* d_final, const int* d_final_cnt,
                       int final_cap, int* d_cell_cnt, int* d_cell_off, FinalKp* d_pool, int pool_cap, const long long* d_out_base,
@@ -1051,6 +1109,26 @@ void launch_descriptors_wave(hipStream_t s, const DevPlan* d_plan, const DevPlan
     const unsigned nwg = (dbg & 64) ? 512u : ((dbg & 32) ? 1024u : 2048u);   // timing only: fewer resident waves
     hipLaunchKernelGGL(descriptor_wave_kernel, dim3(nwg), dim3(256), 0, s, d_plan, lv, d_cell_off, d_pool, pool_cap, d_out_base,
                        d_kp_out, d_desc_out, out_cap, plan.n_images, chunks, dbg);
+}
+
+// ints of the tile kernel's draw counters (one per work unit, 128 bytes apart)
+size_t desc_tile_sched_ints(int n_images) { return (size_t)32 * (size_t)(n_images >= 8 ? n_images : 8 * n_images); }
+
+// tile-per-wave form: 2048 one-wave workgroups (eight per CU), whole images per XCD when there are at least 8
+void launch_descriptors_tile(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level, const int* d_cell_off,
+                             const FinalKp* d_pool, int pool_cap, const long long* d_out_base, sift_hip_keypoint* d_kp_out,
+                             float* d_desc_out, long long out_cap, int* d_wire_sums, int* d_sched) {
+    DescGridLevel lv;
+    const int oct = level / (plan.dogs + 1);
+    lv.w = plan.w[oct]; lv.h = plan.h[oct]; lv.dogs = plan.dogs;
+    lv.cw = plan.desc_cw[level]; lv.ch = plan.desc_ch[level]; lv.cell_base = plan.desc_cell_base[level];
+    lv.cells_per_image = plan.desc_cells_per_image;
+    lv.mag = plan.mag[level]; lv.ori = plan.ori[level]; lv.gauss = plan.gauss[level]; lv.w16 = plan.w16[level];
+    lv.wire_sums = d_wire_sums;
+    const int chunks = plan.n_images >= 8 ? 1 : 8;
+    launch_zero_ints(s, d_sched, desc_tile_sched_ints(plan.n_images));
+    hipLaunchKernelGGL(descriptor_tile_kernel<32>, dim3(2048), dim3(64), 0, s, d_plan, lv, d_cell_off, d_pool, pool_cap, d_out_base,
+                           d_kp_out, d_desc_out, out_cap, plan.n_images, chunks, d_sched);
 }
 
 // The runtime builds a translation unit's device code on the first launch of any of its kernels, and two host threads that make

@@ -222,28 +222,36 @@ def test_pipeline_parity(ctx, report_dir, case):
     assert rep["final"] > 0
 
 
-def test_pipeline_parity_tile_descriptor_kernel(ctx, report_dir):
-    """The descriptor stage's other form (option desc_kernel = 0: one workgroup per 48 px tile walking the ordered list)."""
-    ctx.set_option("desc_kernel", 0)
+DESC_KERNEL_DEFAULT = 1   # one wave per keypoint
+
+
+def test_pipeline_parity_tile_per_wave_descriptor_kernel(ctx, report_dir):
+    """The descriptor stage's other form (option desc_kernel = 2): one wave per 32x32 tile of keypoint locations keeps the
+    tile's (orientation, magnitude) pairs in LDS and applies the keypoints that touch it in vector order."""
+    ctx.set_option("desc_kernel", 2)
     try:
-        compare_run(ctx, synth_frame(640, 480, 1), 3, 4, False, "tile descriptor kernel 640x480", report_dir)
-        compare_run(ctx, synth_frame(400, 300, 6), 4, 2, False, "tile descriptor kernel 400x300 4 dogs", report_dir)
+        compare_run(ctx, synth_frame(640, 480, 1), 3, 4, False, "desc_kernel=2 640x480", report_dir)
+        compare_run(ctx, synth_frame(400, 300, 6), 4, 2, False, "desc_kernel=2 400x300 4 dogs", report_dir)
+        compare_run(ctx, synth_frame(333, 251, 9), 3, 3, False, "desc_kernel=2 333x251 (rows not 16-byte aligned)", report_dir)
+        compare_run(ctx, synth_frame(200, 150, 3), 3, 3, True, "desc_kernel=2 200x150 subpixel", report_dir)
+        compare_run(ctx, synth_frame(320, 240, 20), 3, 3, False, "desc_kernel=2 batch of 11", report_dir, batch_of=11)   # whole images per XCD
     finally:
-        ctx.set_option("desc_kernel", 1)
+        ctx.set_option("desc_kernel", DESC_KERNEL_DEFAULT)
 
 
-@pytest.mark.parametrize("desc_kernel", [1, 0])
+@pytest.mark.parametrize("desc_kernel", [1, 2])
 def test_pipeline_parity_dense_keypoints(ctx, report_dir, desc_kernel):
     """A lattice of blobs (sift_amd.synthetic.blob_frame): 0.06 keypoints per pixel, ~140 records in the 3x3 grid cells around
-    a keypoint and windows covered tens of times over: the wave-per-keypoint descriptor kernel's crowded-neighbourhood path
-    (more than 64 records) and long per-pixel chains (sift.cpp:80-92), bit for bit."""
+    a keypoint (~250 in the 4x4 cells around a 32x32 tile) and windows covered tens of times over: the descriptor kernels'
+    crowded-neighbourhood paths (more records than a wave holds / than the sorted list holds) and long per-pixel chains
+    (sift.cpp:80-92), bit for bit."""
     from sift_amd.synthetic import blob_frame
     ctx.set_option("desc_kernel", desc_kernel)
     try:
         rep = compare_run(ctx, blob_frame(352, 264, 5), 3, 3, False, f"blob lattice 352x264 desc_kernel={desc_kernel}", report_dir)
         assert rep["final"] > 3000
     finally:
-        ctx.set_option("desc_kernel", 1)
+        ctx.set_option("desc_kernel", DESC_KERNEL_DEFAULT)
 
 
 def test_pipeline_parity_two_pass_blur(ctx, report_dir):
