@@ -47,6 +47,7 @@ WORKLOADS = {
     "config5": (3840, 2160, 3, 5, 1, 8, "batch of {n} synthetic 3840x2160 frames per GPU, subpixel=1 (7680x4320 base), 5 octaves x 3 DoGs: "
                 "BASELINE config 5 at its nearest non-throwing parameters (6 octaves throws in the reference, App. B-14)"),
 }
+GATHER_SETTLE_STEPS = 16
 PROFILE_EVERY = 4            # the events cost ~10 us per blur launch (0.16 ms per step): sample
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 CPU_SAMPLE_FRAMES = 8
@@ -206,7 +207,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-every", type=int, default=PROFILE_EVERY, help="every N-th batch of a context carries the per-launch timing events of the roofline figure")
     ap.add_argument("--host-loop", choices=("stream", "dispatch"), default="stream",
-                    help="N = 1: 'stream' - each context's host thread takes its next step itself; 'dispatch' - one thread submits and collects (rounds 1 - 3)")
+                    help="'stream' - each context's host thread takes its next step itself (N > 1: and packs its lists for the gather thread); "
+                         "'dispatch' - one thread submits, collects and pushes to the gather (rounds 1 - 3)")
     ap.add_argument("--no-extras", action="store_true", help="skip the legs beside the headline: host-buffer rate, single-frame latency, live PMC traffic")
     ap.add_argument("--pmc-traffic", type=int, default=1, choices=[0, 1],
                     help="1 (default): roofline.traffic is measured live by two child passes of this bench under rocprofv3 --pmc "
@@ -226,6 +228,10 @@ def main():
     ap.add_argument("--rccl-loopback", action="store_true",
                     help="N = 1 only: every step's keypoint lists also travel through RCCL point-to-point to this same rank "
                          "(KeypointGather(loopback=True)): the N > 1 gather path, messages and sizes, on a one-GPU box")
+    ap.add_argument("--check-gather", action="store_true",
+                    help="N > 1, after the timed region: rank 0 runs every rank's frames itself, rank by rank, and compares the lists that "
+                         "arrived through the gather in the last step with its own - records, descriptor floats and per-image counts in "
+                         "global image order (seeds 1 .. N x frames); the line then carries gather_check")
     ap.add_argument("--pipeline-gate", type=int, default=1, choices=[0, 1],
                     help="pipeline depth > 1: 1 (default) joins the contexts with a phase gate (sift_amd/csrc/phase_gate.h); 0 leaves the interleaving to the GPU's queues")
     args = ap.parse_args()
@@ -290,7 +296,7 @@ def main():
     params = _lib.Params(DOGS, OCTAVES, SIGMA, K_SQRT2, SUBPIXEL)
     L = ctx._L
 
-    from sift_amd.gather import KeypointGather, device_results
+    from sift_amd.gather import GatherThread, KeypointGather, device_results
 
     # N > 1: the gather of step k (keypoint records + descriptors to rank 0 over RCCL point-to-point, never images) rides
     # behind the header of step k+1 and overlaps the kernels of the following steps, which run on the library's own
@@ -300,10 +306,13 @@ def main():
     keep = []               # tensors of the last pushes (the gather reads them until two pushes later)
     tickets = []            # submitted steps whose results have not been collected yet (at most depth - 1 between steps)
 
+    last_gathered = [None]  # the newest step that arrived on rank 0: (records_all, values_all, counts_all)
+
     def note(done):
         for recs, vals, counts in done:
             gathered[0] += 1
             gathered[1] += int(counts.sum())
+            last_gathered[0] = (recs, vals, counts)
 
     def collect(ticket):
         """Finish one step: wait for its batch, hand its keypoint lists to the gather (N > 1), free its slot."""
@@ -335,11 +344,79 @@ def main():
             total += collect(tickets.pop(0))
         return total
 
-    for _ in range(args.warmup):
-        step()
-    drain()
-    if gatherer is not None:     # the warm-up steps' lists are gathered too, before the clock starts
-        note(gatherer.flush())
+    slot_streams = [torch.cuda.Stream(device=dev) for _ in range(depth)] if gatherer is not None else []
+
+    def run_steps(n_steps):
+        """`n_steps` passes over the batch through the host loop the run was asked for; returns the keypoints they produced.
+        The warm-up takes the same path as the timed region (same threads, torch streams and allocator pools)."""
+        if not (args.host_loop == "stream" and depth > 1):
+            kps_ = 0
+            for _ in range(n_steps):
+                kps_ += step()
+            kps_ += drain()
+            if gatherer is not None:
+                note(gatherer.flush())
+            return kps_
+        # every context's host thread takes its next step itself (BatchPipeline.run_stream): no dispatching thread between the end
+        # of a context's batch and the start of its next.  N > 1: that thread also packs the batch's lists into the wire format
+        # (beside the other context's batch) and hands them to ONE gather thread, which pushes them in step order - the
+        # point-to-point messages of a rank are then issued by one thread, in the same order on every rank.
+        import threading
+        left, per_slot = [n_steps], [0] * depth
+        item = (d_frames.data_ptr(), nf, W, H, params)
+        seq_next, seq_of = [0], {}
+
+        def source():
+            if left[0] <= 0:
+                return None
+            left[0] -= 1
+            seq_of[threading.get_ident()] = seq_next[0]     # (called under run_stream's lock, on the thread that will run the batch)
+            seq_next[0] += 1
+            return item
+
+        # A torch stream per context thread: the message buffers are allocated on it and nothing else ever runs on it, so the
+        # thread never waits for the gather's transfers (torch's default stream, the gather thread's, is made to wait for every
+        # receive it posts; allocating there and synchronising it - what device_results does before it hands memory to the
+        # library's kernels - would park this thread behind the previous steps' messages).  (slot_streams, made once: the
+        # allocator keeps a pool per stream, and the warm-up is there to fill them.)
+        def sink(c, slot, _item):
+            total = c.total()
+            per_slot[slot] += total
+            if gatherer is None:
+                return
+            torch.cuda.set_device(local_rank)
+            with torch.cuda.stream(slot_streams[slot]):
+                rec_out = None
+                if args.wire == "sparse" and ((comm_dev.type != "cpu" and gatherer.rank != gatherer.dst) or loopback):
+                    rec_out = gatherer.records_buffer(total * 34)   # the records are packed straight into their message buffer
+                # the pack is only queued (side stream): this thread goes straight on to the context's next batch, whose descriptor
+                # stage waits for it on the device; the gather thread waits for it on the host before it pushes the lists
+                defer = args.wire == "sparse" and comm_dev.type != "cpu" and total > 0
+                kp, desc = device_results(c, total, dev, wire=args.wire, rec_out=rec_out, defer_pack=defer)
+            counts = c.counts().copy()
+            if comm_dev.type == "cpu":     # test backend: stage through host memory
+                kp, desc = kp.cpu(), desc.cpu()
+            gthread.put(seq_of[threading.get_ident()], kp, desc, counts, ready=c.pack_wait if defer else None)
+
+        gthread = GatherThread(gatherer, note, cuda_device=local_rank) if gatherer is not None else None
+        try:
+            pipe.run_stream(source, sink)
+        finally:
+            if gthread is not None:
+                gthread.close()      # pushes what is queued, flushes the gather, re-raises what the thread raised
+        return sum(per_slot)
+
+    # N > 1: the gather path reaches its steady state only after a dozen steps (the transport's first messages set up its
+    # connections, lists arrive two pushes after they went in, and torch's allocator has to have seen every message buffer of the
+    # cycle once: measured on one GPU through RCCL, 4.8 ms per step over the 20 steps behind a warm-up of 4, 2.98 behind one of 20).
+    # That is set-up, not a step of the workload: it is done before the W warm-up steps the caller asked for, untimed like them.
+    settle = GATHER_SETTLE_STEPS if gatherer is not None else 0
+    if settle:
+        run_steps(settle)
+        gatherer = KeypointGather(nf, comm_dev, dst=0, loopback=loopback)
+    if args.warmup:
+        run_steps(args.warmup)
+    if gatherer is not None:     # the warm-up steps' lists were gathered too, before the clock starts
         gatherer = KeypointGather(nf, comm_dev, dst=0, loopback=loopback)
         gatherer_t0 = (gathered[0], gathered[1])
     for c in ctxs:
@@ -349,30 +426,7 @@ def main():
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    kps = 0
-    if gatherer is None and args.host_loop == "stream" and depth > 1:
-        # every context's host thread takes its next step itself (BatchPipeline.run_stream): no dispatching thread between the end
-        # of a context's batch and the start of its next
-        left, per_slot = [args.steps], [0] * depth
-        item = (d_frames.data_ptr(), nf, W, H, params)
-
-        def source():
-            if left[0] <= 0:
-                return None
-            left[0] -= 1
-            return item
-
-        def sink(c, slot, _item):
-            per_slot[slot] += c.total()
-
-        pipe.run_stream(source, sink)
-        kps = sum(per_slot)
-    else:
-        for _ in range(args.steps):
-            kps += step()
-        kps += drain()
-    if gatherer is not None:
-        note(gatherer.flush())
+    kps = run_steps(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -412,10 +466,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": label.format(n=nf),
-                       "frames_per_gpu": nf, "frames_total": nf * world, "pipeline_depth": depth, "host_loop": (args.host_loop if (world == 1 and not loopback and depth > 1) else "dispatch"), "pipeline_gate": bool(args.pipeline_gate) and depth > 1, "keypoints_per_step": kps // max(args.steps, 1),
+                       "frames_per_gpu": nf, "frames_total": nf * world, "pipeline_depth": depth, "host_loop": (args.host_loop if depth > 1 else "dispatch"), "pipeline_gate": bool(args.pipeline_gate) and depth > 1, "keypoints_per_step": kps // max(args.steps, 1),
                        "frames_per_s": nf * world * args.steps / dt,
                        "rccl_ranks": rccl_ranks,   # as the RCCL communicator reports it (0: no RCCL communicator in this run)
                        "rccl_loopback": loopback,   # N = 1 with the N > 1 gather messages sent through RCCL to this same rank
+                       "gather_settle_steps": settle,   # untimed set-up steps of the gather path in front of the warm-up (N > 1 only)
                        "gather_steps_on_rank0": (gathered[0] - gatherer_t0[0]) if gatherer is not None else None,
                        "gather_keypoints_on_rank0": (gathered[1] - gatherer_t0[1]) if gatherer is not None else None,
                        "gather_ms_per_step": (gatherer.wait_s / args.steps * 1e3) if gatherer is not None else None,
@@ -437,6 +492,24 @@ def main():
                          "achieved_over_sum_of_durations": achieved_sum, "frac_over_sum_of_durations": achieved_sum / HBM_PEAK_GBS,
                          "sum_of_durations_ms_per_launch": ms / launches if launches else None},
         }
+        if args.check_gather and gatherer is not None and not loopback:
+            # ---- what arrived through the gather against this rank's own run of EVERY rank's frames (outside the timed region)
+            recs_all, vals_all, counts_all = last_gathered[0]
+            ok, ro, vo, io = True, 0, 0, 0
+            for r in range(world):
+                fr = np.stack([synth_frame(W, H, r * nf + i + 1) for i in range(nf)])
+                ctx.calculate_batch(fr, params)
+                tot = ctx.total()
+                kp_r, val_r = device_results(ctx, tot, dev, wire=args.wire)
+                kp_r, val_r, cnt_r = kp_r.cpu(), val_r.cpu(), ctx.counts().copy()
+                ok = ok and bool((counts_all[io:io + nf].cpu().numpy() == cnt_r).all())
+                ok = ok and recs_all[ro:ro + kp_r.numel()].cpu().numpy().tobytes() == kp_r.numpy().tobytes()
+                ok = ok and vals_all[vo:vo + val_r.numel()].cpu().numpy().tobytes() == val_r.numpy().tobytes()
+                ro, vo, io = ro + kp_r.numel(), vo + val_r.numel(), io + nf
+            ok = ok and ro == recs_all.numel() and vo == vals_all.numel() and io == counts_all.numel()
+            out["config"]["gather_check"] = bool(ok)
+            out["config"]["gather_check_what"] = (f"the last step's lists on rank 0 (records, descriptor floats, counts of {world * nf} images) equal "
+                                                  f"rank 0's own run of every rank's frames, seeds 1..{world * nf} in order")
         if world == 1:
             # ---- the blur family ALONE on the chip: a few steps one at a time after the timed region, every one instrumented
             ctx.set_option("profile", 1)

@@ -163,6 +163,14 @@ int sift_hip_result_device(sift_hip_ctx* ctx, const void** dev_keypoints, const 
  * the current results hold such a value: send the plain arrays of sift_hip_result_device instead. */
 int sift_hip_result_sparse_size(sift_hip_ctx* ctx, int64_t* n_values, int* lossless);
 int sift_hip_result_sparse_pack(sift_hip_ctx* ctx, void* dev_records, void* dev_values);
+/* _pack without the wait, for a host that gathers every batch of a pipeline: the pack is queued on the context's side stream
+ * and the call returns; the context's NEXT batch may be started at once (its descriptor stage - the first thing that rewrites
+ * the arrays the pack reads - waits for the pack on the device, never the host).  sift_hip_result_pack_wait returns once the
+ * lists are complete in dev_records / dev_values; it touches nothing but that event and may be called from another thread
+ * while the context's own thread is inside its next sift_hip_calculate_batch*.  With option wire_count the batch itself
+ * counts and scans (sift_hip_result_sparse_size then returns without a pass or a wait). */
+int sift_hip_result_sparse_pack_async(sift_hip_ctx* ctx, void* dev_records, void* dev_values);
+int sift_hip_result_pack_wait(sift_hip_ctx* ctx);
 /* The same lists to HOST memory (page-locked memory moves at the link's rate): packed on the GPU, so ~200 instead of 532 bytes
  * per keypoint cross the link.  After sift_hip_result_sparse_size (use sift_hip_result_copy when it reports lossless = 0);
  * records: sift_hip_result_total() * 34 bytes, values: n_values floats. */
@@ -271,6 +279,11 @@ int sift_hip_group_result_device(sift_hip_group* group, const void** dev_keypoin
 int sift_hip_group_timing(sift_hip_group* group, double* compute_ms, double* gather_ms, int64_t* gather_bytes);
 /* ... and how much of that gather time the collect call itself had to wait for (the rest ran under the next batch). */
 int sift_hip_group_gather_exposed(sift_hip_group* group, double* exposed_ms);
+/* The library serialises, PER DEVICE, its kernel launches against the runtime calls that crashed beside them (allocations,
+ * stream / event creation, the runtime's own copies): sift_amd/csrc/launch_guard.h.  *ms = the time all host threads of the
+ * process have spent waiting for such a lock since it started - what a one-process host of several GPUs (sift_hip_group) or
+ * of several contexts per GPU pays for that. */
+int sift_hip_lock_wait_ms(double* ms);
 
 /* ---- image files and the result overlay (host code, no GPU) ------------------------------------------
  * What /root/reference/main.cpp does around calculate(): vigra::importImage (main.cpp:52-54), cv::imread (:59), the

@@ -10,7 +10,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsift_hip.so")
+# SIFT_HIP_LIBRARY: file name of another build in sift_amd/lib (tools/ use libsift_hip_diag.so, `make -C sift_amd/csrc diag`: the
+# measurement options); read here, in the binding - the library itself reads no environment variable
+LIB_PATH = os.path.join(_HERE, "lib", os.path.basename(os.environ.get("SIFT_HIP_LIBRARY", "libsift_hip.so")))
 
 OK, EPRECONDITION, EASSERT, EINVAL, EHIP = 0, 1, 2, 3, 4
 
@@ -24,12 +26,12 @@ SYMBOLS = [
     "sift_hip_reduce_to_next_level", "sift_hip_increase_to_next_level", "sift_hip_dog", "sift_hip_gradient",
     "sift_hip_edge_responses", "sift_hip_vertex_parabola", "sift_hip_sort_by_filter", "sift_hip_cleanup_survivors", "sift_hip_profile_get", "sift_hip_profile_get_busy",
     "sift_hip_profile_reset", "sift_hip_version", "sift_hip_gate_create", "sift_hip_gate_destroy", "sift_hip_set_gate",
-    "sift_hip_result_sparse_size", "sift_hip_result_sparse_pack", "sift_hip_sparse_unpack",
+    "sift_hip_result_sparse_size", "sift_hip_result_sparse_pack", "sift_hip_result_sparse_pack_async", "sift_hip_result_pack_wait", "sift_hip_sparse_unpack",
     "sift_hip_host_alloc", "sift_hip_host_free",
     "sift_hip_group_create", "sift_hip_group_destroy", "sift_hip_group_shards", "sift_hip_group_set_option", "sift_hip_group_calculate",
     "sift_hip_group_result_images", "sift_hip_group_result_status", "sift_hip_group_result_counts", "sift_hip_group_result_total",
     "sift_hip_group_result_copy", "sift_hip_group_result_device", "sift_hip_group_timing", "sift_hip_group_submit", "sift_hip_group_collect",
-    "sift_hip_group_transport", "sift_hip_group_gather_exposed", "sift_hip_calculate_batch_u8", "sift_hip_calculate_batch_device_u8",
+    "sift_hip_group_transport", "sift_hip_group_gather_exposed", "sift_hip_lock_wait_ms", "sift_hip_calculate_batch_u8", "sift_hip_calculate_batch_device_u8",
     "sift_hip_result_copy_sparse", "sift_hip_sparse_unpack_host",
     "sift_hip_image_info", "sift_hip_image_read_band0", "sift_hip_image_read_bgr8", "sift_hip_png_write_bgr8",
     "sift_hip_rotated_rect_points", "sift_hip_overlay_box", "sift_hip_overlay_draw",
@@ -95,6 +97,8 @@ def load():
     L.sift_hip_set_gate.argtypes = [vp, vp]
     L.sift_hip_result_sparse_size.argtypes = [vp, C.POINTER(C.c_int64), ip]
     L.sift_hip_result_sparse_pack.argtypes = [vp, vp, vp]
+    L.sift_hip_result_sparse_pack_async.argtypes = [vp, vp, vp]
+    L.sift_hip_result_pack_wait.argtypes = [vp]
     L.sift_hip_sparse_unpack.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
     L.sift_hip_set_option.argtypes = [vp, cs, ci]
     L.sift_hip_calculate_batch.argtypes = [vp, fp, ci, ci, ci, C.POINTER(Params), cs, ci]
@@ -142,6 +146,7 @@ def load():
     L.sift_hip_group_collect.argtypes = [vp, cs, ci]
     L.sift_hip_group_transport.argtypes = [vp, cs, ci]
     L.sift_hip_group_gather_exposed.argtypes = [vp, C.POINTER(C.c_double)]
+    L.sift_hip_lock_wait_ms.argtypes = [C.POINTER(C.c_double)]
     L.sift_hip_group_result_images.argtypes = [vp]
     L.sift_hip_group_result_status.argtypes = [vp, i32p, ci]
     L.sift_hip_group_result_counts.argtypes = [vp, i32p, ci]

@@ -16,36 +16,34 @@
 // for the call only, a batch makes ~60 such calls of a few microseconds); no spin-wait; no null stream; 4 / 24 hardware queues -
 // none of it changed the rate.  Replacing the runtime's device-to-device copies by kernels of this library (group.cpp) did:
 // 1 crash in 200 runs, and none in 150 runs of examples/sift_pipeline.cpp, which never used such copies.
-#include <mutex>
+#include "launch_guard.h"   // one lock per device since round 4, waiting time accounted, deferred frees
 namespace sift_hip {
-std::recursive_mutex& launch_lock();   // kernels_io.hip
 // ... and so are the calls that create or destroy what a launch touches (device and pinned memory, streams, events): the
 // crashes went on, always below hipLaunchKernel, until hipMalloc / hipFree / hipStreamCreate / hipEventCreate of one thread could
 // no longer run beside a launch of another (tools/example_loop.sh: 9 of 120 runs before).
-struct ApiGuard {
-    std::lock_guard<std::recursive_mutex> g{launch_lock()};
-};
+using ApiGuard = LaunchGuard;
 }
 // ... and the calls that put the runtime's OWN kernels and markers on a stream (copies and fills are blit kernels here; event
 // records and stream waits are marker packets): the guard lives for the call (a temporary in a comma expression), never for a wait.
-#define hipMemcpyAsync(...) (::sift_hip::ApiGuard{}, (hipMemcpyAsync)(__VA_ARGS__))
-#define hipMemcpyPeerAsync(...) (::sift_hip::ApiGuard{}, (hipMemcpyPeerAsync)(__VA_ARGS__))
-#define hipMemcpy(...) (::sift_hip::ApiGuard{}, (hipMemcpy)(__VA_ARGS__))
-#define hipMemsetAsync(...) (::sift_hip::ApiGuard{}, (hipMemsetAsync)(__VA_ARGS__))
-#define hipMemset(...) (::sift_hip::ApiGuard{}, (hipMemset)(__VA_ARGS__))
-#define hipEventRecord(...) (::sift_hip::ApiGuard{}, (hipEventRecord)(__VA_ARGS__))
-#define hipStreamWaitEvent(...) (::sift_hip::ApiGuard{}, (hipStreamWaitEvent)(__VA_ARGS__))
+#define hipSetDevice(...) ((hipError_t)::sift_hip::set_device_tracked(__VA_ARGS__))   // the launch locks are per device: launch_guard.h
+#define hipMemcpyAsync(...) (::sift_hip::LaunchGuard{}, (hipMemcpyAsync)(__VA_ARGS__))
+#define hipMemcpyPeerAsync(...) (::sift_hip::LaunchGuard{}, (hipMemcpyPeerAsync)(__VA_ARGS__))
+#define hipMemcpy(...) (::sift_hip::LaunchGuard{}, (hipMemcpy)(__VA_ARGS__))
+#define hipMemsetAsync(...) (::sift_hip::LaunchGuard{}, (hipMemsetAsync)(__VA_ARGS__))
+#define hipMemset(...) (::sift_hip::LaunchGuard{}, (hipMemset)(__VA_ARGS__))
+#define hipEventRecord(...) (::sift_hip::LaunchGuard{}, (hipEventRecord)(__VA_ARGS__))
+#define hipStreamWaitEvent(...) (::sift_hip::LaunchGuard{}, (hipStreamWaitEvent)(__VA_ARGS__))
 #ifdef __HIPCC__
 #include <hip/hip_ext.h>
 #undef hipLaunchKernelGGL
 #define hipLaunchKernelGGL(kernelName, ...)                                   \
     do {                                                                      \
-        std::lock_guard<std::recursive_mutex> sift_launch_guard_(::sift_hip::launch_lock()); \
+        ::sift_hip::LaunchGuard sift_launch_guard_;                           \
         hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__);                \
     } while (0)
 #define hipExtLaunchKernelGGL(...)                                            \
     do {                                                                      \
-        std::lock_guard<std::recursive_mutex> sift_launch_guard_(::sift_hip::launch_lock()); \
+        ::sift_hip::LaunchGuard sift_launch_guard_;                           \
         (hipExtLaunchKernelGGL)(__VA_ARGS__);                                 \
     } while (0)
 #endif
@@ -148,40 +146,12 @@ void set_orient_dbg(int v);        // timing ablations of the orientation kernel
 void launch_resample(hipStream_t s, const float* src, float* dst, int ws, int hs, int wd, int hd, int n,
                      const int* d_lutx, const int* d_luty);
 void launch_dog(hipStream_t s, const float* lower, const float* higher, float* out, size_t count);
-void set_fused_grid_mode(int v);
-void set_extrema_stream(int v);
 bool launch_blur_reduce_kept(hipStream_t s, const float* in, float* dst, int w, int h, int wd, int hd, int n, const float* d_taps, int radius,
                              int sx, int sy, int min_waves, hipEvent_t ev_start, hipEvent_t ev_stop);
 int stream_min_waves_now();
 void launch_widen_u8(hipStream_t s, const uint8_t* in, float* out, size_t count);
-void launch_io_copy(hipStream_t s, const void* src, void* dst, size_t bytes);      // kernels_io.hip: transfers as small kernels
-void launch_io_widen(hipStream_t s, const void* src, float* dst, size_t count);
+void launch_io_copy(hipStream_t s, const void* src, void* dst, size_t bytes);      // kernels_io.hip: device-to-device copies as small kernels (group.cpp)
 void launch_zero_ints(hipStream_t s, int* p, size_t n);
-// kernels_chain.hip: the rest of the pyramid from a given octave on as one launch of (stage, image, tile) work items
-constexpr int kChainMaxStages = 16;
-struct ChainStage {
-    const float* src;          // level the blur reads (all images)
-    float* dst;                // blurred level, or the next octave's first level for a reduction
-    float* dog;                // mode 0
-    const int* inv_x;          // mode 1: source column / row -> destination column / row, or -1
-    const int* inv_y;
-    const float* taps;
-    int w, h;                  // size the blur runs on
-    int wd, hd;                // mode 1: destination size
-    int radius, mode;          // mode 0: level blur + DoG; 1: reduction
-    int tiles_x, tiles_y;      // 64 x 48 tiles
-    int dep, dep_tiles;        // stage that must be complete for the image (-1: its source exists before the launch), tiles per image of it
-};
-struct ChainPlan {
-    int n_stages, n_images;
-    int q_off[9];              // items of queue q (images with index mod 8 == q): [q_off[q], q_off[q+1])
-    ChainStage st[kChainMaxStages];
-};
-bool chain_radius_supported(int radius, int mode);
-size_t chain_sync_ints(int n_stages, int n_images);
-int chain_sync_error_index();
-void launch_blur_chain(hipStream_t s, const ChainPlan& cp, const unsigned* d_items, int* d_sync, int mode, hipEvent_t ev_start, hipEvent_t ev_stop);
-void tu_touch_chain(hipStream_t s);
 // one empty launch per translation unit: makes the runtime build that unit's device code (see kernels_*.hip, sift_hip_create)
 void tu_touch_pyramid(hipStream_t s);
 void tu_touch_reduce(hipStream_t s);

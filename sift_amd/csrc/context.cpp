@@ -31,7 +31,13 @@ struct DevBuf {
     void ensure(size_t bytes) {
         if (bytes <= cap) return;
         ApiGuard api;
-        if (p) SIFT_HIP_CHECK(hipFree(p));
+        if (p) {
+            if (sift_hip::frees_deferred()) {   // a transfer of this GPU may be waiting for its peer: hipFree would wait with it (launch_guard.h)
+                sift_hip::retire_device_memory(sift_hip::tracked_device(), p);
+            } else {
+                SIFT_HIP_CHECK(hipFree(p));
+            }
+        }
         p = nullptr;
         cap = 0;
         SIFT_HIP_CHECK(hipMalloc(&p, bytes));
@@ -104,13 +110,6 @@ struct Plan {
     std::vector<float> taps16;        // taps of convolveWithGauss(level, 1.6f) (sift.cpp:87)
     int radius16 = 0;
     size_t max_level_floats = 0;      // per image, largest level
-    // level chain (kernels_chain.hip): ops [chain_first_op, end) as one launch
-    int chain_state = 0;              // 0 not decided, 1 usable, -1 not
-    size_t chain_first_op = 0;
-    ChainPlan chain{};
-    std::vector<unsigned> chain_items;
-    std::vector<int> chain_levels;    // Gaussian levels the chain produces (w16 launches follow it)
-    double chain_bytes = 0.0;         // algorithmic bytes of its stages
 };
 
 }  // namespace
@@ -126,8 +125,6 @@ struct sift_hip_ctx {
     bool fused = true;
     bool fused_edge = true;   // extremum scan and edge filter in one LDS-tiled pass
     bool fused_reduce = true; // reduceToNextLevel: blur and decimation in one pass
-    bool stage_kernels = false;  // option (off): staged (pageable) transfers move their chunks between staging buffer and HBM by a kernel of the library
-    bool io_kernels = false;  // option "io_kernels" (measured alternative, off): page-locked host memory is read / written in place by small kernels (kernels_io.hip) instead of hipMemcpyAsync
     bool reduce_kept = true;  // ... that evaluates the kept pixels only (option "reduce_kept"; 0: blur_stream_kernel<..., DEC>)
     bool orient_general = false;  // tests: orientation histogram with per-sample bins even when every bin is 0
     bool gpu_cleanup = true;
@@ -139,11 +136,7 @@ struct sift_hip_ctx {
     int host_threads = 0;
     int desc_dbg = 0;
     Plan plan;
-    DevBuf arena, d_plan, d_taps, d_luts, d_taps16, d_input, d_input_u8, d_base, d_tmp, d_tmp2, d_chain_items, d_chain_sync;
-    bool chain_ran = false;          // this batch's pyramid ended with the chain launch
-    int chain_from = 0;              // option "chain_from" = o > 0: octaves >= o of the pyramid run as ONE launch (kernels_chain.hip); 0 (default): a launch per level
-    int chain_mode = 1;              // option "chain_mode": 1 agent-scope accesses, 0 ordinary accesses + fences per tile, 2 as 1 with every image's tiles spread over all XCDs (tests)
-    int chain_spread = 0;            // option "chain_spread": parts an octave's top level is cut into between the next octave's stages (0: one per stage)
+    DevBuf arena, d_plan, d_taps, d_luts, d_taps16, d_input, d_input_u8, d_base, d_tmp, d_tmp2;
     DevBuf d_sparse_rec, d_sparse_val;   // sift_hip_result_copy_sparse: the packed lists on their way to the host
     DevBuf d_masks, d_fmasks, d_counts, d_totals, d_cands, d_flags;
     DevBuf d_wk, d_wi, d_wi2, d_wp, d_status, d_pool;
@@ -153,9 +146,7 @@ struct sift_hip_ctx {
     DevBuf d_cell_cnt, d_cell_off;   // descriptor grid: keypoints per 16 px cell, exclusive scan (+ total)
     DevBuf d_desc_sched;             // tile-per-wave descriptor kernel: draw counters
     bool desc_tile = false;          // option "desc_kernel": 1 wave-per-keypoint kernel (the default), 2 tile-per-wave kernel
-    bool gate_early_chain = false;   // option "gate_early_chain" (measured alternative, off)
     int diag_repeat = 1;             // option "diag_repeat" (diagnostics, sift_hip_calculate_batch_device only)
-    int gate_mid = 0;                // option "gate_mid" = o > 0: the previous batch's descriptors start when this pyramid reaches octave o
     int gate_schedule = 1;           // option "gate_schedule" (phase_gate.h; 1 since round 3): applies to the gate this context is joined to
     // option "pyramid_side" (default on): the top Gaussian level of an octave (it only feeds the octave's last DoG) is formed on
     // the side stream, beside the reduction and the first levels of the next octave, which are too small to fill the chip alone
@@ -168,6 +159,9 @@ struct sift_hip_ctx {
     long long wire_values = -1, wire_for_total = -1;
     bool wire_count = false;          // option "wire_count": the descriptor kernel also counts the floats of the sparse wire format
     bool wire_counted = false;        // ... and has done so for the current batch
+    bool wire_scanned = false;        // ... and the block offsets + the number of floats were queued behind it (h_wire holds them once the batch is done)
+    hipEvent_t ev_pack = nullptr;     // sift_hip_result_sparse_pack_async: recorded behind the pack kernel on the side stream
+    bool pack_pending = false;        // ... and not yet waited for by this context's main stream
     DevBuf d_lrank, d_ochunk, d_ocnt, d_recs;   // list position -> orientation result; kept counts per 1024 candidates; early/late counts
     HostBuf h_flags, h_orient, h_peaks, h_status;
     hipEvent_t ev_sync = nullptr;
@@ -538,111 +532,6 @@ void early_w16(sift_hip_ctx* c, int level) {
     launch_w16(c->stream2, P.dev, level, c->d_taps16.as<float>(), P.radius16);
 }
 
-// The ops from the first level blur of octave `chain_from` on as one launch (kernels_chain.hip): stages, their dependencies
-// and the eight item queues.  Decided once per plan; anything the kernel has no body for leaves the per-level launches in place.
-void build_chain(sift_hip_ctx* c) {
-    Plan& P = c->plan;
-    const DevPlan& dv = P.dev;
-    const int n = P.n, O = P.O, D = P.D;
-    P.chain_state = -1;
-    if (c->chain_from <= 0 || c->chain_from >= O || !c->fused || !c->fused_reduce || n > 4096 || P.fail_status) return;
-    size_t k0 = P.ops.size();
-    for (size_t k = 0; k < P.ops.size(); ++k)
-        if (P.ops[k].kind == 2 && P.ops[k].octave == c->chain_from && P.ops[k].j == 1) { k0 = k; break; }
-    if (k0 >= P.ops.size() || P.fail_op != (size_t)-1 || P.ops.size() - k0 > (size_t)kChainMaxStages) return;
-    ChainPlan cp{};
-    cp.n_images = n;
-    std::vector<int> stage_of_level((size_t)O * (size_t)(D + 1), -1);
-    std::vector<int> is_leaf;
-    std::vector<int> levels;
-    double bytes = 0.0;
-    for (size_t k = k0; k < P.ops.size(); ++k) {
-        const BlurOp& op = P.ops[k];
-        ChainStage st{};
-        const int o = op.octave;
-        int src_level, dst_level;
-        if (op.kind == 2) {
-            st.mode = 0;
-            dst_level = o * (D + 1) + op.j;
-            src_level = dst_level - 1;
-            st.dog = dv.dog[o * D + op.j - 1];
-            is_leaf.push_back(op.j == D && o + 1 < O ? 1 : 0);
-            bytes += 12.0 * (double)op.w * (double)op.h * (double)n;
-            levels.push_back(dst_level);
-        } else if (op.kind == 3) {
-            if (P.inv_x_off[(size_t)o] == (size_t)-1 || P.inv_y_off[(size_t)o] == (size_t)-1) return;
-            st.mode = 1;
-            src_level = o * (D + 1) + D - 1;
-            dst_level = (o + 1) * (D + 1);
-            st.inv_x = c->d_luts.as<int>() + P.inv_x_off[(size_t)o];
-            st.inv_y = c->d_luts.as<int>() + P.inv_y_off[(size_t)o];
-            st.wd = dv.w[o + 1];
-            st.hd = dv.h[o + 1];
-            is_leaf.push_back(0);
-            bytes += 4.0 * (double)op.w * (double)op.h * (double)n + 4.0 * (double)st.wd * (double)st.hd * (double)n;
-            levels.push_back(dst_level);
-        } else {
-            return;
-        }
-        if (!chain_radius_supported(op.radius, st.mode) || op.w % 4 != 0) return;
-        st.src = dv.gauss[src_level];
-        st.dst = dv.gauss[dst_level];
-        if ((((uintptr_t)st.src | (uintptr_t)st.dst | (uintptr_t)st.dog) & 15u) != 0) return;
-        st.taps = c->d_taps.as<float>() + op.tap_off;
-        st.w = op.w;
-        st.h = op.h;
-        st.radius = op.radius;
-        st.tiles_x = (op.w + 63) / 64;
-        st.tiles_y = (op.h + 47) / 48;
-        if ((long long)st.tiles_x * st.tiles_y > 65536) return;
-        st.dep = stage_of_level[(size_t)src_level];
-        st.dep_tiles = st.dep >= 0 ? cp.st[st.dep].tiles_x * cp.st[st.dep].tiles_y : 0;
-        stage_of_level[(size_t)dst_level] = cp.n_stages;
-        cp.st[cp.n_stages++] = st;
-    }
-    // the queues: images with index mod 8 == q; within a queue every item after the items it waits for (op order is such an
-    // order); the top level of an octave (a leaf: only its own DoG needs it) is held back and dealt out in parts after the
-    // next stages, where it fills what the smaller next octave leaves idle
-    std::vector<unsigned> items;
-    for (int q = 0; q < 8; ++q) {
-        cp.q_off[q] = (int)items.size();
-        std::vector<unsigned> held;
-        size_t part = 0;
-        auto emit = [&](int sidx, std::vector<unsigned>& to) {
-            const int tiles = cp.st[sidx].tiles_x * cp.st[sidx].tiles_y;
-            for (int img = q; img < n; img += 8)
-                for (int t = 0; t < tiles; ++t) to.push_back(((unsigned)sidx << 28) | ((unsigned)img << 16) | (unsigned)t);
-        };
-        for (int sidx = 0; sidx < cp.n_stages; ++sidx) {
-            if (is_leaf[(size_t)sidx]) {
-                emit(sidx, held);
-                const int parts = c->chain_spread > 0 ? c->chain_spread : D;
-                part = (held.size() + (size_t)parts - 1) / (size_t)parts;
-                continue;
-            }
-            emit(sidx, items);
-            if (cp.st[sidx].mode == 0 && !held.empty()) {
-                const size_t take = std::min(part, held.size());
-                items.insert(items.end(), held.begin(), held.begin() + (long)take);
-                held.erase(held.begin(), held.begin() + (long)take);
-            }
-        }
-        items.insert(items.end(), held.begin(), held.end());
-    }
-    cp.q_off[8] = (int)items.size();
-    if (items.empty()) return;
-    c->d_chain_items.ensure(items.size() * sizeof(unsigned));
-    c->d_chain_sync.ensure(chain_sync_ints(cp.n_stages, n) * sizeof(int));
-    SIFT_HIP_CHECK(hipMemcpyAsync(c->d_chain_items.p, items.data(), items.size() * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
-    SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));   // `items` is pageable host memory
-    P.chain = cp;
-    P.chain_items.swap(items);
-    P.chain_levels.swap(levels);
-    P.chain_bytes = bytes;
-    P.chain_first_op = k0;
-    P.chain_state = 1;
-}
-
 // ---- pyramid (Sift::_createDOGs, sift.cpp:381-417) ---------------------------------------------
 void run_pyramid(sift_hip_ctx* c, const float* d_in) {
     Plan& P = c->plan;
@@ -658,21 +547,8 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
             (void)hipStreamWaitEvent(c->stream, c->ev_side_join, 0);
         }
     } side_join{c, &side_used};
-    if (P.chain_state == 0) build_chain(c);
-    c->chain_ran = false;
-    if (P.chain_state == 1)   // tickets and completion counters of the chain launch: cleared long before it runs
-        launch_zero_ints(c->stream, c->d_chain_sync.as<int>(), chain_sync_ints(P.chain.n_stages, n));
     for (size_t k = 0; k < P.ops.size(); ++k) {
         if (k >= P.fail_op) break;
-        if (P.chain_state == 1 && k == P.chain_first_op) {   // the rest of the pyramid in one launch
-            hipEvent_t a = nullptr, b = nullptr;
-            if (c->profile) { a = get_event(c); b = get_event(c); }
-            launch_blur_chain(c->stream, P.chain, c->d_chain_items.as<unsigned>(), c->d_chain_sync.as<int>(), c->chain_mode, a, b);
-            if (c->profile) c->pending.push_back({a, b, 0, P.chain_bytes});
-            c->chain_ran = true;
-            for (int l : P.chain_levels) early_w16(c, l);
-            break;
-        }
         const BlurOp& op = P.ops[k];
         switch (op.kind) {
             case 0: {  // increaseToNextLevel(img, 1.0): blur then 2x nearest upsample
@@ -706,7 +582,6 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
             }
             case 3: {  // reduceToNextLevel(g(o, D-1), g(o, D-1).scale)
                 const int o = op.octave;
-                if (c->gate && c->gate_mid > 0 && o + 1 == c->gate_mid) c->gate->mark(c->gate_ticket, sift_hip::PhaseGate::kM, c->stream);
                 const float* src = dv.gauss[o * (D + 1) + D - 1];
                 float* dst = dv.gauss[(o + 1) * (D + 1)];
                 bool done = false;
@@ -884,6 +759,7 @@ void mid_host(sift_hip_ctx* c) {
 
 void ensure_outputs(sift_hip_ctx* c, long long keypoints) {
     if (keypoints <= c->out_cap) return;
+    if (c->pack_pending) SIFT_HIP_CHECK(hipEventSynchronize(c->ev_pack));   // the arrays about to be freed are still being read
     c->out_cap = 0;   // until both arrays exist at the new size (an allocation that throws leaves them freed)
     c->d_kp.ensure((size_t)keypoints * sizeof(sift_hip_keypoint));
     c->d_desc.ensure((size_t)keypoints * 128 * sizeof(float));
@@ -893,6 +769,10 @@ void ensure_outputs(sift_hip_ctx* c, long long keypoints) {
 void launch_descriptor_stage(sift_hip_ctx* c) {
     Plan& P = c->plan;
     const DevPlan& dv = P.dev;
+    if (c->pack_pending) {   // the previous batch's lists are still being packed from the arrays this stage rewrites
+        SIFT_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_pack, 0));
+        c->pack_pending = false;
+    }
     // grid of 16 px cells over the final keypoints, then one wave per keypoint - or per tile of 2 x 2 cells (kernels_desc.hip)
     launch_desc_grid(c->stream, c->d_plan.as<DevPlan>(), dv, c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(), kListCap,
                      c->d_cell_cnt.as<int>(), c->d_cell_off.as<int>(), c->d_pool.as<FinalKp>(), kPoolCap, c->d_out_base.as<long long>(),
@@ -915,6 +795,19 @@ void launch_descriptor_stage(sift_hip_ctx* c) {
             launch_descriptors_wave(c->stream, c->d_plan.as<DevPlan>(), dv, lvl, c->d_cell_off.as<int>(), c->d_pool.as<FinalKp>(), kPoolCap,
                                     c->d_out_base.as<long long>(), c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->out_cap, c->desc_dbg,
                                     wire_sums);
+    c->wire_scanned = false;
+    if (c->wire_counted) {
+        // ... and the scan of the per-block counts, over the blocks of the arrays' CAPACITY (the number of keypoints is not on
+        // the host yet; blocks behind the last keypoint count zero), with the number of floats and the bin-7 flag sent to the
+        // host behind it: when the batch is done sift_hip_result_sparse_size has its answer without a pass or a wait of its own
+        const size_t nbc = wire_blocks(c->out_cap);
+        c->d_wire_off.ensure((nbc + 1) * sizeof(long long));
+        c->h_wire.ensure(2 * sizeof(long long));
+        launch_wire_count(c->stream, c->d_desc.as<float>(), c->out_cap, c->d_wire_sums.as<int>(), c->d_wire_off.as<long long>(), true);
+        SIFT_HIP_CHECK(hipMemcpyAsync(c->h_wire.p, c->d_wire_off.as<long long>() + nbc, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+        SIFT_HIP_CHECK(hipMemcpyAsync(c->h_wire.as<long long>() + 1, c->d_wire_sums.as<int>(), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        c->wire_scanned = true;
+    }
 }
 
 // Wait for everything queued on `s`.  Polling an event returns within a microsecond or two of the GPU finishing;
@@ -973,12 +866,9 @@ bool mid_gpu(sift_hip_ctx* c) {
     SIFT_HIP_CHECK(hipGetLastError());
     if (c->gate) c->gate->mark(c->gate_ticket, sift_hip::PhaseGate::kD, s);
     c->described = true;
-    c->h_status.ensure(((size_t)n * 5 + 1) * sizeof(int));
+    c->h_status.ensure((size_t)n * 5 * sizeof(int));
     const int* st = c->h_status.as<int>();   // pinned: the copy is a real asynchronous DMA
     SIFT_HIP_CHECK(hipMemcpyAsync(c->h_status.p, c->d_status.p, (size_t)n * 5 * sizeof(int), hipMemcpyDeviceToHost, s));
-    if (c->chain_ran)   // the chain launch's "gave up waiting" flag
-        SIFT_HIP_CHECK(hipMemcpyAsync(c->h_status.as<int>() + (size_t)n * 5, c->d_chain_sync.as<int>() + chain_sync_error_index(), sizeof(int),
-                                      hipMemcpyDeviceToHost, s));
     resolve_events(c);   // the pyramid's timing events completed long ago: read them while the GPU is still busy
     wait_stream(c, s);
     if (c->diag_cleanup_stamps) {   // diagnostics: phases of the second cleanup (image 0)
@@ -996,7 +886,6 @@ bool mid_gpu(sift_hip_ctx* c) {
             std::fprintf(stderr, "\n");
         }
     }
-    if (c->chain_ran && st[(size_t)n * 5] != 0) throw std::runtime_error("sift_hip: the pyramid's level chain gave up waiting for a level (kernels_chain.hip)");
     for (int i = 0; i < n; ++i)
         if (st[(size_t)i * 4 + 1] || st[(size_t)n * 4 + (size_t)i]) {
             c->described = false;
@@ -1078,21 +967,6 @@ bool is_pinned(const void* p) {
     return a.type == hipMemoryTypeHost || a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
-// Address under which a kernel of this device reaches `p` (page-locked host memory is mapped into the GPU's address space;
-// device memory is its own address), or nullptr: ordinary memory, or memory only a copy engine can reach.
-void* kernel_visible(const void* p) {
-    hipPointerAttribute_t a;
-    std::memset(&a, 0, sizeof(a));
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    if (a.type == hipMemoryTypeDevice) return const_cast<void*>(p);
-    if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
-    // the attributes describe the allocation's base: apply the caller's offset into it
-    return static_cast<char*>(a.devicePointer) + (static_cast<const char*>(p) - static_cast<const char*>(a.hostPointer));
-}
-
 struct CopyJob { char* dst; const char* src; size_t bytes; int parts; };
 void copy_part(int i, void* arg) {
     const CopyJob* j = static_cast<const CopyJob*>(arg);
@@ -1115,29 +989,17 @@ void ensure_staging(sift_hip_ctx* c) {
 
 // host -> device on stream s; returns once `host` may be reused (pageable) or at once (pinned: the caller keeps the
 // buffer until the batch is done, which calculate only returns after)
-// One chunk between the context's page-locked staging buffer and device memory: hipMemcpyAsync, or (option "stage_kernels",
-// off) a kernel of this library reading / writing the mapped staging buffer - tried against the runtime's crashes in
-// multi-threaded hosts (common.h); it did not lower their rate (11 of 200 runs of examples/sift_multi_gpu.cpp).
-void stage_move(sift_hip_ctx* c, void* dst, const void* src, size_t bytes, bool to_device, hipStream_t s) {
-    if (c->stage_kernels && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 3u) == 0 && bytes % 4 == 0) {
-        launch_io_copy(s, src, dst, bytes);
-        SIFT_HIP_CHECK(hipGetLastError());
-        return;
-    }
+// One chunk between the context's page-locked staging buffer and device memory.  (Measured in rounds 2 - 3 and removed in
+// round 4: the same moves, and the transfers of page-locked caller memory, as kernels of this library reading / writing the
+// mapped host memory in place - they disturb the bandwidth-bound kernels less than the runtime's blit kernels but read the link
+// at ~28 GB/s and lose overall, 6.5 against 4.5 - 5.5 ms per host-to-host batch; they did not lower the rate of the runtime's
+// crashes in multi-threaded hosts either.)
+void stage_move(sift_hip_ctx*, void* dst, const void* src, size_t bytes, bool to_device, hipStream_t s) {
     SIFT_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, s));
 }
 
 void upload(sift_hip_ctx* c, void* dev, const void* host, size_t bytes, hipStream_t s) {
     if (bytes == 0) return;
-    // option "io_kernels" (off): a kernel of a few workgroups reads page-locked memory in place (kernels_io.hip)
-    if (c->io_kernels) {
-        const void* kv = kernel_visible(host);
-        if (kv && ((reinterpret_cast<uintptr_t>(kv) | reinterpret_cast<uintptr_t>(dev)) & 15u) == 0) {
-            launch_io_copy(s, kv, dev, bytes);
-            SIFT_HIP_CHECK(hipGetLastError());
-            return;
-        }
-    }
     if (is_pinned(host)) {
         SIFT_HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s));
         return;
@@ -1157,15 +1019,6 @@ void upload(sift_hip_ctx* c, void* dev, const void* host, size_t bytes, hipStrea
 // device -> caller memory (host or device), complete on return
 void download(sift_hip_ctx* c, void* dst, const void* dev, size_t bytes, hipStream_t s) {
     if (bytes == 0) return;
-    if (c->io_kernels) {
-        void* kv = kernel_visible(dst);
-        if (kv && ((reinterpret_cast<uintptr_t>(kv) | reinterpret_cast<uintptr_t>(dev)) & 15u) == 0) {
-            launch_io_copy(s, dev, kv, bytes);
-            SIFT_HIP_CHECK(hipGetLastError());
-            wait_stream(c, s);
-            return;
-        }
-    }
     if (is_pinned(dst)) {
         SIFT_HIP_CHECK(hipMemcpyAsync(dst, dev, bytes, hipMemcpyDefault, s));
         wait_stream(c, s);
@@ -1211,6 +1064,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     c->described = false;
     c->wire_values = c->wire_for_total = -1;
     c->wire_counted = false;
+    c->wire_scanned = false;
     c->profile = c->profile_every > 0 && (c->profile_batches++ % c->profile_every) == 0;
 
     // Batches of several contexts in flight on this GPU: the gate orders their phases (phase_gate.h).  Whatever
@@ -1226,7 +1080,6 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     run_pyramid(c, d_in);
     SIFT_HIP_CHECK(hipGetLastError());   // a rejected launch configuration must not go unnoticed
     if (c->gate) {
-        if (c->gate_mid > 0) c->gate->mark(c->gate_ticket, sift_hip::PhaseGate::kM, s);   // no-op when the pyramid marked it on the way (unused and left to finish() otherwise)
         c->gate->mark(c->gate_ticket, sift_hip::PhaseGate::kP, s);
     }
     c->have_pyramid = true;
@@ -1275,16 +1128,10 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
         // cleanup chain C
         if (gs != s) SIFT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_grad, 0));
         c->gate->mark(c->gate_ticket, sift_hip::PhaseGate::kE, s);
-        if (!c->gate_early_chain) c->gate->before_cleanup(c->gate_ticket, s);
+        c->gate->before_cleanup(c->gate_ticket, s);
     }
     SIFT_HIP_CHECK(hipEventRecord(c->ev_fork, s));
     SIFT_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    // "gate_early_chain" (measured alternative, off by default): only the chip-filling orientation stage waits for the next
-    // batch's pyramid; the first cleanup (32 workgroups that each need a whole CU) starts at once and shares the chip with
-    // that pyramid instead of starving behind the next batch's persistent extrema pass.  It then finishes early (0.47 ms
-    // instead of 1.3), but the descriptors still wait for the orientation stage, which the next batch's extrema pass slows
-    // just as much: 3.30 vs 3.25 ms per step, and the blur launches that share the chip drop from 0.46 to 0.43 of the roofline.
-    if (c->gate && c->gate_early_chain) c->gate->before_cleanup(c->gate_ticket, c->stream2);
     if (c->gpu_cleanup) {
         launch_orient_prepare(c->stream2, n, c->d_flags.as<uint8_t>(), c->d_totals.as<int>(), dv.cand_capacity,
                               c->d_ochunk.as<int>(), c->d_cands.as<Candidate>(), kListCap, c->d_order.as<OrientIn>(),
@@ -1390,7 +1237,7 @@ int sift_hip_create(int device, sift_hip_ctx** out, char* err, int errlen) {
             static bool touched[64] = {false};
             std::lock_guard<std::mutex> lk(touch_lock);
             if (device < 64 && !touched[device]) {
-                tu_touch_pyramid(c->stream); tu_touch_reduce(c->stream); tu_touch_chain(c->stream); tu_touch_extrema(c->stream); tu_touch_orient(c->stream);
+                tu_touch_pyramid(c->stream); tu_touch_reduce(c->stream); tu_touch_extrema(c->stream); tu_touch_orient(c->stream);
                 tu_touch_desc(c->stream); tu_touch_cleanup(c->stream); tu_touch_wire(c->stream); tu_touch_io(c->stream);
                 SIFT_HIP_CHECK(hipGetLastError());
                 SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -1421,6 +1268,7 @@ void sift_hip_destroy(sift_hip_ctx* c) {
     (void)hipEventDestroy(c->ev_fork);
     (void)hipEventDestroy(c->ev_join);
     (void)hipEventDestroy(c->ev_sync);
+    if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
     if (c->ev_side_fork) (void)hipEventDestroy(c->ev_side_fork);
     if (c->ev_side_join) (void)hipEventDestroy(c->ev_side_join);
     (void)hipStreamDestroy(c->stream2);
@@ -1484,7 +1332,7 @@ int sift_hip_set_gate(sift_hip_ctx* c, sift_hip_gate* g) {
     }
     c->gate_owner = g;
     c->gate = g ? &g->gate : nullptr;
-    if (c->gate) { c->gate->set_schedule(c->gate_schedule); c->gate->set_mid(c->gate_mid > 0); }
+    if (c->gate) c->gate->set_schedule(c->gate_schedule);
     return SIFT_HIP_OK;
 }
 
@@ -1493,17 +1341,13 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     if (!std::strcmp(name, "fused_blur")) { c->fused = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "fused_edge")) { c->fused_edge = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "fused_reduce")) { c->fused_reduce = value != 0; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "stage_kernels")) { c->stage_kernels = value != 0; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "io_kernels")) { c->io_kernels = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "reduce_kept")) { c->reduce_kept = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "spin_wait")) { c->spin_wait = value != 0; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "desc_dbg")) { c->desc_dbg = value; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "desc_kernel")) {
         if (value != 1 && value != 2) return SIFT_HIP_EINVAL;
         c->desc_tile = value == 2;
         return SIFT_HIP_OK;
     }
-    if (!std::strcmp(name, "gate_early_chain")) { c->gate_early_chain = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "wire_count")) { c->wire_count = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "pyramid_side")) {
         ApiGuard api;
@@ -1516,15 +1360,6 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
         c->pyramid_side = value != 0;
         return SIFT_HIP_OK;
     }
-    if (!std::strcmp(name, "chain_from")) { c->chain_from = value; c->plan.chain_state = 0; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "diag_repeat")) { c->diag_repeat = value > 1 ? value : 1; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "chain_mode")) { c->chain_mode = value; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "chain_spread")) { c->chain_spread = value; c->plan.chain_state = 0; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "gate_mid")) {
-        c->gate_mid = value;
-        if (c->gate) c->gate->set_mid(value > 0);
-        return SIFT_HIP_OK;
-    }
     if (!std::strcmp(name, "gate_schedule")) {
         if (value < 0 || value > 1) return SIFT_HIP_EINVAL;
         c->gate_schedule = value;
@@ -1535,14 +1370,18 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     if (!std::strcmp(name, "profile")) { c->profile_every = value > 0 ? value : 0; c->profile_batches = 0; c->profile = false; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "orient_general")) { c->orient_general = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "stream_min_waves")) { set_stream_min_waves(value); return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "extrema_stream")) { set_extrema_stream(value); return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "fused_grid")) { set_fused_grid_mode(value); return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "host_threads")) { c->host_threads = value; return SIFT_HIP_OK; }
+#ifdef SIFT_HIP_DIAG
+    // Measurement aids of tools/ (`make -C sift_amd/csrc diag` -> libsift_hip_diag.so): phases of kernels switched off for timing
+    // (the results are then WRONG), stamps, the batch repeated inside one call.  The shipped library does not know these names.
+    if (!std::strcmp(name, "desc_dbg")) { c->desc_dbg = value; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "diag_repeat")) { c->diag_repeat = value > 1 ? value : 1; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "stream_waves")) { set_stream_waves(value); return SIFT_HIP_OK; }
     if (!std::strcmp(name, "orient_dbg")) { set_orient_dbg(value); return SIFT_HIP_OK; }
     if (!std::strcmp(name, "diag_pyramid_span")) { c->diag_pyramid_span = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "diag_serial_gradient")) { c->diag_serial_gradient = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "diag_cleanup_stamps")) { c->diag_cleanup_stamps = value != 0; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "host_threads")) { c->host_threads = value; return SIFT_HIP_OK; }
+#endif
     return SIFT_HIP_EINVAL;
 }
 
@@ -1591,15 +1430,9 @@ int sift_hip_calculate_batch_u8(sift_hip_ctx* c, const uint8_t* host_imgs, int n
         c->have_result = c->have_pyramid = false;
         const size_t count = (size_t)n * (size_t)w * (size_t)h;
         c->d_input.ensure(count * sizeof(float));
-        const void* kv = c->io_kernels ? kernel_visible(host_imgs) : nullptr;
-        if (kv && (reinterpret_cast<uintptr_t>(kv) & 15u) == 0) {
-            // page-locked frames: widened on the way in, by a kernel of a few workgroups that reads the host memory in place
-            launch_io_widen(c->stream, kv, c->d_input.as<float>(), count);
-        } else {
-            c->d_input_u8.ensure(count);
-            upload(c, c->d_input_u8.p, host_imgs, count, c->stream);
-            launch_widen_u8(c->stream, c->d_input_u8.as<uint8_t>(), c->d_input.as<float>(), count);
-        }
+        c->d_input_u8.ensure(count);
+        upload(c, c->d_input_u8.p, host_imgs, count, c->stream);
+        launch_widen_u8(c->stream, c->d_input_u8.as<uint8_t>(), c->d_input.as<float>(), count);
         SIFT_HIP_CHECK(hipGetLastError());
         std::string msg;
         const int rc = build_plan(c, n, w, h, *params, msg);
@@ -1673,6 +1506,13 @@ int sift_hip_result_device(sift_hip_ctx* c, const void** kp, const void** desc) 
 int sift_hip_result_sparse_size(sift_hip_ctx* c, int64_t* n_values, int* lossless) {
     if (!c || !c->have_result || !n_values) return SIFT_HIP_EINVAL;
     char err[256];
+    if (c->wire_scanned && c->total <= c->out_cap) {   // counted and scanned by the batch itself (option wire_count): the host already has the answer
+        c->wire_values = *c->h_wire.as<long long>();
+        if (lossless) *lossless = *reinterpret_cast<const int*>(c->h_wire.as<long long>() + 1) ? 0 : 1;
+        c->wire_for_total = c->total;
+        *n_values = c->wire_values;
+        return SIFT_HIP_OK;
+    }
     return guarded(err, sizeof(err), [&]() {
         SIFT_HIP_CHECK(hipSetDevice(c->device));
         const size_t nb = wire_blocks(c->total);
@@ -1706,6 +1546,37 @@ int sift_hip_result_sparse_pack(sift_hip_ctx* c, void* d_records, void* d_values
     });
 }
 
+// The pack without the wait: the kernel goes to the context's SIDE stream and an event behind it, and the call returns.  The
+// caller may start the context's next batch at once - its descriptor stage, the first thing that rewrites the arrays the pack
+// reads, waits for that event on the device - and calls sift_hip_result_pack_wait (any thread) before it reads the packed lists.
+int sift_hip_result_sparse_pack_async(sift_hip_ctx* c, void* d_records, void* d_values) {
+    if (!c || !c->have_result || c->wire_for_total != c->total || c->wire_values < 0) return SIFT_HIP_EINVAL;
+    if (c->total > 0 && (!d_records || (c->wire_values > 0 && !d_values))) return SIFT_HIP_EINVAL;
+    char err[256];
+    return guarded(err, sizeof(err), [&]() {
+        SIFT_HIP_CHECK(hipSetDevice(c->device));
+        if (!c->ev_pack) { ApiGuard api; SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming)); }
+        launch_wire_emit(c->stream2, c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->total, c->d_wire_off.as<long long>(),
+                         static_cast<uint8_t*>(d_records), static_cast<float*>(d_values));
+        SIFT_HIP_CHECK(hipGetLastError());
+        SIFT_HIP_CHECK(hipEventRecord(c->ev_pack, c->stream2));
+        c->pack_pending = true;
+        return SIFT_HIP_OK;
+    });
+}
+
+int sift_hip_result_pack_wait(sift_hip_ctx* c) {
+    if (!c) return SIFT_HIP_EINVAL;
+    hipEvent_t ev = c->ev_pack;     // (only the event is touched: the context's own thread may be inside its next batch)
+    if (!ev) return SIFT_HIP_OK;
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return SIFT_HIP_OK;
+        if (e != hipErrorNotReady) return SIFT_HIP_EHIP;
+        __builtin_ia32_pause();
+    }
+}
+
 // The same lists to HOST memory: packed on the GPU, then only the 34-byte records and the floats that are set cross the link
 // (~200 instead of 532 bytes per keypoint).  After sift_hip_result_sparse_size; records: total * 34 bytes, values: n_values floats.
 int sift_hip_result_copy_sparse(sift_hip_ctx* c, void* records, float* values) {
@@ -1720,15 +1591,7 @@ int sift_hip_result_copy_sparse(sift_hip_ctx* c, void* records, float* values) {
         launch_wire_emit(c->stream, c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->total, c->d_wire_off.as<long long>(),
                          c->d_sparse_rec.as<uint8_t>(), c->d_sparse_val.as<float>());
         SIFT_HIP_CHECK(hipGetLastError());
-        void* kr = c->io_kernels ? kernel_visible(records) : nullptr;
-        void* kvv = c->io_kernels ? kernel_visible(values) : nullptr;
-        if (kr && kvv && ((reinterpret_cast<uintptr_t>(kr) | reinterpret_cast<uintptr_t>(kvv)) & 15u) == 0) {
-            // page-locked destination: two small kernels behind the pack kernel, one wait
-            launch_io_copy(c->stream, c->d_sparse_rec.p, kr, (size_t)c->total * 34);
-            if (c->wire_values > 0) launch_io_copy(c->stream, c->d_sparse_val.p, kvv, (size_t)c->wire_values * sizeof(float));
-            SIFT_HIP_CHECK(hipGetLastError());
-            wait_stream(c, c->stream);
-        } else if (is_pinned(records) && is_pinned(values)) {   // both copies queued behind the kernel, one wait
+        if (is_pinned(records) && is_pinned(values)) {   // both copies queued behind the kernel, one wait
             SIFT_HIP_CHECK(hipMemcpyAsync(records, c->d_sparse_rec.p, (size_t)c->total * 34, hipMemcpyDefault, c->stream));
             if (c->wire_values > 0) SIFT_HIP_CHECK(hipMemcpyAsync(values, c->d_sparse_val.p, (size_t)c->wire_values * sizeof(float), hipMemcpyDefault, c->stream));
             wait_stream(c, c->stream);

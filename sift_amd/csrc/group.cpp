@@ -45,16 +45,13 @@
 
 extern "C" int sift_hip_internal_copy(void* stream, const void* src, void* dst, size_t bytes);   // kernels_io.hip
 
-namespace sift_hip {
-std::recursive_mutex& launch_lock();   // common.h: allocations and stream / event creation never run beside another thread's launch
-}
+#include "launch_guard.h"   // per-device launch locks (allocations and stream / event creation never run beside another thread's launch on that device), deferred frees
 
 namespace {
 
-struct ApiGuard {
-    std::lock_guard<std::recursive_mutex> g{sift_hip::launch_lock()};
-};
+using ApiGuard = sift_hip::LaunchGuard;
 // the runtime's own kernels and markers (copies, event records) go on their streams under the same lock (common.h)
+#define hipSetDevice(...) ((hipError_t)sift_hip::set_device_tracked(__VA_ARGS__))
 #define hipMemcpyAsync(...) (ApiGuard{}, (hipMemcpyAsync)(__VA_ARGS__))
 #define hipMemcpyPeerAsync(...) (ApiGuard{}, (hipMemcpyPeerAsync)(__VA_ARGS__))
 #define hipMemcpy(...) (ApiGuard{}, (hipMemcpy)(__VA_ARGS__))
@@ -107,9 +104,11 @@ struct DevMem {   // grow-only device buffer on a fixed device
     long long cap = 0;
     bool fit(int device, long long want) {
         if (want <= cap) return true;
-        ApiGuard api;
+        ApiGuard api(device);
         if (hipSetDevice(device) != hipSuccess) return false;
-        if (p) (void)hipFree(p);
+        // never hipFree here: it waits for the whole device, and a send of this GPU may be waiting for a receive that is only
+        // posted once other threads got on (the group runs with deferred frees: launch_guard.h); freed when the group is idle
+        if (p) sift_hip::retire_device_memory(device, p);
         p = nullptr;
         cap = 0;
         const long long take = want + want / 4 + 256;
@@ -119,7 +118,7 @@ struct DevMem {   // grow-only device buffer on a fixed device
     }
     void release(int device) {
         if (!p) return;
-        ApiGuard api;
+        ApiGuard api(device);
         (void)hipSetDevice(device);
         (void)hipFree(p);
         p = nullptr;
@@ -161,6 +160,8 @@ struct Batch {
 
 struct sift_hip_group {
     std::vector<int> devices;
+    bool defers = false;                      // this group has switched the process to deferred frees (launch_guard.h)
+    std::vector<char> peer_ok;                // per shard: its GPU can write devices[0]'s memory in place (same device, or peer access enabled)
     std::vector<sift_hip_ctx*> ctx;
     sift_hip_ctx* unpack_ctx = nullptr;       // on devices[0]: the gather thread's own (sift_hip_sparse_unpack beside shard 0's kernels)
     int S = 0;
@@ -303,10 +304,12 @@ void shard_main(sift_hip_group* g, int s) {
                         if (e1 == ncclSuccess && nb) e1 = r.Send(src_b, nb, ncclUint8, 0, g->comm[(size_t)s], g->send_stream[(size_t)s]);
                         const ncclResult_t e2 = r.GroupEnd();
                         if (e1 != ncclSuccess || e2 != ncclSuccess) {
+                            // nothing was queued: no receive may be posted for this shard (it would never complete)
                             R.rc = SIFT_HIP_EHIP;
                             R.msg = std::string("sift_hip_group: ncclSend failed: ") + r.GetErrorString(e1 != ncclSuccess ? e1 : e2);
+                        } else {
+                            R.sent = true;
                         }
-                        R.sent = true;
                     } else {
                         // copies: straight into this shard's arrival area on devices[0], over this GPU's own link (a shard on
                         // devices[0] itself moves its lists aside the same way: its context is then free for the next batch)
@@ -315,7 +318,7 @@ void shard_main(sift_hip_group* g, int s) {
                         const bool ok = ia.fit(g->devices[0], (long long)na) && ib.fit(g->devices[0], (long long)std::max<size_t>(nb, 4));
                         (void)hipSetDevice(dev);
                         hipError_t h1 = hipSuccess, h2 = hipSuccess;
-                        if (ok && g->copy_kernels && ((reinterpret_cast<uintptr_t>(src_a) | reinterpret_cast<uintptr_t>(src_b)) & 3u) == 0 && na % 4 == 0 && nb % 4 == 0) {
+                        if (ok && g->copy_kernels && g->peer_ok[(size_t)s] && ((reinterpret_cast<uintptr_t>(src_a) | reinterpret_cast<uintptr_t>(src_b)) & 3u) == 0 && na % 4 == 0 && nb % 4 == 0) {
                             // a kernel of the library, run by THIS GPU: it writes the arrival area in place (its own memory, or the
                             // first GPU's through peer access over the link)
                             if (sift_hip_internal_copy(g->send_stream[(size_t)s], src_a, ia.p, na)) h1 = hipErrorUnknown;
@@ -516,6 +519,7 @@ int sift_hip_group_create(const int* devices, int n_devices, sift_hip_group** ou
     g->S = n_devices;
     auto bail = [&](int rc, const char* m) {
         if (m) set_err(err, errlen, m);
+        if (g->defers) sift_hip::defer_frees(false);
         for (auto* p : g->ctx) sift_hip_destroy(p);
         if (g->unpack_ctx) sift_hip_destroy(g->unpack_ctx);
         delete g;
@@ -532,29 +536,39 @@ int sift_hip_group_create(const int* devices, int n_devices, sift_hip_group** ou
         if (rc != SIFT_HIP_OK) return bail(rc, nullptr);
     }
     // direct peer copies into shard 0's device (already-enabled and same-device answers are fine)
+    // (recorded per shard: only a GPU that CAN write the first GPU's memory in place runs the library's copy kernel against it -
+    // anywhere else that would be a memory fault that ends the process; the runtime's peer copy stages through the host instead)
+    g->peer_ok.assign((size_t)n_devices, 1);
     for (int s = 1; s < n_devices; ++s)
         if (devices[s] != devices[0]) {
             int can = 0;
+            bool ok = false;
             if (hipDeviceCanAccessPeer(&can, devices[s], devices[0]) == hipSuccess && can) {
+                ApiGuard api(devices[s]);
                 (void)hipSetDevice(devices[s]);
-                (void)hipDeviceEnablePeerAccess(devices[0], 0);
+                const hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
+                ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
             }
             (void)hipGetLastError();
+            g->peer_ok[(size_t)s] = ok ? 1 : 0;
         }
     g->send_stream.assign((size_t)n_devices, nullptr);
-    ApiGuard api;
     for (int b = 0; b < kSlots; ++b) {
         g->sent_ev[b].assign((size_t)n_devices, nullptr);
         g->pack_rec[b].resize((size_t)n_devices); g->pack_val[b].resize((size_t)n_devices);
         g->in_rec[b].resize((size_t)n_devices); g->in_val[b].resize((size_t)n_devices);
     }
     for (int s = 0; s < n_devices; ++s) {
+        ApiGuard api(devices[s]);
         if (hipSetDevice(devices[s]) != hipSuccess || hipStreamCreateWithFlags(&g->send_stream[(size_t)s], hipStreamNonBlocking) != hipSuccess)
             return bail(SIFT_HIP_EHIP, "sift_hip_group_create: cannot create a shard's transfer stream");
         for (int b = 0; b < kSlots; ++b)
             if (hipEventCreateWithFlags(&g->sent_ev[b][(size_t)s], hipEventDisableTiming) != hipSuccess)
                 return bail(SIFT_HIP_EHIP, "sift_hip_group_create: cannot create an event");
     }
+    sift_hip::defer_frees(true);   // until sift_hip_group_destroy: see launch_guard.h
+    g->defers = true;
+    ApiGuard api(devices[0]);
     (void)hipSetDevice(devices[0]);
     if (hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&g->user_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -592,8 +606,10 @@ void sift_hip_group_destroy(sift_hip_group* g) {
         Rccl& r = rccl();
         for (auto c : g->comm) if (c) (void)r.CommDestroy(c);
     }
-    ApiGuard api;
+    if (g->defers) sift_hip::defer_frees(false);
+    sift_hip::drain_retired_memory();      // nothing is in flight any more
     for (int s = 0; s < g->S; ++s) {
+        ApiGuard api(g->devices[(size_t)s]);
         (void)hipSetDevice(g->devices[(size_t)s]);
         if (g->send_stream[(size_t)s]) { (void)hipStreamSynchronize(g->send_stream[(size_t)s]); (void)hipStreamDestroy(g->send_stream[(size_t)s]); }
         for (int b = 0; b < kSlots; ++b) {
@@ -604,6 +620,7 @@ void sift_hip_group_destroy(sift_hip_group* g) {
             g->in_val[b][(size_t)s].release(g->devices[0]);
         }
     }
+    ApiGuard api0(g->devices[0]);
     (void)hipSetDevice(g->devices[0]);
     for (int b = 0; b < kSlots; ++b) { g->out_kp[b].release(g->devices[0]); g->out_desc[b].release(g->devices[0]); }
     if (g->copy_stream) { (void)hipStreamSynchronize(g->copy_stream); (void)hipStreamDestroy(g->copy_stream); }
@@ -717,7 +734,12 @@ int sift_hip_group_collect(sift_hip_group* g, char* err, int errlen) {
     g->exposed_ms = std::max(0.0, B.t_gathered - std::max(t_wait, B.t_computed));   // the part of it this call had to wait for
     g->gather_bytes = B.wire_bytes;
     if (B.rc != SIFT_HIP_OK) set_err(err, errlen, B.msg);
-    return B.rc;
+    const int rc = B.rc;
+    const bool idle = g->collected == g->submitted;
+    lk.unlock();
+    // nothing of this group is in flight: what its buffers retired while they grew can be freed now (launch_guard.h)
+    if (idle) sift_hip::drain_retired_memory();
+    return rc;
 }
 
 int sift_hip_group_calculate(sift_hip_group* g, const float* host_imgs, int n, int w, int h, const sift_hip_params* params,
@@ -807,6 +829,12 @@ int sift_hip_group_timing(sift_hip_group* g, double* compute_ms, double* gather_
     if (compute_ms) *compute_ms = g->compute_ms;
     if (gather_ms) *gather_ms = g->gather_ms;
     if (gather_bytes) *gather_bytes = g->gather_bytes;
+    return SIFT_HIP_OK;
+}
+/* Time the process's host threads have spent waiting for a launch lock (launch_guard.h: one per device) since it started. */
+int sift_hip_lock_wait_ms(double* ms) {
+    if (!ms) return SIFT_HIP_EINVAL;
+    *ms = sift_hip::launch_lock_wait_ms();
     return SIFT_HIP_OK;
 }
 int sift_hip_group_gather_exposed(sift_hip_group* g, double* exposed_ms) {

@@ -513,199 +513,10 @@ __global__ __launch_bounds__(256) void extrema_edge_kernel(const float* __restri
 #undef SIFT_FX_LOAD
 }
 
-// ---------------------------------------------------------------------------------------------
-// Fused scan + edge filter, STREAMING form (option "extrema_stream").  Every WAVE is on its own: a strip of 248 output columns
-// (lanes 1..62 hold four consecutive columns each; lanes 0 and 63 only supply the x-1 / x+1 neighbours of the strip's ends) and
-// one 64-row block, walked top to bottom:
-//   * a row of the three DoG levels is one 16-byte load per lane and level, fetched kSxPF rows ahead into registers; three
-//     rows (y-1, y, y+1) of the three levels live in registers together with the samples left and right of the lane's four
-//     columns (two wavefront shuffles per level and row) - every DoG pixel is read from HBM once per block (+2 rows, +8 columns);
-//   * the 12-sample non-strict extremum test of row y runs on registers (pairwise max / min over {x-1, x} per level and row),
-//     one candidate bit per pixel into the lane's four 64-bit column words;
-//   * a candidate's 18 samples for the edge filter (3x3 of its own level, a cross in the level below, c / l / r / d above:
-//     all in the lane's registers at that moment, at compile-time indices) go into the wave's LDS queue (structure of arrays,
-//     a ring of 128 entries); whenever 64 are queued, the wave takes them one per lane: the two curvature tests
-//     (sift.cpp:334-343), which most candidates fail, then the 3x3 Householder-QR body (linalg3.h) for the rest; verdicts are
-//     OR-ed into per-column words in LDS (every test of the reference's per-point body only sets `filtered`, so order is free);
-//   * at the end of the block the queue is drained and a lane writes its columns' candidate word, filtered word and count -
-//     the same words extrema_edge_kernel writes.
-// No tile in LDS, no workgroup barrier, no partial cache lines: rows are read in whole 1 KB runs.
-// ---------------------------------------------------------------------------------------------
-constexpr int kSxOut = 248;      // output columns per wave
-constexpr int kSxPF = 2;         // rows in flight per wave (registers; 12 waves per CU x 2 rows x 3 KB cover the latency)
-constexpr int kSxQ = 128;        // queue entries per wave (a ring; a batch is 64)
-constexpr int kSxFields = 19;    // 18 samples + (column | row << 8)
-
-__device__ __noinline__ void sx_run_batch(float (*q)[kSxQ], unsigned long long* fmw, int q_head, int cnt, int lane) {
-    if (lane < cnt) {
-        const int e = (q_head + lane) & (kSxQ - 1);
-        const unsigned id = __float_as_uint(q[18][e]);
-        const int col = (int)(id & 255u), rowbit = (int)(id >> 8);
-        EdgeTaps tp;
-        tp.i1c = q[0][e]; tp.i1l = q[1][e]; tp.i1r = q[2][e]; tp.i1u = q[3][e]; tp.i1d = q[4][e];
-        tp.i1ul = q[5][e]; tp.i1ur = q[6][e]; tp.i1dl = q[7][e]; tp.i1dr = q[8][e];
-        bool filtered = edge_curvature_filtered(tp.i1c, tp.i1l, tp.i1r, tp.i1u, tp.i1d, tp.i1ul, tp.i1ur, tp.i1dl, tp.i1dr);
-        if (!filtered) {
-            tp.i0c = q[9][e]; tp.i0l = q[10][e]; tp.i0r = q[11][e]; tp.i0u = q[12][e]; tp.i0d = q[13][e];
-            tp.i2c = q[14][e]; tp.i2l = q[15][e]; tp.i2r = q[16][e]; tp.i2d = q[17][e];
-            filtered = edge_response_core(tp);
-        }
-        if (filtered) atomicOr(&fmw[col], 1ull << rowbit);
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-
-__global__ __launch_bounds__(256, 3) void extrema_stream_kernel(const float* __restrict__ d0, const float* __restrict__ d1,
-                                                                const float* __restrict__ d2, int w, int h, int nyb, int strips,
-                                                                int word_base, int words_per_image, int total_units,
-                                                                unsigned long long* __restrict__ masks,
-                                                                unsigned long long* __restrict__ fmasks, int* __restrict__ counts) {
-    __shared__ float s_q[4][kSxFields][kSxQ];
-    __shared__ unsigned long long s_fmw[4][256];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int unit = (int)blockIdx.x * 4 + wave;
-    if (unit >= total_units) return;
-    const int per_img = strips * nyb;
-    const int img = unit / per_img;
-    const int rem = unit - img * per_img;
-    const int yb = rem / strips;
-    const int strip = rem - yb * strips;
-    const int ya = yb * 64;
-    const int x_first = strip * kSxOut - 4 + 4 * lane;          // first of the lane's four columns (lane 0: the columns left of the strip)
-    // loads are clamped into the image (w is a multiple of 4): clamped lanes repeat real pixels and never own a candidate
-    const int gx = x_first < 0 ? 0 : (x_first > w - 4 ? w - 4 : x_first);
-    const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
-    const float* __restrict__ p0 = d0 + img_off + gx;
-    const float* __restrict__ p1 = d1 + img_off + gx;
-    const float* __restrict__ p2 = d2 + img_off + gx;
-    const bool owner = lane >= 1 && lane <= 62 && x_first >= 0 && x_first < w;
-    float (*q)[kSxQ] = s_q[wave];
-    unsigned long long* fmw = s_fmw[wave];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fmw[4 * lane + i] = 0ull;
-    int q_head = 0, q_n = 0;      // wave-uniform: first queued entry, entries queued
-
-    struct Row {                  // one image row: the lane's four columns of the three levels and the samples beside them
-        float4 v[3];
-        float l[3], r[3];
-    };
-    auto row_ptr_off = [&](int t) {   // stream row t = image row ya - 1 + t, clamped into the image
-        const int y = ya - 1 + t;
-        return (size_t)(y < 0 ? 0 : (y >= h ? h - 1 : y)) * (size_t)w;
-    };
-    float4 f[kSxPF][3];
-#define SIFT_SX_FETCH(T, U)                                                        \
-    {                                                                              \
-        const size_t o_ = row_ptr_off(T);                                          \
-        f[U][0] = *reinterpret_cast<const float4*>(p0 + o_);                       \
-        f[U][1] = *reinterpret_cast<const float4*>(p1 + o_);                       \
-        f[U][2] = *reinterpret_cast<const float4*>(p2 + o_);                       \
-    }
-    auto make_row = [&](const float4 (&src)[3]) {
-        Row r;
-#pragma unroll
-        for (int L = 0; L < 3; ++L) {
-            r.v[L] = src[L];
-            r.l[L] = __shfl_up(src[L].w, 1);
-            r.r[L] = __shfl_down(src[L].x, 1);
-        }
-        return r;
-    };
-    // one batch: up to 64 queued candidates, one per lane (ONE copy of the curvature tests and the QR body in the kernel's code:
-    // inlined at every point where the queue can fill up it was 17 copies and the kernel ran out of instruction cache)
-    auto run_batch = [&](int cnt) {
-        sx_run_batch(q, fmw, q_head, cnt, lane);
-        q_head = (q_head + cnt) & (kSxQ - 1);
-        q_n -= cnt;
-    };
-
-    static_assert(kSxPF == 2, "the slots of the unrolled steps are spelled out");
-    SIFT_SX_FETCH(0, 0)
-    SIFT_SX_FETCH(1, 1)
-    Row prev = make_row(f[0]);
-    SIFT_SX_FETCH(2, 0)
-    Row cur = make_row(f[1]);
-    SIFT_SX_FETCH(3, 1)
-    unsigned long long cm[4] = {0ull, 0ull, 0ull, 0ull};
-
-    // step: `nxt` = stream row T (image row ya - 1 + T); the candidates of `cur` (image row ya + T - 2) are decided
-#define SIFT_SX_STEP(T, U)                                                                                           \
-    {                                                                                                                \
-        const Row nxt = make_row(f[U]);                                                                              \
-        SIFT_SX_FETCH((T) + kSxPF, U)                                                                                \
-        const int yrow = (T) - 2;                     /* bit of this row in the block's words */                     \
-        const int y = ya + yrow;                                                                                     \
-        const bool y_ok = y >= 1 && y <= h - 2;       /* wave-uniform */                                             \
-        if (y_ok) {                                                                                                  \
-            float pv[3][5], cv[3][5], nv[3][5];       /* columns x-1 .. x+3 of rows y-1, y and y+1 */                \
-            _Pragma("unroll") for (int L = 0; L < 3; ++L) {                                                          \
-                nv[L][0] = nxt.l[L]; nv[L][1] = nxt.v[L].x; nv[L][2] = nxt.v[L].y; nv[L][3] = nxt.v[L].z; nv[L][4] = nxt.v[L].w;     \
-                pv[L][0] = prev.l[L]; pv[L][1] = prev.v[L].x; pv[L][2] = prev.v[L].y; pv[L][3] = prev.v[L].z; pv[L][4] = prev.v[L].w; \
-                cv[L][0] = cur.l[L]; cv[L][1] = cur.v[L].x; cv[L][2] = cur.v[L].y; cv[L][3] = cur.v[L].z; cv[L][4] = cur.v[L].w;     \
-            }                                                                                                        \
-            unsigned bits = 0u;                                                                                      \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
-                const int x = x_first + i;                                                                           \
-                const float c = cv[1][i + 1];                                                                        \
-                float nmax = fmaxf(pv[0][i], pv[0][i + 1]), nmin = fminf(pv[0][i], pv[0][i + 1]);                    \
-                nmax = fmaxf(nmax, fmaxf(pv[1][i], pv[1][i + 1])); nmin = fminf(nmin, fminf(pv[1][i], pv[1][i + 1])); \
-                nmax = fmaxf(nmax, fmaxf(pv[2][i], pv[2][i + 1])); nmin = fminf(nmin, fminf(pv[2][i], pv[2][i + 1])); \
-                nmax = fmaxf(nmax, fmaxf(cv[0][i], cv[0][i + 1])); nmin = fminf(nmin, fminf(cv[0][i], cv[0][i + 1])); \
-                nmax = fmaxf(nmax, fmaxf(cv[2][i], cv[2][i + 1])); nmin = fminf(nmin, fminf(cv[2][i], cv[2][i + 1])); \
-                nmax = fmaxf(nmax, cv[1][i]); nmin = fminf(nmin, cv[1][i]);                                          \
-                const bool cand = owner && x >= 1 && x <= w - 2 && (!(nmax > c) || !(nmin < c));                     \
-                bits |= (cand ? 1u : 0u) << i;                                                                       \
-                cm[i] |= (unsigned long long)(cand ? 1u : 0u) << yrow;                                               \
-            }                                                                                                        \
-            /* queue the candidates with their 18 samples, column position by column position */                    \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
-                const bool mine = (bits >> i) & 1u;                                                                  \
-                const unsigned long long bal = __ballot(mine);                                                       \
-                if (bal != 0ull) {                    /* wave-uniform */                                             \
-                    if (mine) {                                                                                      \
-                        const int pos = (q_head + q_n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))) & (kSxQ - 1); \
-                        const float nl1 = nv[1][i], nr1 = i == 3 ? nxt.r[1] : nv[1][i + 2];                          \
-                        const float pl1 = pv[1][i], pr1 = i == 3 ? prev.r[1] : pv[1][i + 2];                         \
-                        q[0][pos] = cv[1][i + 1]; q[1][pos] = cv[1][i]; q[2][pos] = i == 3 ? cur.r[1] : cv[1][i + 2]; \
-                        q[3][pos] = pv[1][i + 1]; q[4][pos] = nv[1][i + 1];                                          \
-                        q[5][pos] = pl1; q[6][pos] = pr1; q[7][pos] = nl1; q[8][pos] = nr1;                          \
-                        q[9][pos] = cv[0][i + 1]; q[10][pos] = cv[0][i]; q[11][pos] = i == 3 ? cur.r[0] : cv[0][i + 2]; \
-                        q[12][pos] = pv[0][i + 1]; q[13][pos] = nv[0][i + 1];                                        \
-                        q[14][pos] = cv[2][i + 1]; q[15][pos] = cv[2][i]; q[16][pos] = i == 3 ? cur.r[2] : cv[2][i + 2]; \
-                        q[17][pos] = nv[2][i + 1];                                                                   \
-                        q[18][pos] = __uint_as_float((unsigned)(4 * lane + i) | ((unsigned)yrow << 8));              \
-                    }                                                                                                \
-                    q_n += (int)__popcll(bal);                                                                       \
-                    __builtin_amdgcn_wave_barrier();                                                                 \
-                    if (q_n >= 64) run_batch(64);                                                                    \
-                }                                                                                                    \
-            }                                                                                                        \
-        }                                                                                                            \
-        prev = cur;                                                                                                  \
-        cur = nxt;                                                                                                   \
-    }
-#pragma unroll 1
-    for (int t = 2; t < 66; t += 4) {
-        SIFT_SX_STEP(t + 0, 0) SIFT_SX_STEP(t + 1, 1) SIFT_SX_STEP(t + 2, 0) SIFT_SX_STEP(t + 3, 1)
-    }
-#undef SIFT_SX_STEP
-#undef SIFT_SX_FETCH
-    if (q_n > 0) run_batch(q_n);
-    __builtin_amdgcn_wave_barrier();
-    if (owner) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int x = x_first + i;
-            if (x < w) {
-                const size_t wi = (size_t)img * (size_t)words_per_image + (size_t)word_base + (size_t)x * (size_t)nyb + (size_t)yb;
-                masks[wi] = cm[i];
-                fmasks[wi] = fmw[4 * lane + i];
-                counts[wi] = __popcll(cm[i]);
-            }
-        }
-    }
-}
+// (Round 3 also built a STREAMING form of this kernel - every wave on its own strip of 248 columns x one 64-row block, three rows
+// of the three levels in registers, candidates queued with their 18 samples in a per-wave LDS ring - which was bit-identical and
+// used 0.64 of this kernel's wave-cycles at octave 0 alone, but took as long beside the gradient kernel and twice as long on the
+// small octaves; it was an option, off, and was removed in round 4.)
 
 __global__ __launch_bounds__(256) void edge_filter_kernel(const DevPlan* __restrict__ plan,
                                                           const Candidate* __restrict__ cands,
@@ -758,25 +569,6 @@ void launch_extrema_mask(hipStream_t s, const DevPlan* d_plan, const DevPlan& pl
     }
 }
 
-static int g_extrema_stream = 0;   // option "extrema_stream": 1 = the streaming form for launches of at least 1024 waves
-void set_extrema_stream(int v) { g_extrema_stream = v; }
-
-// false: not launched (too few waves to be worth it: the tile kernel takes the level)
-static bool launch_extrema_stream_level(hipStream_t s, const DevPlan& plan, int k, unsigned long long* d_masks, unsigned long long* d_fmasks,
-                                        int* d_counts) {
-    const int o = plan.scan_octave[k], i = plan.scan_dog[k];
-    const int w = plan.w[o], h = plan.h[o];
-    const int l = o * plan.dogs + i;
-    const int strips = (w + kSxOut - 1) / kSxOut;
-    const long long total = (long long)strips * plan.scan_nyb[k] * plan.n_images;
-    // a wave's 66 rows are a chain of ~2.8 us each: a level needs several waves per SIMD slot (octave 0 of a batch) to stream at rate
-    if (total < (g_extrema_stream >= 2 ? 1 : 4000) || total > 0x7fffffffLL) return false;
-    hipLaunchKernelGGL(extrema_stream_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, (const float*)plan.dog[l - 1],
-                       (const float*)plan.dog[l], (const float*)plan.dog[l + 1], w, h, plan.scan_nyb[k], strips, plan.scan_word_base[k],
-                       plan.words_per_image, (int)total, d_masks, d_fmasks, d_counts);
-    return true;
-}
-
 // the fused kernel stages 16-byte groups: every scanned octave's rows must be 16-byte aligned and at least one group wide
 bool extrema_edge_supported(const DevPlan& plan) {
     for (int k = 0; k < plan.n_scan; ++k) {
@@ -792,7 +584,6 @@ bool extrema_edge_supported(const DevPlan& plan) {
 void launch_extrema_edge(hipStream_t s, const DevPlan& plan, unsigned long long* d_masks, unsigned long long* d_fmasks,
                          int* d_counts) {
     for (int k = 0; k < plan.n_scan; ++k) {
-        if (g_extrema_stream && launch_extrema_stream_level(s, plan, k, d_masks, d_fmasks, d_counts)) continue;
         const int o = plan.scan_octave[k], i = plan.scan_dog[k];
         const int w = plan.w[o], h = plan.h[o];
         const int l = o * plan.dogs + i;

@@ -13,13 +13,66 @@
 // and for platforms where the runtime's copies behave differently; the default path is hipMemcpyAsync.
 #include <algorithm>
 
+#include <atomic>
+#include <chrono>
+#include <utility>
+#include <vector>
+
 #include "common.h"
 
 namespace sift_hip {
 
-std::recursive_mutex& launch_lock() {
-    static std::recursive_mutex m;
-    return m;
+// ---- launch locks (launch_guard.h) -------------------------------------------------------------------------------------
+constexpr int kMaxLockDevices = 64;
+std::recursive_mutex& launch_lock_of(int device) {
+    static std::recursive_mutex m[kMaxLockDevices];
+    return m[(unsigned)device % (unsigned)kMaxLockDevices];
+}
+static thread_local int t_device = 0;
+int set_device_tracked(int device) {
+    const hipError_t e = (hipSetDevice)(device);
+    if (e == hipSuccess) t_device = device;
+    return (int)e;
+}
+int tracked_device() { return t_device; }
+std::recursive_mutex& launch_lock() { return launch_lock_of(t_device); }
+static std::atomic<long long> g_lock_wait_ns{0};
+void launch_lock_note_wait(double ms) { g_lock_wait_ns.fetch_add((long long)(ms * 1e6), std::memory_order_relaxed); }
+double launch_lock_wait_ms() { return (double)g_lock_wait_ns.load(std::memory_order_relaxed) / 1e6; }
+static void lock_accounted(std::recursive_mutex& m) {
+    if (m.try_lock()) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    m.lock();
+    g_lock_wait_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
+}
+LaunchGuard::LaunchGuard() : m(launch_lock()) { lock_accounted(m); }
+LaunchGuard::LaunchGuard(int device) : m(launch_lock_of(device)) { lock_accounted(m); }
+
+// ---- deferred frees (launch_guard.h) -----------------------------------------------------------------------------------
+static std::mutex g_retire_m;
+static std::vector<std::pair<int, void*>> g_retired;
+static std::atomic<int> g_defer{0};
+void defer_frees(bool on) { g_defer.fetch_add(on ? 1 : -1); }
+bool frees_deferred() { return g_defer.load() > 0; }
+void retire_device_memory(int device, void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_retire_m);
+    g_retired.emplace_back(device, p);
+}
+void drain_retired_memory() {
+    std::vector<std::pair<int, void*>> take;
+    {
+        std::lock_guard<std::mutex> lk(g_retire_m);
+        take.swap(g_retired);
+    }
+    if (take.empty()) return;
+    const int cur = t_device;
+    for (auto& e : take) {
+        LaunchGuard g(e.first);
+        (void)set_device_tracked(e.first);
+        (void)(hipFree)(e.second);
+    }
+    (void)set_device_tracked(cur);
 }
 
 constexpr int kIoWorkgroups = 16;
@@ -28,7 +81,7 @@ constexpr int kIoUnroll = 4;
 typedef unsigned u4v __attribute__((ext_vector_type(4)));   // a 16-byte unit the nontemporal builtins accept
 typedef float f4v __attribute__((ext_vector_type(4)));
 
-// 16-byte units [0, n16) of src -> dst (either side may be mapped host memory)
+// 16-byte units [0, n16) of src -> dst (device memory of this GPU, or a peer's through peer access)
 __global__ __launch_bounds__(256) void io_copy_kernel(const u4v* __restrict__ src, u4v* __restrict__ dst, size_t n16) {
     const size_t stride = (size_t)gridDim.x * 256;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -42,31 +95,9 @@ __global__ __launch_bounds__(256) void io_copy_kernel(const u4v* __restrict__ sr
     for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
-// 16 samples of 8 bits per unit -> 16 floats
-__global__ __launch_bounds__(256) void io_widen_kernel(const u4v* __restrict__ src, f4v* __restrict__ dst, size_t n16) {
-    const size_t stride = (size_t)gridDim.x * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    auto put = [&](size_t at, const u4v v) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            dst[4 * at + k] = f4v{(float)(v[k] & 255u), (float)((v[k] >> 8) & 255u), (float)((v[k] >> 16) & 255u), (float)(v[k] >> 24)};
-    };
-    for (; i + (kIoUnroll - 1) * stride < n16; i += kIoUnroll * stride) {
-        u4v v[kIoUnroll];
-#pragma unroll
-        for (int k = 0; k < kIoUnroll; ++k) v[k] = __builtin_nontemporal_load(src + i + k * stride);
-#pragma unroll
-        for (int k = 0; k < kIoUnroll; ++k) put(i + k * stride, v[k]);
-    }
-    for (; i < n16; i += stride) put(i, __builtin_nontemporal_load(src + i));
-}
-
-__global__ void io_tail_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, float* __restrict__ dstf, int n) {
+__global__ void io_tail_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int n) {
     const int i = threadIdx.x;
-    if (i < n) {
-        if (dstf) dstf[i] = (float)src[i];
-        else dst[i] = src[i];
-    }
+    if (i < n) dst[i] = src[i];
 }
 
 __global__ __launch_bounds__(256) void io_copy4_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst, size_t n4) {
@@ -85,17 +116,7 @@ void launch_io_copy(hipStream_t s, const void* src, void* dst, size_t bytes) {
     const int tail = (int)(bytes - n16 * 16);
     if (tail)
         hipLaunchKernelGGL(io_tail_kernel, dim3(1), dim3(64), 0, s, static_cast<const unsigned char*>(src) + n16 * 16,
-                           static_cast<unsigned char*>(dst) + n16 * 16, (float*)nullptr, tail);
-}
-
-// count 8-bit samples of src -> count floats at dst; src 16-byte aligned, dst 16-byte aligned
-void launch_io_widen(hipStream_t s, const void* src, float* dst, size_t count) {
-    const size_t n16 = count / 16;
-    if (n16) hipLaunchKernelGGL(io_widen_kernel, dim3(kIoWorkgroups), dim3(256), 0, s, static_cast<const u4v*>(src), reinterpret_cast<f4v*>(dst), n16);
-    const int tail = (int)(count - n16 * 16);
-    if (tail)
-        hipLaunchKernelGGL(io_tail_kernel, dim3(1), dim3(64), 0, s, static_cast<const unsigned char*>(src) + n16 * 16, (unsigned char*)nullptr,
-                           dst + n16 * 16, tail);
+                           static_cast<unsigned char*>(dst) + n16 * 16, tail);
 }
 
 // A few counters to zero between kernels of one stream: a kernel of our own, not hipMemsetAsync - the runtime's fill kernel was

@@ -505,15 +505,12 @@ static thread_local hipEvent_t t_ev_start = nullptr, t_ev_stop = nullptr;
 
 constexpr long long kSmallTileLaunch = 4096;   // 64x64 tiles: up to 16 per CU
 
-static int g_fused_grid_mode = 1;   // option "fused_grid": 1 = as many persistent workgroups as the chip holds at once; 0 = 1024 (round 2)
-void set_fused_grid_mode(int v) { g_fused_grid_mode = v; }
-
 // Workgroups of `kernel` one launch can have resident at a time on this device (CUs x occupancy), asked once per instantiation.
 template <class K>
 static int resident_workgroups(K kernel) {
     static thread_local int cached[16] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    int dev = tracked_device();
+    if (dev < 0 || dev >= 16) dev = 0;
     if (cached[dev] == 0) {
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
@@ -532,8 +529,7 @@ static void launch_fused_rt(hipStream_t s, const float* in, float* out, float* d
     // Persistent workgroups: as many as are resident at once, so that every workgroup starts at once and fetches its next
     // tile under the arithmetic of the current one.  (More than that - 1024 in round 2 - run in a second round that begins
     // when the first ends: two tile latencies back to back and nothing prefetched.)
-    int cap = 1024;
-    if (g_fused_grid_mode == 1) cap = dog ? resident_workgroups(blur_fused_kernel<R, true, TH>) : resident_workgroups(blur_fused_kernel<R, false, TH>);
+    const int cap = dog ? resident_workgroups(blur_fused_kernel<R, true, TH>) : resident_workgroups(blur_fused_kernel<R, false, TH>);
     int grid = total < cap ? total : cap;
     if (grid >= 8) grid &= ~7;
     const bool aligned = (((uintptr_t)in | (uintptr_t)out | (uintptr_t)dog) & 15u) == 0;

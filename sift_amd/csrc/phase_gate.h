@@ -36,18 +36,12 @@ namespace sift_hip {
 
 class PhaseGate {
 public:
-    enum Phase { kP = 0, kE = 1, kD = 2, kC = 3, kM = 4 };   // kM: a point inside the pyramid (set_mid)
+    enum Phase { kP = 0, kE = 1, kD = 2, kC = 3 };
     // 0: the schedule above.  1 (option "gate_schedule"): the cleanup chain C(g) runs under the next pyramid P(g+1) and the
     // descriptors D(g) under the next extrema / gradient pass E(g+1):  ... | P(g+1) || C(g) | E(g+1) || D(g) | P(g+2) || C(g+1) | ...
     void set_schedule(int m) {
         std::lock_guard<std::mutex> lk(m_);
         schedule_ = m;
-    }
-
-    // descriptors of batch g wait for the successor's mark kM (somewhere inside its pyramid) instead of its whole pyramid
-    void set_mid(bool on) {
-        std::lock_guard<std::mutex> lk(m_);
-        mid_ = on;
     }
 
     PhaseGate() {
@@ -141,9 +135,8 @@ public:
         while (next_ <= g + 1 && hipEventQuery(me.ev[kC]) == hipErrorNotReady) cv_.wait_for(lk, std::chrono::microseconds(20));
         if (next_ > g + 1) {
             Slot& succ = slot(g + 1);
-            const Phase w = mid_ ? kM : kP;
-            cv_.wait(lk, [&] { return succ.g == g + 1 && succ.rec[w]; });
-            (void)hipStreamWaitEvent(s, succ.ev[w], 0);
+            cv_.wait(lk, [&] { return succ.g == g + 1 && succ.rec[kP]; });
+            (void)hipStreamWaitEvent(s, succ.ev[kP], 0);
         }
         me.entered_d = true;
         cv_.notify_all();
@@ -154,7 +147,7 @@ public:
         std::lock_guard<std::mutex> lk(m_);
         Slot& me = slot(g);
         if (me.g != g) return;
-        for (int ph = 0; ph < 5; ++ph)
+        for (int ph = 0; ph < 4; ++ph)
             if (!me.rec[ph]) {
                 (void)hipEventRecord(me.ev[ph], s);
                 me.rec[ph] = true;
@@ -171,8 +164,8 @@ public:
 private:
     struct Slot {
         long long g = -1;
-        hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-        bool rec[5] = {false, false, false, false, false};
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        bool rec[4] = {false, false, false, false};
         bool entered_c = false, entered_d = false;
     };
     Slot& slot(long long g) { return ring_[g % kRing]; }
@@ -180,7 +173,6 @@ private:
     std::condition_variable cv_;
     long long next_ = 0;
     int schedule_ = 1;
-    bool mid_ = false;
     Slot ring_[kRing];
 };
 

@@ -104,7 +104,8 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
-def device_results(ctx, total: int, device, packed: bool = True, wire: str | None = None, rec_out: torch.Tensor | None = None):
+def device_results(ctx, total: int, device, packed: bool = True, wire: str | None = None, rec_out: torch.Tensor | None = None,
+                   defer_pack: bool = False):
     """The context's current results as torch tensors on `device`, in a wire format:
         "full"    (records uint8 [total*20], descriptors float32 [total*128])
         "packed"  (records uint8 [total*20], descriptors float32 [total*112])            see pack_descriptors
@@ -112,7 +113,9 @@ def device_results(ctx, total: int, device, packed: bool = True, wire: str | Non
     (`packed=True/False` selects "packed"/"full" when `wire` is not given.)  The library's arrays are read in place
     (no staging copy) by copies on torch's current stream, which this function waits for: nothing orders torch's stream
     against the library's own (non-blocking) streams, so the context must not start its next batch before the copies are
-    done.  On return the tensors own their data and the context's slot may be released."""
+    done.  On return the tensors own their data and the context's slot may be released.
+    defer_pack (wire "sparse"): the pack kernel is only queued (Context.sparse_pack(wait=False)); the context may start its next
+    batch at once and the tensors are complete after `ctx.pack_wait()`, which any thread may call."""
     wire = wire or ("packed" if packed else "full")
     if total == 0:
         return (rec_out if rec_out is not None and rec_out.numel() == 0 else torch.empty(0, dtype=torch.uint8, device=device),
@@ -127,7 +130,7 @@ def device_results(ctx, total: int, device, packed: bool = True, wire: str | Non
         assert rec.numel() == total * (20 + SPARSE_MASK_BYTES) and rec.dtype == torch.uint8
         values = torch.empty(nnz, dtype=torch.float32, device=device)
         torch.cuda.current_stream(device).synchronize()   # the allocator may hand out memory still in use on torch's stream
-        ctx.sparse_pack(rec.data_ptr(), values.data_ptr())
+        ctx.sparse_pack(rec.data_ptr(), values.data_ptr(), wait=not defer_pack)
         return rec, values
     out = kp.clone(), (pack_descriptors(d) if wire == "packed" else d.clone())
     torch.cuda.current_stream(device).synchronize()   # the library may rewrite its arrays as soon as the slot is released
@@ -167,6 +170,8 @@ class KeypointGather:
         self.hdr_bytes = 8 * self.hdr_words
         self.step = 0
         self._rec_bufs = {}            # records_buffer: data_ptr of a records view -> the allocation with header room in front
+        import threading
+        self._rec_lock = threading.Lock()   # records_buffer may be called by the threads that pack, push by the one that gathers
         self.wire_bytes = 0            # received (dst) or sent (others), payload and headers
         self.wait_s = 0.0              # host time spent waiting for transfers / reading headers
         # sender side
@@ -203,16 +208,18 @@ class KeypointGather:
             return torch.empty(0, dtype=torch.uint8, device=self.dev)
         buf = torch.empty(self.hdr_bytes + nbytes, dtype=torch.uint8, device=self.dev)
         view = buf[self.hdr_bytes:]
-        self._rec_bufs[view.data_ptr()] = buf
-        while len(self._rec_bufs) > 4:     # a view that was staged elsewhere instead of being pushed as it is must not pin its buffer for ever
-            self._rec_bufs.pop(next(iter(self._rec_bufs)))
+        with self._rec_lock:
+            self._rec_bufs[view.data_ptr()] = buf
+            while len(self._rec_bufs) > 6:     # a view that was staged elsewhere instead of being pushed as it is must not pin its buffer for ever
+                self._rec_bufs.pop(next(iter(self._rec_bufs)))
         return view
 
     def _send_ops(self, total, records, values, counts):
         """message = [header of this step | records of the previous step], then the previous step's values"""
         prev_rec, prev_val = self._prev if self._prev is not None else (torch.empty(0, dtype=torch.uint8, device=self.dev), torch.empty(0, dtype=torch.float32, device=self.dev))
         head = self._header(total, 0 if records is None else records.numel(), 0 if values is None else values.numel(), counts)
-        a = self._rec_bufs.pop(prev_rec.data_ptr(), None) if prev_rec.numel() else None
+        with self._rec_lock:
+            a = self._rec_bufs.pop(prev_rec.data_ptr(), None) if prev_rec.numel() else None
         if a is not None and a.numel() == self.hdr_bytes + prev_rec.numel():
             a[:self.hdr_bytes].copy_(head)           # the message buffer was laid out by records_buffer
         else:
@@ -335,6 +342,66 @@ class KeypointGather:
                 out.append(self._finish(hk - 1, bufs, rec_sizes))
             self._msgs = None
         return out
+
+
+class GatherThread:
+    """The one thread of a rank that talks to the gather.  The host threads that run batches (BatchPipeline.run_stream: one
+    per context, each taking its next step itself) hand their packed lists to `put(seq, records, values, counts)` and go on;
+    this thread pushes them to the KeypointGather in step order `seq` = 0, 1, 2, ... (the batches of two contexts may finish
+    out of order), so that a rank's point-to-point messages are issued by one thread in the same order on every rank, and
+    no batch waits for a transfer.  `close()` flushes the gather, joins the thread and re-raises what it raised.
+    `on_done(list of (records_all, values_all, counts_all))` is called on this thread with the steps completed on `dst`."""
+
+    def __init__(self, gatherer: "KeypointGather", on_done=None, cuda_device: int | None = None, keep: int = 3):
+        import queue
+        import threading
+        self._g, self._on_done, self._dev, self._keep_n = gatherer, on_done, cuda_device, keep
+        self._q = queue.Queue()
+        self._error = None
+        self._t = threading.Thread(target=self._run, name="sift-gather")
+        self._t.start()
+
+    def _run(self):
+        closed = False
+        try:
+            if self._dev is not None:
+                torch.cuda.set_device(self._dev)
+            pending, want, keep = {}, 0, []
+            while True:
+                got = self._q.get()
+                if got is None:
+                    closed = True
+                    break
+                pending[got[0]] = got[1:]
+                while want in pending:
+                    rec, val, counts, ready = pending.pop(want)
+                    if ready is not None:
+                        ready()
+                    keep.append((rec, val))        # the gather reads them until two pushes later
+                    del keep[:-self._keep_n]
+                    done = self._g.push(rec, val, counts)
+                    if self._on_done is not None and done:
+                        self._on_done(done)
+                    want += 1
+            if pending:
+                raise RuntimeError(f"gather thread closed with steps {sorted(pending)} waiting for step {want}")
+            done = self._g.flush()
+            if self._on_done is not None and done:
+                self._on_done(done)
+        except BaseException as e:   # noqa: BLE001
+            self._error = e
+            while not closed:           # keep draining so that no producer blocks; close() reports the error
+                closed = self._q.get() is None
+
+    def put(self, seq: int, records, values, counts, ready=None) -> None:
+        """`ready`, if given, is called on the gather thread right before the push (e.g. Context.pack_wait of a deferred pack)."""
+        self._q.put((seq, records, values, counts, ready))
+
+    def close(self) -> None:
+        self._q.put(None)
+        self._t.join()
+        if self._error is not None:
+            raise self._error
 
 
 class GatherHandle:

@@ -215,10 +215,17 @@ class Context:
             raise ValueError("the sparse wire format would lose a bin 7 that is not +0.0f: send the full descriptors")
         return int(n.value)
 
-    def sparse_pack(self, dev_records: int, dev_values: int):
-        """Write total*34 record bytes and sparse_size() floats to the device addresses given."""
-        if self._L.sift_hip_result_sparse_pack(self._h, C.c_void_p(dev_records), C.c_void_p(dev_values)):
+    def sparse_pack(self, dev_records: int, dev_values: int, wait: bool = True):
+        """Write total*34 record bytes and sparse_size() floats to the device addresses given.  wait=False: the pack is only
+        queued (side stream) and this context's next batch may be started at once; `pack_wait()` - from any thread - returns
+        when the lists are complete."""
+        f = self._L.sift_hip_result_sparse_pack if wait else self._L.sift_hip_result_sparse_pack_async
+        if f(self._h, C.c_void_p(dev_records), C.c_void_p(dev_values)):
             raise HipError("sift_hip_result_sparse_pack failed")
+
+    def pack_wait(self):
+        if self._L.sift_hip_result_pack_wait(self._h):
+            raise HipError("sift_hip_result_pack_wait failed")
 
     def sparse_unpack(self, dev_records: int, dev_values: int, n_keypoints: int, dev_keypoints: int, dev_descriptors: int):
         """34-byte records + set floats (device addresses, from any context's sparse_pack) -> n_keypoints 20-byte keypoint
@@ -433,6 +440,14 @@ class Group:
         if self._L.sift_hip_group_timing(self._h, C.byref(a), C.byref(b), C.byref(n)):
             raise HipError("no result")
         return a.value, b.value, n.value
+
+
+def lock_wait_ms() -> float:
+    """Time this process's host threads have spent waiting for the library's per-device launch locks (sift_hip_lock_wait_ms)."""
+    v = C.c_double()
+    if _lib.load().sift_hip_lock_wait_ms(C.byref(v)):
+        raise HipError("sift_hip_lock_wait_ms failed")
+    return v.value
 
 
 def unpack_sparse_host(rec, val, kp_out=None, desc_out=None, threads: int = 8):

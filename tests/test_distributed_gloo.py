@@ -202,6 +202,91 @@ def test_keypoint_gather_three_ranks_single_step():
     _run_kg(3, 1)
 
 
+def test_keypoint_gather_eight_ranks():
+    """The world size of the target node (8 GPUs, BASELINE config 4): eight processes, ragged lists, four steps; rank 0 ends up
+    with every step's lists in rank order = global image order."""
+    _run_kg(8, 4)
+
+
+def _gt_worker(rank, world, port, q, steps):
+    """bench.py's N > 1 host loop without a GPU: two threads (the contexts' host threads of BatchPipeline.run_stream) hand their
+    steps' lists to the rank's GatherThread, deliberately out of order; the thread pushes them in step order."""
+    import threading
+    import time
+    from sift_amd.gather import GatherThread, KeypointGather
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = KeypointGather(2 + rank, torch.device("cpu"), dst=0)
+    done = []
+    gt = GatherThread(g, done.extend)
+
+    def producer(slot):
+        for step in range(slot, steps, 2):
+            c, r, v = _step_data(rank, step)
+            if slot == 0:
+                time.sleep(0.02 * ((rank + step) % 3))      # slot 1's steps often overtake slot 0's
+            gt.put(step, torch.from_numpy(r), torch.from_numpy(v), c)
+
+    ts = [threading.Thread(target=producer, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    gt.close()
+    if rank == 0:
+        q.put([(a.numpy().copy(), b.numpy().copy(), cc.numpy().copy()) for a, b, cc in done] + [g.wire_bytes])
+    else:
+        assert done == []
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_thread_pushes_in_step_order_eight_ranks():
+    world, steps = 8, 5
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gt_worker, args=(r, world, port, q, steps)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got.pop()
+    assert len(got) == steps
+    for step, (rec, val, counts) in enumerate(got):
+        parts = [_step_data(r, step) for r in range(world)]
+        assert counts.tolist() == np.concatenate([p[0] for p in parts]).tolist()
+        assert rec.tobytes() == np.concatenate([p[1] for p in parts]).tobytes()
+        assert val.tobytes() == np.concatenate([p[2] for p in parts]).tobytes()
+
+
+def test_gather_thread_reports_a_gap():
+    """A step that never arrives is an error at close(), not a hang."""
+    from sift_amd.gather import GatherThread
+
+    class _G:
+        def push(self, *a):
+            return []
+
+        def flush(self):
+            return []
+
+    gt = GatherThread(_G())
+    gt.put(1, torch.zeros(0, dtype=torch.uint8), torch.zeros(0), [0])
+    try:
+        gt.close()
+    except RuntimeError as e:
+        assert "waiting for step 0" in str(e)
+    else:
+        raise AssertionError("no error for the missing step 0")
+
+
 class _DoneWork:
     def wait(self):
         return True

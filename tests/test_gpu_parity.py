@@ -329,118 +329,17 @@ def test_pipeline_parity_kept_pixels_reduce(ctx, report_dir, case):
         ctx.set_option("stream_min_waves", 0)
 
 
-CHAIN_VARIANTS = [
-    # chain_from, chain_mode, blur launches per batch with 4 octaves x 3 DoGs (16 without the chain)
-    (2, 1, 10),   # octaves 2 - 3 as one launch, agent-scope accesses
-    (2, 2, 10),   # the same with every image's tiles spread over all XCDs (any workgroup reads any workgroup's level)
-    (2, 0, 10),   # ordinary accesses, agent-scope release / acquire fences around every tile
-    (1, 1, 6),    # octaves 1 - 3
-    (3, 1, 14),   # octave 3 only
-]
-
-
-def test_level_chain_on_alternating_batches(ctx):
-    """The rest of the pyramid from an octave on as ONE launch of (stage, image, tile) items that wait for their source level per
-    image (kernels_chain.hip; Sift::_createDOGs, sift.cpp:388-411).  Two batches of 11 DIFFERENT frames alternate on one context -
-    a level read stale would be the other batch's, a wait that lets a tile start early would read a half-written level - in every
-    variant of the kernel: all results against the per-level launches (which the other tests pin to the oracle), and for three
-    frames of each batch every Gaussian and DoG level of every octave against the oracle itself."""
-    dogs, octaves, n = 3, 4, 11
-    params = _lib.Params(dogs, octaves, 1.6, O.K_SQRT2, 0)
-    batches = [np.stack([synth_frame(640, 480, 100 * (b + 1) + s) for s in range(n)]) for b in range(2)]
-    probe = (0, 5, 10)
-    runs = [{i: O.OracleRun(batches[b][i], dogs, octaves) for i in probe} for b in range(2)]
-
-    def run(b):
-        ctx.profile_reset()
-        ctx.calculate_batch(batches[b], params)
-        kp, desc = ctx.results()
-        return ctx.counts().copy(), kp.copy(), desc.copy(), ctx.profile(0)[1]
-
-    try:
-        ctx.set_option("profile", 1)
-        ctx.set_option("chain_from", 0)
-        ref = [run(b) for b in range(2)]
-        assert ref[0][3] == 16 and ref[0][0].tolist() != ref[1][0].tolist()
-        for chain_from, mode, launches in CHAIN_VARIANTS:
-            ctx.set_option("chain_from", chain_from)
-            ctx.set_option("chain_mode", mode)
-            for rep in range(4):
-                b = rep % 2
-                counts, kp, desc, got_launches = run(b)
-                what = f"chain_from {chain_from} chain_mode {mode} pass {rep}"
-                assert got_launches == launches, f"{what}: {got_launches} blur launches - the chain did not run"
-                assert counts.tolist() == ref[b][0].tolist(), f"{what}: counts"
-                assert kp.tobytes() == ref[b][1].tobytes() and desc.tobytes() == ref[b][2].tobytes(), f"{what}: results"
-                if rep < 2:
-                    for i in probe:
-                        for o in range(octaves):
-                            for j in range(dogs + 1):
-                                assert_bits_equal(ctx.level("gaussian", o, j, i), runs[b][i].level("gaussian", o, j), f"{what}: frame {i} gaussian({o},{j})")
-                            for j in range(dogs):
-                                assert_bits_equal(ctx.level("dog", o, j, i), runs[b][i].level("dog", o, j), f"{what}: frame {i} dog({o},{j})")
-    finally:
-        ctx.set_option("profile", 0)
-        ctx.set_option("chain_from", 0)
-        ctx.set_option("chain_mode", 1)
-
-
-def test_level_chain_falls_back(ctx, report_dir):
-    """What the chain kernel has no body for keeps the launch per level: a width that is no multiple of 4 in the octave the chain
-    would start at (1000 -> 500 -> 250)."""
-    ctx.set_option("profile", 1)
-    ctx.set_option("chain_from", 2)
-    try:
-        ctx.profile_reset()
-        compare_run(ctx, synth_frame(1000, 600, 77), 3, 3, False, "chain fallback 1000x600", report_dir, batch_of=2)
-        assert ctx.profile(0)[1] == 12, "one blur launch per level and reduction expected"
-    finally:
-        ctx.set_option("profile", 0)
-        ctx.set_option("chain_from", 0)
-
-
-SX_CASES = [
-    ("streaming extrema 640x480 4x3 x2", 640, 480, 41, 3, 4, 2),
-    ("streaming extrema 1000x600 (strips of 248 columns: 5th strip 8 columns wide)", 1000, 600, 42, 3, 3, 1),
-    ("streaming extrema 252x130 (one strip and a bit, blocks of 64 rows: 3rd block 2 rows)", 252, 130, 43, 3, 2, 3),
-    ("streaming extrema 768x576 4 dogs (two scanned levels per octave)", 768, 576, 44, 4, 2, 1),
-]
-
-
-@pytest.mark.parametrize("case", SX_CASES, ids=[c[0] for c in SX_CASES])
-def test_pipeline_parity_streaming_extrema(ctx, report_dir, case):
-    """The streaming form of the fused scan + edge filter (extrema_stream_kernel: rows in registers, candidates queued with their
-    18 samples, curvature tests and QR bodies on batches of 64), forced onto small inputs (option extrema_stream = 2): candidate
-    lists, edge-filter flags and everything after them against the oracle."""
-    name, w, h, seed, dogs, octaves, frames = case
-    ctx.set_option("extrema_stream", 2)
-    try:
-        rep = compare_run(ctx, synth_frame(w, h, seed), dogs, octaves, False, name, report_dir, batch_of=frames)
-        assert rep["final"] > 0 and rep["candidates"] > 100
-    finally:
-        ctx.set_option("extrema_stream", 0)
-
-
-def test_streaming_extrema_on_ties(ctx):
-    """A constant image makes EVERY interior pixel a candidate (248 per row and wave: the queue drains a batch at every column
-    position) and every one of them is filtered (H = 0); a checkerboard of two values gives alternating ties."""
-    params = _lib.Params(3, 2, 1.6, O.K_SQRT2, 0)
-    yy, xx = np.mgrid[0:200, 0:512]
-    for img in (np.full((200, 512), 77.0, np.float32), (((xx // 3 + yy // 5) % 2) * 60 + 40).astype(np.float32)):
-        ctx.set_option("extrema_stream", 2)
-        try:
-            ctx.calculate_batch(img[None], params)
-            got = ctx.stage("candidates").copy()
-            counts = ctx.counts().copy()
-        finally:
-            ctx.set_option("extrema_stream", 0)
-        run = O.OracleRun(img, 3, 2)
-        want = run.points("candidates")[0]
-        assert got.size == want.size and got.size > 2000
-        for f in ("x", "y", "octave", "index"):
-            assert (got[f] == want[f]).all(), f
-        assert (got["filtered"].astype(bool) == want["filtered"].astype(bool)).all()
-        assert counts[0] == run.points("final")[0].size
+def test_release_library_rejects_measurement_options(ctx):
+    """The options that switch phases of kernels off for timing (wrong results), stamp or repeat batches exist only in the
+    measurement build (`make -C sift_amd/csrc diag`, -DSIFT_HIP_DIAG); the shipped library answers SIFT_HIP_EINVAL, as it does
+    for the variants removed in round 4 and for any unknown name."""
+    from sift_amd.sift import HipError
+    for name in ("desc_dbg", "orient_dbg", "diag_repeat", "diag_pyramid_span", "diag_serial_gradient", "diag_cleanup_stamps", "stream_waves",
+                 "chain_from", "chain_mode", "chain_spread", "gate_mid", "gate_early_chain", "extrema_stream", "io_kernels", "stage_kernels",
+                 "fused_grid", "no_such_option"):
+        assert ctx._L.sift_hip_set_option(ctx._h, name.encode(), 1) == _lib.EINVAL, name
+    assert ctx._L.sift_hip_set_option(ctx._h, b"desc_kernel", 0) == _lib.EINVAL      # the round-1 tile kernel is gone
+    assert ctx._L.sift_hip_set_option(ctx._h, b"desc_kernel", 1) == _lib.OK
 
 
 def test_pipeline_parity_general_orientation_bins(ctx, report_dir):
@@ -549,6 +448,33 @@ def test_bench_starts_its_own_ranks():
                         "--steps", "1", "--warmup", "0", "--frames", "2", "--no-cpu-baseline", "--no-extras", "--set", "no_such_option=1"],
                        env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode != 0
+
+
+@pytest.mark.parametrize("host_loop", ["stream", "dispatch"])
+def test_bench_eight_ranks_sharing_the_gpu(host_loop):
+    """BASELINE config 4's world size on this one-GPU box: `bench.py --gpus 8` with all eight ranks on GPU 0 (gloo as the
+    transport), 4 frames per rank = seeds 1 .. 32 block-sharded.  `--check-gather` makes rank 0 run all 32 frames itself after
+    the timed region and compare the lists that came through the gather in the last step with its own: records, descriptor
+    floats and per-image counts, in global image order.  Both host loops: every context's thread feeding itself with one
+    gather thread per rank (the default), and the single dispatching thread."""
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--share-device", "--backend", "gloo",
+                        "--steps", "3", "--warmup", "1", "--frames", "4", "--no-cpu-baseline", "--no-extras", "--check-gather",
+                        "--host-loop", host_loop],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert out["n_gpus"] == 8 and out["steps"] == 3 and cfg["frames_total"] == 32 and cfg["host_loop"] == host_loop
+    assert cfg["gather_steps_on_rank0"] == 3
+    assert cfg["gather_keypoints_on_rank0"] == cfg["keypoints_per_step"] * 3
+    assert cfg["gather_check"] is True, cfg.get("gather_check_what")
+    assert out["value"] > 0
 
 
 def test_pipeline_parity_256_frame_batch(ctx, report_dir):
@@ -944,6 +870,26 @@ for wire in (1, 2):
         assert counts.tolist() == ctx.counts().tolist()
         assert kp.tobytes() == wkp.tobytes() and desc.tobytes() == wdesc.tobytes()
     g.close()
+# batches that GROW while two are in flight: the pack buffers, arrival areas and result arrays of both slots and the shards'
+# context buffers are reallocated under way - with deferred frees (launch_guard.h: no hipFree on a GPU while one of its
+# transfers may be waiting for its peer; the retired allocations go when the group is idle)
+from sift_amd.sift import lock_wait_ms
+grow = [np.stack([synth_frame(320, 240, 700 + 16 * b + i) for i in range(3 * 2 ** b)]) for b in range(4)]      # 3, 6, 12, 24 frames
+g = Group([0, 0, 0])
+got = []
+g.submit(grow[0], params)
+for b in range(1, len(grow) + 1):
+    if b < len(grow):
+        g.submit(grow[b], params)
+    g.collect()
+    got.append((g.counts().copy(),) + tuple(a.copy() for a in g.results()))
+for b, (counts, kp, desc) in zip(grow, got):
+    ctx.calculate_batch(b, params)
+    wkp, wdesc = ctx.results()
+    assert counts.tolist() == ctx.counts().tolist()
+    assert kp.tobytes() == wkp.tobytes() and desc.tobytes() == wdesc.tobytes()
+g.close()
+assert lock_wait_ms() >= 0.0
 ctx.close()
 print("isolated ok")
 """
@@ -1035,7 +981,7 @@ def test_cli_result_file(ctx, tmp_path, monkeypatch):
     assert cli.main(["parrot_r.pgm", "--no-overlay"]) == 0 and not os.path.exists(tmp_path / "interstpoints.txt")
 
 
-@pytest.mark.parametrize("option", ["gate_schedule=0", "gate_early_chain=1", "pyramid_side=0"])
+@pytest.mark.parametrize("option", ["gate_schedule=0", "pyramid_side=0"])
 def test_other_gate_schedules_leave_the_results_alone(ctx, option):
     """The other orders of the phase gate (sift_amd/csrc/phase_gate.h: schedule 0 keeps the pyramids alone on the chip) and the
     pyramid without its side stream (every launch on one stream) are options: same results."""

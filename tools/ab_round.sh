@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of library options on one box: bench line per option set (ms/step, roofline), then the per-launch table of the default.
-#   bash tools/ab_round.sh "" "fused_grid=0" "stream_min_waves=512"
+#   bash tools/ab_round.sh "" "pyramid_side=0" "stream_min_waves=512"
 set -u
 export TMPDIR=/tmp
 mkdir -p gpurun_out/ab

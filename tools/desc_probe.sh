@@ -1,4 +1,5 @@
 #!/bin/bash
+export SIFT_HIP_LIBRARY=libsift_hip_diag.so   # measurement options (desc_dbg, orient_dbg, diag_*, stream_waves): make -C sift_amd/csrc diag
 # descriptor_wave_kernel: time with phases switched off (desc_dbg bits: 1 no neighbour chains, 2 no histograms; WRONG results) and SQ counters
 export TMPDIR=/tmp
 mkdir -p gpurun_out

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of the kernels whose name matches $1, with bench options $2...:  bash tools/pmc_one.sh extrema_stream --set extrema_stream=1
+# SQ counters of the kernels whose name matches $1, with bench options $2...:  bash tools/pmc_one.sh descriptor_ --set desc_kernel=2
 export TMPDIR=/tmp
 pat=$1; shift
 for c in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD"; do

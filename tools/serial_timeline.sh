@@ -1,4 +1,5 @@
 #!/bin/bash
+export SIFT_HIP_LIBRARY=libsift_hip_diag.so   # measurement options (desc_dbg, orient_dbg, diag_*, stream_waves): make -C sift_amd/csrc diag
 # single-step kernel timeline with the gradient pass serialised behind the extrema pass (every kernel alone on the chip)
 set -u
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+export SIFT_HIP_LIBRARY=libsift_hip_diag.so   # measurement options (desc_dbg, orient_dbg, diag_*, stream_waves): make -C sift_amd/csrc diag
 # A/B of the streaming blur's wave count (library option stream_waves; 0 = tile kernel only)
 export TMPDIR=/tmp
 mkdir -p gpurun_out

@@ -1,4 +1,5 @@
 #!/bin/bash
+export SIFT_HIP_LIBRARY=libsift_hip_diag.so   # measurement options (desc_dbg, orient_dbg, diag_*, stream_waves): make -C sift_amd/csrc diag
 # streaming blur: waves a launch is cut into (option stream_waves), bench line per setting
 export TMPDIR=/tmp
 for sw in ${SWS:-2048 3072 4096 2048 4096}; do

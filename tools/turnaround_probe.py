@@ -1,3 +1,4 @@
+import os as _os; _os.environ.setdefault("SIFT_HIP_LIBRARY", "libsift_hip_diag.so")   # measurement options: `make -C sift_amd/csrc diag`
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
