@@ -16,7 +16,7 @@
 // for the call only, a batch makes ~60 such calls of a few microseconds); no spin-wait; no null stream; 4 / 24 hardware queues -
 // none of it changed the rate.  Replacing the runtime's device-to-device copies by kernels of this library (group.cpp) did:
 // 1 crash in 200 runs, and none in 150 runs of examples/sift_pipeline.cpp, which never used such copies.
-#include "launch_guard.h"   // one lock per device since round 4, waiting time accounted, deferred frees
+#include "launch_guard.h"   // one lock per device since round 4, waiting time accounted
 namespace sift_hip {
 // ... and so are the calls that create or destroy what a launch touches (device and pinned memory, streams, events): the
 // crashes went on, always below hipLaunchKernel, until hipMalloc / hipFree / hipStreamCreate / hipEventCreate of one thread could

@@ -31,13 +31,7 @@ struct DevBuf {
     void ensure(size_t bytes) {
         if (bytes <= cap) return;
         ApiGuard api;
-        if (p) {
-            if (sift_hip::frees_deferred()) {   // a transfer of this GPU may be waiting for its peer: hipFree would wait with it (launch_guard.h)
-                sift_hip::retire_device_memory(sift_hip::tracked_device(), p);
-            } else {
-                SIFT_HIP_CHECK(hipFree(p));
-            }
-        }
+        if (p) SIFT_HIP_CHECK(hipFree(p));
         p = nullptr;
         cap = 0;
         SIFT_HIP_CHECK(hipMalloc(&p, bytes));

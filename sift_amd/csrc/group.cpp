@@ -45,7 +45,7 @@
 
 extern "C" int sift_hip_internal_copy(void* stream, const void* src, void* dst, size_t bytes);   // kernels_io.hip
 
-#include "launch_guard.h"   // per-device launch locks (allocations and stream / event creation never run beside another thread's launch on that device), deferred frees
+#include "launch_guard.h"   // per-device launch locks: allocations and stream / event creation never run beside another thread's launch on that device
 
 namespace {
 
@@ -106,9 +106,9 @@ struct DevMem {   // grow-only device buffer on a fixed device
         if (want <= cap) return true;
         ApiGuard api(device);
         if (hipSetDevice(device) != hipSuccess) return false;
-        // never hipFree here: it waits for the whole device, and a send of this GPU may be waiting for a receive that is only
-        // posted once other threads got on (the group runs with deferred frees: launch_guard.h); freed when the group is idle
-        if (p) sift_hip::retire_device_memory(device, p);
+        // hipFree waits for the whole device - also for an RCCL send of this GPU that is waiting for its receive.  The lock held
+        // meanwhile is THIS device's only (launch_guard.h): the other shards and the gather thread get on and post that receive.
+        if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
         const long long take = want + want / 4 + 256;
@@ -160,7 +160,6 @@ struct Batch {
 
 struct sift_hip_group {
     std::vector<int> devices;
-    bool defers = false;                      // this group has switched the process to deferred frees (launch_guard.h)
     std::vector<char> peer_ok;                // per shard: its GPU can write devices[0]'s memory in place (same device, or peer access enabled)
     std::vector<sift_hip_ctx*> ctx;
     sift_hip_ctx* unpack_ctx = nullptr;       // on devices[0]: the gather thread's own (sift_hip_sparse_unpack beside shard 0's kernels)
@@ -519,7 +518,6 @@ int sift_hip_group_create(const int* devices, int n_devices, sift_hip_group** ou
     g->S = n_devices;
     auto bail = [&](int rc, const char* m) {
         if (m) set_err(err, errlen, m);
-        if (g->defers) sift_hip::defer_frees(false);
         for (auto* p : g->ctx) sift_hip_destroy(p);
         if (g->unpack_ctx) sift_hip_destroy(g->unpack_ctx);
         delete g;
@@ -566,8 +564,6 @@ int sift_hip_group_create(const int* devices, int n_devices, sift_hip_group** ou
             if (hipEventCreateWithFlags(&g->sent_ev[b][(size_t)s], hipEventDisableTiming) != hipSuccess)
                 return bail(SIFT_HIP_EHIP, "sift_hip_group_create: cannot create an event");
     }
-    sift_hip::defer_frees(true);   // until sift_hip_group_destroy: see launch_guard.h
-    g->defers = true;
     ApiGuard api(devices[0]);
     (void)hipSetDevice(devices[0]);
     if (hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -606,8 +602,6 @@ void sift_hip_group_destroy(sift_hip_group* g) {
         Rccl& r = rccl();
         for (auto c : g->comm) if (c) (void)r.CommDestroy(c);
     }
-    if (g->defers) sift_hip::defer_frees(false);
-    sift_hip::drain_retired_memory();      // nothing is in flight any more
     for (int s = 0; s < g->S; ++s) {
         ApiGuard api(g->devices[(size_t)s]);
         (void)hipSetDevice(g->devices[(size_t)s]);
@@ -734,12 +728,7 @@ int sift_hip_group_collect(sift_hip_group* g, char* err, int errlen) {
     g->exposed_ms = std::max(0.0, B.t_gathered - std::max(t_wait, B.t_computed));   // the part of it this call had to wait for
     g->gather_bytes = B.wire_bytes;
     if (B.rc != SIFT_HIP_OK) set_err(err, errlen, B.msg);
-    const int rc = B.rc;
-    const bool idle = g->collected == g->submitted;
-    lk.unlock();
-    // nothing of this group is in flight: what its buffers retired while they grew can be freed now (launch_guard.h)
-    if (idle) sift_hip::drain_retired_memory();
-    return rc;
+    return B.rc;
 }
 
 int sift_hip_group_calculate(sift_hip_group* g, const float* host_imgs, int n, int w, int h, const sift_hip_params* params,

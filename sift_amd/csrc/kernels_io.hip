@@ -37,7 +37,6 @@ int set_device_tracked(int device) {
 int tracked_device() { return t_device; }
 std::recursive_mutex& launch_lock() { return launch_lock_of(t_device); }
 static std::atomic<long long> g_lock_wait_ns{0};
-void launch_lock_note_wait(double ms) { g_lock_wait_ns.fetch_add((long long)(ms * 1e6), std::memory_order_relaxed); }
 double launch_lock_wait_ms() { return (double)g_lock_wait_ns.load(std::memory_order_relaxed) / 1e6; }
 static void lock_accounted(std::recursive_mutex& m) {
     if (m.try_lock()) return;
@@ -47,33 +46,6 @@ static void lock_accounted(std::recursive_mutex& m) {
 }
 LaunchGuard::LaunchGuard() : m(launch_lock()) { lock_accounted(m); }
 LaunchGuard::LaunchGuard(int device) : m(launch_lock_of(device)) { lock_accounted(m); }
-
-// ---- deferred frees (launch_guard.h) -----------------------------------------------------------------------------------
-static std::mutex g_retire_m;
-static std::vector<std::pair<int, void*>> g_retired;
-static std::atomic<int> g_defer{0};
-void defer_frees(bool on) { g_defer.fetch_add(on ? 1 : -1); }
-bool frees_deferred() { return g_defer.load() > 0; }
-void retire_device_memory(int device, void* p) {
-    if (!p) return;
-    std::lock_guard<std::mutex> lk(g_retire_m);
-    g_retired.emplace_back(device, p);
-}
-void drain_retired_memory() {
-    std::vector<std::pair<int, void*>> take;
-    {
-        std::lock_guard<std::mutex> lk(g_retire_m);
-        take.swap(g_retired);
-    }
-    if (take.empty()) return;
-    const int cur = t_device;
-    for (auto& e : take) {
-        LaunchGuard g(e.first);
-        (void)set_device_tracked(e.first);
-        (void)(hipFree)(e.second);
-    }
-    (void)set_device_tracked(cur);
-}
 
 constexpr int kIoWorkgroups = 16;
 constexpr int kIoUnroll = 4;
