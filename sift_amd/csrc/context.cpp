@@ -154,6 +154,8 @@ struct sift_hip_ctx {
     bool wire_count = false;          // option "wire_count": the descriptor kernel also counts the floats of the sparse wire format
     bool wire_counted = false;        // ... and has done so for the current batch
     bool wire_scanned = false;        // ... and the block offsets + the number of floats were queued behind it (h_wire holds them once the batch is done)
+    int warm_calls = 0;               // calculate calls this context has completed (the first ones run alone: FirstBatch)
+    int warm_copies = 0;              // ... and calls that fetch results (their first transfers)
     hipEvent_t ev_pack = nullptr;     // sift_hip_result_sparse_pack_async: recorded behind the pack kernel on the side stream
     bool pack_pending = false;        // ... and not yet waited for by this context's main stream
     DevBuf d_lrank, d_ochunk, d_ocnt, d_recs;   // list position -> orientation result; kept counts per 1024 candidates; early/late counts
@@ -1379,9 +1381,36 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     return SIFT_HIP_EINVAL;
 }
 
+}  // extern "C"
+
+namespace {
+// A context's FIRST batch runs alone in the process.  The HIP runtime sets a good deal up lazily, on first use - a kernel's
+// function object at its first launch, a stream's copy machinery at its first transfer - and it is while several host threads
+// go through those first uses side by side that the launches crash inside the runtime (SEGV below hipLaunchKernel: a launch
+// that finds a null object; common.h, tools/example_loop.sh).  Every launch and every runtime copy of this library is under the
+// device's launch lock anyway, which serialises the CALLS but not what they start; a whole first batch under one process-wide
+// lock serialises that too, and costs nothing once every context has run once.
+std::mutex& first_batch_mutex() {
+    static std::mutex m;
+    return m;
+}
+constexpr int kWarmCalls = 2;     // the second batch still meets first uses (e.g. buffers that only now grow, the gather's first copies)
+struct FirstBatch {
+    int* n;
+    std::unique_lock<std::mutex> lk;
+    explicit FirstBatch(int* counter) : n(counter) {
+        if (*n < kWarmCalls) lk = std::unique_lock<std::mutex>(first_batch_mutex());
+    }
+    ~FirstBatch() { if (*n < kWarmCalls) ++*n; }
+};
+}  // namespace
+
+extern "C" {
+
 int sift_hip_calculate_batch_device(sift_hip_ctx* c, const void* dev_imgs, int n, int w, int h,
                                     const sift_hip_params* params, char* err, int errlen) {
     if (!c || !dev_imgs || !params) return SIFT_HIP_EINVAL;
+    FirstBatch first_batch(&c->warm_calls);
     return guarded(err, errlen, [&]() {
         SIFT_HIP_CHECK(hipSetDevice(c->device));
         c->have_result = c->have_pyramid = false;   // whatever happens next, the previous batch's results are gone
@@ -1401,6 +1430,7 @@ int sift_hip_calculate_batch_device(sift_hip_ctx* c, const void* dev_imgs, int n
 int sift_hip_calculate_batch(sift_hip_ctx* c, const float* host_imgs, int n, int w, int h,
                              const sift_hip_params* params, char* err, int errlen) {
     if (!c || !host_imgs || !params || n <= 0 || w <= 0 || h <= 0) return SIFT_HIP_EINVAL;
+    FirstBatch first_batch(&c->warm_calls);
     return guarded(err, errlen, [&]() {
         SIFT_HIP_CHECK(hipSetDevice(c->device));
         c->have_result = c->have_pyramid = false;   // whatever happens next, the previous batch's results are gone
@@ -1419,6 +1449,7 @@ int sift_hip_calculate_batch(sift_hip_ctx* c, const float* host_imgs, int n, int
 int sift_hip_calculate_batch_u8(sift_hip_ctx* c, const uint8_t* host_imgs, int n, int w, int h,
                                 const sift_hip_params* params, char* err, int errlen) {
     if (!c || !host_imgs || !params || n <= 0 || w <= 0 || h <= 0) return SIFT_HIP_EINVAL;
+    FirstBatch first_batch(&c->warm_calls);
     return guarded(err, errlen, [&]() {
         SIFT_HIP_CHECK(hipSetDevice(c->device));
         c->have_result = c->have_pyramid = false;
@@ -1438,6 +1469,7 @@ int sift_hip_calculate_batch_u8(sift_hip_ctx* c, const uint8_t* host_imgs, int n
 int sift_hip_calculate_batch_device_u8(sift_hip_ctx* c, const void* dev_imgs, int n, int w, int h,
                                        const sift_hip_params* params, char* err, int errlen) {
     if (!c || !dev_imgs || !params || n <= 0 || w <= 0 || h <= 0) return SIFT_HIP_EINVAL;
+    FirstBatch first_batch(&c->warm_calls);
     return guarded(err, errlen, [&]() {
         SIFT_HIP_CHECK(hipSetDevice(c->device));
         c->have_result = c->have_pyramid = false;
@@ -1481,6 +1513,7 @@ int64_t sift_hip_result_total(sift_hip_ctx* c) { return (c && c->have_result) ? 
 
 int sift_hip_result_copy(sift_hip_ctx* c, sift_hip_keypoint* kp, float* desc) {
     if (!c || !c->have_result) return SIFT_HIP_EINVAL;
+    FirstBatch first_copy(&c->warm_copies);
     return guarded(nullptr, 0, [&]() {
         SIFT_HIP_CHECK(hipSetDevice(c->device));
         if (c->total > 0) {
@@ -1575,6 +1608,7 @@ int sift_hip_result_pack_wait(sift_hip_ctx* c) {
 // (~200 instead of 532 bytes per keypoint).  After sift_hip_result_sparse_size; records: total * 34 bytes, values: n_values floats.
 int sift_hip_result_copy_sparse(sift_hip_ctx* c, void* records, float* values) {
     if (!c || !c->have_result || c->wire_for_total != c->total || c->wire_values < 0) return SIFT_HIP_EINVAL;
+    FirstBatch first_copy(&c->warm_copies);
     if (c->total > 0 && (!records || (c->wire_values > 0 && !values))) return SIFT_HIP_EINVAL;
     if (c->total == 0) return SIFT_HIP_OK;
     char err[256];

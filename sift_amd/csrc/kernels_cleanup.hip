@@ -1353,6 +1353,7 @@ void launch_cleanup1(hipStream_t s, int n_images, const uint8_t* d_flags, const 
                      uint32_t* d_lrank, const Candidate* d_cands, int list_cap, int* d_list_cnt, int* d_late_cnt,
                      int* d_fallback) {
     static const bool attr_ok = [] {
+        LaunchGuard guard;   // creates the kernel's function object: never beside another thread's launch (launch_guard.h)
         return hipFuncSetAttribute(reinterpret_cast<const void*>(cleanup1_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kDynLds) == hipSuccess;
     }();
@@ -1381,6 +1382,7 @@ void launch_cleanup_kat(hipStream_t s, const uint8_t* d_flags, int n, uint8_t* w
                         uint32_t* wp, uint32_t* d_out, int* d_info, int force_global, OrientIn* d_ord, uint32_t* d_lrank,
                         const Candidate* d_cd) {
     static const bool attr_ok = [] {
+        LaunchGuard guard;
         return hipFuncSetAttribute(reinterpret_cast<const void*>(cleanup_kat_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, kDynLds) == hipSuccess;
     }();

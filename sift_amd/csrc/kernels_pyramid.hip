@@ -512,6 +512,10 @@ static int resident_workgroups(K kernel) {
     int dev = tracked_device();
     if (dev < 0 || dev >= 16) dev = 0;
     if (cached[dev] == 0) {
+        // under the device's launch lock like a launch: the query makes the runtime create the kernel's function object, and that
+        // beside another thread's launch is one way into the crash below hipLaunchKernel (a launch that finds no device kernel:
+        // launch_guard.h)
+        LaunchGuard guard;
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
