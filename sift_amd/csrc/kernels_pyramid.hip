@@ -505,24 +505,16 @@ static thread_local hipEvent_t t_ev_start = nullptr, t_ev_stop = nullptr;
 
 constexpr long long kSmallTileLaunch = 4096;   // 64x64 tiles: up to 16 per CU
 
-// Workgroups of `kernel` one launch can have resident at a time on this device (CUs x occupancy), asked once per instantiation.
-template <class K>
-static int resident_workgroups(K kernel) {
-    static thread_local int cached[16] = {0};
-    int dev = tracked_device();
-    if (dev < 0 || dev >= 16) dev = 0;
-    if (cached[dev] == 0) {
-        // under the device's launch lock like a launch: the query makes the runtime create the kernel's function object, and that
-        // beside another thread's launch is one way into the crash below hipLaunchKernel (a launch that finds no device kernel:
-        // launch_guard.h)
-        LaunchGuard guard;
-        int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        (void)hipGetLastError();
-        cached[dev] = per_cu * cus;
-    }
-    return cached[dev];
+// Workgroups of blur_fused_kernel<R, ., TH> one launch has resident at a time: CUs x the workgroups per CU its launch bounds ask
+// for.  (Round 3 asked the runtime - hipOccupancyMaxActiveBlocksPerMultiprocessor, once per thread and instantiation, in front of
+// the launch: a runtime call that creates the kernel's function object beside other threads' launches.  The launch path makes
+// no such call any more; the CU count is read once per device when the first context is created, sift_hip_create.)
+static int g_cus[64] = {0};
+template <int R, int TH>
+static int resident_workgroups() {
+    constexpr int per_cu = (R <= 8 ? 3 : ((R <= 24 || (TH <= 48 && R <= 28)) ? 2 : 1));   // blur_fused_kernel's __launch_bounds__
+    const int cus = g_cus[(unsigned)tracked_device() % 64u];
+    return per_cu * (cus > 0 ? cus : 256);
 }
 
 template <int R, int TH>
@@ -533,7 +525,7 @@ static void launch_fused_rt(hipStream_t s, const float* in, float* out, float* d
     // Persistent workgroups: as many as are resident at once, so that every workgroup starts at once and fetches its next
     // tile under the arithmetic of the current one.  (More than that - 1024 in round 2 - run in a second round that begins
     // when the first ends: two tile latencies back to back and nothing prefetched.)
-    const int cap = dog ? resident_workgroups(blur_fused_kernel<R, true, TH>) : resident_workgroups(blur_fused_kernel<R, false, TH>);
+    const int cap = resident_workgroups<R, TH>();
     int grid = total < cap ? total : cap;
     if (grid >= 8) grid &= ~7;
     const bool aligned = (((uintptr_t)in | (uintptr_t)out | (uintptr_t)dog) & 15u) == 0;
@@ -714,6 +706,12 @@ void launch_dog(hipStream_t s, const float* lower, const float* higher, float* o
 // their first launches at the same time (several contexts, one thread each) were seen to crash inside that step
 // (tools/asan_example.sh: SEGV below hipLaunchKernel).  sift_hip_create touches every unit once, under a lock.
 __global__ void tu_probe_pyramid_kernel() {}
-void tu_touch_pyramid(hipStream_t s) { hipLaunchKernelGGL(tu_probe_pyramid_kernel, dim3(1), dim3(1), 0, s); }
+void tu_touch_pyramid(hipStream_t s) {
+    int cus = 0;
+    const int dev = tracked_device();
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) g_cus[(unsigned)dev % 64u] = cus;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(tu_probe_pyramid_kernel, dim3(1), dim3(1), 0, s);
+}
 
 }  // namespace sift_hip
