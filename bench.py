@@ -112,10 +112,20 @@ def cpu_baseline(frames, faithful=True):
                       "container (not on this box: the reference does not travel); same keypoints and descriptors, bit for bit"}
     except Exception:
         pass
-    return {"per_frame": per_frame, "reference_binary": ref, "faithful": faith, **host_cpu(), "value": kps / secs, "unit": "keypoints/s", "cores": 1, "kind": "port",
+    lean = {"value": kps / secs, "unit": "keypoints/s", "cores": 1, "kind": "port",
             "sample": f"{len(frames)} of the {FRAMES_PER_GPU} synthetic 1920x1080 frames, 4 oct x 3 DoG, oracle in lean mode "
                       f"(reference's per-candidate image copies and per-keypoint re-blur hoisted; same results), "
                       f"{secs:.1f} s CPU, {kps} keypoints"}
+    out = {"per_frame": per_frame, "reference_binary": ref, "lean_port": lean, **host_cpu()}
+    if faith is not None:
+        # the headline baseline is the REFERENCE'S cost structure (what `Sift::calculate` costs on this host), not the faster port
+        out.update({"value": faith["value"], "unit": "keypoints/s", "cores": 1, "kind": "port", "sample": faith["sample"],
+                    "seconds": faith["seconds"], "keypoints": faith["keypoints"],
+                    "whole_frame_measured_once": {"value": 43.3, "unit": "keypoints/s", "seconds": 456.0, "keypoints": 19764,
+                                                  "what": "the same mode on the whole of frame 1 (1920x1080), this box type, round 2: profiles/r02_bench_full.json"}})
+    else:
+        out.update(lean)
+    return out
 
 
 def pmc_traffic_live(extra_args):  # noqa: C901
@@ -228,6 +238,7 @@ def main():
     ap.add_argument("--rccl-loopback", action="store_true",
                     help="N = 1 only: every step's keypoint lists also travel through RCCL point-to-point to this same rank "
                          "(KeypointGather(loopback=True)): the N > 1 gather path, messages and sizes, on a one-GPU box")
+    ap.add_argument("--repeats", type=int, default=5, help="repetitions of the K-step loop reported as ms_per_step_repeats (the headline is the first)")
     ap.add_argument("--check-gather", action="store_true",
                     help="N > 1, after the timed region: rank 0 runs every rank's frames itself, rank by rank, and compares the lists that "
                          "arrived through the gather in the last step with its own - records, descriptor floats and per-image counts in "
@@ -433,6 +444,22 @@ def main():
     dt = time.perf_counter() - t0
     for c in ctxs:
         c.set_option("profile", 0)
+    gathered_head = (gathered[0] - gatherer_t0[0], gathered[1] - gatherer_t0[1]) if gatherer is not None else (None, None)
+    # the same K steps a few more times, AFTER the headline region (which stays the first repetition, so that `steps` and
+    # `ms_per_step` describe one and the same loop): the spread of a 55 ms sample on this box, max over ranks each
+    repeat_ms = [dt / args.steps * 1e3]
+    for _ in range(max(0, args.repeats - 1)):
+        if gatherer is not None:
+            gatherer = KeypointGather(nf, comm_dev, dst=0, loopback=loopback)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t_r = time.perf_counter()
+        run_steps(args.steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        repeat_ms.append((time.perf_counter() - t_r) / args.steps * 1e3)
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
@@ -441,6 +468,9 @@ def main():
         k = torch.tensor([kps], dtype=torch.int64, device=comm_dev)
         dist.all_reduce(k, op=dist.ReduceOp.SUM)
         kps = int(k.item())
+        rr = torch.tensor(repeat_ms, dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(rr, op=dist.ReduceOp.MAX)
+        repeat_ms = [float(v) for v in rr.tolist()]
 
     if rank == 0:
         prof = [c.profile(0) for c in ctxs]
@@ -460,6 +490,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_repeats": {"n": len(repeat_ms), "min": min(repeat_ms), "median": sorted(repeat_ms)[len(repeat_ms) // 2], "max": max(repeat_ms),
+                                    "all": repeat_ms, "what": "the same K-step loop repeated back to back; the headline ms_per_step is the first repetition"},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -471,8 +503,8 @@ def main():
                        "rccl_ranks": rccl_ranks,   # as the RCCL communicator reports it (0: no RCCL communicator in this run)
                        "rccl_loopback": loopback,   # N = 1 with the N > 1 gather messages sent through RCCL to this same rank
                        "gather_settle_steps": settle,   # untimed set-up steps of the gather path in front of the warm-up (N > 1 only)
-                       "gather_steps_on_rank0": (gathered[0] - gatherer_t0[0]) if gatherer is not None else None,
-                       "gather_keypoints_on_rank0": (gathered[1] - gatherer_t0[1]) if gatherer is not None else None,
+                       "gather_steps_on_rank0": gathered_head[0],
+                       "gather_keypoints_on_rank0": gathered_head[1],
                        "gather_ms_per_step": (gatherer.wait_s / args.steps * 1e3) if gatherer is not None else None,
                        "wire_bytes_per_step": (gatherer.wire_bytes / args.steps) if gatherer is not None else None,
                        "gather": ("RCCL p2p of keypoint records + descriptors to rank 0, no per-step collective (sizes ride one step ahead), overlapped with the following steps; "

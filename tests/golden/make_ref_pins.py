@@ -2,7 +2,7 @@
 """Pins for the CPU oracle, produced by the reference's OWN prebuilt binary.
 
     python tests/golden/make_ref_pins.py                                   (in the build container, where /root/reference is mounted)
-    python tests/golden/make_ref_pins.py bench_frame | truncation | configs   (the long-running pins, one fixture each)
+    python tests/golden/make_ref_pins.py bench_frame | config2 | truncation | configs   (the long-running pins, one fixture each)
 
 /root/reference/bin/arch_x64/sift cannot be started here (Vigra, OpenCV, Boost are DT_NEEDED and absent) and the
 sources cannot be rebuilt for the same reason, but `Sift::calculate` and the `sift::alg` functions inside it only need
@@ -186,6 +186,7 @@ def long_running(which):
     """The pins that take the reference tens of minutes to hours (it copies three DoG images per candidate and re-blurs a
     level per keypoint); each goes to its own fixture.
         bench_frame   frame 1 of the bench workload, 1920x1080, 3 DoGs x 4 octaves          (51 minutes)
+        config2       BASELINE.json configs[1] exactly as written: 640x480 seed 1, 4 octaves x 3 DoGs   (about a minute)
         truncation    blob_frame 1024x1088 seed 5: 66260 survivors of the first cleanup, `u16_t size` keeps 724 (App. B-7); the
                       reference copies three DoG images per candidate (2.7 TB of copies for the 220 716 candidates)
         configs       BASELINE.json configs[2] exactly as written (throws after 14 s; configs[4] as written would run for days)"""
@@ -202,6 +203,20 @@ def long_running(which):
                      "levels_wh": np.array(r["levels_wh"], np.int64), "level_dims": r["level_dims"],
                      "level_scale_bits": r["level_scale_bits"], "level_sha": np.array(r["level_sha"])}
             np.savez_compressed(os.path.join(HERE, "refpin_bench_frame.npz"), **store)
+        elif which == "config2":
+            # BASELINE.json configs[1] exactly as written: one 640x480 greyscale frame (seed 1: CASES[1] of tests/test_gpu_parity.py),
+            # 4 octaves x 3 DoGs - octave 3 is 80x60 with radii up to 27
+            img = synth_frame(640, 480, 1)
+            t0 = time.time()
+            r = ref_calculate(img, 3, 4, 0, tmp)
+            store = {"params": np.array([3, 4, 0, 640, 480, 1], np.int64), "image_sha": np.array(sha(img)), "seconds": np.array(time.time() - t0),
+                     "points": r["points"], "desc_sha": np.array(hashlib.sha256(r["desc"].tobytes()).hexdigest()),
+                     "levels_wh": np.array(r["levels_wh"], np.int64), "level_dims": r["level_dims"],
+                     "level_scale_bits": r["level_scale_bits"], "level_sha": np.array(r["level_sha"]),
+                     "dogs_wh": np.array(r["dogs_wh"], np.int64), "dog_dims": r["dog_dims"], "dog_scale_bits": r["dog_scale_bits"],
+                     "dog_sha": np.array(r["dog_sha"]), "mag_sha": np.array(r["mag_sha"]), "ori_sha": np.array(r["ori_sha"])}
+            np.savez_compressed(os.path.join(HERE, "refpin_config2.npz"), **store)
+            print("config2:", r["points"].size, "points in", float(store["seconds"]), "s")
         elif which == "truncation":
             w, h, seed = 1024, 1088, 5
             img = blob_frame(w, h, seed)
@@ -230,7 +245,7 @@ def long_running(which):
                 store[name + "/seconds"] = np.array(time.time() - t0)
             np.savez_compressed(os.path.join(HERE, "refpin_configs_as_written.npz"), **store)
         else:
-            raise SystemExit("bench_frame | truncation | configs")
+            raise SystemExit("bench_frame | config2 | truncation | configs")
 
 
 if __name__ == "__main__":

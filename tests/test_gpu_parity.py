@@ -1435,6 +1435,31 @@ def test_hip_bench_frame_matches_the_reference_binary(ctx):
             assert sha(ctx.level("gaussian", o, j, 0)) == str(pin["level_sha"][o * mh + j]), f"gaussian({o},{j})"
 
 
+def test_hip_config2_as_written_matches_the_reference_binary(ctx):
+    """BASELINE.json configs[1] exactly as written (one 640x480 frame, seed 1, 4 octaves x 3 DoGs) against what the reference's
+    own binary returned for it: keypoints, scales, orientations, descriptors, every Gaussian and DoG level - no oracle in between."""
+    import hashlib
+    pin = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refpin_config2.npz"))
+    img = synth_frame(640, 480, 1)
+    assert sha(img) == str(pin["image_sha"])
+    ctx.calculate_batch(img[None], _lib.Params(3, 4, 1.6, O.K_SQRT2, 0))
+    kp, desc = ctx.results()
+    ref = pin["points"]
+    assert kp.size == ref.size
+    for f in ("x", "y", "octave", "index"):
+        assert (kp[f] == ref[f]).all(), f
+    assert kp["scale"].tobytes() == ref["scale"].tobytes() and kp["orientation"].tobytes() == ref["orientation"].tobytes()
+    assert hashlib.sha256(desc[kp["has_descriptor"].astype(bool)].tobytes()).hexdigest() == str(pin["desc_sha"])
+    mw, mh = (int(v) for v in pin["levels_wh"])
+    for o in range(mw):
+        for j in range(mh):
+            assert sha(ctx.level("gaussian", o, j, 0)) == str(pin["level_sha"][o * mh + j]), f"gaussian({o},{j})"
+    dw, dh = (int(v) for v in pin["dogs_wh"])
+    for o in range(dw):
+        for j in range(dh):
+            assert sha(ctx.level("dog", o, j, 0)) == str(pin["dog_sha"][o * dh + j]), f"dog({o},{j})"
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refpin_u16_truncation.npz")),
                     reason="fixture not generated")
 def test_hip_u16_truncation_matches_the_reference_binary(ctx):

@@ -169,6 +169,34 @@ def test_bench_frame_matches_the_reference_binary():
             assert sha(run.level("gaussian", o, j)) == str(pin["level_sha"][o * mh + j]), f"gaussian({o},{j})"
 
 
+CONFIG2_PIN = os.path.join(HERE, "golden", "refpin_config2.npz")
+
+
+@pytest.mark.skipif(not os.path.exists(CONFIG2_PIN), reason="fixture not generated")
+def test_config2_as_written_matches_the_reference_binary():
+    """BASELINE.json configs[1] exactly as written: one 640x480 frame (seed 1), 4 octaves x 3 DoGs - keypoints, orientations,
+    descriptors, every Gaussian and DoG level (octave 3 is 80x60 with radii up to 27, sift.cpp:381-417) and the final gradient
+    maps as the reference's own binary returned them."""
+    pin = np.load(CONFIG2_PIN)
+    dogs, octaves, sub, w, h, seed = (int(v) for v in pin["params"])
+    assert (dogs, octaves, sub, w, h, seed) == (3, 4, 0, 640, 480, 1)
+    img = synth_frame(w, h, seed)
+    assert sha(img) == str(pin["image_sha"])
+    run = O.OracleRun(img, dogs, octaves)
+    got, gdesc = run.points("final")
+    d = _compare_points(got, gdesc, pin["points"])
+    assert hashlib.sha256(d.tobytes()).hexdigest() == str(pin["desc_sha"])
+    mw, mh = (int(v) for v in pin["levels_wh"])
+    for o in range(mw):
+        for j in range(mh):
+            assert sha(run.level("gaussian", o, j)) == str(pin["level_sha"][o * mh + j]), f"gaussian({o},{j})"
+            assert run.scale("gaussian", o, j) == float(np.array(pin["level_scale_bits"][o * mh + j], np.uint32).view(np.float32))
+    dw, dh = (int(v) for v in pin["dogs_wh"])
+    for o in range(dw):
+        for j in range(dh):
+            assert sha(run.level("dog", o, j)) == str(pin["dog_sha"][o * dh + j]), f"dog({o},{j})"
+
+
 @pytest.mark.skipif(not os.path.exists(TRUNC_PIN), reason="fixture not generated")
 def test_u16_size_truncation_matches_the_reference_binary():
     """App. B-7 against the reference binary itself: 66260 points survive the first cleanup of this 1024x1088 blob lattice
