@@ -421,10 +421,13 @@ def main():
     # connections, lists arrive two pushes after they went in, and torch's allocator has to have seen every message buffer of the
     # cycle once: measured on one GPU through RCCL, 4.8 ms per step over the 20 steps behind a warm-up of 4, 2.98 behind one of 20).
     # That is set-up, not a step of the workload: it is done before the W warm-up steps the caller asked for, untimed like them.
-    settle = GATHER_SETTLE_STEPS if gatherer is not None else 0
+    # N = 1: a context's first two batches run alone in the process (the library serialises the runtime's lazy first-use set-up:
+    # context.cpp, FirstBatch), so the first 2 x depth steps are set-up as well, whatever W the caller passes.
+    settle = GATHER_SETTLE_STEPS if gatherer is not None else 2 * depth
     if settle:
         run_steps(settle)
-        gatherer = KeypointGather(nf, comm_dev, dst=0, loopback=loopback)
+        if gatherer is not None:
+            gatherer = KeypointGather(nf, comm_dev, dst=0, loopback=loopback)
     if args.warmup:
         run_steps(args.warmup)
     if gatherer is not None:     # the warm-up steps' lists were gathered too, before the clock starts
@@ -502,7 +505,7 @@ def main():
                        "frames_per_s": nf * world * args.steps / dt,
                        "rccl_ranks": rccl_ranks,   # as the RCCL communicator reports it (0: no RCCL communicator in this run)
                        "rccl_loopback": loopback,   # N = 1 with the N > 1 gather messages sent through RCCL to this same rank
-                       "gather_settle_steps": settle,   # untimed set-up steps of the gather path in front of the warm-up (N > 1 only)
+                       "setup_steps": settle,   # untimed set-up steps in front of the W warm-up steps: the library's first batches (2 per context); N > 1: the gather path settling (16)
                        "gather_steps_on_rank0": gathered_head[0],
                        "gather_keypoints_on_rank0": gathered_head[1],
                        "gather_ms_per_step": (gatherer.wait_s / args.steps * 1e3) if gatherer is not None else None,
