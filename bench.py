@@ -312,7 +312,7 @@ def main():
     # N > 1: the gather of step k (keypoint records + descriptors to rank 0 over RCCL point-to-point, never images) rides
     # behind the header of step k+1 and overlaps the kernels of the following steps, which run on the library's own
     # streams (sift_amd/gather.py: KeypointGather, no per-step collective); every transfer completes inside the timed region.
-    gatherer = KeypointGather(nf, comm_dev, dst=0, loopback=loopback) if (world > 1 or loopback) else None
+    gatherer = KeypointGather(nf, comm_dev, dst=0, loopback=loopback, concat=False) if (world > 1 or loopback) else None
     gathered = [0, 0]       # steps and keypoints that have arrived on rank 0
     keep = []               # tensors of the last pushes (the gather reads them until two pushes later)
     tickets = []            # submitted steps whose results have not been collected yet (at most depth - 1 between steps)
@@ -427,11 +427,11 @@ def main():
     if settle:
         run_steps(settle)
         if gatherer is not None:
-            gatherer = KeypointGather(nf, comm_dev, dst=0, loopback=loopback)
+            gatherer = KeypointGather(nf, comm_dev, dst=0, loopback=loopback, concat=False)
     if args.warmup:
         run_steps(args.warmup)
     if gatherer is not None:     # the warm-up steps' lists were gathered too, before the clock starts
-        gatherer = KeypointGather(nf, comm_dev, dst=0, loopback=loopback)
+        gatherer = KeypointGather(nf, comm_dev, dst=0, loopback=loopback, concat=False)
         gatherer_t0 = (gathered[0], gathered[1])
     for c in ctxs:
         c.set_option("profile", args.profile_every)   # every N-th batch of a context carries the per-launch timing events
@@ -453,7 +453,7 @@ def main():
     repeat_ms = [dt / args.steps * 1e3]
     for _ in range(max(0, args.repeats - 1)):
         if gatherer is not None:
-            gatherer = KeypointGather(nf, comm_dev, dst=0, loopback=loopback)
+            gatherer = KeypointGather(nf, comm_dev, dst=0, loopback=loopback, concat=False)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -529,8 +529,8 @@ def main():
         }
         if args.check_gather and gatherer is not None and not loopback:
             # ---- what arrived through the gather against this rank's own run of EVERY rank's frames (outside the timed region)
-            recs_all, vals_all, counts_all = last_gathered[0]
-            ok, ro, vo, io = True, 0, 0, 0
+            recs_parts, vals_parts, counts_all = last_gathered[0]     # one tensor per rank (KeypointGather(concat=False)), rank order
+            ok, io = len(recs_parts) == world and len(vals_parts) == world, 0
             for r in range(world):
                 fr = np.stack([synth_frame(W, H, r * nf + i + 1) for i in range(nf)])
                 ctx.calculate_batch(fr, params)
@@ -538,10 +538,10 @@ def main():
                 kp_r, val_r = device_results(ctx, tot, dev, wire=args.wire)
                 kp_r, val_r, cnt_r = kp_r.cpu(), val_r.cpu(), ctx.counts().copy()
                 ok = ok and bool((counts_all[io:io + nf].cpu().numpy() == cnt_r).all())
-                ok = ok and recs_all[ro:ro + kp_r.numel()].cpu().numpy().tobytes() == kp_r.numpy().tobytes()
-                ok = ok and vals_all[vo:vo + val_r.numel()].cpu().numpy().tobytes() == val_r.numpy().tobytes()
-                ro, vo, io = ro + kp_r.numel(), vo + val_r.numel(), io + nf
-            ok = ok and ro == recs_all.numel() and vo == vals_all.numel() and io == counts_all.numel()
+                ok = ok and recs_parts[r].cpu().numpy().tobytes() == kp_r.numpy().tobytes()
+                ok = ok and vals_parts[r].cpu().numpy().tobytes() == val_r.numpy().tobytes()
+                io += nf
+            ok = ok and io == counts_all.numel()
             out["config"]["gather_check"] = bool(ok)
             out["config"]["gather_check_what"] = (f"the last step's lists on rank 0 (records, descriptor floats, counts of {world * nf} images) equal "
                                                   f"rank 0's own run of every rank's frames, seeds 1..{world * nf} in order")

@@ -150,13 +150,17 @@ class KeypointGather:
     construction (images per rank).  All ranks must call `push` the same number of times, then `flush` once.
     """
 
-    def __init__(self, n_images_local: int, device, dst: int = 0, loopback: bool = False):
+    def __init__(self, n_images_local: int, device, dst: int = 0, loopback: bool = False, concat: bool = True):
         """loopback (a world of ONE process, testing the transport itself on a one-GPU box): the process plays two ranks of the
         protocol — rank 0, the receiver, with no images of its own, and rank 1, the sender of its lists — and every message
         really goes through the backend's point-to-point path, to itself (sends and receives of a round in one group, as RCCL
         requires of a send to oneself)."""
         self.world, self.rank, self.dst, self.dev = dist.get_world_size(), dist.get_rank(), dst, device
         self.loopback = bool(loopback)
+        # concat=False: a completed step is handed out as (list of per-rank records tensors, list of per-rank values tensors,
+        # counts) in rank order - no copy on `dst`, whose own lists and every arrival stay where they are (with eight ranks the
+        # concatenation is 0.17 GB of records and the own-values copy 0.1 GB per step on the one rank that also takes seven receives)
+        self.concat = bool(concat)
         t = torch.tensor([n_images_local], dtype=torch.int64, device=device)
         allt = [torch.empty_like(t) for _ in range(self.world)]
         dist.all_gather(allt, t)                       # once, at construction
@@ -271,12 +275,19 @@ class KeypointGather:
             for r in range(self.world):
                 offs[r] = run
                 run += n_val[r]
-            vals = torch.empty(run, dtype=torch.float32, device=self.dev)
-            vals[offs[self.dst]:offs[self.dst] + n_val[self.dst]].copy_(own_val)
-            for r in others:
-                if n_val[r]:
-                    ops.append(dist.P2POp(dist.irecv, vals[offs[r]:offs[r] + n_val[r]], self._peer(r)))
-            self._assembled[k - 1] = vals
+            if self.concat:
+                vals = torch.empty(run, dtype=torch.float32, device=self.dev)
+                vals[offs[self.dst]:offs[self.dst] + n_val[self.dst]].copy_(own_val)
+                for r in others:
+                    if n_val[r]:
+                        ops.append(dist.P2POp(dist.irecv, vals[offs[r]:offs[r] + n_val[r]], self._peer(r)))
+                self._assembled[k - 1] = vals
+            else:
+                parts = [own_val if r == self.dst else torch.empty(n_val[r], dtype=torch.float32, device=self.dev) for r in range(self.world)]
+                for r in others:
+                    if n_val[r]:
+                        ops.append(dist.P2POp(dist.irecv, parts[r], self._peer(r)))
+                self._assembled[k - 1] = parts
             self.wire_bytes += sum(rec_sizes.values()) + 4 * sum(n_val[r] for r in others)
         self.wire_bytes += self.hdr_bytes * len(others)
         works = dist.batch_isend_irecv(ops) if ops else []
@@ -295,13 +306,16 @@ class KeypointGather:
             else:
                 parts.append(bufs[r][self.hdr_bytes:self.hdr_bytes + rec_sizes[r]])
                 counts.append(sizes[r][2])
+        if not self.concat:
+            return parts, self._assembled.pop(j), torch.cat(counts)
         return torch.cat(parts), self._assembled.pop(j), torch.cat(counts)
 
     # ---- API ---------------------------------------------------------------------------------------------------------
     def push(self, records: torch.Tensor, values: torch.Tensor, counts):
         """Hand over this rank's lists of one step (records uint8, descriptor values float32, per-image counts).  Returns the
         list of steps completed on `dst` by this call, each (records_all, values_all, counts_all) in rank order (= global
-        image order for block sharding); always [] on the other ranks.  The tensors must stay untouched until two pushes (or
+        image order for block sharding; with concat=False records_all / values_all are lists of one tensor per rank instead of
+        one concatenated tensor); always [] on the other ranks.  The tensors must stay untouched until two pushes (or
         the flush) later."""
         k = self.step
         self.step += 1
@@ -312,7 +326,8 @@ class KeypointGather:
             self._own[k] = (torch.empty(0, dtype=torch.uint8, device=self.dev), torch.empty(0, dtype=torch.float32, device=self.dev), [])
             return self._receive_round(k, True, extra_ops=ops)                  # ... in one group with the receiver's
         if self.world == 1:
-            return [(records, values, torch.as_tensor(counts, dtype=torch.int32))]
+            c = torch.as_tensor(counts, dtype=torch.int32)
+            return [(records, values, c)] if self.concat else [([records], [values], c)]
         if self.rank != self.dst:
             self._send(total, records, values, counts)
             return []

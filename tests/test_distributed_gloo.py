@@ -142,12 +142,12 @@ def _step_data(rank, step):
     return counts, rec, val
 
 
-def _kg_worker(rank, world, port, q, steps):
+def _kg_worker(rank, world, port, q, steps, concat=True):
     from sift_amd.gather import KeypointGather
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    g = KeypointGather(2 + rank, torch.device("cpu"), dst=0)
+    g = KeypointGather(2 + rank, torch.device("cpu"), dst=0, concat=concat)
     done = []
     for step in range(steps):
         c, r, v = _step_data(rank, step)
@@ -159,6 +159,9 @@ def _kg_worker(rank, world, port, q, steps):
         done += g.push(rt, torch.from_numpy(v), c)
     done += g.flush()
     if rank == 0:
+        if not concat:     # one tensor per rank and step, nothing copied on rank 0: its own lists are the tensors it pushed
+            assert all(len(a) == world and len(b) == world for a, b, _ in done)
+            done = [(torch.cat(list(a)), torch.cat(list(b)), cc) for a, b, cc in done]
         q.put([(a.numpy().copy(), b.numpy().copy(), cc.numpy().copy()) for a, b, cc in done] + [g.wire_bytes])
     else:
         assert done == []
@@ -166,14 +169,14 @@ def _kg_worker(rank, world, port, q, steps):
     dist.destroy_process_group()
 
 
-def _run_kg(world, steps):
+def _run_kg(world, steps, concat=True):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_kg_worker, args=(r, world, port, q, steps)) for r in range(world)]
+    procs = [ctx.Process(target=_kg_worker, args=(r, world, port, q, steps, concat)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=180)
@@ -200,6 +203,11 @@ def test_keypoint_gather_without_per_step_collectives_two_ranks():
 
 def test_keypoint_gather_three_ranks_single_step():
     _run_kg(3, 1)
+
+
+def test_keypoint_gather_per_rank_lists_three_ranks():
+    """concat=False (what bench.py uses): completed steps come out as one tensor per rank, in rank order."""
+    _run_kg(3, 4, concat=False)
 
 
 def test_keypoint_gather_eight_ranks():
