@@ -50,6 +50,15 @@ using ApiGuard = LaunchGuard;
 
 namespace sift_hip {
 
+// Measurement switches inside kernels (options desc_dbg, orient_dbg, the cleanup stamps): phases switched off for timing - the
+// results are then WRONG.  They exist in the measurement build only (-DSIFT_HIP_DIAG, `make diag`); in the shipped library the
+// mask is 0 and the compiler removes every branch that tests them.
+#ifdef SIFT_HIP_DIAG
+constexpr int kDiagMask = ~0;
+#else
+constexpr int kDiagMask = 0;
+#endif
+
 constexpr int kMaxOctaves = 16;
 constexpr int kMaxDogs = 16;                       // dogsPerEpoch upper bound of this build
 constexpr int kMaxLevels = kMaxOctaves * (kMaxDogs + 1);

@@ -74,7 +74,7 @@ constexpr int kDynLds = kBitCap / 8 + 1024 * kMoveSlots * 8;
 // optional phase stamps (diagnostic builds of the KAT entry only): 100 MHz wall clock
 __device__ unsigned long long* g_stamp = nullptr;
 __device__ __forceinline__ void stamp(int slot) {
-    if (g_stamp && threadIdx.x == 0 && blockIdx.x == 0) g_stamp[slot] = wall_clock64();
+    if (kDiagMask && g_stamp && threadIdx.x == 0 && blockIdx.x == 0) g_stamp[slot] = wall_clock64();
 }
 
 // Ranks of this thread's four elements (one in each of four consecutive 1024-element chunks, so the
@@ -566,7 +566,7 @@ __device__ void introsort_bits(CleanupShared& sh, int n, const LdsBitKeys K, uin
         if (p == 0) {
             const int T0 = round_kept_pivot(sh, K, I, P, F, L);
             __syncthreads();
-            if (round < 120 && g_stamp && tid == 0 && blockIdx.x == 0)
+            if (kDiagMask && round < 120 && g_stamp && tid == 0 && blockIdx.x == 0)
                 g_stamp[16 + 4 * round + 3] = (wall_clock64() & 0xffffffffull) | ((unsigned long long)(L - F) << 32);
             ++round;
             if (tid == 0) {
@@ -585,7 +585,7 @@ __device__ void introsort_bits(CleanupShared& sh, int n, const LdsBitKeys K, uin
         if (L - F <= kSmallRange) {
             const int T1 = round_filtered_pivot_small(sh, K, I, P, F, L);
             __syncthreads();
-            if (round < 120 && g_stamp && tid == 0 && blockIdx.x == 0)
+            if (kDiagMask && round < 120 && g_stamp && tid == 0 && blockIdx.x == 0)
                 g_stamp[16 + 4 * round + 3] = (wall_clock64() & 0xffffffffull) | ((unsigned long long)(L - F) << 32) | (1ull << 60);
             ++round;
             if (tid == 0) {
@@ -719,7 +719,7 @@ __device__ void introsort_bits(CleanupShared& sh, int n, const LdsBitKeys K, uin
         }
         flush_moves();
         __syncthreads();
-        if (round < 120 && g_stamp && tid == 0 && blockIdx.x == 0)
+        if (kDiagMask && round < 120 && g_stamp && tid == 0 && blockIdx.x == 0)
             g_stamp[16 + 4 * round + 3] = (wall_clock64() & 0xffffffffull) | ((unsigned long long)(L - F) << 32) | ((unsigned long long)p << 60);
         ++round;
         const int T = (sh.T == 0x7fffffff) ? total : sh.T;
@@ -732,7 +732,7 @@ __device__ void introsort_bits(CleanupShared& sh, int n, const LdsBitKeys K, uin
         __syncthreads();
     }
     __syncthreads();
-    if (g_stamp && tid == 0 && blockIdx.x == 0) g_stamp[7] = (unsigned long long)round;
+    if (kDiagMask && g_stamp && tid == 0 && blockIdx.x == 0) g_stamp[7] = (unsigned long long)round;
     stamp(2);
     // Only kept elements are ever read back.  Outside the all-kept ranges they stay where the loop
     // left them; inside, each one moves to its closed-form final position.
@@ -1331,7 +1331,7 @@ __global__ __launch_bounds__(kCT) void cleanup_kat_kernel(const uint8_t* __restr
         __syncthreads();
         size = s_cnt[0];
         stamp(5);
-        if (threadIdx.x == 0 && g_stamp) g_stamp[6] = (unsigned long long)sh.npure;
+        if (kDiagMask && threadIdx.x == 0 && g_stamp) g_stamp[6] = (unsigned long long)sh.npure;
     } else {
         const GlobalKeys K{Kg};
         for (int i = threadIdx.x; i < n; i += kCT) {

@@ -261,7 +261,8 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
                                                                  const long long* __restrict__ out_base,
                                                                  sift_hip_keypoint* __restrict__ kp_out,
                                                                  float* __restrict__ desc_out, long long out_cap, int n_images,
-                                                                 int chunks, int dbg) {
+                                                                 int chunks, int dbg_arg) {
+    const int dbg = dbg_arg & kDiagMask;   // measurement build only (common.h)
     __shared__ float s_w16t[kW16Size];
     __shared__ uint4 s_list[4][64];   // per wave: preceding neighbours in vector order (orientation bits, table offset, dx, dy)
     __shared__ __attribute__((aligned(16))) unsigned s_keys[4][68];   // per wave: their vector indices, compacted (+ sentinels)
@@ -1106,7 +1107,7 @@ void launch_descriptors_wave(hipStream_t s, const DevPlan* d_plan, const DevPlan
     lv.wire_sums = d_wire_sums;
     // 2048 workgroups of four waves (8 per CU); whole images per XCD when there are at least 8, eighths of an image otherwise
     const int chunks = plan.n_images >= 8 ? 1 : 8;
-    const unsigned nwg = (dbg & 64) ? 512u : ((dbg & 32) ? 1024u : 2048u);   // timing only: fewer resident waves
+    const unsigned nwg = (dbg & kDiagMask & 64) ? 512u : ((dbg & kDiagMask & 32) ? 1024u : 2048u);   // timing only (measurement build): fewer resident waves
     hipLaunchKernelGGL(descriptor_wave_kernel, dim3(nwg), dim3(256), 0, s, d_plan, lv, d_cell_off, d_pool, pool_cap, d_out_base,
                        d_kp_out, d_desc_out, out_cap, plan.n_images, chunks, dbg);
 }

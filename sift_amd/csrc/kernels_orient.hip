@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
                                                           const int* __restrict__ list_cnt, int list_cap,
                                                           OrientOut* __restrict__ out,
                                                           float* __restrict__ peaks_out, int* __restrict__ next_group,
-                                                          const int* __restrict__ any_bin, int dbg) {
+                                                          const int* __restrict__ any_bin, int dbg_arg) {
+    const int dbg = dbg_arg & kDiagMask;   // measurement build only (common.h)
     // staging (phase 1) and the peak sets (phase 2) are never live together: they share storage
     __shared__ __attribute__((aligned(16))) float s_stage[4 * kOrientSub * kOrientStride];
     __shared__ __attribute__((aligned(16))) unsigned char s_sbin[4 * kOrientSub * kOrientStride];
