@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <immintrin.h>
+
 #include <chrono>
 #include <cstring>
 #include <mutex>
@@ -1638,6 +1640,7 @@ struct UnpackJob {
     const uint8_t* rec; const float* val; int64_t n; sift_hip_keypoint* kp; float* desc;
     std::vector<int64_t> start;   // first value of every chunk
     int64_t chunk;
+    const float* vend;            // one past the last value (the vector form reads 8 floats at a time)
 };
 inline int popcount_mask(const uint8_t* m) {
     uint64_t a, b;
@@ -1645,19 +1648,63 @@ inline int popcount_mask(const uint8_t* m) {
     std::memcpy(&b, m + 6, 8);   // bytes 6..13: keep the top 6 bytes (8..13)
     return __builtin_popcountll(a) + __builtin_popcountll(b >> 16);
 }
+// AVX2 form of one descriptor: a cell's (at most 7) set floats are the next popcount(bits) values; one unaligned 8-float load,
+// one lane permutation by a table entry (lane b <- the rank of bit b among the set bits) and one AND with the entry's lane mask
+// put them in place - 3 vector instructions per cell instead of a 7-trip loop of tests.  The load may look up to 7 floats past
+// the cell's own values, so it is only used while 8 floats remain before `vend`; the tail takes the scalar loop.
+struct CellLut {
+    alignas(32) int idx[128][8];
+    alignas(32) int msk[128][8];
+    CellLut() {
+        for (int m = 0; m < 128; ++m) {
+            int rank = 0;
+            for (int b = 0; b < 8; ++b) {
+                const bool set = b < 7 && ((m >> b) & 1);
+                idx[m][b] = set ? rank : 0;
+                msk[m][b] = set ? -1 : 0;
+                rank += set ? 1 : 0;
+            }
+        }
+    }
+};
+inline unsigned cell_bits(const uint8_t* m, int cell) {
+    // presence bit cell*7+bin <-> descriptor float cell*8+bin; bin 7 is never on the wire (+0.0f)
+    const int bit0 = cell * 7;
+    return (unsigned)((m[bit0 >> 3] | (m[(bit0 >> 3) + 1 < 14 ? (bit0 >> 3) + 1 : 13] << 8)) >> (bit0 & 7)) & 0x7fu;
+}
+__attribute__((target("avx2"))) const float* unpack_desc_avx2(const uint8_t* m, const float* v, const float* vend, float* d, const CellLut& lut) {
+    for (int cell = 0; cell < 16; ++cell) {
+        const unsigned bits = cell_bits(m, cell);
+        float* dc = d + cell * 8;
+        if (v + 8 <= vend) {
+            const __m256 x = _mm256_loadu_ps(v);
+            const __m256 y = _mm256_permutevar8x32_ps(x, _mm256_load_si256(reinterpret_cast<const __m256i*>(lut.idx[bits])));
+            _mm256_storeu_ps(dc, _mm256_and_ps(y, _mm256_castsi256_ps(_mm256_load_si256(reinterpret_cast<const __m256i*>(lut.msk[bits])))));
+            v += __builtin_popcount(bits);
+        } else {
+            for (int b = 0; b < 7; ++b) { dc[b] = (bits >> b) & 1u ? *v++ : 0.0f; }
+            dc[7] = 0.0f;
+        }
+    }
+    return v;
+}
 void unpack_chunk(int part, void* arg) {
     const UnpackJob* j = static_cast<const UnpackJob*>(arg);
     const int64_t i0 = (int64_t)part * j->chunk, i1 = std::min(j->n, i0 + j->chunk);
     const float* v = j->val + j->start[(size_t)part];
+    static const CellLut lut;
+    static const bool avx2 = __builtin_cpu_supports("avx2");
     for (int64_t i = i0; i < i1; ++i) {
         const uint8_t* r = j->rec + i * 34;
         if (j->kp) std::memcpy(&j->kp[i], r, sizeof(sift_hip_keypoint));
         const uint8_t* m = r + 20;
         float* d = j->desc ? j->desc + i * 128 : nullptr;
+        if (d && avx2) {
+            v = unpack_desc_avx2(m, v, j->vend, d, lut);
+            continue;
+        }
         for (int cell = 0; cell < 16; ++cell) {
-            // presence bit cell*7+bin <-> descriptor float cell*8+bin; bin 7 is never on the wire (+0.0f)
-            const int bit0 = cell * 7;
-            unsigned bits = (unsigned)((m[bit0 >> 3] | (m[(bit0 >> 3) + 1 < 14 ? (bit0 >> 3) + 1 : 13] << 8)) >> (bit0 & 7)) & 0x7fu;
+            const unsigned bits = cell_bits(m, cell);
             if (d) {
                 float* dc = d + cell * 8;
                 for (int b = 0; b < 7; ++b) { dc[b] = (bits >> b) & 1u ? *v++ : 0.0f; }
@@ -1675,7 +1722,7 @@ int sift_hip_sparse_unpack_host(const void* records, const float* values, int64_
     if (n_keypoints < 0 || (n_keypoints > 0 && !records)) return SIFT_HIP_EINVAL;
     if (n_keypoints == 0) return SIFT_HIP_OK;
     try {
-        UnpackJob j{static_cast<const uint8_t*>(records), values, n_keypoints, keypoints, descriptors, {}, 0};
+        UnpackJob j{static_cast<const uint8_t*>(records), values, n_keypoints, keypoints, descriptors, {}, 0, nullptr};
         const int parts = (int)std::min<int64_t>(std::max(threads, 1), (n_keypoints + 1023) / 1024);
         j.chunk = (n_keypoints + parts - 1) / parts;
         j.start.assign((size_t)parts, 0);
@@ -1683,9 +1730,9 @@ int sift_hip_sparse_unpack_host(const void* records, const float* values, int64_
         for (int p = 0; p < parts; ++p) {   // where every chunk's floats begin: one pass over the presence bits
             j.start[(size_t)p] = at;
             const int64_t i1 = std::min(n_keypoints, (int64_t)(p + 1) * j.chunk);
-            if (p + 1 < parts)
-                for (int64_t i = (int64_t)p * j.chunk; i < i1; ++i) at += popcount_mask(j.rec + i * 34 + 20);
+            for (int64_t i = (int64_t)p * j.chunk; i < i1; ++i) at += popcount_mask(j.rec + i * 34 + 20);
         }
+        j.vend = values ? values + at : nullptr;
         parallel_for(parts, parts, unpack_chunk, &j);
         return SIFT_HIP_OK;
     } catch (const std::exception&) {
