@@ -607,7 +607,7 @@ def main():
 
             def fetch_sparse_unpacked(c, slot):   # ... and expanded again on the host into records + 128-float descriptors
                 rec, val = c.results_sparse(pin_sp[slot][0], pin_sp[slot][1])
-                unpack_sparse_host(rec, val, dense[slot][0], dense[slot][1], threads=min(16, os.cpu_count() or 1))
+                unpack_sparse_host(rec, val, dense[slot][0], dense[slot][1], threads=min(64, os.cpu_count() or 1))
                 return rec.shape[0]
 
             host_loop(pin_u8, fetch_sparse, 2)
@@ -634,7 +634,7 @@ def main():
                                              "floats vigra::importImage yields), keypoint lists to page-locked host memory out in the lossless sparse format "
                                              "(sift_hip_result_copy_sparse: 34-byte records + the descriptor floats that are not +0.0f), per step; three batches in flight (BatchPipeline depth 3)",
                                      "with_host_unpack_ms_per_step": t_spu * 1e3,
-                                     "with_host_unpack_what": "the same plus sift_hip_sparse_unpack_host on up to 16 host threads: dense 20-byte records + 128-float descriptors in ordinary memory",
+                                     "with_host_unpack_what": "the same plus sift_hip_sparse_unpack_host (AVX2) on up to 64 host threads: dense 20-byte records + 128-float descriptors in ordinary memory",
                                      "float_dense_ms_per_step": t_pin * 1e3, "float_dense_keypoints_per_s": k_pin / t_pin,
                                      "float_dense_pcie_gbytes_per_step": nbytes_io / 1e9, "float_dense_pcie_gb_per_s": nbytes_io / 1e9 / t_pin,
                                      "float_dense_what": "float32 frames in, 20-byte records + 128-float descriptors out, page-locked memory on both sides (round 2's boundary)",

@@ -12,6 +12,7 @@
 #include <exception>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../sift_hip.h"
@@ -141,18 +142,15 @@ private:
             std::vector<unsigned char> rec((size_t)n * 34);
             std::vector<float> val((size_t)(nnz > 0 ? nnz : 1));
             if (sift_hip_result_copy_sparse(_ctx, rec.data(), val.data()) != SIFT_HIP_OK) throw std::runtime_error("sift_hip_result_copy_sparse failed");
-            const float* v = val.data();
+            // expanded by the library's host routine (vectorised, a few threads), then handed to the InterestPoints
+            std::vector<sift_hip_keypoint> kp((size_t)n);
+            std::vector<float> desc((size_t)n * 128);
+            unsigned hw = std::thread::hardware_concurrency();
+            if (sift_hip_sparse_unpack_host(rec.data(), val.data(), n, kp.data(), desc.data(), (int)(hw > 8 ? 8 : (hw ? hw : 1))) != SIFT_HIP_OK)
+                throw std::runtime_error("sift_hip_sparse_unpack_host failed");
             for (size_t i = 0; i < out.size(); ++i) {
-                sift_hip_keypoint k;
-                std::memcpy(&k, &rec[i * 34], sizeof(k));
-                fill(out[i], k);
-                const unsigned char* m = &rec[i * 34 + 20];
-                if (k.has_descriptor) out[i].descriptors.assign(128, 0.0f);
-                for (int j = 0; j < 112; ++j)      // presence bit j = cell * 7 + bin  <->  descriptor float cell * 8 + bin
-                    if ((m[j >> 3] >> (j & 7)) & 1) {
-                        const float x = *v++;
-                        if (k.has_descriptor) out[i].descriptors[(size_t)(j / 7 * 8 + j % 7)] = x;
-                    }
+                fill(out[i], kp[i]);
+                if (kp[i].has_descriptor) out[i].descriptors.assign(desc.begin() + (std::ptrdiff_t)i * 128, desc.begin() + (std::ptrdiff_t)(i + 1) * 128);
             }
             return out;
         }
