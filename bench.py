@@ -568,19 +568,24 @@ def main():
             hdepth = 3
             hpipe = BatchPipeline(local_rank, hdepth, options, gated=bool(args.pipeline_gate))
 
-            def host_loop(src, fetch, n_steps):
-                """n_steps batches from host memory `src`, `hdepth` in flight; `fetch(context, slot)` brings the oldest batch's lists to the host.
+            def host_loop(src, fetch, n_steps, on_worker=False):
+                """n_steps batches from host memory `src`, `hdepth` in flight; `fetch(context, slot)` brings the oldest batch's lists to the host -
+                on the dispatching thread, or (on_worker) on the batch's own worker thread right behind the batch, beside the other batches.
                 (One dispatching thread: this loop is bound by the link and the copies' interference with the kernels, and letting every
                 context's thread feed itself - BatchPipeline.run_stream, the headline loop - made no difference here: 8.0 against 7.4 - 7.6 ms
                 on the box of that comparison.)"""
-                pend, total = [], 0
+                pend, total, got = [], 0, {}
                 t_0 = time.perf_counter()
                 for i in range(n_steps + hdepth):
                     if i < n_steps:
-                        pend.append(hpipe.submit(src, params))
+                        if on_worker:
+                            pend.append(hpipe.submit(src, params, then=lambda c, slot: got.__setitem__(slot, fetch(c, slot))))
+                        else:
+                            pend.append(hpipe.submit(src, params))
                     if pend and (len(pend) >= hdepth or i >= n_steps):
                         tk = pend.pop(0)
-                        total += fetch(tk.result(), tk.slot)
+                        c = tk.result()
+                        total += got.pop(tk.slot) if on_worker else fetch(c, tk.slot)
                         tk.release()
                 return (time.perf_counter() - t_0) / n_steps, total // n_steps
 
@@ -607,13 +612,13 @@ def main():
 
             def fetch_sparse_unpacked(c, slot):   # ... and expanded again on the host into records + 128-float descriptors
                 rec, val = c.results_sparse(pin_sp[slot][0], pin_sp[slot][1])
-                unpack_sparse_host(rec, val, dense[slot][0], dense[slot][1], threads=min(64, os.cpu_count() or 1))
+                unpack_sparse_host(rec, val, dense[slot][0], dense[slot][1], threads=min(16, os.cpu_count() or 1))
                 return rec.shape[0]
 
             host_loop(pin_u8, fetch_sparse, 2)
             t_sp, k_sp = host_loop(pin_u8, fetch_sparse, hs)
-            host_loop(pin_u8, fetch_sparse_unpacked, 2)
-            t_spu, _ = host_loop(pin_u8, fetch_sparse_unpacked, hs)
+            host_loop(pin_u8, fetch_sparse_unpacked, 2, on_worker=True)
+            t_spu, _ = host_loop(pin_u8, fetch_sparse_unpacked, hs, on_worker=True)
             for c in hpipe.contexts:
                 c.set_option("wire_count", int(options.get("wire_count", 0)))
             # (b) float32 frames in, dense 532-byte records out (round 2's figure)
@@ -634,7 +639,7 @@ def main():
                                              "floats vigra::importImage yields), keypoint lists to page-locked host memory out in the lossless sparse format "
                                              "(sift_hip_result_copy_sparse: 34-byte records + the descriptor floats that are not +0.0f), per step; three batches in flight (BatchPipeline depth 3)",
                                      "with_host_unpack_ms_per_step": t_spu * 1e3,
-                                     "with_host_unpack_what": "the same plus sift_hip_sparse_unpack_host (AVX2) on up to 64 host threads: dense 20-byte records + 128-float descriptors in ordinary memory",
+                                     "with_host_unpack_what": "the same plus sift_hip_sparse_unpack_host (AVX2) on up to 16 host threads, run by the batch's own worker thread right behind its download (`then=`), beside the other batches: dense 20-byte records + 128-float descriptors in ordinary memory",
                                      "float_dense_ms_per_step": t_pin * 1e3, "float_dense_keypoints_per_s": k_pin / t_pin,
                                      "float_dense_pcie_gbytes_per_step": nbytes_io / 1e9, "float_dense_pcie_gb_per_s": nbytes_io / 1e9 / t_pin,
                                      "float_dense_what": "float32 frames in, 20-byte records + 128-float descriptors out, page-locked memory on both sides (round 2's boundary)",
