@@ -615,9 +615,9 @@ def main():
                 unpack_sparse_host(rec, val, dense[slot][0], dense[slot][1], threads=min(16, os.cpu_count() or 1))
                 return rec.shape[0]
 
-            host_loop(pin_u8, fetch_sparse, 2)
+            host_loop(pin_u8, fetch_sparse, 3 * hdepth)     # set-up: every context's first batches run alone (FirstBatch), buffers grow
             t_sp, k_sp = host_loop(pin_u8, fetch_sparse, hs)
-            host_loop(pin_u8, fetch_sparse_unpacked, 2, on_worker=True)
+            host_loop(pin_u8, fetch_sparse_unpacked, hdepth, on_worker=True)
             t_spu, _ = host_loop(pin_u8, fetch_sparse_unpacked, hs, on_worker=True)
             for c in hpipe.contexts:
                 c.set_option("wire_count", int(options.get("wire_count", 0)))
@@ -626,7 +626,7 @@ def main():
             pin_frames[...] = frames
             pin_out = [(pinned_array((cap,), _lib.KEYPOINT_DTYPE), pinned_array((cap, 128), np.float32)) for _ in range(hdepth)]
             fetch_dense = lambda c, slot: c.results(pin_out[slot][0], pin_out[slot][1])[0].size   # noqa: E731
-            host_loop(pin_frames, fetch_dense, 2)
+            host_loop(pin_frames, fetch_dense, hdepth)
             t_pin, k_pin = host_loop(pin_frames, fetch_dense, hs)
             fetch_page = lambda c, slot: c.results()[0].size   # noqa: E731
             host_loop(frames, fetch_page, 1)
