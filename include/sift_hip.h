@@ -78,22 +78,19 @@ void sift_hip_destroy(sift_hip_ctx* ctx);
  * inputs), "orient_general" (0 default; 1: orientationHistogram36 reads every sample's bin even when the gradient pass
  * found all bins of the frame to be 0, which is what the reference's radians-as-degrees maps always give), "wire_count"
  * (0 default; 1: the descriptor kernel also counts the floats the sparse wire format will carry, so that
- * sift_hip_result_sparse_size needs no pass of its own over the descriptors: for hosts that gather every batch); measurement
- * aids, results unchanged unless stated: "stream_waves" (process-wide; waves a streaming blur launch is cut into, default
- * 2048, 0 = tile kernel only), "desc_kernel" (1 default: one wave per keypoint over a grid of 16 px cells; 0: one workgroup
- * per 48 px tile walking the ordered keypoint list), "desc_dbg" / "orient_dbg" (phases switched off: timing only, WRONG results),
- * "gate_schedule" (order of the phases of batches joined by a gate, sift_amd/csrc/phase_gate.h: 1 default - the cleanup chain under the
- * next batch's pyramid, the descriptors under its extrema / gradient pass; 0 - no pyramid shares the chip, the order of rounds 1 - 2),
- * "gate_early_chain" (measured, slower, off), "pyramid_side" (1 default: the top Gaussian level of an octave, which only feeds the
- * octave's last DoG, is formed on the side stream beside the reduction and the next octave's small launches; 0: every launch on
- * one stream), "reduce_kept" (1 default: reduceToNextLevel evaluates the kept pixels only), "extrema_stream" (0 default; 1 / 2: the
- * strip-walking form of the scan + edge filter for large / all launches), "chain_from" (0 default; o > 0: the pyramid's octaves >= o as
- * ONE launch of per-image work items, sift_amd/csrc/kernels_chain.hip; "chain_mode" 1 / 0 / 2: agent-scope accesses, ordinary accesses +
- * fences, tiles of an image spread over all XCDs), "gate_mid" (0 default; o > 0: a gated batch's descriptors start when the next batch's
- * pyramid reaches octave o instead of when it ends), "fused_grid", "stream_min_waves", "io_kernels",
- * "stage_kernels" (measured alternatives), "diag_pyramid_span", "diag_serial_gradient", "diag_cleanup_stamps" (print to stderr), "diag_repeat" (k > 1: sift_hip_calculate_batch_device runs
- * its batch k times before it returns; timing only).  The library reads no
- * environment variable. */
+ * sift_hip_result_sparse_size needs no pass of its own over the descriptors: for hosts that gather every batch),
+ * "desc_kernel" (1 default: one wave per keypoint over a grid of 16 px cells; 2: one wave per 32 x 32 px tile of keypoint
+ * locations, its gradient samples held in LDS; other values: SIFT_HIP_EINVAL), "gate_schedule" (order of the phases of batches
+ * joined by a gate, sift_amd/csrc/phase_gate.h: 1 default - the cleanup steps under the next batch's pyramid, the descriptors
+ * under its extrema / gradient pass; 0 - no pyramid shares the chip, the order of rounds 1 - 2), "pyramid_side" (1 default: the
+ * top Gaussian level of an octave, which only feeds the octave's last DoG, is formed on the side stream beside the reduction
+ * and the next octave's small launches; 0: every launch on one stream), "reduce_kept" (1 default: reduceToNextLevel evaluates
+ * the kept pixels only), "spin_wait" (1 default: the end of a batch is awaited by polling its event - tens of microseconds per batch sooner than
+ * sleeping in hipStreamSynchronize, which is what 0 selects).
+ * These 14 names are all a release build knows; any other name returns SIFT_HIP_EINVAL.  The measurement build
+ * (libsift_hip_diag.so: make -C sift_amd/csrc diag, -DSIFT_HIP_DIAG) adds "desc_dbg" / "orient_dbg" (phases of a kernel
+ * switched off: timing only, WRONG results), "stream_waves", "diag_repeat", "diag_pyramid_span", "diag_serial_gradient" and
+ * "diag_cleanup_stamps" for the scripts under tools/.  The library reads no environment variable. */
 int sift_hip_set_option(sift_hip_ctx* ctx, const char* name, int value);
 
 /* ---- several batches in flight on one GPU --------------------------------------------------------

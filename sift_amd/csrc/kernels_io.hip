@@ -1,16 +1,8 @@
-// Frames in, keypoint lists out, between PAGE-LOCKED host memory and HBM, as kernels of a few workgroups (option "io_kernels",
-// a measured alternative that is OFF by default).
-//
-// The caller of Sift::calculate holds its image in host memory and takes a vector back (/root/reference/main.cpp:52-57).  With
-// batches in flight the transfers of one batch run beside the kernels of the others, and on this platform the runtime moves
-// page-locked memory partly with blit kernels (__amd_rocclr_copyBuffer in the traces) during which a bandwidth-bound launch of
-// another context was measured up to 12x slower (profiles/r03_host_trace.txt).  Page-locked memory is mapped into the GPU's
-// address space, so the transfer can be an ordinary kernel of kIoWorkgroups workgroups instead, every lane keeping kIoUnroll
-// 16-byte accesses in flight; the 8-bit ingest (sift_hip_calculate_batch_u8) then widens on the way in.  Measured (round 3,
-// tools/host_trace.sh): the HBM-bound launches beside such a kernel still slow down (4x instead of 12x: traffic that CUs send
-// over PCIe holds up the memory pipeline whoever issues it), reads over the link reach only ~28 GB/s with this much in
-// flight, and a step of the host loop takes 6.5 - 6.8 ms against 4.5 - 5.5 ms with the runtime's copies.  Kept for the record
-// and for platforms where the runtime's copies behave differently; the default path is hipMemcpyAsync.
+// Plumbing kernels and the launch locks: device-to-device copies as a kernel of the library (the one-process multi-GPU gather,
+// group.cpp), the few counters cleared between kernels of a stream, and the per-device locks every HIP call of the library is
+// made under (launch_guard.h).  Transfers between page-locked host memory and HBM as kernels of our own (options "io_kernels",
+// "stage_kernels") were measured in rounds 2 - 3, lost to the runtime's copies (6.5 - 6.8 ms a step against
+// 4.5 - 5.5 ms; reads over the link reach ~28 GB/s with this much in flight) and were removed in round 4.
 #include <algorithm>
 
 #include <atomic>

@@ -1377,6 +1377,44 @@ def test_sparse_wire_kernels_match_the_reference_packing(ctx):
         ctx.set_option("wire_count", 0)
 
 
+def test_deferred_sparse_pack_survives_the_next_batch(ctx):
+    """sift_hip_result_sparse_pack_async only QUEUES the pack (side stream) and lets the context start its next batch at once
+    (what bench.py's N > 1 loop does): the lists packed from batch A must be A's, bit for bit, although batch B - other frames,
+    other keypoints - rewrites the context's arrays right behind the call; sift_hip_result_pack_wait may come from another
+    thread."""
+    import threading
+    import torch
+    from sift_amd.gather import device_results
+    params = _lib.Params(3, 3, 1.6, O.K_SQRT2, 0)
+    frames_a = np.stack([synth_frame(640, 480, 50 + i) for i in range(4)])
+    frames_b = np.stack([synth_frame(640, 480, 90 + i) for i in range(4)])
+    dev = torch.device("cuda", 0)
+    ctx.set_option("wire_count", 1)
+    try:
+        ctx.calculate_batch(frames_b, params)
+        total_b = ctx.total()
+        rec_b, val_b = device_results(ctx, total_b, dev, wire="sparse")
+        ctx.calculate_batch(frames_a, params)
+        total_a = ctx.total()
+        rec_a, val_a = device_results(ctx, total_a, dev, wire="sparse")          # the synchronous pack: the expectation
+        assert total_a != total_b or rec_a.cpu().numpy().tobytes() != rec_b.cpu().numpy().tobytes()
+        for round_ in range(6):
+            ctx.calculate_batch(frames_a, params)
+            rec, val = device_results(ctx, total_a, dev, wire="sparse", defer_pack=True)
+            ctx.calculate_batch(frames_b, params)                                   # no wait in between
+            waiter = threading.Thread(target=ctx.pack_wait)
+            waiter.start()
+            waiter.join()
+            assert rec.cpu().numpy().tobytes() == rec_a.cpu().numpy().tobytes(), round_
+            assert val.cpu().numpy().tobytes() == val_a.cpu().numpy().tobytes(), round_
+            assert ctx.total() == total_b
+            rec2, val2 = device_results(ctx, total_b, dev, wire="sparse")
+            assert rec2.cpu().numpy().tobytes() == rec_b.cpu().numpy().tobytes() and val2.cpu().numpy().tobytes() == val_b.cpu().numpy().tobytes()
+        ctx.pack_wait()      # nothing pending: returns at once
+    finally:
+        ctx.set_option("wire_count", 0)
+
+
 # ------------------------------------------------------------------------------------------------
 # the HIP path against what the reference's own prebuilt binary returned (tests/golden/refpin.npz, see
 # tests/test_ref_pins.py): no oracle in between
