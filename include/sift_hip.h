@@ -85,9 +85,10 @@ void sift_hip_destroy(sift_hip_ctx* ctx);
  * under its extrema / gradient pass; 0 - no pyramid shares the chip, the order of rounds 1 - 2), "pyramid_side" (1 default: the
  * top Gaussian level of an octave, which only feeds the octave's last DoG, is formed on the side stream beside the reduction
  * and the next octave's small launches; 0: every launch on one stream), "reduce_kept" (1 default: reduceToNextLevel evaluates
- * the kept pixels only), "spin_wait" (1 default: the end of a batch is awaited by polling its event - tens of microseconds per batch sooner than
+ * the kept pixels only), "lazy_top" (1 default: the top Gaussian level of an octave is not written at all by the batch - nothing
+ * on the path reads it again - and is formed when sift_hip_level_copy asks for it; 0: every level is written), "spin_wait" (1 default: the end of a batch is awaited by polling its event - tens of microseconds per batch sooner than
  * sleeping in hipStreamSynchronize, which is what 0 selects).
- * These 14 names are all a release build knows; any other name returns SIFT_HIP_EINVAL.  The measurement build
+ * These 15 names are all a release build knows; any other name returns SIFT_HIP_EINVAL.  The measurement build
  * (libsift_hip_diag.so: make -C sift_amd/csrc diag, -DSIFT_HIP_DIAG) adds "desc_dbg" / "orient_dbg" (phases of a kernel
  * switched off: timing only, WRONG results), "stream_waves", "diag_repeat", "diag_pyramid_span", "diag_serial_gradient" and
  * "diag_cleanup_stamps" for the scripts under tools/.  The library reads no environment variable. */

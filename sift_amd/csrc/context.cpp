@@ -147,6 +147,11 @@ struct sift_hip_ctx {
     // option "pyramid_side" (default on): the top Gaussian level of an octave (it only feeds the octave's last DoG) is formed on
     // the side stream, beside the reduction and the first levels of the next octave, which are too small to fill the chip alone
     bool pyramid_side = true;
+    // option "lazy_top" (default on): that top level is not WRITTEN at all - nothing on the path reads it again (the next octave
+    // starts from the level below, sift.cpp:406-409; keypoints never refer to it) - unless it is a gradient level; a caller that
+    // asks for it (sift_hip_level_copy) gets it formed then, by the same kernel
+    bool lazy_top = true;
+    std::vector<char> top_missing;   // per octave: this batch's top Gaussian level has not been formed
     hipEvent_t ev_side_fork = nullptr, ev_side_join = nullptr;
     DevBuf d_list, d_list_cnt, d_orient, d_peaks, d_final, d_final_cnt, d_out_base, d_kp, d_desc;
     DevBuf d_wire_sums, d_wire_off;   // sparse wire format: floats per block of keypoints, their exclusive scan
@@ -265,7 +270,7 @@ void run_blur(sift_hip_ctx* c, const float* in, float* out, float* dog, int w, i
                 radius, a, b);
     if (c->profile) {
         const double px = (double)w * (double)h * (double)n;
-        c->pending.push_back({a, b, is_fused ? 0 : 1, px * (dog ? 12.0 : 8.0)});
+        c->pending.push_back({a, b, is_fused ? 0 : 1, px * (4.0 + (out ? 4.0 : 0.0) + (dog ? 4.0 : 0.0))});   // algorithmic bytes: read + levels written
     }
 }
 
@@ -567,13 +572,16 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
                 // next octave's levels (fused kernels only: the two-pass fallback shares a scratch image with them).
                 const bool side = c->pyramid_side && c->ev_side_fork && op.j == D && op.octave + 1 < O && c->fused && op.radius >= 1 &&
                                   op.radius <= kMaxRadiusFused && std::find(P.grad_levels.begin(), P.grad_levels.end(), l) == P.grad_levels.end();
+                const bool skip = c->lazy_top && op.j == D && std::find(P.grad_levels.begin(), P.grad_levels.end(), l) == P.grad_levels.end();
+                float* g_out = skip ? nullptr : dv.gauss[l];
+                if (skip) c->top_missing[(size_t)op.octave] = 1;
                 if (side) {
                     SIFT_HIP_CHECK(hipEventRecord(c->ev_side_fork, c->stream));
                     SIFT_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_side_fork, 0));
-                    run_blur(c, dv.gauss[l - 1], dv.gauss[l], dv.dog[op.octave * D + op.j - 1], op.w, op.h, n, op.tap_off, op.radius, c->stream2);
+                    run_blur(c, dv.gauss[l - 1], g_out, dv.dog[op.octave * D + op.j - 1], op.w, op.h, n, op.tap_off, op.radius, c->stream2);
                     side_used = true;
                 } else {
-                    run_blur(c, dv.gauss[l - 1], dv.gauss[l], dv.dog[op.octave * D + op.j - 1], op.w, op.h, n, op.tap_off, op.radius);
+                    run_blur(c, dv.gauss[l - 1], g_out, dv.dog[op.octave * D + op.j - 1], op.w, op.h, n, op.tap_off, op.radius);
                     early_w16(c, l);
                 }
                 break;
@@ -1075,6 +1083,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
         }
     } gate_scope{c};
     c->gate_ticket = c->gate ? c->gate->begin_batch(s) : -1;
+    c->top_missing.assign((size_t)P.O, 0);
     run_pyramid(c, d_in);
     SIFT_HIP_CHECK(hipGetLastError());   // a rejected launch configuration must not go unnoticed
     if (c->gate) {
@@ -1346,6 +1355,7 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
         c->desc_tile = value == 2;
         return SIFT_HIP_OK;
     }
+    if (!std::strcmp(name, "lazy_top")) { c->lazy_top = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "wire_count")) { c->wire_count = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "pyramid_side")) {
         ApiGuard api;
@@ -1808,6 +1818,19 @@ int sift_hip_level_copy(sift_hip_ctx* c, int image, int kind, int octave, int le
     if (!p) return SIFT_HIP_EINVAL;
     return guarded(nullptr, 0, [&]() {
         SIFT_HIP_CHECK(hipSetDevice(c->device));
+        if (kind == 0 && level == c->plan.D && (size_t)octave < c->top_missing.size() && c->top_missing[(size_t)octave]) {
+            // option "lazy_top": the batch did not write this level; the launch that would have, now without the DoG
+            const Plan& P = c->plan;
+            for (size_t k = 0; k < P.ops.size() && k < P.fail_op; ++k) {
+                const BlurOp& op = P.ops[k];
+                if (op.kind != 2 || op.octave != octave || op.j != P.D) continue;
+                const int l = octave * (P.D + 1) + P.D;
+                run_blur(c, P.dev.gauss[l - 1], P.dev.gauss[l], nullptr, op.w, op.h, P.n, op.tap_off, op.radius);
+                SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
+                c->top_missing[(size_t)octave] = 0;
+            }
+            if (c->top_missing[(size_t)octave]) return (int)SIFT_HIP_EINVAL;   // the pyramid stopped before this level (precondition)
+        }
         const size_t px = (size_t)w * (size_t)h;
         SIFT_HIP_CHECK(hipMemcpy(out, p + (size_t)image * px, px * sizeof(float), hipMemcpyDeviceToHost));
         return SIFT_HIP_OK;

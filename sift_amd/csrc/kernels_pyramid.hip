@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, (R <= 8 ? 3 : ((R <= 24 || (TH <= 48 && R <= 2
                         d4 = make_float4(128.0f + dx, 128.0f + dy, 128.0f + dz, 128.0f + dw);
                     }
                     if (vec_ok && x + 3 < w) {
-                        *reinterpret_cast<float4*>(out + o) = acc[i];
+                        if (out) *reinterpret_cast<float4*>(out + o) = acc[i];   // out == nullptr: only the DoG is wanted
                         if (DOG) *reinterpret_cast<float4*>(dog + o) = d4;
                     } else {
                         const float av[4] = {acc[i].x, acc[i].y, acc[i].z, acc[i].w};
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, (R <= 8 ? 3 : ((R <= 24 || (TH <= 48 && R <= 2
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             if (x + j < w) {
-                                out[o + j] = av[j];
+                                if (out) out[o + j] = av[j];
                                 if (DOG) dog[o + j] = dv[j];
                             }
                     }
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256, stream_occ(R, CPL)) void blur_stream_kernel(co
                     _Pragma("unroll") for (int e = 0; e < CPL; ++e)                                                   \
                         if (dcol[e] >= 0) drow[dcol[e]] = A[0][e];   /* consecutive lanes, consecutive columns */     \
                 }                                                                                                     \
-            } else {                                                                                                  \
+            } else if (out) {   /* out == nullptr: only the DoG is wanted (wave-uniform) */                            \
                 *reinterpret_cast<f4v*>(reinterpret_cast<char*>(out + o) + moff) = A[0];                              \
             }                                                                                                         \
         }                                                                                                             \
@@ -470,7 +470,7 @@ __global__ void gauss_col_generic(const float* __restrict__ tmp, const float* __
         sum += s_tap[2 * r - t] * tmp[base + (size_t)q * (size_t)w + x];
     }
     const size_t o = base + (size_t)y * (size_t)w + x;
-    out[o] = sum;
+    if (out) out[o] = sum;
     if (DOG) {
         const float dif = sum - prev[o];
         dog[o] = 128.0f + dif;

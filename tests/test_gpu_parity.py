@@ -329,6 +329,37 @@ def test_pipeline_parity_kept_pixels_reduce(ctx, report_dir, case):
         ctx.set_option("stream_min_waves", 0)
 
 
+def test_top_gaussian_level_formed_on_demand(ctx):
+    """Option lazy_top (default on): the launch that forms an octave's top Gaussian level stores its DoG only - nothing on the
+    path reads the level again (sift.cpp:406-409) - and sift_hip_level_copy forms the level when asked.  Same keypoints and
+    descriptors either way; the level asked for later is the level written eagerly, bit for bit, for every image of the batch,
+    and also when the next octave's DoGs were fetched first."""
+    frames = np.stack([synth_frame(640, 480, 70 + i) for i in range(3)])
+    params = _lib.Params(4, 2, 1.6, O.K_SQRT2, 0)   # 4 DoGs per octave (Gaussian levels 0 .. 4), 2 octaves
+    ctx.set_option("stream_min_waves", 1)
+    try:
+        ctx.set_option("lazy_top", 0)
+        ctx.calculate_batch(frames, params)
+        kp0, d0 = ctx.results()
+        eager = {(o, i): ctx.level("gaussian", o, 4, i) for o in range(2) for i in range(3)}
+        dogs = {(o, i): ctx.level("dog", o, 3, i) for o in range(2) for i in range(3)}
+        ctx.set_option("lazy_top", 1)
+        ctx.calculate_batch(frames, params)
+        kp1, d1 = ctx.results()
+        assert kp0.tobytes() == kp1.tobytes() and d0.tobytes() == d1.tobytes()
+        for o in (1, 0):
+            for i in range(3):
+                assert ctx.level("dog", o, 3, i).tobytes() == dogs[(o, i)].tobytes(), (o, i)
+                assert ctx.level("gaussian", o, 4, i).tobytes() == eager[(o, i)].tobytes(), (o, i)
+                assert ctx.level("gaussian", o, 4, i).tobytes() == eager[(o, i)].tobytes(), (o, i)   # second request: already there
+        run = O.OracleRun(frames[1], 4, 2)
+        for o in range(2):
+            assert_bits_equal(ctx.level("gaussian", o, 4, 1), run.level("gaussian", o, 4), f"gaussian({o},4)")
+    finally:
+        ctx.set_option("lazy_top", 1)
+        ctx.set_option("stream_min_waves", 0)
+
+
 def test_release_library_rejects_measurement_options(ctx):
     """The options that switch phases of kernels off for timing (wrong results), stamp or repeat batches exist only in the
     measurement build (`make -C sift_amd/csrc diag`, -DSIFT_HIP_DIAG); the shipped library answers SIFT_HIP_EINVAL, as it does

@@ -10,6 +10,8 @@ Sift::_createDOGs schedules it (/root/reference/sift.cpp:388-411; radius = (int)
 every launch is priced at its ALGORITHMIC bytes:
     g(0,0)                        4 B read + 4 B written per pixel                      8 N
     level blur + DoG              4 B read + 4 B + 4 B written                          12 N
+    top level of an octave        4 B read + 4 B written: the DoG only (option lazy_top,  8 N
+                                  the default since round 4; --lazy-top 0 prices the old 12 N)
     reduceToNextLevel, fused      4 B read per source pixel + 4 B per KEPT pixel         4 N + 4 N_next
     reduceToNextLevel, unfused    the blur alone (the resampling launch is not a blur)   8 N
 against the HBM3E peak of 8 TB/s (MI355X_MICROARCH.md).  `--trace` walks the dispatches in order and matches the i-th blur
@@ -26,7 +28,7 @@ import numpy as np
 PEAK = 8000.0  # GB/s
 
 
-def plan(w, h, n, dogs, octaves, sigma, k, subpixel):
+def plan(w, h, n, dogs, octaves, sigma, k, subpixel, lazy_top=True):
     """[(what, octave, level, radius, pixels per launch, algorithmic bytes if fused, ... unfused)]"""
     ops = []
     f32 = np.float32
@@ -51,7 +53,10 @@ def plan(w, h, n, dogs, octaves, sigma, k, subpixel):
     for o in range(octaves):
         px = ws[o] * hs[o] * n
         for j in range(1, dogs + 1):
-            ops.append((f"g({o},{j}) + dog({o},{j - 1})", o, j, rad(gs[(o, j)]), px, 12.0 * px, 12.0 * px))
+            if j == dogs and lazy_top:   # the top Gaussian level only feeds this DoG and is not written (context.cpp: lazy_top)
+                ops.append((f"dog({o},{j - 1}) [g({o},{j}) not kept]", o, j, rad(gs[(o, j)]), px, 8.0 * px, 8.0 * px))
+            else:
+                ops.append((f"g({o},{j}) + dog({o},{j - 1})", o, j, rad(gs[(o, j)]), px, 12.0 * px, 12.0 * px))
         if o < octaves - 1:
             pd = ws[o + 1] * hs[o + 1] * n
             ops.append((f"reduce g({o},{dogs - 1}) -> g({o + 1},0)", o, dogs - 1, rad(gs[(o, dogs - 1)]), px, 4.0 * px + 4.0 * pd, 8.0 * px))
@@ -77,13 +82,14 @@ def main():
     ap.add_argument("--w", type=int, default=1920)
     ap.add_argument("--h", type=int, default=1080)
     ap.add_argument("--n", type=int, default=32)
+    ap.add_argument("--lazy-top", type=int, default=1, choices=[0, 1])
     ap.add_argument("--dogs", type=int, default=3)
     ap.add_argument("--octaves", type=int, default=4)
     ap.add_argument("--sigma", type=float, default=1.6)
     ap.add_argument("--k", type=float, default=float(np.float32(np.sqrt(2.0))))
     ap.add_argument("--subpixel", type=int, default=0)
     a = ap.parse_args()
-    ops = plan(a.w, a.h, a.n, a.dogs, a.octaves, a.sigma, a.k, a.subpixel)
+    ops = plan(a.w, a.h, a.n, a.dogs, a.octaves, a.sigma, a.k, a.subpixel, bool(a.lazy_top))
     per_step_bytes = None
 
     if a.stats:
