@@ -83,7 +83,6 @@ struct DevPlan {
     float* mag[kMaxLevels];          // gradient maps, null unless the level is selected
     float* ori[kMaxLevels];
     float* prod[kMaxLevels];         // magnitude * gaussian of the initial maps (orientationHistogram36 weight)
-    uint8_t* obin[kMaxLevels];       // (u16)floor(ori/10) % 35 of the initial orientation map
     float* w16[kMaxLevels];          // n x 256: top-left 16x16 of convolveWithGauss(level, 1.6)
     float gauss_scale[kMaxLevels];
     float dog_scale[kMaxLevels];
@@ -186,7 +185,7 @@ void launch_edge_filter_points(hipStream_t s, const float* d0, const float* d1, 
                                const uint16_t* xs, const uint16_t* ys, int m, uint8_t* flags);
 void launch_vertex_parabola(hipStream_t s, const uint16_t* lnx, const float* lny, const uint16_t* px,
                             const float* py, const uint16_t* rnx, const float* rny, int m, float* out);
-void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, float* prod, uint8_t* obin, int w, int h,
+void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, float* prod, int w, int h,
                      int n, int* d_any_bin = nullptr);
 void launch_orientation(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const Candidate* d_cands,
                         const OrientIn* d_oin, const int* d_list_cnt, int list_cap, OrientOut* d_out,

@@ -455,7 +455,7 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
 
     // ---- device memory ----------------------------------------------------------------------------
     size_t total = 0;
-    std::vector<size_t> goff((size_t)O * (D + 1)), doff((size_t)O * D), moff(P.grad_levels.size()), ooff(P.grad_levels.size()), woff(P.grad_levels.size()), poff(P.grad_levels.size()), boff(P.grad_levels.size());
+    std::vector<size_t> goff((size_t)O * (D + 1)), doff((size_t)O * D), moff(P.grad_levels.size()), ooff(P.grad_levels.size()), woff(P.grad_levels.size()), poff(P.grad_levels.size());
     P.max_level_floats = (size_t)std::max(w * (size_t)h, (size_t)P.bw * (size_t)P.bh);
     auto carve = [&](size_t floats) { const size_t o = total; total = align_up(total + floats * sizeof(float), 256); return o; };
     for (int o = 0; o < O; ++o) {
@@ -470,7 +470,6 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
         ooff[g] = carve(px);
         woff[g] = carve((size_t)256 * (size_t)n);
         poff[g] = carve(px);
-        boff[g] = carve((px + 3) / 4);
     }
     c->arena.ensure(total + 256);   // slack: the kept-pixels decimating blur may read the float after a level's last row (kernels_reduce.hip)
     char* base = c->arena.as<char>();
@@ -481,7 +480,6 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
         dv.ori[P.grad_levels[g]] = reinterpret_cast<float*>(base + ooff[g]);
         dv.w16[P.grad_levels[g]] = reinterpret_cast<float*>(base + woff[g]);
         dv.prod[P.grad_levels[g]] = reinterpret_cast<float*>(base + poff[g]);
-        dv.obin[P.grad_levels[g]] = reinterpret_cast<uint8_t*>(base + boff[g]);
     }
     const size_t lvl_bytes = P.max_level_floats * (size_t)n * sizeof(float);
     c->d_tmp.ensure(lvl_bytes);
@@ -1110,7 +1108,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     launch_zero_ints(gs, c->d_ocnt.as<int>() + 4 * n, (size_t)n);   // "some sample has a bin != 0" per image
     for (int lvl : P.grad_levels) {
         const int o = lvl / (P.D + 1);
-        launch_gradient(gs, dv.gauss[lvl], dv.mag[lvl], dv.ori[lvl], dv.prod[lvl], dv.obin[lvl], dv.w[o], dv.h[o], n,
+        launch_gradient(gs, dv.gauss[lvl], dv.mag[lvl], dv.ori[lvl], dv.prod[lvl], dv.w[o], dv.h[o], n,
                         (c->orient_general ? nullptr : c->d_ocnt.as<int>() + 4 * n));
     }
     if (c->gate) SIFT_HIP_CHECK(hipEventRecord(c->ev_grad, gs));
@@ -2014,8 +2012,7 @@ int sift_hip_gradient(sift_hip_ctx* c, const float* in, int w, int h, float* mag
         float* m = s.dev<float>(px);
         float* o = s.dev<float>(px);
         float* pr = s.dev<float>(px);
-        uint8_t* ob = s.dev<uint8_t>(px);
-        launch_gradient(c->stream, a, m, o, pr, ob, w, h, 1);
+        launch_gradient(c->stream, a, m, o, pr, w, h, 1);
         SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
         SIFT_HIP_CHECK(hipMemcpy(mag, m, px * sizeof(float), hipMemcpyDeviceToHost));
         SIFT_HIP_CHECK(hipMemcpy(ori, o, px * sizeof(float), hipMemcpyDeviceToHost));

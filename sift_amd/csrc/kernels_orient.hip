@@ -30,6 +30,16 @@ __device__ __forceinline__ unsigned f32_to_u16_x86(float v) {
     return (unsigned)i & 0xffffu;
 }
 
+// alg::orientationHistogram36's bin of a sample (algorithms.cpp:126-128): (u16)floor(orientation / 10) % 35.
+// a is in [0, 360).  RN(a / 10) is monotone, so a < 9.5 gives floor 0 and 350.5 <= a < 360 gives floor 35, i.e.
+// bin 0 after % 35 either way - which is every pixel, the reference feeding radians (App. B-9); the division
+// only runs for values in between.
+__device__ __forceinline__ unsigned orientation_bin(float a) {
+    unsigned bin = 0u;
+    if (!(a < 9.5f || (a >= 350.5f && a < 360.0f))) bin = f32_to_u16_x86(__builtin_floorf(a / 10.0f)) % 35u;
+    return bin;
+}
+
 // One pixel of the gradient maps (sift.cpp:130-160 with alg::gradientMagnitude / Orientation, algorithms.cpp:108-116):
 // magnitude, orientation, and the per-pixel inputs of alg::orientationHistogram36 (algorithms.cpp:126-128), which
 // reads the INITIAL maps: weight = magnitude * gaussian, bin = (u16)floor(orientation / 10) % 35.
@@ -51,16 +61,11 @@ __device__ __forceinline__ void gradient_pixel(bool interior, float left, float 
         a = (float)(s >= 360.0 ? s - 360.0 : s);
     }
     pr = m * centre;
-    // a is in [0, 360).  RN(a / 10) is monotone, so a < 9.5 gives floor 0 and 350.5 <= a < 360 gives floor 35, i.e.
-    // bin 0 after % 35 either way — which is every pixel, the reference feeding radians (App. B-9); the division
-    // only runs for values in between.
-    bin = 0u;
-    if (!(a < 9.5f || (a >= 350.5f && a < 360.0f))) bin = f32_to_u16_x86(__builtin_floorf(a / 10.0f)) % 35u;
+    bin = orientation_bin(a);
 }
 
 __global__ __launch_bounds__(256) void gradient_kernel(const float* __restrict__ g, float* __restrict__ mag,
-                                                       float* __restrict__ ori, float* __restrict__ prod,
-                                                       uint8_t* __restrict__ obin, int w, int h,
+                                                       float* __restrict__ ori, float* __restrict__ prod, int w, int h,
                                                        int* __restrict__ any_bin) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
@@ -75,7 +80,6 @@ __global__ __launch_bounds__(256) void gradient_kernel(const float* __restrict__
     mag[o] = m;
     ori[o] = a;
     prod[o] = pr;
-    obin[o] = (uint8_t)bin;
     // The reference feeds radians where degrees were meant (App. B-9): every sample lands in bin 0.  The
     // orientation stage skips the bin map of an image as long as this flag stays clear.
     if (bin != 0u && any_bin) any_bin[blockIdx.z] = 1;
@@ -84,12 +88,13 @@ __global__ __launch_bounds__(256) void gradient_kernel(const float* __restrict__
 // Four pixels of a row per thread (rows 16-byte aligned), kGradRows consecutive rows per thread: the three source rows a
 // pixel needs roll through registers (row y+1 is fetched while row y is computed and becomes row y the step after), so the
 // level is read 1 + 2 / kGradRows times instead of three times (consecutive workgroups are dealt to different XCDs, whose L2s
-// do not share the neighbouring rows: measured 3.0x before).  16-byte loads and stores, a 4-byte store of the bins.
+// do not share the neighbouring rows: measured 3.0x before).  16-byte loads and stores.  The samples' histogram bins are not
+// stored (until round 4: one byte per pixel): every bin of an image is 0 unless its flag says otherwise, and the orientation
+// stage then forms the bins from the orientation map itself.
 constexpr int kGradRows = 16;
 
 __global__ __launch_bounds__(256, 8) void gradient4_kernel(const float* __restrict__ g, float* __restrict__ mag,
-                                                        float* __restrict__ ori, float* __restrict__ prod,
-                                                        uint8_t* __restrict__ obin, int w, int h,
+                                                        float* __restrict__ ori, float* __restrict__ prod, int w, int h,
                                                         int* __restrict__ any_bin) {
     const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int y0 = blockIdx.y * kGradRows;
@@ -126,7 +131,6 @@ __global__ __launch_bounds__(256, 8) void gradient4_kernel(const float* __restri
         *reinterpret_cast<float4*>(mag + o) = make_float4(m[0], m[1], m[2], m[3]);
         *reinterpret_cast<float4*>(ori + o) = make_float4(a[0], a[1], a[2], a[3]);
         *reinterpret_cast<float4*>(prod + o) = make_float4(pr[0], pr[1], pr[2], pr[3]);
-        *reinterpret_cast<unsigned*>(obin + o) = bin[0] | (bin[1] << 8) | (bin[2] << 16) | (bin[3] << 24);
         any |= bin[0] | bin[1] | bin[2] | bin[3];
         u4 = c4; c4 = d4; lf = nlf; rt = nrt;
     }
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
         int wh;        // w | h << 16 of the nearest Gaussian level's octave
         int dead;      // dead_blur_radius code
         const float* prod;
-        const uint8_t* obin;
+        const float* ori;      // the samples' bins come from here (orientation_bin) when the image's flag is set
     };
     __shared__ LevelInfo s_lvl[kMaxLevels];
     static_assert(sizeof(float) * 4 * kOrientSub * kOrientStride >= sizeof(float) * 36 * kOrientGroup, "s_set overlay");
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
         li.wh = plan->w[no] | (plan->h[no] << 16);
         li.dead = plan->dead_blur_radius[l];
         li.prod = plan->prod[lvl];
-        li.obin = plan->obin[lvl];
+        li.ori = plan->ori[lvl];
         s_lvl[l] = li;
     }
     // The survivor count lives on the device; the groups of an image are dealt round-robin to its workgroups.  (Until round 3
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
         const int slot_w = wv * (kOrientGroup / 4);          // first slot of this wave
         const int j_lane = grp * kOrientGroup + slot_w + lane;
         const bool have = lane < kOrientGroup / 4 && j_lane < cnt;
-        unsigned long long org_prod = 0ull, org_bin = 0ull;  // byte address of the window's first sample in the weight / bin maps
+        unsigned long long org_prod = 0ull, org_bin = 0ull;  // byte address of the window's first sample in the weight / orientation maps
         int pitch = 0;                                       // row pitch of that level (pixels)
         bool run_l = false;
         if (have) {
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
             s_state[slot_w + lane] = (unsigned char)((border ? 1 : 0) | (throws << 1) | ((!border && throws == 0) ? 0x80 : 0));
             const size_t o = (size_t)img * (size_t)w * (size_t)h + (size_t)(y - kRegion) * (size_t)w + (size_t)(x - kRegion);
             org_prod = (unsigned long long)(uintptr_t)(li.prod + o);
-            org_bin = (unsigned long long)(uintptr_t)(li.obin + o);
+            org_bin = (unsigned long long)(uintptr_t)(li.ori + o);
             pitch = w;
         }
         const unsigned runmask32 = (unsigned)__ballot(run_l);   // bit i: keypoint slot_w + i runs
@@ -247,7 +251,6 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
                     // (pointers made from integers are generic: spelled as global ones, or the loads become FLAT loads, which also
                     // count against the LDS counter the staging below waits on)
                     typedef const __attribute__((address_space(1))) float* gfloat_p;
-                    typedef const __attribute__((address_space(1))) uint8_t* gbyte_p;
                     const gfloat_p gp = (gfloat_p)(uintptr_t)a64;
                     const int w = __builtin_amdgcn_readlane(pitch, src);
                     if (bins_zero) {
@@ -261,14 +264,14 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
                         const unsigned long long b64 =
                             (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)org_bin, src) |
                             ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(org_bin >> 32), src) << 32);
-                        const gbyte_p gb = (gbyte_p)(uintptr_t)b64;
+                        const gfloat_p gb = (gfloat_p)(uintptr_t)b64;
 #pragma unroll
                         for (int it = 0; it < 4; ++it) {
                             const int ly = it * 4 + (lane >> 4);
                             const int lx = lane & 15;
                             const size_t o = (size_t)ly * (size_t)w + (size_t)lx;
                             pp[k][it] = gp[o];
-                            pb[k][it] = gb[o];
+                            pb[k][it] = orientation_bin(gb[o]);
                         }
                     }
                 }
@@ -437,17 +440,16 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
     }
 }
 
-void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, float* prod, uint8_t* obin, int w, int h,
+void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, float* prod, int w, int h,
                      int n, int* d_any_bin) {
-    const bool vec = (w & 3) == 0 && ((((uintptr_t)g | (uintptr_t)mag | (uintptr_t)ori | (uintptr_t)prod) & 15u) == 0) &&
-                     (((uintptr_t)obin & 3u) == 0);
+    const bool vec = (w & 3) == 0 && ((((uintptr_t)g | (uintptr_t)mag | (uintptr_t)ori | (uintptr_t)prod) & 15u) == 0);
     if (vec) {
         const dim3 grid4((unsigned)((w / 4 + 255) / 256), (unsigned)((h + kGradRows - 1) / kGradRows), (unsigned)n);
-        hipLaunchKernelGGL(gradient4_kernel, grid4, dim3(256), 0, s, g, mag, ori, prod, obin, w, h, d_any_bin);
+        hipLaunchKernelGGL(gradient4_kernel, grid4, dim3(256), 0, s, g, mag, ori, prod, w, h, d_any_bin);
         return;
     }
     const dim3 grid((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)n);
-    hipLaunchKernelGGL(gradient_kernel, grid, dim3(256), 0, s, g, mag, ori, prod, obin, w, h, d_any_bin);
+    hipLaunchKernelGGL(gradient_kernel, grid, dim3(256), 0, s, g, mag, ori, prod, w, h, d_any_bin);
 }
 
 static int g_orient_dbg = 0;
