@@ -510,7 +510,8 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
         }
         const long long ok = obase + (long long)myk;
         if (ok < out_cap && !((dbg & 16) && h0 == 12345.0f)) {   // (the output arrays are sized before the final counts reach the host: see run_batch)
-            *reinterpret_cast<float2*>(desc_out + (size_t)ok * 128 + (size_t)(2 * lane)) = make_float2(h0, h1);
+            typedef float f2nt __attribute__((ext_vector_type(2)));
+            __builtin_nontemporal_store((f2nt){h0, h1}, reinterpret_cast<f2nt*>(desc_out + (size_t)ok * 128 + (size_t)(2 * lane)));
             if (lv.wire_sums != nullptr) {
                 // the counting pass of the sparse wire format (kernels_wire.hip: wire_count_kernel) while the 128 floats are
                 // still in registers: floats that are not +0.0f outside bin 7, per block of 64 output slots

@@ -128,9 +128,12 @@ __global__ __launch_bounds__(256, 8) void gradient4_kernel(const float* __restri
             gradient_pixel(interior, cv[e], cv[e + 2], uv[e], dv[e], cv[e + 1], m[e], a[e], pr[e], bin[e]);
         }
         const size_t o = base + (size_t)y * (size_t)w + (size_t)x;
-        *reinterpret_cast<float4*>(mag + o) = make_float4(m[0], m[1], m[2], m[3]);
-        *reinterpret_cast<float4*>(ori + o) = make_float4(a[0], a[1], a[2], a[3]);
-        *reinterpret_cast<float4*>(prod + o) = make_float4(pr[0], pr[1], pr[2], pr[3]);
+        // streamed out: nothing in this launch reads the maps again, and lines that are not left dirty in L2 need no write-back
+        // when the kernel ends
+        typedef float f4nt __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store((f4nt){m[0], m[1], m[2], m[3]}, reinterpret_cast<f4nt*>(mag + o));
+        __builtin_nontemporal_store((f4nt){a[0], a[1], a[2], a[3]}, reinterpret_cast<f4nt*>(ori + o));
+        __builtin_nontemporal_store((f4nt){pr[0], pr[1], pr[2], pr[3]}, reinterpret_cast<f4nt*>(prod + o));
         any |= bin[0] | bin[1] | bin[2] | bin[3];
         u4 = c4; c4 = d4; lf = nlf; rt = nrt;
     }

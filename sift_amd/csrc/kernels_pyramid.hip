@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256, stream_occ(R, CPL)) void blur_stream_kernel(co
             const size_t o = img_off + (size_t)y * (size_t)w;                                                         \
             if (DOG) {                                                                                                \
                 const f4v dif = A[0] - prev;                                                                          \
-                *reinterpret_cast<f4v*>(reinterpret_cast<char*>(dog + o) + moff) = 128.0f + dif;                      \
+                __builtin_nontemporal_store((f4v)(128.0f + dif), reinterpret_cast<f4v*>(reinterpret_cast<char*>(dog + o) + moff)); \
             }                                                                                                         \
             if (DEC) {                                                                                                \
                 const int jd = dec.inv_y[y];   /* wave-uniform: half of the rows are dropped */                       \
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256, stream_occ(R, CPL)) void blur_stream_kernel(co
                         if (dcol[e] >= 0) drow[dcol[e]] = A[0][e];   /* consecutive lanes, consecutive columns */     \
                 }                                                                                                     \
             } else if (out) {   /* out == nullptr: only the DoG is wanted (wave-uniform) */                            \
-                *reinterpret_cast<f4v*>(reinterpret_cast<char*>(out + o) + moff) = A[0];                              \
+                __builtin_nontemporal_store(A[0], reinterpret_cast<f4v*>(reinterpret_cast<char*>(out + o) + moff));   \
             }                                                                                                         \
         }                                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
