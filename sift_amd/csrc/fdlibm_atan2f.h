@@ -4,6 +4,18 @@
 // rounds differently in the last bit.  Restating the published fdlibm algorithm with one IEEE
 // operation per operator (compile with -ffp-contract=off) makes the device result bit-identical
 // to the host libm's; tests/test_host_math.py checks this file against glibc on the CPU.
+// The algorithm and its constants restate e_atan2f.c / s_atanf.c of Sun's fdlibm, whose licence
+// asks for this notice to be preserved:
+//
+// ====================================================
+// Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+//
+// Developed at SunPro, a Sun Microsystems, Inc. business.
+// Permission to use, copy, modify, and distribute this
+// software is freely granted, provided that this notice
+// is preserved.
+// ====================================================
+//
 #pragma once
 #include <stdint.h>
 
