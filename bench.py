@@ -205,6 +205,40 @@ def launch_ranks(n):
     return status
 
 
+def dropin_cpp_leg(frame, iterations=50):
+    """The reference's ACTUAL boundary, timed outside the timed region: examples/sift_dropin_bench.cpp calls
+    sift::Sift::calculate(Image2f&) (include/sift/sift.hpp: float host image in, std::vector<InterestPoint> with a heap
+    std::vector<f32_t> per point out - /root/reference/sift.hpp:78, interestpoint.hpp:46, main.cpp:52-57) `iterations` times
+    on frame 1 of the batch from one thread, then from two gated Sift objects on two threads.  A child process of its own
+    (started, not exec'ed); a host without g++ or a failing run reports the reason instead of figures."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "sift_amd", "lib", "sift_dropin_bench")
+    src = os.path.join(ROOT, "examples", "sift_dropin_bench.cpp")
+    hdr = os.path.join(ROOT, "include", "sift", "sift.hpp")
+    try:
+        if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "include"), src,
+                                   "-L" + os.path.join(ROOT, "sift_amd", "lib"), "-lsift_hip",
+                                   "-Wl,-rpath," + os.path.join(ROOT, "sift_amd", "lib"), "-o", exe], timeout=300)
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "frame.f32")
+            np.ascontiguousarray(frame, np.float32).tofile(path)
+            h, w = frame.shape
+            r = subprocess.run([exe, path, str(w), str(h), str(iterations)], capture_output=True, text=True, timeout=600,
+                               env=dict(os.environ, GPU_MAX_HW_QUEUES="8"))
+        if r.returncode != 0:
+            return {"error": f"exit status {r.returncode}: {r.stderr[-300:]}"}
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        d = json.loads(line)["dropin_cpp"]
+        d["what"] = ("sift::Sift::calculate(Image2f&) of include/sift/sift.hpp in a C++ host (examples/sift_dropin_bench.cpp): pageable float "
+                     "frame in, std::vector<InterestPoint> with one heap vector of 128 floats per keypoint out, the result dropped again "
+                     "(ms_per_frame = call + drop, mean); two_gated_objects: two Sift objects joined by a gate, one host thread each")
+        return d
+    except Exception as e:   # noqa: BLE001 - a leg beside the headline must not take the line with it
+        return {"error": repr(e)[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -655,6 +689,7 @@ def main():
                 ctx.results(pin_out[0][0], pin_out[0][1])
                 lat.append(time.perf_counter() - t_0)
             out["single_frame_ms"] = float(np.median(lat[2:]) * 1e3)
+            out["dropin_cpp"] = dropin_cpp_leg(frames[0])
             if args.pmc_traffic:
                 extra = ["--workload", args.workload, "--frames", str(nf)] + [a for kv in args.set for a in ("--set", kv)]
                 traffic, src = pmc_traffic_live(extra)

@@ -132,6 +132,36 @@ private:
     // The keypoint lists come down in the library's sparse format (34-byte records = the 20-byte keypoint + 112 presence bits,
     // and only the descriptor floats that are not +0.0f: ~200 instead of 532 bytes per keypoint over the link) and are expanded
     // straight into the InterestPoints; results the format would lose (a bin 7 that is not +0.0f) take the dense arrays.
+    //
+    // The reference's return type fixes one heap block per keypoint (`std::vector<f32_t> descriptors`, interestpoint.hpp:46):
+    // what is left to this function is everything else.  The transfer buffers live in the object (a fresh 10 MB vector per call
+    // is ~2500 page faults), no dense n x 128 array is built on the way (a block of 64 descriptors is expanded into a scratch
+    // that stays in L1 and handed to the points at once), and a few threads share the points of a large result - each its own
+    // contiguous range, so every thread allocates from its own malloc arena.
+    static int mask_popcount(const unsigned char* m) {   // set bits of a record's 14 presence bytes
+        unsigned long long a, b;
+        std::memcpy(&a, m, 8);
+        std::memcpy(&b, m + 6, 8);
+        return __builtin_popcountll(a) + __builtin_popcountll(b >> 16);
+    }
+    void expand_range(std::vector<InterestPoint>& out, size_t i0, size_t i1, const float* val) const {
+        constexpr size_t kBlock = 64;
+        sift_hip_keypoint kp[kBlock];
+        float desc[kBlock * 128];
+        for (size_t i = i0; i < i1; i += kBlock) {
+            const size_t m = i1 - i < kBlock ? i1 - i : kBlock;
+            const unsigned char* r = _rec.data() + i * 34;
+            size_t nv = 0;
+            for (size_t k = 0; k < m; ++k) nv += (size_t)mask_popcount(r + k * 34 + 20);
+            // (the library's vector form looks 8 floats ahead; _val keeps 8 floats of slack behind the last value)
+            if (sift_hip_sparse_unpack_host(r, val, (int64_t)m, kp, desc, 1) != SIFT_HIP_OK) throw std::runtime_error("sift_hip_sparse_unpack_host failed");
+            for (size_t k = 0; k < m; ++k) {
+                fill(out[i + k], kp[k]);
+                if (kp[k].has_descriptor) out[i + k].descriptors.assign(desc + k * 128, desc + (k + 1) * 128);
+            }
+            val += nv;
+        }
+    }
     std::vector<InterestPoint> collect() {
         const long long n = sift_hip_result_total(_ctx);
         std::vector<InterestPoint> out((size_t)(n > 0 ? n : 0));
@@ -139,30 +169,51 @@ private:
         int64_t nnz = 0;
         int lossless = 0;
         if (sift_hip_result_sparse_size(_ctx, &nnz, &lossless) == SIFT_HIP_OK && lossless) {
-            std::vector<unsigned char> rec((size_t)n * 34);
-            std::vector<float> val((size_t)(nnz > 0 ? nnz : 1));
-            if (sift_hip_result_copy_sparse(_ctx, rec.data(), val.data()) != SIFT_HIP_OK) throw std::runtime_error("sift_hip_result_copy_sparse failed");
-            // expanded by the library's host routine (vectorised, a few threads), then handed to the InterestPoints
-            std::vector<sift_hip_keypoint> kp((size_t)n);
-            std::vector<float> desc((size_t)n * 128);
+            if (_rec.size() < (size_t)n * 34) _rec.resize((size_t)n * 34);
+            if (_val.size() < (size_t)nnz + 8) _val.resize((size_t)nnz + 8);
+            if (sift_hip_result_copy_sparse(_ctx, _rec.data(), _val.data()) != SIFT_HIP_OK) throw std::runtime_error("sift_hip_result_copy_sparse failed");
             unsigned hw = std::thread::hardware_concurrency();
-            if (sift_hip_sparse_unpack_host(rec.data(), val.data(), n, kp.data(), desc.data(), (int)(hw > 8 ? 8 : (hw ? hw : 1))) != SIFT_HIP_OK)
-                throw std::runtime_error("sift_hip_sparse_unpack_host failed");
-            for (size_t i = 0; i < out.size(); ++i) {
-                fill(out[i], kp[i]);
-                if (kp[i].has_descriptor) out[i].descriptors.assign(desc.begin() + (std::ptrdiff_t)i * 128, desc.begin() + (std::ptrdiff_t)(i + 1) * 128);
+            const size_t threads = (size_t)n < 4096 ? 1 : (hw >= 8 ? 4 : (hw >= 4 ? 2 : 1));
+            if (threads == 1) {
+                expand_range(out, 0, (size_t)n, _val.data());
+                return out;
             }
+            // first value of every thread's range: the presence bits say how many floats the points in front of it own
+            const size_t per = (((size_t)n + threads - 1) / threads + 63) / 64 * 64;
+            std::vector<size_t> first(threads, 0);
+            {
+                size_t v = 0;
+                for (size_t i = 0; i < (size_t)n; ++i) {
+                    if (i % per == 0) first[i / per] = v;
+                    v += (size_t)mask_popcount(_rec.data() + i * 34 + 20);
+                }
+            }
+            std::vector<std::thread> pool;
+            std::vector<std::exception_ptr> failed(threads);
+            for (size_t t = 1; t < threads; ++t)
+                pool.emplace_back([&, t] {
+                    const size_t i0 = t * per < (size_t)n ? t * per : (size_t)n, i1 = i0 + per < (size_t)n ? i0 + per : (size_t)n;
+                    try { if (i0 < i1) expand_range(out, i0, i1, _val.data() + first[t]); } catch (...) { failed[t] = std::current_exception(); }
+                });
+            try { expand_range(out, 0, per < (size_t)n ? per : (size_t)n, _val.data()); } catch (...) { failed[0] = std::current_exception(); }
+            for (auto& th : pool) th.join();
+            for (auto& f : failed) if (f) std::rethrow_exception(f);
             return out;
         }
-        std::vector<sift_hip_keypoint> kp((size_t)n);
-        std::vector<float> desc((size_t)n * 128);
-        if (sift_hip_result_copy(_ctx, kp.data(), desc.data()) != SIFT_HIP_OK) throw std::runtime_error("sift_hip_result_copy failed");
+        if (_kp.size() < (size_t)n) _kp.resize((size_t)n);
+        if (_desc.size() < (size_t)n * 128) _desc.resize((size_t)n * 128);
+        if (sift_hip_result_copy(_ctx, _kp.data(), _desc.data()) != SIFT_HIP_OK) throw std::runtime_error("sift_hip_result_copy failed");
         for (size_t i = 0; i < out.size(); ++i) {
-            fill(out[i], kp[i]);
-            if (kp[i].has_descriptor) out[i].descriptors.assign(desc.begin() + (std::ptrdiff_t)i * 128, desc.begin() + (std::ptrdiff_t)(i + 1) * 128);
+            fill(out[i], _kp[i]);
+            if (_kp[i].has_descriptor) out[i].descriptors.assign(_desc.begin() + (std::ptrdiff_t)i * 128, _desc.begin() + (std::ptrdiff_t)(i + 1) * 128);
         }
         return out;
     }
+    // transfer buffers, kept between calls (collect)
+    std::vector<unsigned char> _rec;
+    std::vector<float> _val;
+    std::vector<sift_hip_keypoint> _kp;
+    std::vector<float> _desc;
 };
 
 }  // namespace sift

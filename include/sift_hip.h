@@ -87,10 +87,15 @@ void sift_hip_destroy(sift_hip_ctx* ctx);
  * and the next octave's small launches; 0: every launch on one stream), "reduce_kept" (1 default: reduceToNextLevel evaluates
  * the kept pixels only), "lazy_top" (1 default: the top Gaussian level of an octave is not written at all by the batch - nothing
  * on the path reads it again - and is formed when sift_hip_level_copy asks for it; 0: every level is written), "spin_wait" (1 default: the end of a batch is awaited by polling its event - tens of microseconds per batch sooner than
- * sleeping in hipStreamSynchronize, which is what 0 selects).
- * These 15 names are all a release build knows; any other name returns SIFT_HIP_EINVAL.  The measurement build
+ * sleeping in hipStreamSynchronize, which is what 0 selects), "tail_async" (0 default; 1: the pyramid's small octaves - a level of at
+ * most 6 Mpx over the whole batch, octaves 2 and 3 of 32 1080p frames - leave the main stream at the reduction that feeds them
+ * and run beside the batch's extremum scans of the large octaves; only the scans of those octaves wait for them),
+ * "tail_kernel" (0 default; those octaves as ONE launch of one 1024-thread workgroup per image, sift_amd/csrc/kernels_tail.hip,
+ * instead of a launch per level: 1 - for batches of at least 16 images; 2 - whenever the levels fit the kernel.  Both were built
+ * and measured in round 5, are bit-exact and do not shorten a step: DESIGN.md section 7).
+ * These 17 names are all a release build knows; any other name returns SIFT_HIP_EINVAL.  The measurement build
  * (libsift_hip_diag.so: make -C sift_amd/csrc diag, -DSIFT_HIP_DIAG) adds "desc_dbg" / "orient_dbg" (phases of a kernel
- * switched off: timing only, WRONG results), "stream_waves", "diag_repeat", "diag_pyramid_span", "diag_serial_gradient" and
+ * switched off: timing only, WRONG results), "stream_waves", "diag_repeat", "diag_pyramid_span", "diag_serial_gradient", "diag_skip_tail" and
  * "diag_cleanup_stamps" for the scripts under tools/.  The library reads no environment variable. */
 int sift_hip_set_option(sift_hip_ctx* ctx, const char* name, int value);
 

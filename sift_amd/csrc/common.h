@@ -33,9 +33,16 @@ using ApiGuard = LaunchGuard;
 #define hipMemset(...) (::sift_hip::LaunchGuard{}, (hipMemset)(__VA_ARGS__))
 #define hipEventRecord(...) (::sift_hip::LaunchGuard{}, (hipEventRecord)(__VA_ARGS__))
 #define hipStreamWaitEvent(...) (::sift_hip::LaunchGuard{}, (hipStreamWaitEvent)(__VA_ARGS__))
+namespace sift_hip {
+// what a stage's launches left behind: an error the module launch path returned (launch_cache.h), else the runtime's own
+hipError_t combined_last_error();
+}
+#define hipGetLastError() (::sift_hip::combined_last_error())
 #ifdef __HIPCC__
 #include <hip/hip_ext.h>
+#include "launch_cache.h"
 #undef hipLaunchKernelGGL
+#ifdef SIFT_HIP_STATIC_LAUNCH   // the runtime's own launch path (a lookup of the host stub per launch): A/B builds only
 #define hipLaunchKernelGGL(kernelName, ...)                                   \
     do {                                                                      \
         ::sift_hip::LaunchGuard sift_launch_guard_;                           \
@@ -46,6 +53,13 @@ using ApiGuard = LaunchGuard;
         ::sift_hip::LaunchGuard sift_launch_guard_;                           \
         (hipExtLaunchKernelGGL)(__VA_ARGS__);                                 \
     } while (0)
+#else
+// every launch of the library: function object resolved once per device, module launch (launch_cache.h)
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...) \
+    ::sift_hip::launch_cached((kernelName), dim3(numBlocks), dim3(numThreads), (unsigned)(memPerBlock), (streamId), nullptr, nullptr, ##__VA_ARGS__)
+#define hipExtLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, startEvent, stopEvent, flags, ...) \
+    ::sift_hip::launch_cached((kernelName), dim3(numBlocks), dim3(numThreads), (unsigned)(memPerBlock), (streamId), (startEvent), (stopEvent), ##__VA_ARGS__)
+#endif
 #endif
 
 namespace sift_hip {
@@ -174,8 +188,10 @@ void launch_extrema_mask(hipStream_t s, const DevPlan* d_plan, const DevPlan& pl
                          unsigned long long* d_masks, int* d_counts);
 void launch_extrema_scan(hipStream_t s, const DevPlan& plan, int* d_counts, int* d_totals);
 bool extrema_edge_supported(const DevPlan& plan);
+// scan levels [k_begin, k_end) of the plan (k_end < 0: all the rest)
 void launch_extrema_edge(hipStream_t s, const DevPlan& plan, unsigned long long* d_masks, unsigned long long* d_fmasks,
-                         int* d_counts);
+                         int* d_counts, int k_begin = 0, int k_end = -1, int busy_cus = 0);
+int resident_cus();   // CUs of the calling thread's device (kernels_pyramid.hip; 256 until sift_hip_create has asked)
 void launch_extrema_expand(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan,
                            const unsigned long long* d_masks, const int* d_offsets, Candidate* d_cands,
                            const unsigned long long* d_fmasks = nullptr, uint8_t* d_flags = nullptr);

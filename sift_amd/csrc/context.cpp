@@ -18,6 +18,7 @@
 
 #include "common.h"
 #include "phase_gate.h"
+#include "tail_plan.h"
 #include "host_glue.h"
 
 using namespace sift_hip;
@@ -26,6 +27,8 @@ namespace {
 
 constexpr int kPoolCap = 65536;  // records of the descriptor stage's cell grid: every keypoint once (u16_t size, sift.cpp:53)
 constexpr int kListCap = 65536;  // cleanup keeps at most 65535 points (u16_t size, sift.cpp:41)
+constexpr int kTailKernelImages = 16;
+constexpr long long kTailPixels = 6ll << 20;   // a level of the pyramid's tail: at most this many pixels over the whole batch (1080p x 32: octaves 2 and 3)
 
 struct DevBuf {
     void* p = nullptr;
@@ -103,6 +106,9 @@ struct Plan {
     size_t fail_op = (size_t)-1;      // first op that cannot run
     std::string fail_msg;
     std::vector<int> grad_levels;     // levels some keypoint scale selects
+    int tail_from = 0;                // first octave of the pyramid's tail (option "tail_async"); O: no tail
+    TailPlan tail{};                  // ... as the argument block of pyramid_tail_kernel; n_ops == 0: the kernel cannot take it
+    double tail_bytes = 0;            // algorithmic bytes of the tail's ops over the whole batch
     std::vector<float> taps16;        // taps of convolveWithGauss(level, 1.6f) (sift.cpp:87)
     int radius16 = 0;
     size_t max_level_floats = 0;      // per image, largest level
@@ -153,6 +159,24 @@ struct sift_hip_ctx {
     bool lazy_top = true;
     std::vector<char> top_missing;   // per octave: this batch's top Gaussian level has not been formed
     hipEvent_t ev_side_fork = nullptr, ev_side_join = nullptr;
+    // option "tail_async" (round 5; measured, NOT the default - DESIGN.md section 7): the octaves from `Plan::tail_from` on - a
+    // few tiles per CU and launch, 5 % of the pyramid's bytes in a fifth of its time - leave the main stream: they run on a
+    // stream of their own from the reduction that feeds them on, beside the rest of the batch (and beside the partner batch's
+    // descriptors), and only the extremum scans of THOSE octaves wait for them.  The pyramid phase the gate orders (P) then ends
+    // with the last launch of the octaves in front.  Not running the tail at all would be worth 0.21 ms of a 2.79 ms step;
+    // moved aside, its launches starve behind the extrema pass's persistent workgroups and the step does not move.
+    bool tail_async = false;
+    // option "tail_kernel" (round 5; measured, NOT the default): those octaves as ONE launch of one workgroup per image
+    // (kernels_tail.hip) on that stream, started before the extrema pass so that it holds its CUs.  Bit-exact; ~0.93 ms on 32
+    // CUs (arithmetic-bound: the reference's 2 (2R+1) multiply-adds per pixel and level at 64 lanes per clock and CU), which
+    // the phase it runs beside pays for in full: 2.74 - 2.81 against 2.73 - 2.78 ms per step, 3.31 against 3.12 one batch at
+    // a time.  0: never; 1: for batches of at least kTailKernelImages images; 2: whenever the plan allows (tests).  Implies
+    // tail_async for the batches it takes.
+    int tail_kernel = 0;
+    hipStream_t stream3 = nullptr;
+    hipEvent_t ev_tail_fork = nullptr, ev_tail_done = nullptr;
+    bool tail_pending = false;       // this batch has launches on stream3 that the main stream has not waited for yet
+    bool tail_in_kernel = false;     // ... as the tail kernel: one workgroup per image holds a CU while it runs
     DevBuf d_list, d_list_cnt, d_orient, d_peaks, d_final, d_final_cnt, d_out_base, d_kp, d_desc;
     DevBuf d_wire_sums, d_wire_off;   // sparse wire format: floats per block of keypoints, their exclusive scan
     DevBuf d_unpack_sums, d_unpack_off;   // the same for sift_hip_sparse_unpack (lists that arrive from other GPUs)
@@ -171,6 +195,7 @@ struct sift_hip_ctx {
     bool spin_wait = true;    // poll an event instead of sleeping in hipStreamSynchronize (tens of microseconds per batch)
     // diagnostics (options "diag_pyramid_span", "diag_serial_gradient", "diag_cleanup_stamps"): all off by default
     bool diag_pyramid_span = false, diag_serial_gradient = false, diag_cleanup_stamps = false;
+    bool diag_skip_tail = false;   // timing only (results WRONG): the tail's launches are not made at all
     // results of the last batch
     std::vector<int32_t> status, counts;
     std::vector<std::string> messages;
@@ -189,10 +214,11 @@ struct sift_hip_ctx {
     struct EvPair { hipEvent_t a, b; int which; double bytes; };
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> event_pool;
-    double prof_ms[2] = {0, 0};
-    long long prof_launches[2] = {0, 0};
-    double prof_bytes[2] = {0, 0};
-    double prof_busy_ms[2] = {0, 0};   // time during which at least one launch of the class was running (union of the launches' intervals)
+    // classes: 0 the fused blur launches (streaming / tile / kept-pixels reduction), 1 the two-pass fallback, 2 the tail kernel
+    double prof_ms[3] = {0, 0, 0};
+    long long prof_launches[3] = {0, 0, 0};
+    double prof_bytes[3] = {0, 0, 0};
+    double prof_busy_ms[3] = {0, 0, 0};   // time during which at least one launch of the class was running (union of the launches' intervals)
 };
 
 namespace {
@@ -227,7 +253,7 @@ void resolve_events(sift_hip_ctx* c) {
         for (auto& p : c->pending) { float ms = 0; (void)hipEventElapsedTime(&ms, p.a, p.b); sum += ms; }
         std::fprintf(stderr, "pyramid span %.3f ms, sum of blur kernels %.3f ms, launches %zu\n", span, sum, c->pending.size());
     }
-    std::vector<std::pair<float, float>> iv[2];   // launch intervals, milliseconds after the batch's first launch began
+    std::vector<std::pair<float, float>> iv[3];   // launch intervals, milliseconds after the batch's first launch began
     for (auto& p : c->pending) {
         float ms = 0, t0 = 0;
         SIFT_HIP_CHECK(hipEventSynchronize(p.b));
@@ -238,7 +264,7 @@ void resolve_events(sift_hip_ctx* c) {
         if (&p != &c->pending.front()) SIFT_HIP_CHECK(hipEventElapsedTime(&t0, c->pending.front().a, p.a));
         iv[p.which].emplace_back(t0, t0 + ms);
     }
-    for (int wch = 0; wch < 2; ++wch) {   // launches on two streams overlap (option "pyramid_side"): count that time once
+    for (int wch = 0; wch < 3; ++wch) {   // launches on two streams overlap (option "pyramid_side"): count that time once
         std::sort(iv[wch].begin(), iv[wch].end());
         float end = -1e30f;
         for (auto& x : iv[wch]) {
@@ -452,6 +478,23 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
     dv.words_per_image = std::max(words, 1);
     dv.cand_capacity = (std::max(cap, 1LL) + 15) / 16 * 16;   // every image's flag bytes start 16-byte aligned
     gauss_taps(1.6f, P.taps16, P.radius16);
+    // The pyramid's tail (option "tail_async"): the octaves whose levels are a few tiles per CU for the whole batch.  They must
+    // not hold a gradient level (the gradient maps and W16 are launched beside the main stream's octaves) and every blur of
+    // theirs must have a fused kernel (the two-pass fallback shares the context's scratch image).
+    P.tail_from = O;
+    if (P.fail_status == 0) {
+        int from = O;
+        for (int o = O - 1; o >= 1; --o) {
+            if ((long long)dv.w[o] * dv.h[o] * n > kTailPixels) break;
+            bool ok_o = true;
+            for (int lvl : P.grad_levels) ok_o = ok_o && lvl / (D + 1) != o;
+            for (const BlurOp& op : P.ops)
+                if ((op.kind == 2 || op.kind == 3) && op.octave == o) ok_o = ok_o && op.radius >= 1 && op.radius <= kMaxRadiusFused;
+            if (!ok_o) break;
+            from = o;
+        }
+        P.tail_from = from;
+    }
 
     // ---- device memory ----------------------------------------------------------------------------
     size_t total = 0;
@@ -533,6 +576,53 @@ void early_w16(sift_hip_ctx* c, int level) {
     launch_w16(c->stream2, P.dev, level, c->d_taps16.as<float>(), P.radius16);
 }
 
+// The ops from P.ops[first] on as the argument block of pyramid_tail_kernel (kernels_tail.hip).  false: a level does not fit
+// the kernel's LDS, a reduction's index maps have no inverse-free form here, or there are more ops than the block holds - the
+// tail then stays a launch per level.
+bool make_tail_plan(sift_hip_ctx* c, size_t first, TailPlan& tp, double& bytes, std::vector<int>& skipped_tops) {
+    Plan& P = c->plan;
+    const DevPlan& dv = P.dev;
+    const int n = P.n, O = P.O, D = P.D;
+    tp.n_ops = 0;
+    bytes = 0;
+    skipped_tops.clear();
+    for (size_t k = first; k < P.ops.size() && k < P.fail_op; ++k) {
+        const BlurOp& op = P.ops[k];
+        if (op.kind != 2 && op.kind != 3) return false;
+        if (tp.n_ops >= kMaxTailOps) return false;
+        TailOp& t = tp.op[tp.n_ops++];
+        t = TailOp{};
+        t.kind = op.kind;
+        t.w = op.w; t.h = op.h;
+        t.radius = op.radius;
+        t.tap_off = (int)op.tap_off;
+        t.band = tail_band_rows(op.w, op.h, op.radius);
+        if (t.band <= 0) return false;
+        const double px = (double)op.w * (double)op.h * (double)n;
+        if (op.kind == 2) {
+            const int l = op.octave * (D + 1) + op.j;
+            const bool skip = c->lazy_top && op.j == D && std::find(P.grad_levels.begin(), P.grad_levels.end(), l) == P.grad_levels.end();
+            t.wd = op.w; t.hd = op.h;
+            t.src = dv.gauss[l - 1];
+            t.dst = skip ? nullptr : dv.gauss[l];
+            t.dog = dv.dog[op.octave * D + op.j - 1];
+            if (skip) skipped_tops.push_back(op.octave);
+            bytes += px * (4.0 + (t.dst ? 4.0 : 0.0) + 4.0);
+        } else {
+            const int o = op.octave;
+            if (o + 1 >= O) return false;
+            t.wd = dv.w[o + 1]; t.hd = dv.h[o + 1];
+            t.src = dv.gauss[o * (D + 1) + D - 1];
+            t.dst = dv.gauss[(o + 1) * (D + 1)];
+            t.dog = nullptr;
+            t.lut_x = (int)P.lut_x_off[(size_t)o];
+            t.lut_y = (int)P.lut_y_off[(size_t)o];
+            bytes += px * 4.0 + (double)t.wd * (double)t.hd * (double)n * 4.0;
+        }
+    }
+    return tp.n_ops > 0;
+}
+
 // ---- pyramid (Sift::_createDOGs, sift.cpp:381-417) ---------------------------------------------
 void run_pyramid(sift_hip_ctx* c, const float* d_in) {
     Plan& P = c->plan;
@@ -540,6 +630,17 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
     const int n = P.n, O = P.O, D = P.D;
     const float* base = d_in;
     bool side_used = false;
+    // the pyramid's tail runs on a stream of its own (option "tail_async"; Plan::tail_from)
+    const bool want_kernel = c->tail_kernel == 2 || (c->tail_kernel == 1 && n >= kTailKernelImages);
+    const bool use_tail = (c->tail_async || want_kernel) && c->stream3 && c->fused && P.tail_from < O;
+    hipStream_t ms = c->stream;   // stream of the launches that are not the side stream's
+    bool in_tail = false;
+    struct TailMark {   // the tail's end, recorded however the loop ends
+        sift_hip_ctx* c; bool* in_tail;
+        ~TailMark() {
+            if (*in_tail) (void)hipEventRecord(c->ev_tail_done, c->stream3);
+        }
+    } tail_mark{c, &in_tail};
     struct SideJoin {   // whatever ran on the side stream is part of the pyramid: the main stream goes on after it
         sift_hip_ctx* c; bool* used;
         ~SideJoin() {
@@ -551,6 +652,28 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
     for (size_t k = 0; k < P.ops.size(); ++k) {
         if (k >= P.fail_op) break;
         const BlurOp& op = P.ops[k];
+        if (c->diag_skip_tail && (op.kind == 2 || op.kind == 3) && op.octave >= P.tail_from) continue;
+        if (use_tail && !in_tail && (op.kind == 2 || op.kind == 3) && op.octave >= P.tail_from) {
+            SIFT_HIP_CHECK(hipEventRecord(c->ev_tail_fork, c->stream));
+            SIFT_HIP_CHECK(hipStreamWaitEvent(c->stream3, c->ev_tail_fork, 0));
+            in_tail = true;
+            c->tail_pending = true;
+            ms = c->stream3;
+            // ... as ONE launch, a workgroup per image (option "tail_kernel"), where the plan and the batch allow it
+            if (want_kernel) {
+                std::vector<int> tops;
+                double bytes = 0;
+                if (make_tail_plan(c, k, P.tail, bytes, tops)) {
+                    hipEvent_t a = nullptr, b = nullptr;
+                    if (c->profile) { a = get_event(c); b = get_event(c); }
+                    launch_pyramid_tail(c->stream3, P.tail, n, c->d_taps.as<float>(), c->d_luts.as<int>(), a, b);
+                    if (c->profile) c->pending.push_back({a, b, 2, bytes});
+                    for (int o : tops) c->top_missing[(size_t)o] = 1;
+                    c->tail_in_kernel = true;
+                    break;   // every op from here on was the tail's
+                }
+            }
+        }
         switch (op.kind) {
             case 0: {  // increaseToNextLevel(img, 1.0): blur then 2x nearest upsample
                 run_blur(c, d_in, c->d_tmp2.as<float>(), nullptr, op.w, op.h, n, op.tap_off, op.radius);
@@ -568,7 +691,7 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
                 // The top level of an octave only feeds the octave's last DoG; the next octave starts from the level below it
                 // (sift.cpp:406-409).  Option "pyramid_side": it is formed on the side stream beside the reduction and the
                 // next octave's levels (fused kernels only: the two-pass fallback shares a scratch image with them).
-                const bool side = c->pyramid_side && c->ev_side_fork && op.j == D && op.octave + 1 < O && c->fused && op.radius >= 1 &&
+                const bool side = !in_tail && c->pyramid_side && c->ev_side_fork && op.j == D && op.octave + 1 < O && c->fused && op.radius >= 1 &&
                                   op.radius <= kMaxRadiusFused && std::find(P.grad_levels.begin(), P.grad_levels.end(), l) == P.grad_levels.end();
                 const bool skip = c->lazy_top && op.j == D && std::find(P.grad_levels.begin(), P.grad_levels.end(), l) == P.grad_levels.end();
                 float* g_out = skip ? nullptr : dv.gauss[l];
@@ -579,8 +702,8 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
                     run_blur(c, dv.gauss[l - 1], g_out, dv.dog[op.octave * D + op.j - 1], op.w, op.h, n, op.tap_off, op.radius, c->stream2);
                     side_used = true;
                 } else {
-                    run_blur(c, dv.gauss[l - 1], g_out, dv.dog[op.octave * D + op.j - 1], op.w, op.h, n, op.tap_off, op.radius);
-                    early_w16(c, l);
+                    run_blur(c, dv.gauss[l - 1], g_out, dv.dog[op.octave * D + op.j - 1], op.w, op.h, n, op.tap_off, op.radius, ms);
+                    if (!in_tail) early_w16(c, l);   // (no gradient level lies in the tail)
                 }
                 break;
             }
@@ -596,10 +719,10 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
                     // kept pixels only (kernels_reduce.hip) where the index maps and the shape allow it, else the streaming blur
                     // that stores the kept quarter of a full-resolution result
                     if (c->reduce_kept && P.red_sx[(size_t)o] >= 0 && P.red_sy[(size_t)o] >= 0)
-                        done = launch_blur_reduce_kept(c->stream, src, dst, op.w, op.h, dv.w[o + 1], dv.h[o + 1], n, c->d_taps.as<float>() + op.tap_off,
+                        done = launch_blur_reduce_kept(ms, src, dst, op.w, op.h, dv.w[o + 1], dv.h[o + 1], n, c->d_taps.as<float>() + op.tap_off,
                                                        op.radius, P.red_sx[(size_t)o], P.red_sy[(size_t)o], std::min(stream_min_waves_now(), 256), a, b);
                     if (!done)
-                        done = launch_blur_reduce(c->stream, src, dst, op.w, op.h, dv.w[o + 1], dv.h[o + 1], n,
+                        done = launch_blur_reduce(ms, src, dst, op.w, op.h, dv.w[o + 1], dv.h[o + 1], n,
                                               c->d_taps.as<float>() + op.tap_off, op.radius, c->d_luts.as<int>() + P.inv_x_off[(size_t)o],
                                               c->d_luts.as<int>() + P.inv_y_off[(size_t)o], c->d_tmp.as<float>(), a, b);
                     if (c->profile) {
@@ -613,8 +736,8 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
                     }
                 }
                 if (!done) {
-                    run_blur(c, src, c->d_tmp2.as<float>(), nullptr, op.w, op.h, n, op.tap_off, op.radius);
-                    launch_resample(c->stream, c->d_tmp2.as<float>(), dst, dv.w[o], dv.h[o], dv.w[o + 1],
+                    run_blur(c, src, c->d_tmp2.as<float>(), nullptr, op.w, op.h, n, op.tap_off, op.radius, ms);
+                    launch_resample(ms, c->d_tmp2.as<float>(), dst, dv.w[o], dv.h[o], dv.w[o + 1],
                                     dv.h[o + 1], n, c->d_luts.as<int>() + P.lut_x_off[(size_t)o], c->d_luts.as<int>() + P.lut_y_off[(size_t)o]);
                 }
                 break;
@@ -765,6 +888,7 @@ void ensure_outputs(sift_hip_ctx* c, long long keypoints) {
     if (keypoints <= c->out_cap) return;
     if (c->pack_pending) SIFT_HIP_CHECK(hipEventSynchronize(c->ev_pack));   // the arrays about to be freed are still being read
     c->out_cap = 0;   // until both arrays exist at the new size (an allocation that throws leaves them freed)
+    c->wire_counted = c->wire_scanned = false;   // counts of a stage that wrote the old arrays
     c->d_kp.ensure((size_t)keypoints * sizeof(sift_hip_keypoint));
     c->d_desc.ensure((size_t)keypoints * 128 * sizeof(float));
     c->out_cap = keypoints;
@@ -893,6 +1017,7 @@ bool mid_gpu(sift_hip_ctx* c) {
     for (int i = 0; i < n; ++i)
         if (st[(size_t)i * 4 + 1] || st[(size_t)n * 4 + (size_t)i]) {
             c->described = false;
+            c->wire_counted = c->wire_scanned = false;   // the speculative descriptor stage's counts are not this batch's
             return false;
         }
     for (int i = 0; i < n; ++i) {
@@ -1082,13 +1207,24 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     } gate_scope{c};
     c->gate_ticket = c->gate ? c->gate->begin_batch(s) : -1;
     c->top_missing.assign((size_t)P.O, 0);
+    if (c->tail_pending) {   // a batch that ended early left its tail behind: nothing of it may run beside this pyramid
+        SIFT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_tail_done, 0));
+        c->tail_pending = false;
+    }
+    c->tail_in_kernel = false;
     run_pyramid(c, d_in);
     SIFT_HIP_CHECK(hipGetLastError());   // a rejected launch configuration must not go unnoticed
     if (c->gate) {
         c->gate->mark(c->gate_ticket, sift_hip::PhaseGate::kP, s);
     }
     c->have_pyramid = true;
+    auto join_tail = [&]() {   // the main stream goes on behind the tail's last launch
+        if (!c->tail_pending) return;
+        SIFT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_tail_done, 0));
+        c->tail_pending = false;
+    };
     if (P.fail_status) {
+        join_tail();
         SIFT_HIP_CHECK(hipStreamSynchronize(s));
         resolve_events(c);
         for (int i = 0; i < n; ++i) { c->status[(size_t)i] = P.fail_status; c->messages[(size_t)i] = P.fail_msg; }
@@ -1115,11 +1251,19 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     // extrema + edge responses (sift.cpp:33-34)
     if (c->fused_edge && extrema_edge_supported(dv)) {
         // one pass over the DoG levels: extremum test and edge-response filter from LDS tiles
-        launch_extrema_edge(s, dv, c->d_masks.as<unsigned long long>(), c->d_fmasks.as<unsigned long long>(), c->d_counts.as<int>());
+        // (the scans of the tail's octaves wait for the tail; the others do not)
+        int k_split = dv.n_scan;
+        if (c->tail_pending)
+            for (int k = dv.n_scan - 1; k >= 0 && dv.scan_octave[k] >= P.tail_from; --k) k_split = k;
+        launch_extrema_edge(s, dv, c->d_masks.as<unsigned long long>(), c->d_fmasks.as<unsigned long long>(), c->d_counts.as<int>(), 0, k_split,
+                            c->tail_in_kernel ? n : 0);
+        join_tail();
+        launch_extrema_edge(s, dv, c->d_masks.as<unsigned long long>(), c->d_fmasks.as<unsigned long long>(), c->d_counts.as<int>(), k_split, dv.n_scan);
         launch_extrema_scan(s, dv, c->d_counts.as<int>(), c->d_totals.as<int>());
         launch_extrema_expand(s, dpl, dv, c->d_masks.as<unsigned long long>(), c->d_counts.as<int>(), c->d_cands.as<Candidate>(),
                               c->d_fmasks.as<unsigned long long>(), c->d_flags.as<uint8_t>());
     } else {
+        join_tail();
         launch_extrema_mask(s, dpl, dv, c->d_masks.as<unsigned long long>(), c->d_counts.as<int>());
         launch_extrema_scan(s, dv, c->d_counts.as<int>(), c->d_totals.as<int>());
         launch_extrema_expand(s, dpl, dv, c->d_masks.as<unsigned long long>(), c->d_counts.as<int>(), c->d_cands.as<Candidate>());
@@ -1228,6 +1372,9 @@ int sift_hip_create(int device, sift_hip_ctx** out, char* err, int errlen) {
         c->device = device;
         SIFT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         SIFT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        SIFT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+        SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_tail_fork, hipEventDisableTiming));
+        SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_tail_done, hipEventDisableTiming));
         SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork0, hipEventDisableTiming));
         SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -1242,7 +1389,7 @@ int sift_hip_create(int device, sift_hip_ctx** out, char* err, int errlen) {
             static bool touched[64] = {false};
             std::lock_guard<std::mutex> lk(touch_lock);
             if (device < 64 && !touched[device]) {
-                tu_touch_pyramid(c->stream); tu_touch_reduce(c->stream); tu_touch_extrema(c->stream); tu_touch_orient(c->stream);
+                tu_touch_pyramid(c->stream); tu_touch_tail(c->stream); tu_touch_reduce(c->stream); tu_touch_extrema(c->stream); tu_touch_orient(c->stream);
                 tu_touch_desc(c->stream); tu_touch_cleanup(c->stream); tu_touch_wire(c->stream); tu_touch_io(c->stream);
                 SIFT_HIP_CHECK(hipGetLastError());
                 SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -1276,6 +1423,9 @@ void sift_hip_destroy(sift_hip_ctx* c) {
     if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
     if (c->ev_side_fork) (void)hipEventDestroy(c->ev_side_fork);
     if (c->ev_side_join) (void)hipEventDestroy(c->ev_side_join);
+    if (c->ev_tail_fork) (void)hipEventDestroy(c->ev_tail_fork);
+    if (c->ev_tail_done) (void)hipEventDestroy(c->ev_tail_done);
+    if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
     (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1354,6 +1504,12 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
         return SIFT_HIP_OK;
     }
     if (!std::strcmp(name, "lazy_top")) { c->lazy_top = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "tail_async")) { c->tail_async = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "tail_kernel")) {
+        if (value < 0 || value > 2) return SIFT_HIP_EINVAL;
+        c->tail_kernel = value;
+        return SIFT_HIP_OK;
+    }
     if (!std::strcmp(name, "wire_count")) { c->wire_count = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "pyramid_side")) {
         ApiGuard api;
@@ -1387,6 +1543,7 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     if (!std::strcmp(name, "diag_pyramid_span")) { c->diag_pyramid_span = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "diag_serial_gradient")) { c->diag_serial_gradient = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "diag_cleanup_stamps")) { c->diag_cleanup_stamps = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "diag_skip_tail")) { c->diag_skip_tail = value != 0; return SIFT_HIP_OK; }
 #endif
     return SIFT_HIP_EINVAL;
 }
@@ -1398,18 +1555,18 @@ namespace {
 // function object at its first launch, a stream's copy machinery at its first transfer - and it is while several host threads
 // go through those first uses side by side that the launches crash inside the runtime (SEGV below hipLaunchKernel: a launch
 // that finds a null object; common.h, tools/example_loop.sh).  Every launch and every runtime copy of this library is under the
-// device's launch lock anyway, which serialises the CALLS but not what they start; a whole first batch under one process-wide
-// lock serialises that too, and costs nothing once every context has run once.
-std::mutex& first_batch_mutex() {
-    static std::mutex m;
-    return m;
+// device's launch lock anyway, which serialises the CALLS but not what they start; a whole first batch under one lock per
+// DEVICE serialises that too (the first uses that collide are per device), and costs nothing once every context has run once.
+std::mutex& first_batch_mutex(int device) {   // one per device: a first batch that waits device-wide - growing a buffer while this
+    static std::mutex m[64];                  // shard's RCCL send is unmatched - must not hold up the other devices' shards, whose reports post the receive
+    return m[(unsigned)device % 64u];
 }
 constexpr int kWarmCalls = 2;     // the second batch still meets first uses (e.g. buffers that only now grow, the gather's first copies)
 struct FirstBatch {
     int* n;
     std::unique_lock<std::mutex> lk;
-    explicit FirstBatch(int* counter) : n(counter) {
-        if (*n < kWarmCalls) lk = std::unique_lock<std::mutex>(first_batch_mutex());
+    FirstBatch(int* counter, int device) : n(counter) {
+        if (*n < kWarmCalls) lk = std::unique_lock<std::mutex>(first_batch_mutex(device));
     }
     ~FirstBatch() { if (*n < kWarmCalls) ++*n; }
 };
@@ -1420,7 +1577,7 @@ extern "C" {
 int sift_hip_calculate_batch_device(sift_hip_ctx* c, const void* dev_imgs, int n, int w, int h,
                                     const sift_hip_params* params, char* err, int errlen) {
     if (!c || !dev_imgs || !params) return SIFT_HIP_EINVAL;
-    FirstBatch first_batch(&c->warm_calls);
+    FirstBatch first_batch(&c->warm_calls, c->device);
     return guarded(err, errlen, [&]() {
         SIFT_HIP_CHECK(hipSetDevice(c->device));
         c->have_result = c->have_pyramid = false;   // whatever happens next, the previous batch's results are gone
@@ -1440,7 +1597,7 @@ int sift_hip_calculate_batch_device(sift_hip_ctx* c, const void* dev_imgs, int n
 int sift_hip_calculate_batch(sift_hip_ctx* c, const float* host_imgs, int n, int w, int h,
                              const sift_hip_params* params, char* err, int errlen) {
     if (!c || !host_imgs || !params || n <= 0 || w <= 0 || h <= 0) return SIFT_HIP_EINVAL;
-    FirstBatch first_batch(&c->warm_calls);
+    FirstBatch first_batch(&c->warm_calls, c->device);
     return guarded(err, errlen, [&]() {
         SIFT_HIP_CHECK(hipSetDevice(c->device));
         c->have_result = c->have_pyramid = false;   // whatever happens next, the previous batch's results are gone
@@ -1459,7 +1616,7 @@ int sift_hip_calculate_batch(sift_hip_ctx* c, const float* host_imgs, int n, int
 int sift_hip_calculate_batch_u8(sift_hip_ctx* c, const uint8_t* host_imgs, int n, int w, int h,
                                 const sift_hip_params* params, char* err, int errlen) {
     if (!c || !host_imgs || !params || n <= 0 || w <= 0 || h <= 0) return SIFT_HIP_EINVAL;
-    FirstBatch first_batch(&c->warm_calls);
+    FirstBatch first_batch(&c->warm_calls, c->device);
     return guarded(err, errlen, [&]() {
         SIFT_HIP_CHECK(hipSetDevice(c->device));
         c->have_result = c->have_pyramid = false;
@@ -1479,7 +1636,7 @@ int sift_hip_calculate_batch_u8(sift_hip_ctx* c, const uint8_t* host_imgs, int n
 int sift_hip_calculate_batch_device_u8(sift_hip_ctx* c, const void* dev_imgs, int n, int w, int h,
                                        const sift_hip_params* params, char* err, int errlen) {
     if (!c || !dev_imgs || !params || n <= 0 || w <= 0 || h <= 0) return SIFT_HIP_EINVAL;
-    FirstBatch first_batch(&c->warm_calls);
+    FirstBatch first_batch(&c->warm_calls, c->device);
     return guarded(err, errlen, [&]() {
         SIFT_HIP_CHECK(hipSetDevice(c->device));
         c->have_result = c->have_pyramid = false;
@@ -1496,7 +1653,7 @@ int sift_hip_calculate_batch_device_u8(sift_hip_ctx* c, const void* dev_imgs, in
 
 void* sift_hip_host_alloc(size_t bytes) {
     void* p = nullptr;
-    ApiGuard api;
+    LaunchGuard api(current_device_refreshed());   // no context here: the lock of the device the HOST put this thread on
     if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
@@ -1504,7 +1661,7 @@ void* sift_hip_host_alloc(size_t bytes) {
     return p;
 }
 void sift_hip_host_free(void* p) {
-    ApiGuard api;
+    LaunchGuard api(current_device_refreshed());
     if (p) (void)hipHostFree(p);
 }
 
@@ -1523,7 +1680,7 @@ int64_t sift_hip_result_total(sift_hip_ctx* c) { return (c && c->have_result) ? 
 
 int sift_hip_result_copy(sift_hip_ctx* c, sift_hip_keypoint* kp, float* desc) {
     if (!c || !c->have_result) return SIFT_HIP_EINVAL;
-    FirstBatch first_copy(&c->warm_copies);
+    FirstBatch first_copy(&c->warm_copies, c->device);
     return guarded(nullptr, 0, [&]() {
         SIFT_HIP_CHECK(hipSetDevice(c->device));
         if (c->total > 0) {
@@ -1543,7 +1700,14 @@ int sift_hip_result_device(sift_hip_ctx* c, const void** kp, const void** desc) 
 int sift_hip_result_sparse_size(sift_hip_ctx* c, int64_t* n_values, int* lossless) {
     if (!c || !c->have_result || !n_values) return SIFT_HIP_EINVAL;
     char err[256];
-    if (c->wire_scanned && c->total <= c->out_cap) {   // counted and scanned by the batch itself (option wire_count): the host already has the answer
+    if (c->total == 0) {   // nothing to send
+        c->wire_values = 0;
+        c->wire_for_total = 0;
+        *n_values = 0;
+        if (lossless) *lossless = 1;
+        return SIFT_HIP_OK;
+    }
+    if (c->wire_scanned && c->described && c->total <= c->out_cap) {   // counted and scanned by the batch itself (option wire_count): the host already has the answer
         c->wire_values = *c->h_wire.as<long long>();
         if (lossless) *lossless = *reinterpret_cast<const int*>(c->h_wire.as<long long>() + 1) ? 0 : 1;
         c->wire_for_total = c->total;
@@ -1618,7 +1782,7 @@ int sift_hip_result_pack_wait(sift_hip_ctx* c) {
 // (~200 instead of 532 bytes per keypoint).  After sift_hip_result_sparse_size; records: total * 34 bytes, values: n_values floats.
 int sift_hip_result_copy_sparse(sift_hip_ctx* c, void* records, float* values) {
     if (!c || !c->have_result || c->wire_for_total != c->total || c->wire_values < 0) return SIFT_HIP_EINVAL;
-    FirstBatch first_copy(&c->warm_copies);
+    FirstBatch first_copy(&c->warm_copies, c->device);
     if (c->total > 0 && (!records || (c->wire_values > 0 && !values))) return SIFT_HIP_EINVAL;
     if (c->total == 0) return SIFT_HIP_OK;
     char err[256];
@@ -2145,7 +2309,7 @@ int sift_hip_cleanup_survivors(sift_hip_ctx* c, const uint8_t* flags, int n, int
 }
 
 int sift_hip_profile_get(sift_hip_ctx* c, int which, double* ms, int64_t* launches, double* bytes) {
-    if (!c || which < 0 || which > 1) return SIFT_HIP_EINVAL;
+    if (!c || which < 0 || which > 2) return SIFT_HIP_EINVAL;
     if (ms) *ms = c->prof_ms[which];
     if (launches) *launches = c->prof_launches[which];
     if (bytes) *bytes = c->prof_bytes[which];
@@ -2153,13 +2317,13 @@ int sift_hip_profile_get(sift_hip_ctx* c, int which, double* ms, int64_t* launch
 }
 
 int sift_hip_profile_get_busy(sift_hip_ctx* c, int which, double* busy_ms) {
-    if (!c || which < 0 || which > 1 || !busy_ms) return SIFT_HIP_EINVAL;
+    if (!c || which < 0 || which > 2 || !busy_ms) return SIFT_HIP_EINVAL;
     *busy_ms = c->prof_busy_ms[which];
     return SIFT_HIP_OK;
 }
 int sift_hip_profile_reset(sift_hip_ctx* c) {
     if (!c) return SIFT_HIP_EINVAL;
-    for (int i = 0; i < 2; ++i) { c->prof_ms[i] = 0; c->prof_launches[i] = 0; c->prof_bytes[i] = 0; c->prof_busy_ms[i] = 0; }
+    for (int i = 0; i < 3; ++i) { c->prof_ms[i] = 0; c->prof_launches[i] = 0; c->prof_bytes[i] = 0; c->prof_busy_ms[i] = 0; }
     return SIFT_HIP_OK;
 }
 

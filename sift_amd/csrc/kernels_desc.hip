@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
 }
 
 // =====================================================================================================
-// Tile-per-wave form (round 4, the default).  The wave-per-keypoint kernel above recomputes, for every keypoint, the float
+// Tile-per-wave form (round 4; option desc_kernel = 2, NOT the default: context.cpp).  The wave-per-keypoint kernel above recomputes, for every keypoint, the float
 // chains of its 256 window pixels from the initial maps: a keypoint's additions are applied once for itself and once more
 // for each of the ~8.5 later keypoints whose window overlaps its own, and three quarters of those lane-pixel updates fall
 // outside the neighbour's window.  Here ONE WAVE owns a core of 32 x CH pixels of keypoint locations ("home" keypoints)

@@ -582,14 +582,21 @@ bool extrema_edge_supported(const DevPlan& plan) {
 }
 
 void launch_extrema_edge(hipStream_t s, const DevPlan& plan, unsigned long long* d_masks, unsigned long long* d_fmasks,
-                         int* d_counts) {
-    for (int k = 0; k < plan.n_scan; ++k) {
+                         int* d_counts, int k_begin, int k_end, int busy_cus) {
+    if (k_end < 0 || k_end > plan.n_scan) k_end = plan.n_scan;
+    // persistent workgroups, 4 per CU, with EQUAL shares of the tiles: a workgroup that finds no CU free starts when the
+    // others end and doubles the launch's time - so the grid leaves out the CUs another kernel is known to hold (the
+    // pyramid's tail kernel: one workgroup per image, a whole CU each)
+    const int cus = resident_cus();
+    int cap = 4 * (cus > busy_cus + 8 ? cus - busy_cus : cus);
+    cap &= ~7;
+    for (int k = k_begin; k < k_end; ++k) {
         const int o = plan.scan_octave[k], i = plan.scan_dog[k];
         const int w = plan.w[o], h = plan.h[o];
         const int l = o * plan.dogs + i;
         const int tiles_x = (w + kFxCols - 1) / kFxCols;
         const long long total = (long long)tiles_x * plan.scan_nyb[k] * plan.n_images;
-        int grid = total < 1024 ? (int)total : 1024;   // persistent workgroups: 4 per CU
+        int grid = total < cap ? (int)total : cap;
         if (grid >= 8) grid &= ~7;
         hipLaunchKernelGGL(extrema_edge_kernel, dim3((unsigned)grid), dim3(256), 0, s, (const float*)plan.dog[l - 1],
                            (const float*)plan.dog[l], (const float*)plan.dog[l + 1], w, h, plan.scan_nyb[k],

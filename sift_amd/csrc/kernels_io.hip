@@ -7,6 +7,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -27,6 +28,12 @@ int set_device_tracked(int device) {
     return (int)e;
 }
 int tracked_device() { return t_device; }
+int current_device_refreshed() {
+    int d = t_device;
+    if (hipGetDevice(&d) == hipSuccess) t_device = d;
+    else (void)hipGetLastError();
+    return t_device;
+}
 std::recursive_mutex& launch_lock() { return launch_lock_of(t_device); }
 static std::atomic<long long> g_lock_wait_ns{0};
 double launch_lock_wait_ms() { return (double)g_lock_wait_ns.load(std::memory_order_relaxed) / 1e6; }
@@ -37,6 +44,32 @@ static void lock_accounted(std::recursive_mutex& m) {
     g_lock_wait_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
 }
 LaunchGuard::LaunchGuard() : m(launch_lock()) { lock_accounted(m); }
+
+// ---- function objects of the library's kernels, per device (launch_cache.h) ------------------------------------------------
+static std::unordered_map<const void*, hipFunction_t> g_functions[kMaxLockDevices];   // each under its device's launch lock
+hipFunction_t cached_function(const void* host_stub) {
+    auto& table = g_functions[(unsigned)t_device % (unsigned)kMaxLockDevices];
+    const auto it = table.find(host_stub);
+    if (it != table.end()) return it->second;
+    hipFunction_t f = nullptr;
+    if (hipGetFuncBySymbol(&f, host_stub) != hipSuccess || !f) {
+        (void)(hipGetLastError)();
+        return nullptr;
+    }
+    table.emplace(host_stub, f);
+    return f;
+}
+static thread_local hipError_t t_launch_error = hipSuccess;
+void note_launch_error(hipError_t e) { if (t_launch_error == hipSuccess) t_launch_error = e; }
+hipError_t take_launch_error() {
+    const hipError_t e = t_launch_error;
+    t_launch_error = hipSuccess;
+    return e;
+}
+hipError_t combined_last_error() {
+    const hipError_t mine = take_launch_error(), runtime = (hipGetLastError)();
+    return mine != hipSuccess ? mine : runtime;
+}
 LaunchGuard::LaunchGuard(int device) : m(launch_lock_of(device)) { lock_accounted(m); }
 
 constexpr int kIoWorkgroups = 16;

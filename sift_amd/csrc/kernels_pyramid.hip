@@ -510,6 +510,10 @@ constexpr long long kSmallTileLaunch = 4096;   // 64x64 tiles: up to 16 per CU
 // the launch: a runtime call that creates the kernel's function object beside other threads' launches.  The launch path makes
 // no such call any more; the CU count is read once per device when the first context is created, sift_hip_create.)
 static int g_cus[64] = {0};
+int resident_cus() {
+    const int cus = g_cus[(unsigned)tracked_device() % 64u];
+    return cus > 0 ? cus : 256;
+}
 template <int R, int TH>
 static int resident_workgroups() {
     constexpr int per_cu = (R <= 8 ? 3 : ((R <= 24 || (TH <= 48 && R <= 28)) ? 2 : 1));   // blur_fused_kernel's __launch_bounds__

@@ -24,6 +24,9 @@ namespace sift_hip {
 // did is on device 0, the runtime's default).
 int set_device_tracked(int device);           // hipSetDevice + the thread-local; returns the hipError_t as an int
 int tracked_device();
+// ... and as the RUNTIME reports it (one hipGetDevice; refreshes the thread-local): for entry points that take no context and
+// may be called by a thread whose device the host set itself - torch.cuda.set_device, a gather thread
+int current_device_refreshed();
 
 std::recursive_mutex& launch_lock_of(int device);
 std::recursive_mutex& launch_lock();          // of the calling thread's tracked device

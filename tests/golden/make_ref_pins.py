@@ -2,7 +2,7 @@
 """Pins for the CPU oracle, produced by the reference's OWN prebuilt binary.
 
     python tests/golden/make_ref_pins.py                                   (in the build container, where /root/reference is mounted)
-    python tests/golden/make_ref_pins.py bench_frame | config2 | truncation | configs   (the long-running pins, one fixture each)
+    python tests/golden/make_ref_pins.py bench_frame | config2 | truncation | configs | config5   (the long-running pins, one fixture each)
 
 /root/reference/bin/arch_x64/sift cannot be started here (Vigra, OpenCV, Boost are DT_NEEDED and absent) and the
 sources cannot be rebuilt for the same reason, but `Sift::calculate` and the `sift::alg` functions inside it only need
@@ -189,7 +189,8 @@ def long_running(which):
         config2       BASELINE.json configs[1] exactly as written: 640x480 seed 1, 4 octaves x 3 DoGs   (about a minute)
         truncation    blob_frame 1024x1088 seed 5: 66260 survivors of the first cleanup, `u16_t size` keeps 724 (App. B-7); the
                       reference copies three DoG images per candidate (2.7 TB of copies for the 220 716 candidates)
-        configs       BASELINE.json configs[2] exactly as written (throws after 14 s; configs[4] as written would run for days)"""
+        configs       BASELINE.json configs[2] exactly as written (throws after 14 s; configs[4] as written would run for days)
+        config5       configs[4]'s failure mode (the dead 16x16 blur of an octave-5 keypoint) on a 1792x1792 frame, 6 octaves x 3 DoGs"""
     import time
     assert os.path.exists(REF_BIN), "the reference is not mounted here"
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_ref/refexec"])
@@ -230,9 +231,15 @@ def long_running(which):
                 store["points"] = np.fromfile(out + ".points", np.uint8).view(POINT_DTYPE).reshape(-1)
                 store["desc"] = np.fromfile(out + ".desc", np.float32)
             np.savez_compressed(os.path.join(HERE, "refpin_u16_truncation.npz"), **store)
-        elif which == "configs":
-            store = {}
-            for name, (w, h, seed, dogs, octaves, sub) in {"config3_as_written": (1920, 1080, 3, 5, 4, 1)}.items():
+        elif which in ("configs", "config5"):
+            # configs[4] as written (4K, subpixel, 6 octaves) would keep the reference busy for days before it reaches its throw -
+            # the dead 16x16 blur of an octave-5 keypoint (sift.cpp:184, App. B-14).  The SAME failure mode on a frame the binary
+            # can finish: 1792x1792 (octave 5 is 56x56: larger than the pyramid's largest radius, 54), 6 octaves x 3 DoGs, no
+            # subpixel - kept in the same fixture, beside config 3
+            cases = {"config3_as_written": (1920, 1080, 3, 5, 4, 1)} if which == "configs" else {"config5_octave5_1792": (1792, 1792, 5, 3, 6, 0)}
+            dst = os.path.join(HERE, "refpin_configs_as_written.npz")
+            store = dict(np.load(dst)) if os.path.exists(dst) else {}
+            for name, (w, h, seed, dogs, octaves, sub) in cases.items():
                 img = synth_frame(w, h, seed)
                 src, out = os.path.join(tmp, "in.f32"), os.path.join(tmp, "out")
                 img.tofile(src)
@@ -243,9 +250,9 @@ def long_running(which):
                 store[name + "/rc"] = np.array(rc)
                 store[name + "/stdout"] = np.array(so)
                 store[name + "/seconds"] = np.array(time.time() - t0)
-            np.savez_compressed(os.path.join(HERE, "refpin_configs_as_written.npz"), **store)
+            np.savez_compressed(dst, **store)
         else:
-            raise SystemExit("bench_frame | config2 | truncation | configs")
+            raise SystemExit("bench_frame | config2 | truncation | configs | config5")
 
 
 if __name__ == "__main__":

@@ -329,6 +329,39 @@ def test_pipeline_parity_kept_pixels_reduce(ctx, report_dir, case):
         ctx.set_option("stream_min_waves", 0)
 
 
+TAIL_CASES = [
+    # name, w, h, seed, dogs, octaves, subpixel, frames
+    ("tail kernel 640x480 4x3 (config 2: radii up to 27, three reductions inside)", 640, 480, 1, 3, 4, False, 1),
+    ("tail kernel 333x257 odd sizes (no 16-byte rows, maps without a parity split)", 333, 257, 9, 3, 3, False, 2),
+    ("tail kernel 322x250 widths 2 mod 4", 322, 250, 12, 3, 3, False, 1),
+    ("tail kernel 320x240 subpixel", 320, 240, 5, 3, 3, True, 1),
+    ("tail kernel 400x300 4 dogs", 400, 300, 6, 4, 2, False, 3),
+    ("tail kernel 1024x768 4x3", 1024, 768, 13, 3, 4, False, 2),
+    ("tail kernel 200x1000 tall (many bands)", 200, 1000, 17, 3, 3, False, 1),
+    ("tail kernel 1400x120 wide (short levels: the whole level is one band)", 1400, 120, 18, 3, 3, False, 2),
+]
+
+
+@pytest.mark.parametrize("case", TAIL_CASES, ids=[c[0] for c in TAIL_CASES])
+def test_pipeline_parity_tail_kernel(ctx, report_dir, case):
+    """The pyramid's small octaves as ONE launch of one workgroup per image (kernels_tail.hip; option tail_kernel = 2 forces it
+    for any batch size; built and measured in round 5, off by default): every Gaussian and DoG level, every stage list and the
+    descriptors against the oracle; then the same tail as a launch per level on a stream of its own (tail_async = 1).  The
+    default - the tail in line on the main stream - is what every other test runs."""
+    name, w, h, seed, dogs, octaves, subpixel, frames = case
+    img = synth_frame(w, h, seed)
+    try:
+        ctx.set_option("tail_kernel", 2)
+        rep = compare_run(ctx, img, dogs, octaves, subpixel, name, report_dir, batch_of=frames)
+        assert rep["final"] > 0
+        ctx.set_option("tail_kernel", 0)
+        ctx.set_option("tail_async", 1)
+        compare_run(ctx, img, dogs, octaves, subpixel, name + " [tail_async = 1, a launch per level]", report_dir, batch_of=frames)
+    finally:
+        ctx.set_option("tail_kernel", 0)
+        ctx.set_option("tail_async", 0)
+
+
 def test_top_gaussian_level_formed_on_demand(ctx):
     """Option lazy_top (default on): the launch that forms an octave's top Gaussian level stores its DoG only - nothing on the
     path reads the level again (sift.cpp:406-409) - and sift_hip_level_copy forms the level when asked.  Same keypoints and
