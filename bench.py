@@ -205,6 +205,27 @@ def launch_ranks(n):
     return status
 
 
+def whole_step_fraction(nf, W, H, keypoints, seconds):
+    """All stages' algorithmic bytes of one step (4 octaves x 3 DoGs) over the step's time, against the 8 TB/s peak, with SURVEY.md
+    section 8(d)'s per-unit figures: pyramid 4 B read + 4 B per level written per pixel (with lazy_top: g(o,1..2) and three DoGs
+    per octave; a reduction reads its source and writes a quarter), gradient maps 12 B per pixel of level (0,0), extremum scan
+    12 B per pixel of every octave's middle DoG, descriptor stages 3.5 KB per keypoint."""
+    px = [W * H] + [((W + (1 << o) - 1) >> o) * ((H + (1 << o) - 1) >> o) for o in range(1, 4)]
+    pyramid = 0.0
+    for o in range(4):
+        pyramid += px[o] * (8 if o == 0 else 0)          # g(0,0) from the input
+        pyramid += px[o] * (12 + 12 + 8)                 # g(o,1) + dog, g(o,2) + dog, dog(o,2) alone (top level not kept)
+        if o < 3:
+            pyramid += px[o] * 4 + px[o + 1] * 4         # reduceToNextLevel: source read, kept pixels written
+    gradient = px[0] * 12
+    extrema = sum(px) * 12
+    descriptors = keypoints / nf * 3584
+    total = nf * (pyramid + gradient + extrema + descriptors)
+    return {"algorithmic_gbytes_per_step": total / 1e9, "achieved": total / 1e9 / seconds, "frac": total / 1e9 / seconds / HBM_PEAK_GBS,
+            "what": "algorithmic bytes of ALL stages of a step (pyramid, gradient maps, extremum scan, 3.5 KB per keypoint for the descriptor stages: "
+                    "SURVEY.md section 8(d)) over ms_per_step, against the same 8 TB/s"}
+
+
 def dropin_cpp_leg(frame, iterations=50):
     """The reference's ACTUAL boundary, timed outside the timed region: examples/sift_dropin_bench.cpp calls
     sift::Sift::calculate(Image2f&) (include/sift/sift.hpp: float host image in, std::vector<InterestPoint> with a heap
@@ -273,10 +294,12 @@ def main():
                     help="N = 1 only: every step's keypoint lists also travel through RCCL point-to-point to this same rank "
                          "(KeypointGather(loopback=True)): the N > 1 gather path, messages and sizes, on a one-GPU box")
     ap.add_argument("--repeats", type=int, default=5, help="repetitions of the K-step loop reported as ms_per_step_repeats (the headline is the first)")
-    ap.add_argument("--check-gather", action="store_true",
-                    help="N > 1, after the timed region: rank 0 runs every rank's frames itself, rank by rank, and compares the lists that "
-                         "arrived through the gather in the last step with its own - records, descriptor floats and per-image counts in "
-                         "global image order (seeds 1 .. N x frames); the line then carries gather_check")
+    ap.add_argument("--check-gather", action="store_true", default=True,
+                    help="N > 1, after the timed region (the default since round 5: a multi-GPU line carries its own evidence): rank 0 runs every "
+                         "rank's frames itself, rank by rank, and compares the lists that arrived through the gather in the last step with its "
+                         "own - records, descriptor floats and per-image counts in global image order (seeds 1 .. N x frames); the line then "
+                         "carries gather_check")
+    ap.add_argument("--no-check-gather", dest="check_gather", action="store_false", help="skip that check (it costs N batches on rank 0 after the timed region)")
     ap.add_argument("--pipeline-gate", type=int, default=1, choices=[0, 1],
                     help="pipeline depth > 1: 1 (default) joins the contexts with a phase gate (sift_amd/csrc/phase_gate.h); 0 leaves the interleaving to the GPU's queues")
     args = ap.parse_args()
@@ -561,6 +584,16 @@ def main():
                          "achieved_over_sum_of_durations": achieved_sum, "frac_over_sum_of_durations": achieved_sum / HBM_PEAK_GBS,
                          "sum_of_durations_ms_per_launch": ms / launches if launches else None},
         }
+        # The tail kernel (option tail_kernel, off by default) is a launch of its own class: arithmetic-bound on one CU per image
+        # by design, it is reported beside the bandwidth-bound launches, never mixed into their fraction
+        tail_prof = [c.profile(2) for c in ctxs]
+        if sum(p[1] for p in tail_prof) > 0:
+            t_ms, t_n, t_b = (sum(p[i] for p in tail_prof) for i in range(3))
+            out["roofline"]["tail_kernel"] = {"launches": t_n, "avg_launch_ms": t_ms / t_n, "algorithmic_bytes_per_launch": t_b / t_n,
+                                              "what": "pyramid_tail_kernel: octaves 2 - 3 of the batch, one workgroup per image (VALU-bound; not part of frac)"}
+        # the whole step against the same peak: every stage's algorithmic bytes over the step's time
+        if args.workload == "config4" and not SUBPIXEL:
+            out["roofline"]["whole_step"] = whole_step_fraction(nf, W, H, kps / max(args.steps, 1) / max(world, 1), dt / args.steps)
         if args.check_gather and gatherer is not None and not loopback:
             # ---- what arrived through the gather against this rank's own run of EVERY rank's frames (outside the timed region)
             recs_parts, vals_parts, counts_all = last_gathered[0]     # one tensor per rank (KeypointGather(concat=False)), rank order

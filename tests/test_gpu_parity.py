@@ -1622,10 +1622,11 @@ def test_hip_u16_truncation_matches_the_reference_binary(ctx):
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refpin_configs_as_written.npz")),
                     reason="fixture not generated")
-@pytest.mark.parametrize("name", ["config3_as_written", "config5_as_written"])
+@pytest.mark.parametrize("name", ["config3_as_written", "config5_octave5_1792"])
 def test_hip_baseline_configs_as_written_end_like_in_the_reference_binary(ctx, name):
-    """BASELINE.json configs[2] and configs[4] exactly as written throw in the reference binary; so does the HIP path, with
-    the same text."""
+    """BASELINE.json configs[2] exactly as written, and configs[4]'s failure mode (the dead 16x16 blur of an octave-5 keypoint) on
+    the 1792x1792 six-octave frame the reference binary was run on (tests/golden/make_ref_pins.py config5): the binary throws;
+    so does the HIP path, with the same text."""
     import re
     pin = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refpin_configs_as_written.npz"))
     if name + "/rc" not in pin.files:

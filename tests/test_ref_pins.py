@@ -221,10 +221,12 @@ CFG_PIN = os.path.join(HERE, "golden", "refpin_configs_as_written.npz")
 
 
 @pytest.mark.skipif(not os.path.exists(CFG_PIN), reason="fixture not generated")
-@pytest.mark.parametrize("name", ["config3_as_written", "config5_as_written"])
+@pytest.mark.parametrize("name", ["config3_as_written", "config5_octave5_1792"])
 def test_baseline_configs_as_written_end_like_in_the_reference_binary(name):
-    """BASELINE.json configs[2] (1080p, subpixel, 4 octaves x 5 DoGs) and configs[4] (4K, subpixel, 6 octaves) as written:
-    what the reference binary does with them (App. B-13 / B-14) is what the oracle does."""
+    """BASELINE.json configs[2] (1080p, subpixel, 4 octaves x 5 DoGs) exactly as written, and configs[4]'s failure mode - the
+    dead 16x16 blur of an octave-5 keypoint, sift.cpp:184, App. B-14 - on a frame the reference binary can finish (1792x1792,
+    6 octaves x 3 DoGs, no subpixel: 68 minutes; the 4K frame as written would keep it busy for days): what the binary does
+    with them is what the oracle does."""
     pin = np.load(CFG_PIN)
     if name + "/rc" not in pin.files:
         pytest.skip("case not in the fixture")
