@@ -16,6 +16,12 @@
 // for the call only, a batch makes ~60 such calls of a few microseconds); no spin-wait; no null stream; 4 / 24 hardware queues -
 // none of it changed the rate.  Replacing the runtime's device-to-device copies by kernels of this library (group.cpp) did:
 // 1 crash in 200 runs, and none in 150 runs of examples/sift_pipeline.cpp, which never used such copies.
+// Round 5, what ended it: the crashing instruction sits behind hipLaunchKernel's lookup of the kernel's HOST STUB in the runtime's
+// table of registered functions, made on every launch; the library now makes that lookup once per (device, kernel) under the
+// device's lock - hipGetFuncBySymbol - and launches the function object it got (hipExtModuleLaunchKernel: launch_cache.h).  Same
+// box, blocks of 100 runs of examples/sift_multi_gpu.cpp alternately: 0 crashes in 300 against 13 in 300 for a build that differs
+// only in -DSIFT_HIP_STATIC_LAUNCH (tools/launch_ab.sh, profiles/r05_launch_ab_soak.txt).  The locks below stay: they order the
+// runtime's own calls per device and cost ~60 uncontended acquisitions per batch.
 #include "launch_guard.h"   // one lock per device since round 4, waiting time accounted
 namespace sift_hip {
 // ... and so are the calls that create or destroy what a launch touches (device and pinned memory, streams, events): the
@@ -191,6 +197,7 @@ bool extrema_edge_supported(const DevPlan& plan);
 // scan levels [k_begin, k_end) of the plan (k_end < 0: all the rest)
 void launch_extrema_edge(hipStream_t s, const DevPlan& plan, unsigned long long* d_masks, unsigned long long* d_fmasks,
                          int* d_counts, int k_begin = 0, int k_end = -1, int busy_cus = 0);
+void set_extrema_per_cu(int v);
 int resident_cus();   // CUs of the calling thread's device (kernels_pyramid.hip; 256 until sift_hip_create has asked)
 void launch_extrema_expand(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan,
                            const unsigned long long* d_masks, const int* d_offsets, Candidate* d_cands,
