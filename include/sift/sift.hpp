@@ -8,8 +8,11 @@
 #define SIFT_AMD_SIFT_HPP
 #include <cassert>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
 #include <exception>
+#include <functional>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -41,10 +44,16 @@ public:
         char err[512] = "";
         if (sift_hip_create(device, &_ctx, err, sizeof(err)) != SIFT_HIP_OK)
             throw std::runtime_error(std::string("sift_hip_create: ") + err);
+        // the lists come down in the sparse format (collect): let the descriptor kernel count its floats while they are in
+        // registers, so that the size is known when the batch ends (no counting pass, no second wait)
+        (void)sift_hip_set_option(_ctx, "wire_count", 1);
     }
     Sift(const Sift&) = delete;
     Sift& operator=(const Sift&) = delete;
-    ~Sift() { sift_hip_destroy(_ctx); }
+    ~Sift() {
+        stop_workers();
+        sift_hip_destroy(_ctx);
+    }
 
     std::vector<InterestPoint> calculate(Image2f& img) {
         const int w = (int)img.width(), h = (int)img.height();
@@ -188,15 +197,16 @@ private:
                     v += (size_t)mask_popcount(_rec.data() + i * 34 + 20);
                 }
             }
-            std::vector<std::thread> pool;
+            // the object's worker threads (started at the first large result, parked on a condition variable between calls:
+            // starting threads per call costs as much as a worker's share of the expansion)
             std::vector<std::exception_ptr> failed(threads);
-            for (size_t t = 1; t < threads; ++t)
-                pool.emplace_back([&, t] {
-                    const size_t i0 = t * per < (size_t)n ? t * per : (size_t)n, i1 = i0 + per < (size_t)n ? i0 + per : (size_t)n;
-                    try { if (i0 < i1) expand_range(out, i0, i1, _val.data() + first[t]); } catch (...) { failed[t] = std::current_exception(); }
-                });
-            try { expand_range(out, 0, per < (size_t)n ? per : (size_t)n, _val.data()); } catch (...) { failed[0] = std::current_exception(); }
-            for (auto& th : pool) th.join();
+            auto part = [&](size_t t) {
+                const size_t i0 = t * per < (size_t)n ? t * per : (size_t)n, i1 = i0 + per < (size_t)n ? i0 + per : (size_t)n;
+                try { if (i0 < i1) expand_range(out, i0, i1, _val.data() + first[t]); } catch (...) { failed[t] = std::current_exception(); }
+            };
+            run_on_workers(threads - 1, [&](size_t w) { part(w + 1); });
+            part(0);
+            wait_workers();
             for (auto& f : failed) if (f) std::rethrow_exception(f);
             return out;
         }
@@ -208,6 +218,62 @@ private:
             if (_kp[i].has_descriptor) out[i].descriptors.assign(_desc.begin() + (std::ptrdiff_t)i * 128, _desc.begin() + (std::ptrdiff_t)(i + 1) * 128);
         }
         return out;
+    }
+    // ---- worker threads of collect(): a job is a function of the worker's index; run_on_workers hands the first `count` workers
+    // the job, wait_workers returns when they are done
+    std::vector<std::thread> _workers;
+    std::mutex _wm;
+    std::condition_variable _wcv;
+    std::function<void(size_t)> _job;
+    size_t _job_workers = 0, _job_done = 0;
+    unsigned long long _job_id = 0;
+    bool _stop = false;
+    void worker_main(size_t index) {
+        unsigned long long seen = 0;
+        for (;;) {
+            std::function<void(size_t)> job;
+            {
+                std::unique_lock<std::mutex> lk(_wm);
+                _wcv.wait(lk, [&] { return _stop || (_job_id != seen && index < _job_workers); });
+                if (_stop) return;
+                seen = _job_id;
+                job = _job;
+            }
+            job(index);
+            {
+                std::lock_guard<std::mutex> lk(_wm);
+                ++_job_done;
+            }
+            _wcv.notify_all();
+        }
+    }
+    void run_on_workers(size_t count, std::function<void(size_t)> job) {
+        while (_workers.size() < count) {
+            const size_t index = _workers.size();
+            _workers.emplace_back([this, index] { worker_main(index); });
+        }
+        {
+            std::lock_guard<std::mutex> lk(_wm);
+            _job = std::move(job);
+            _job_workers = count;
+            _job_done = 0;
+            ++_job_id;
+        }
+        _wcv.notify_all();
+    }
+    void wait_workers() {
+        std::unique_lock<std::mutex> lk(_wm);
+        _wcv.wait(lk, [&] { return _job_done == _job_workers; });
+        _job_workers = 0;
+    }
+    void stop_workers() {
+        {
+            std::lock_guard<std::mutex> lk(_wm);
+            _stop = true;
+        }
+        _wcv.notify_all();
+        for (auto& t : _workers) t.join();
+        _workers.clear();
     }
     // transfer buffers, kept between calls (collect)
     std::vector<unsigned char> _rec;

@@ -79,9 +79,17 @@ constexpr int kCellShift = 4;            // 16 px grid cells
 // either side, so that EVERY window-local coordinate a neighbour's window can put a pixel at (-15 .. 30 in x and y) reads a
 // real +0.0f outside the 16x16 window: adding it changes nothing (a magnitude is never -0.0f), which spares the walk over the
 // neighbours a select per pixel.  Stride 52: the four column groups of a wave (x = 0, 4, 8, 12) start 16 banks apart.
-constexpr int kW16Stride = 52;
+constexpr int kW16Stride = 46;   // (round 5: 8-byte entries are conflict-free at any stride; 46 = 15 + 16 + 15 keeps eight workgroups per CU)
 constexpr int kW16Bias = 15 * kW16Stride + 15;
 constexpr int kW16Size = 46 * kW16Stride;
+// Round 5: an entry of the table is a PAIR {weighting, mask}: mask = all ones inside the 16x16 window, 0 outside.  A neighbour's
+// orientation is added as `ori + (theta & mask)` - theta inside its window, +0.0f outside, and an orientation is never -0.0f
+// (it starts as a value >= +0 or NaN - kernels_orient.hip - and only (-0) + (-0) makes a -0), so `+ 0.0f` leaves every value,
+// NaNs included, as it was.  One 8-byte LDS read per pixel and neighbour then serves BOTH chains and the walk needs no
+// coverage test at all: add, and, add - three instructions per pixel where the compare / add / select / add form took five
+// and a row test per neighbour (583 -> ~455 vector instructions per keypoint; the 16 lanes an 8-byte read serves together
+// hold 16 consecutive y of one column: 128 contiguous bytes, conflict-free at any column stride).
+struct W16Entry { float w; unsigned mask; };
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at a 4-byte aligned address
 
@@ -263,8 +271,8 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
                                                                  float* __restrict__ desc_out, long long out_cap, int n_images,
                                                                  int chunks, int dbg_arg) {
     const int dbg = dbg_arg & kDiagMask;   // measurement build only (common.h)
-    __shared__ float s_w16t[kW16Size];
-    __shared__ uint4 s_list[4][64];   // per wave: preceding neighbours in vector order (orientation bits, table offset, dx, dy)
+    __shared__ __attribute__((aligned(8))) W16Entry s_w16t[kW16Size];
+    __shared__ __attribute__((aligned(16))) uint2 s_list[4][64];   // per wave: preceding neighbours in vector order (orientation bits, table offset)
     __shared__ __attribute__((aligned(16))) unsigned s_keys[4][68];   // per wave: their vector indices, compacted (+ sentinels)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
     const int ly = lane & 15, lx0 = (lane >> 4) * 4;   // this lane's row and first column inside a window
     const int tbase = kW16Bias + lx0 * kW16Stride + ly;
     const unsigned b0 = 2u * (unsigned)(lane & 3), b1 = b0 + 1u;   // the two bins this lane accumulates for its cell
-    for (int i = tid; i < kW16Size; i += 256) s_w16t[i] = 0.0f;
+    for (int i = tid; i < kW16Size; i += 256) s_w16t[i] = W16Entry{0.0f, 0u};
     // Work units = (image, chunk of the image's records): workgroups with equal blockIdx % 8 (observed to share an XCD and
     // its 4 MB L2; a different placement only costs speed) take the units u = blockIdx % 8, + 8, + 16 ... one after the
     // other, all of them striding through the SAME unit at a time.  The records of a unit are consecutive grid cells, i.e. a
@@ -288,11 +296,11 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
     // weighting(x, y) (sift.cpp:87-90), x-major: index bias + 20 * x + y.  Entries outside 0..15 x 0..15 are only ever
     // read by lanes that then discard them.
     __syncthreads();   // the previous unit's readers are done
-    s_w16t[kW16Bias + (tid & 15) * kW16Stride + (tid >> 4)] = lv.w16[(size_t)img * 256 + tid];
+    s_w16t[kW16Bias + (tid & 15) * kW16Stride + (tid >> 4)] = W16Entry{lv.w16[(size_t)img * 256 + tid], 0xffffffffu};
     __syncthreads();
     float wself[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wself[i] = s_w16t[tbase + i * kW16Stride];
+    for (int i = 0; i < 4; ++i) wself[i] = s_w16t[tbase + i * kW16Stride].w;
     const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
     const float* __restrict__ gm = lv.mag + img_off;
     const float* __restrict__ go = lv.ori + img_off;
@@ -384,8 +392,8 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
         const float vg[4] = {w0.g.x, w0.g.y, w0.g.z, w0.g.w};
 
         // one preceding neighbour q: the lane's pixels that q's window covers receive q's additions (sift.cpp:80-92).
-        // The four weighting values are fetched by `weights_of` (which can run one neighbour ahead) and consumed by `apply`.
-        struct Wq { float v[4]; };
+        // The four table entries are fetched by `weights_at` (which can run one neighbour ahead) and consumed by `apply_w`.
+        struct Wq { W16Entry v[4]; };
         // dx, dy: p's window-local (x, y) is q's (x + dx, y + dy); toff = dx * kW16Stride + dy
         auto weights_at = [&](int toff) {
             Wq r;
@@ -393,19 +401,16 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
             for (int i = 0; i < 4; ++i) r.v[i] = s_w16t[tbase + toff + i * kW16Stride];
             return r;
         };
-        auto apply_w = [&](int dx, int dy, float qtheta, const Wq& wq) {
-            const bool row_in = (unsigned)(ly + dy) < 16u;
+        auto apply_w = [&](unsigned qtheta_bits, const Wq& wq) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const bool in = row_in && (unsigned)(lx0 + i + dx) < 16u;
-                const float no = vo[i] + qtheta;
-                vo[i] = in ? no : vo[i];
-                vm[i] = vm[i] + wq.v[i];   // +0.0f from the table's padding where q's window does not cover the pixel
+                vo[i] = vo[i] + __uint_as_float(qtheta_bits & wq.v[i].mask);   // + theta inside q's window, + 0.0f outside
+                vm[i] = vm[i] + wq.v[i].w;                                     // + 0.0f from the table's padding outside
             }
         };
         auto apply = [&](unsigned qxy, float qtheta) {
             const int dx = px - (int)(qxy & 0xffffu), dy = py - (int)(qxy >> 16);
-            apply_w(dx, dy, qtheta, weights_at(dx * kW16Stride + dy));
+            apply_w(__float_as_uint(qtheta), weights_at(dx * kW16Stride + dy));
         };
 
         // ---- neighbours: the 3x3 cells around p's --------------------------------------------------------------------
@@ -437,22 +442,22 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
                     }
                     // each lane works out what the walk needs of ITS neighbour once (offsets, table address), so the walk's body
                     // is a broadcast read and the additions, two neighbours per trip
-                    uint4* list = s_list[wave];
+                    uint2* list = s_list[wave];
                     if (pass) {
                         const int dx = px - (int)(c.z & 0xffffu), dy = py - (int)(c.z >> 16);
-                        list[rank] = make_uint4(c.y, (unsigned)(dx * kW16Stride + dy), (unsigned)dx, (unsigned)dy);
+                        list[rank] = make_uint2(c.y, (unsigned)(dx * kW16Stride + dy));
                     }
                     __builtin_amdgcn_wave_barrier();
                     int r = 0;
                     for (; r + 1 < n_prev; r += 2) {
-                        const uint4 q0 = list[r], q1 = list[r + 1];
-                        const Wq wq0 = weights_at((int)q0.y), wq1 = weights_at((int)q1.y);
-                        apply_w((int)q0.z, (int)q0.w, __uint_as_float(q0.x), wq0);
-                        apply_w((int)q1.z, (int)q1.w, __uint_as_float(q1.x), wq1);
+                        const uint4 q01 = *reinterpret_cast<const uint4*>(&list[r]);   // two neighbours per 16-byte broadcast read
+                        const Wq wq0 = weights_at((int)q01.y), wq1 = weights_at((int)q01.w);
+                        apply_w(q01.x, wq0);
+                        apply_w(q01.z, wq1);
                     }
                     if (r < n_prev) {
-                        const uint4 q0 = list[r];
-                        apply_w((int)q0.z, (int)q0.w, __uint_as_float(q0.x), weights_at((int)q0.y));
+                        const uint2 q0 = list[r];
+                        apply_w(q0.x, weights_at((int)q0.y));
                     }
                     __builtin_amdgcn_wave_barrier();   // the list is rewritten for the wave's next keypoint
                 }

@@ -57,8 +57,11 @@ __device__ __forceinline__ void gradient_pixel(bool interior, float left, float 
         // branch-free common path (one division for every argument range); rare inputs take the full routine
         float r;
         if (!fdlibm_atan2f_common(dy, dx, r)) r = fdlibm_atan2f(dy, dx);
-        const double s = (double)(r + 360.0f);
-        a = (float)(s >= 360.0 ? s - 360.0 : s);
+        // ... and needs no double: s = r + 360.f is a float in [360 - pi, 360 + pi]; below 360 fmod returns it unchanged, from 360
+        // on s - 360 is a multiple of ulp(360) = 2^-15 below 4, i.e. a float, so the float subtraction is exact too and
+        // (float)fmod((double)s, 360.) == s - 360.f bit for bit (a NaN stays the NaN it was)
+        const float s = r + 360.0f;
+        a = s >= 360.0f ? s - 360.0f : s;
     }
     pr = m * centre;
     bin = orientation_bin(a);

@@ -158,3 +158,16 @@ def test_sparse_unpack_host_restores_records_and_descriptors():
     d2 = np.empty((n, 128), np.float32)
     assert L.sift_hip_sparse_unpack_host(rec.ctypes.data, val.ctypes.data, n, None, d2.ctypes.data, 2) == 0 and d2.tobytes() == want.tobytes()
     assert L.sift_hip_sparse_unpack_host(None, None, 0, None, None, 1) == 0
+
+
+def test_fmod_360_of_the_gradient_orientation_is_one_exact_float_subtraction():
+    """alg::gradientOrientation (/root/reference/algorithms.cpp:113-116) returns (float)fmod((double)(atan2f(dy, dx) + 360.f), 360.).
+    The kernel (kernels_orient.hip: gradient_pixel) computes s = r + 360.f and `s >= 360.f ? s - 360.f : s` in float.  EVERY float
+    the sum can be - all of [360 - 4, 360 + 4], a superset of 360 +- pi - gives the same bits both ways."""
+    lo = np.float32(356.0).view(np.uint32)
+    hi = np.float32(364.0).view(np.uint32)
+    s = np.arange(int(lo), int(hi) + 1, dtype=np.uint32).view(np.float32)
+    want = np.fmod(s.astype(np.float64), 360.0).astype(np.float32)
+    got = np.where(s >= np.float32(360.0), s - np.float32(360.0), s).astype(np.float32)
+    assert s.size > 250000
+    assert got.tobytes() == want.tobytes()
