@@ -41,6 +41,8 @@ STEPS=20 bash tools/desc_ab.sh > $O/desc_ab.txt 2>&1
 bash tools/pmc_one.sh descriptor_tile --set desc_kernel=2 > $O/pmc_desc_tile.txt 2>&1
 bash tools/loopback_ab.sh > $O/loopback_ab.txt 2>&1
 python3 tools/gather_probe.py 40 2>&1 | grep "ms/step" > $O/gather_probe.txt
+# 6. round 5: the pyramid's tail as one launch per image / on a stream of its own against the launches in line
+bash tools/tail_kernel_ab.sh 1 > $O/tail_kernel_ab.txt 2>&1
 rm -rf gpurun_out/prof_d1 gpurun_out/prof_d2
 cat $O/roofline.txt; python3 -c "
 import json
