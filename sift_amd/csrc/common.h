@@ -209,10 +209,10 @@ void launch_edge_filter_points(hipStream_t s, const float* d0, const float* d1, 
 void launch_vertex_parabola(hipStream_t s, const uint16_t* lnx, const float* lny, const uint16_t* px,
                             const float* py, const uint16_t* rnx, const float* rny, int m, float* out);
 void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, float* prod, int w, int h,
-                     int n, int* d_any_bin = nullptr);
+                     int n, int* d_any_bin = nullptr, int stamp = 1);
 void launch_orientation(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const Candidate* d_cands,
                         const OrientIn* d_oin, const int* d_list_cnt, int list_cap, OrientOut* d_out,
-                        float* d_peaks, int* d_next_group, const int* d_any_bin = nullptr, int zero_counters = 1);
+                        float* d_peaks, int* d_next_group, const int* d_any_bin = nullptr, int zero_counters = 1, int stamp = 1);
 // host-glue path: orientation inputs in list order from an uploaded survivor list
 void launch_build_orient_in(hipStream_t s, const Candidate* d_cands, long long cand_cap, const uint32_t* d_list,
                             const int* d_list_cnt, int list_cap, int n_images, OrientIn* d_oin);
@@ -232,10 +232,9 @@ void launch_cleanup_kat(hipStream_t s, const uint8_t* d_flags, int n, uint8_t* w
                         uint32_t* wp, uint32_t* d_out, int* d_info, int force_global, OrientIn* d_ord,
                         uint32_t* d_lrank, const Candidate* d_cd);
 void launch_w16(hipStream_t s, const DevPlan& plan, int level, const float* d_taps16, int radius16);
-void launch_out_base(hipStream_t s, const int* d_final_cnt, int n, long long* d_out_base);
 void launch_desc_grid(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const FinalKp* d_final, const int* d_final_cnt,
-                      int final_cap, int* d_cell_cnt, int* d_cell_off, FinalKp* d_pool, int pool_cap, const long long* d_out_base,
-                      sift_hip_keypoint* d_kp_out, float* d_desc_out, long long out_cap);
+                      int final_cap, int* d_cell_cnt, int* d_cell_off, FinalKp* d_pool, int pool_cap, long long* d_out_base,
+                      bool compute_base, sift_hip_keypoint* d_kp_out, float* d_desc_out, long long out_cap);
 void launch_descriptors_wave(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level, const int* d_cell_off,
                              const FinalKp* d_pool, int pool_cap, const long long* d_out_base, sift_hip_keypoint* d_kp_out,
                              float* d_desc_out, long long out_cap, int dbg = 0, int* d_wire_sums = nullptr);

@@ -177,6 +177,7 @@ struct sift_hip_ctx {
     hipEvent_t ev_tail_fork = nullptr, ev_tail_done = nullptr;
     bool tail_pending = false;       // this batch has launches on stream3 that the main stream has not waited for yet
     bool tail_in_kernel = false;     // ... as the tail kernel: one workgroup per image holds a CU while it runs
+    int bin_stamp = 0;               // this batch's value of the gradient pass's "some bin != 0" flags (kernels_orient.hip: launch_gradient)
     DevBuf d_list, d_list_cnt, d_orient, d_peaks, d_final, d_final_cnt, d_out_base, d_kp, d_desc;
     DevBuf d_wire_sums, d_wire_off;   // sparse wire format: floats per block of keypoints, their exclusive scan
     DevBuf d_unpack_sums, d_unpack_off;   // the same for sift_hip_sparse_unpack (lists that arrive from other GPUs)
@@ -831,7 +832,8 @@ void mid_host(sift_hip_ctx* c) {
     launch_build_orient_in(s, c->d_cands.as<Candidate>(), dv.cand_capacity, c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
                            kListCap, n, c->d_order.as<OrientIn>());
     launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_order.as<OrientIn>(), c->d_list_cnt.as<int>(), kListCap,
-                       c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 3 * n, (c->orient_general ? nullptr : c->d_ocnt.as<int>() + 4 * n));
+                       c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 3 * n, (c->orient_general ? nullptr : c->d_ocnt.as<int>() + 4 * n),
+                       1, c->bin_stamp);
     c->h_orient.ensure((size_t)n * kListCap * sizeof(OrientOut));
     for (int i = 0; i < n; ++i)
         if (cnt1[(size_t)i])
@@ -894,7 +896,7 @@ void ensure_outputs(sift_hip_ctx* c, long long keypoints) {
     c->out_cap = keypoints;
 }
 
-void launch_descriptor_stage(sift_hip_ctx* c) {
+void launch_descriptor_stage(sift_hip_ctx* c, bool base_on_device = false) {
     Plan& P = c->plan;
     const DevPlan& dv = P.dev;
     if (c->pack_pending) {   // the previous batch's lists are still being packed from the arrays this stage rewrites
@@ -904,7 +906,7 @@ void launch_descriptor_stage(sift_hip_ctx* c) {
     // grid of 16 px cells over the final keypoints, then one wave per keypoint - or per tile of 2 x 2 cells (kernels_desc.hip)
     launch_desc_grid(c->stream, c->d_plan.as<DevPlan>(), dv, c->d_final.as<FinalKp>(), c->d_final_cnt.as<int>(), kListCap,
                      c->d_cell_cnt.as<int>(), c->d_cell_off.as<int>(), c->d_pool.as<FinalKp>(), kPoolCap, c->d_out_base.as<long long>(),
-                     c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->out_cap);
+                     base_on_device, c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->out_cap);
     int* wire_sums = nullptr;
     c->wire_counted = false;
     if (c->wire_count) {   // multi-GPU jobs: the counting pass of the wire format rides in the descriptor kernel
@@ -977,7 +979,7 @@ bool mid_gpu(sift_hip_ctx* c) {
     // late launch: only the images whose survivor list was truncated (counts are 0 for the others)
     launch_orientation(s, dpl, dv, c->d_cands.as<Candidate>(), c->d_order.as<OrientIn>(), d_late, kListCap,
                        c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 3 * n, (c->orient_general ? nullptr : c->d_ocnt.as<int>() + 4 * n),
-                       0 /* its group counters were cleared together with the early launch's */);
+                       0 /* its group counters were cleared together with the early launch's */, c->bin_stamp);
     launch_cleanup2(s, n, c->d_cands.as<Candidate>(), dv.cand_capacity, c->d_list.as<uint32_t>(), c->d_list_cnt.as<int>(),
                     kListCap, c->d_orient.as<OrientOut>(), c->d_lrank.as<uint32_t>(), c->d_wk.as<uint8_t>(),
                     c->d_wi.as<uint32_t>(), c->d_wi2.as<uint32_t>(), c->d_wp.as<uint32_t>(), c->d_final.as<FinalKp>(),
@@ -985,12 +987,12 @@ bool mid_gpu(sift_hip_ctx* c) {
     // The descriptor stage does not wait for the counts to reach the host: output slots come from a device-side
     // scan and the output arrays keep a generous capacity; should a batch ever exceed it, the (idempotent: the
     // mutated maps only live in LDS) stage is simply run again after growing them.
-    launch_out_base(s, c->d_final_cnt.as<int>(), n, c->d_out_base.as<long long>());
+    // (the images' first output slots - a scan of the final counts - are formed by the descriptor stage's grid kernel itself)
     // capacity guess: a quarter above what this context's previous batch returned; before the first one 24576 keypoints
     // per image (a 1080p frame returns ~20 k; 13 MB of results per image)
     ensure_outputs(c, std::max<long long>(c->out_cap, c->last_total > 0 ? c->last_total + c->last_total / 4 : (long long)n * 24576));
     if (c->gate) c->gate->before_descriptors(c->gate_ticket, s);
-    launch_descriptor_stage(c);
+    launch_descriptor_stage(c, true);
     SIFT_HIP_CHECK(hipGetLastError());
     if (c->gate) c->gate->mark(c->gate_ticket, sift_hip::PhaseGate::kD, s);
     c->described = true;
@@ -1241,11 +1243,12 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     hipStream_t gs = serial_gradient ? s : c->stream2;
     SIFT_HIP_CHECK(hipEventRecord(c->ev_fork0, s));
     SIFT_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_fork0, 0));
-    launch_zero_ints(gs, c->d_ocnt.as<int>() + 4 * n, (size_t)n);   // "some sample has a bin != 0" per image
+    // "some sample has a bin != 0" per image: flagged with this batch's stamp, never cleared (launch_gradient)
+    c->bin_stamp = (c->bin_stamp % 0x3fffffff) + 1;
     for (int lvl : P.grad_levels) {
         const int o = lvl / (P.D + 1);
         launch_gradient(gs, dv.gauss[lvl], dv.mag[lvl], dv.ori[lvl], dv.prod[lvl], dv.w[o], dv.h[o], n,
-                        (c->orient_general ? nullptr : c->d_ocnt.as<int>() + 4 * n));
+                        (c->orient_general ? nullptr : c->d_ocnt.as<int>() + 4 * n), c->bin_stamp);
     }
     if (c->gate) SIFT_HIP_CHECK(hipEventRecord(c->ev_grad, gs));
     // extrema + edge responses (sift.cpp:33-34)
@@ -1287,7 +1290,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
                               c->d_ocnt.as<int>());
         launch_orientation(c->stream2, dpl, dv, c->d_cands.as<Candidate>(), c->d_order.as<OrientIn>(), c->d_ocnt.as<int>(),
                            kListCap, c->d_orient.as<OrientOut>(), c->d_peaks.as<float>(), c->d_ocnt.as<int>() + 2 * n, (c->orient_general ? nullptr : c->d_ocnt.as<int>() + 4 * n),
-                           2 /* also the late launch's counters, which follow */);
+                           2 /* also the late launch's counters, which follow */, c->bin_stamp);
     }
     SIFT_HIP_CHECK(hipEventRecord(c->ev_join, c->stream2));
     SIFT_HIP_CHECK(hipGetLastError());

@@ -119,6 +119,10 @@ __device__ __forceinline__ int desc_cell_of(const DevPlan* __restrict__ plan, co
 // (LDS_COUNTS) and in the image's slice of cell_cnt otherwise; after the scan a cell's counter holds its first free pool
 // slot, so the fill needs one atomic per record and no second array.  A keypoint that fails the descriptor stage's own
 // bounds test (sift.cpp:65-70) is emitted right here: filtered, no descriptor.
+// (Round 5 measured 256 threads / 32 KB of counters - a workgroup that takes the first four wave slots that free instead of
+// waiting for half an empty CU beside the gradient pass's workgroups: 2.72 - 2.77 against 2.68 - 2.73 ms per step with two batches
+// in flight, 3.05 - 3.11 against 3.00 - 3.06 with one: the kernel alone is slower and the later start of the descriptor kernel it was
+// meant to cure is not what bounds the phase.  Not kept; the same for extrema_scan_kernel.)
 constexpr int kGridThreads = 1024;
 constexpr int kGridLdsCells = 16384;   // 64 KB of counters: 1080p has 8160 cells, 4K 32400 (global counters)
 
@@ -127,13 +131,33 @@ __global__ __launch_bounds__(kGridThreads) void desc_grid_kernel(const DevPlan* 
                                                                  const int* __restrict__ final_cnt, int final_cap,
                                                                  int* __restrict__ cell_cnt, int* __restrict__ cell_off,
                                                                  FinalKp* __restrict__ pool, int pool_cap,
-                                                                 const long long* __restrict__ out_base,
+                                                                 long long* out_base, int compute_base,
                                                                  sift_hip_keypoint* __restrict__ kp_out, float* __restrict__ desc_out,
                                                                  long long out_cap) {
     __shared__ int s_cnt[LDS_COUNTS ? kGridLdsCells : 1];
     __shared__ int s_part[kGridThreads];
+    __shared__ long long s_wsum[kGridThreads / 64];
     const int img = blockIdx.x, tid = threadIdx.x;
     const int K = final_cnt[img];
+    // The image's first output slot = the keypoints of the images in front of it.  compute_base: summed right here (round 5: as
+    // a launch of its own - out_base_kernel, one workgroup - the scan was one more dependent launch between the cleanup chain and
+    // the descriptors, ~60 us waiting for a slot beside the partner batch's pyramid); else the host has uploaded the offsets.
+    long long my_base;
+    if (compute_base) {
+        long long sum = 0;
+        for (int i = tid; i < img; i += kGridThreads) sum += final_cnt[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+        if ((tid & 63) == 0) s_wsum[tid >> 6] = sum;
+        __syncthreads();
+        long long t = 0;
+#pragma unroll
+        for (int wv = 0; wv < kGridThreads / 64; ++wv) t += s_wsum[wv];
+        my_base = t;
+        if (tid == 0) out_base[img] = t;
+    } else {
+        my_base = out_base[img];
+    }
     const int cpi = plan->desc_cells_per_image;
     int* cnt = LDS_COUNTS ? s_cnt : cell_cnt + (size_t)img * (size_t)(cpi + 1);
     int* off = cell_off + (size_t)img * (size_t)(cpi + 1);
@@ -147,7 +171,7 @@ __global__ __launch_bounds__(kGridThreads) void desc_grid_kernel(const DevPlan* 
         if (cell >= 0) {
             atomicAdd(&cnt[cell], 1);
         } else {
-            const long long ok = out_base[img] + k;
+            const long long ok = my_base + k;
             if (ok < out_cap) {
                 sift_hip_keypoint r;
                 r.scale = plan->dog_scale[f.octave * plan->dogs + f.index];
@@ -1061,44 +1085,16 @@ void launch_w16(hipStream_t s, const DevPlan& plan, int level, const float* d_ta
                        radius16);
 }
 
-// exclusive scan of the per-image final counts -> first output slot of every image
-__global__ __launch_bounds__(1024) void out_base_kernel(const int* __restrict__ final_cnt, int n,
-                                                        long long* __restrict__ out_base) {
-    __shared__ long long s_part[1024];
-    const int tid = threadIdx.x;
-    const int chunk = (n + 1023) / 1024;
-    const int lo = tid * chunk, hi = min(lo + chunk, n);
-    long long sum = 0;
-    for (int i = lo; i < hi; ++i) sum += final_cnt[i];
-    s_part[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const long long v = tid >= off ? s_part[tid - off] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
-    }
-    long long run = s_part[tid] - sum;
-    for (int i = lo; i < hi; ++i) {
-        out_base[i] = run;
-        run += final_cnt[i];
-    }
-}
-
-void launch_out_base(hipStream_t s, const int* d_final_cnt, int n, long long* d_out_base) {
-    hipLaunchKernelGGL(out_base_kernel, dim3(1), dim3(1024), 0, s, d_final_cnt, n, d_out_base);
-}
-
 // grid of 16 px cells over the final keypoints of every image
 void launch_desc_grid(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const FinalKp* d_final, const int* d_final_cnt,
-                      int final_cap, int* d_cell_cnt, int* d_cell_off, FinalKp* d_pool, int pool_cap, const long long* d_out_base,
-                      sift_hip_keypoint* d_kp_out, float* d_desc_out, long long out_cap) {
+                      int final_cap, int* d_cell_cnt, int* d_cell_off, FinalKp* d_pool, int pool_cap, long long* d_out_base,
+                      bool compute_base, sift_hip_keypoint* d_kp_out, float* d_desc_out, long long out_cap) {
     if (plan.desc_cells_per_image <= kGridLdsCells)
         hipLaunchKernelGGL(desc_grid_kernel<true>, dim3((unsigned)plan.n_images), dim3(kGridThreads), 0, s, d_plan, d_final, d_final_cnt,
-                           final_cap, d_cell_cnt, d_cell_off, d_pool, pool_cap, d_out_base, d_kp_out, d_desc_out, out_cap);
+                           final_cap, d_cell_cnt, d_cell_off, d_pool, pool_cap, d_out_base, compute_base ? 1 : 0, d_kp_out, d_desc_out, out_cap);
     else
         hipLaunchKernelGGL(desc_grid_kernel<false>, dim3((unsigned)plan.n_images), dim3(kGridThreads), 0, s, d_plan, d_final, d_final_cnt,
-                           final_cap, d_cell_cnt, d_cell_off, d_pool, pool_cap, d_out_base, d_kp_out, d_desc_out, out_cap);
+                           final_cap, d_cell_cnt, d_cell_off, d_pool, pool_cap, d_out_base, compute_base ? 1 : 0, d_kp_out, d_desc_out, out_cap);
 }
 
 void launch_descriptors_wave(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level, const int* d_cell_off,

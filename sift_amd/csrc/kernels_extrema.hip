@@ -13,6 +13,8 @@
 //    candidate's final position, and the expansion writes them there — no sort, no atomics.
 #include <float.h>
 
+#include <cstring>
+
 #include "common.h"
 #include "linalg3.h"
 
@@ -94,18 +96,20 @@ __global__ __launch_bounds__(256) void extrema_mask_kernel(const float* __restri
     }
 }
 
-// Exclusive scan of one image's per-word counts (in place) + total.  One 1024-thread workgroup
-// per image; each thread owns a contiguous chunk so the order is the word order.
-__global__ __launch_bounds__(1024) void extrema_scan_kernel(int* __restrict__ counts, int words_per_image,
-                                                            int* __restrict__ totals) {
-    __shared__ int s_part[1024];
+// Exclusive scan of one image's per-word counts (in place) + total.  One workgroup per image; each thread owns a contiguous
+// chunk so the order is the word order.  (1024 threads; 256 - a workgroup that finds a slot sooner beside the partner batch's
+// descriptor kernel - was measured in round 5 and is slower alone and no faster in the pipeline: kernels_desc.hip, kGridThreads.)
+constexpr int kScanThreads = 1024;
+__global__ __launch_bounds__(kScanThreads) void extrema_scan_kernel(int* __restrict__ counts, int words_per_image,
+                                                                    int* __restrict__ totals) {
+    __shared__ int s_part[kScanThreads];
     const int img = blockIdx.x;
     int* __restrict__ c = counts + (size_t)img * (size_t)words_per_image;
     const int tid = threadIdx.x;
     // chunks are multiples of 4 words so that a thread streams its chunk with 16-byte loads / stores
     // (several in flight), when the image's slice of the array is 16-byte aligned
     const bool vec = (words_per_image & 3) == 0 && (reinterpret_cast<uintptr_t>(c) & 15u) == 0;
-    const int chunk = ((words_per_image + 1023) / 1024 + 3) & ~3;
+    const int chunk = ((words_per_image + kScanThreads - 1) / kScanThreads + 3) & ~3;
     const int lo = min(tid * chunk, words_per_image);
     const int hi = min(lo + chunk, words_per_image);
     int sum = 0;
@@ -121,8 +125,8 @@ __global__ __launch_bounds__(1024) void extrema_scan_kernel(int* __restrict__ co
     }
     s_part[tid] = sum;
     __syncthreads();
-    // Hillis-Steele inclusive scan over the 1024 partial sums
-    for (int off = 1; off < 1024; off <<= 1) {
+    // Hillis-Steele inclusive scan over the partial sums
+    for (int off = 1; off < kScanThreads; off <<= 1) {
         const int v = (tid >= off) ? s_part[tid - off] : 0;
         __syncthreads();
         s_part[tid] += v;
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(1024) void extrema_scan_kernel(int* __restrict__ co
             run += v;
         }
     }
-    if (tid == 1023) totals[img] = s_part[1023];
+    if (tid == kScanThreads - 1) totals[img] = s_part[kScanThreads - 1];
 }
 
 // Expansion: one thread per mask word walks its set bits (y ascending) and writes the Candidate
@@ -299,12 +303,32 @@ __device__ __forceinline__ void fx_lds_barrier() { asm volatile("s_waitcnt lgkmc
 constexpr int kFxLoads = (kFxRows * kFxRow4 + 255) / 256;   // float4 per thread, level and tile
 constexpr int kFxQ2 = 1024;   // second-stage list (a tile's 2048 pixels can all be candidates: the overflow runs its QR body in place)
 
-__global__ __launch_bounds__(256) void extrema_edge_kernel(const float* __restrict__ d0, const float* __restrict__ d1,
-                                                           const float* __restrict__ d2, int w, int h, int nyb,
-                                                           int word_base, int words_per_image, int tiles_x, int total_tiles,
-                                                           unsigned long long* __restrict__ masks,
+// Round 5: ONE launch scans every level handed to it (FxPlan: up to kFxMaxLevels scan levels, their tiles numbered through) -
+// the persistent workgroups simply walk on into the next level's tiles.  As a launch per level the three small octaves' scans
+// were three more dependent launches behind octave 0's on the batch's critical chain, each waiting for slots beside the gradient
+// pass and the partner batch's descriptors (0.75 ms for 0.12 ms of work in the pipelined timeline, profiles/r05_timeline_pipelined.txt).
+constexpr int kFxMaxLevels = 16;
+struct FxLevel {
+    const float* d0;
+    const float* d1;
+    const float* d2;
+    int w, h, nyb, word_base, tiles_x, tiles_img, tile_begin, pad;
+};
+struct FxPlan {
+    int n_levels, total_tiles, words_per_image, pad;
+    FxLevel lv[kFxMaxLevels];
+};
+
+__global__ __launch_bounds__(256) void extrema_edge_kernel(FxPlan plan, unsigned long long* __restrict__ masks,
                                                            unsigned long long* __restrict__ fmasks,
                                                            int* __restrict__ counts) {
+    const int total_tiles = plan.total_tiles, words_per_image = plan.words_per_image;
+    // level of a tile (tiles are numbered level after level; wave-uniform: a scalar loop over at most 16 entries)
+    auto level_of = [&](int tile) {
+        int L = 0;
+        for (int i = 1; i < plan.n_levels; ++i) L = tile >= plan.lv[i].tile_begin ? i : L;
+        return L;
+    };
     __shared__ __attribute__((aligned(16))) float s_t[3][kFxRows * kFxPitch];
     __shared__ unsigned short s_q[4][16 * kFxCols];    // per wave: its candidates (column | row << 5)
     __shared__ unsigned short s_q2[kFxQ2];             // candidates the curvature tests let through: the QR bodies' work list
@@ -325,7 +349,6 @@ __global__ __launch_bounds__(256) void extrema_edge_kernel(const float* __restri
         t_end = total_tiles;
         t_step = (int)gridDim.x;
     }
-    const int tiles_img = tiles_x * nyb;
     static_assert(kFxLoads == 3, "the prefetch registers are spelled out (an array here ends up in scratch memory)");
     const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float4 pa0 = z4, pa1 = z4, pa2 = z4, pb0 = z4, pb1 = z4, pb2 = z4, pc0 = z4, pc1 = z4, pc2 = z4;
@@ -347,8 +370,13 @@ __global__ __launch_bounds__(256) void extrema_edge_kernel(const float* __restri
     }
 #define SIFT_FX_LOAD_TILE(TILE)                                                                      \
     {                                                                                                \
-        const int img_ = (TILE) / tiles_img, rem_ = (TILE) - img_ * tiles_img;                       \
-        const int yb_ = rem_ / tiles_x, x0_ = (rem_ - yb_ * tiles_x) * kFxCols, ya_ = yb_ * 64;      \
+        const FxLevel& lv_ = plan.lv[level_of(TILE)];                                                \
+        const float* __restrict__ d0 = lv_.d0;                                                       \
+        const float* __restrict__ d1 = lv_.d1;                                                       \
+        const float* __restrict__ d2 = lv_.d2;                                                       \
+        const int w = lv_.w, h = lv_.h, tl_ = (TILE) - lv_.tile_begin;                               \
+        const int img_ = tl_ / lv_.tiles_img, rem_ = tl_ - img_ * lv_.tiles_img;                     \
+        const int yb_ = rem_ / lv_.tiles_x, x0_ = (rem_ - yb_ * lv_.tiles_x) * kFxCols, ya_ = yb_ * 64; \
         const size_t img_off_ = (size_t)img_ * (size_t)w * (size_t)h;                                \
         SIFT_FX_LOAD(0, pa0, pb0, pc0) SIFT_FX_LOAD(1, pa1, pb1, pc1) SIFT_FX_LOAD(2, pa2, pb2, pc2) \
     }
@@ -363,7 +391,10 @@ __global__ __launch_bounds__(256) void extrema_edge_kernel(const float* __restri
     }
     if (t < t_end) SIFT_FX_LOAD_TILE(t)
     while (t < t_end) {
-        const int img = t / tiles_img, rem = t - img * tiles_img;
+        const FxLevel& lv = plan.lv[level_of(t)];
+        const int w = lv.w, h = lv.h, nyb = lv.nyb, word_base = lv.word_base, tiles_x = lv.tiles_x, tiles_img = lv.tiles_img;
+        const int tl = t - lv.tile_begin;
+        const int img = tl / tiles_img, rem = tl - img * tiles_img;
         const int yb = rem / tiles_x, x0 = (rem - yb * tiles_x) * kFxCols, ya = yb * 64;
         SIFT_FX_STORE(0, pa0, pb0, pc0) SIFT_FX_STORE(1, pa1, pb1, pc1) SIFT_FX_STORE(2, pa2, pb2, pc2)
         if (tid < kFxCols) { s_fm[tid] = 0ull; s_cm[tid] = 0ull; }
@@ -595,22 +626,36 @@ void launch_extrema_edge(hipStream_t s, const DevPlan& plan, unsigned long long*
     const int cus = resident_cus();
     int cap = g_extrema_per_cu * (cus > busy_cus + 8 ? cus - busy_cus : cus);
     cap &= ~7;
-    for (int k = k_begin; k < k_end; ++k) {
-        const int o = plan.scan_octave[k], i = plan.scan_dog[k];
-        const int w = plan.w[o], h = plan.h[o];
-        const int l = o * plan.dogs + i;
-        const int tiles_x = (w + kFxCols - 1) / kFxCols;
-        const long long total = (long long)tiles_x * plan.scan_nyb[k] * plan.n_images;
+    int k = k_begin;
+    while (k < k_end) {   // kFxMaxLevels scan levels per launch (the bench plan has four)
+        FxPlan fp;
+        std::memset(&fp, 0, sizeof(fp));
+        fp.words_per_image = plan.words_per_image;
+        long long total = 0;
+        for (; k < k_end && fp.n_levels < kFxMaxLevels; ++k) {
+            const int o = plan.scan_octave[k], i = plan.scan_dog[k];
+            const int l = o * plan.dogs + i;
+            FxLevel& lv = fp.lv[fp.n_levels];
+            lv.d0 = plan.dog[l - 1]; lv.d1 = plan.dog[l]; lv.d2 = plan.dog[l + 1];
+            lv.w = plan.w[o]; lv.h = plan.h[o]; lv.nyb = plan.scan_nyb[k]; lv.word_base = plan.scan_word_base[k];
+            lv.tiles_x = (lv.w + kFxCols - 1) / kFxCols;
+            lv.tiles_img = lv.tiles_x * lv.nyb;
+            const long long tiles = (long long)lv.tiles_img * plan.n_images;
+            if (total + tiles > 0x7fffffffLL) break;   // (tile numbers are ints)
+            lv.tile_begin = (int)total;
+            total += tiles;
+            ++fp.n_levels;
+        }
+        if (fp.n_levels == 0) break;
+        fp.total_tiles = (int)total;
         int grid = total < cap ? (int)total : cap;
         if (grid >= 8) grid &= ~7;
-        hipLaunchKernelGGL(extrema_edge_kernel, dim3((unsigned)grid), dim3(256), 0, s, (const float*)plan.dog[l - 1],
-                           (const float*)plan.dog[l], (const float*)plan.dog[l + 1], w, h, plan.scan_nyb[k],
-                           plan.scan_word_base[k], plan.words_per_image, tiles_x, (int)total, d_masks, d_fmasks, d_counts);
+        hipLaunchKernelGGL(extrema_edge_kernel, dim3((unsigned)grid), dim3(256), 0, s, fp, d_masks, d_fmasks, d_counts);
     }
 }
 
 void launch_extrema_scan(hipStream_t s, const DevPlan& plan, int* d_counts, int* d_totals) {
-    hipLaunchKernelGGL(extrema_scan_kernel, dim3((unsigned)plan.n_images), dim3(1024), 0, s, d_counts,
+    hipLaunchKernelGGL(extrema_scan_kernel, dim3((unsigned)plan.n_images), dim3(kScanThreads), 0, s, d_counts,
                        plan.words_per_image, d_totals);
 }
 

@@ -69,7 +69,7 @@ __device__ __forceinline__ void gradient_pixel(bool interior, float left, float 
 
 __global__ __launch_bounds__(256) void gradient_kernel(const float* __restrict__ g, float* __restrict__ mag,
                                                        float* __restrict__ ori, float* __restrict__ prod, int w, int h,
-                                                       int* __restrict__ any_bin) {
+                                                       int* __restrict__ any_bin, int stamp) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= w) return;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void gradient_kernel(const float* __restrict__
     prod[o] = pr;
     // The reference feeds radians where degrees were meant (App. B-9): every sample lands in bin 0.  The
     // orientation stage skips the bin map of an image as long as this flag stays clear.
-    if (bin != 0u && any_bin) any_bin[blockIdx.z] = 1;
+    if (bin != 0u && any_bin) any_bin[blockIdx.z] = stamp;   // (the batch's stamp, not 1: the flags are never cleared - launch_gradient)
 }
 
 // Four pixels of a row per thread (rows 16-byte aligned), kGradRows consecutive rows per thread: the three source rows a
@@ -98,7 +98,7 @@ constexpr int kGradRows = 16;
 
 __global__ __launch_bounds__(256, 8) void gradient4_kernel(const float* __restrict__ g, float* __restrict__ mag,
                                                         float* __restrict__ ori, float* __restrict__ prod, int w, int h,
-                                                        int* __restrict__ any_bin) {
+                                                        int* __restrict__ any_bin, int stamp) {
     const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int y0 = blockIdx.y * kGradRows;
     if (x >= w) return;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, 8) void gradient4_kernel(const float* __restri
         any |= bin[0] | bin[1] | bin[2] | bin[3];
         u4 = c4; c4 = d4; lf = nlf; rt = nrt;
     }
-    if (any != 0u && any_bin) any_bin[blockIdx.z] = 1;
+    if (any != 0u && any_bin) any_bin[blockIdx.z] = stamp;
 }
 
 // Two phases per workgroup of 128 keypoints:
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
                                                           const int* __restrict__ list_cnt, int list_cap,
                                                           OrientOut* __restrict__ out,
                                                           float* __restrict__ peaks_out, int* __restrict__ next_group,
-                                                          const int* __restrict__ any_bin, int dbg_arg) {
+                                                          const int* __restrict__ any_bin, int stamp, int dbg_arg) {
     const int dbg = dbg_arg & kDiagMask;   // measurement build only (common.h)
     // staging (phase 1) and the peak sets (phase 2) are never live together: they share storage
     __shared__ __attribute__((aligned(16))) float s_stage[4 * kOrientSub * kOrientStride];
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
     float* __restrict__ wprod = s_stage + wv * kOrientSub * kOrientStride;
     unsigned char* __restrict__ wbin = s_sbin + wv * kOrientSub * kOrientStride;
     if (cnt <= 0) return;
-    const bool bins_zero = any_bin != nullptr && any_bin[img] == 0;   // block-uniform: every sample of this image has bin 0
+    const bool bins_zero = any_bin != nullptr && any_bin[img] != stamp;   // block-uniform: every sample of this image has bin 0
     for (int l = tid; l < plan->octaves * D; l += 256) {
         const int lvl = plan->nearest_level[l];
         const int no = lvl / (D + 1);
@@ -446,16 +446,21 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
     }
 }
 
+// d_any_bin[image] is set to `stamp` when some sample of the image has a histogram bin other than 0 (never, with the reference's
+// radians: App. B-9).  The stamp is the context's batch number, so the flags need no clearing between batches (round 5: the
+// one-workgroup clearing launch in front of the gradient pass waited ~200 us for a slot beside the extrema pass, and the
+// gradient pass behind it); a stale word that happens to equal the stamp only sends the image down the general path, which is
+// always right.
 void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, float* prod, int w, int h,
-                     int n, int* d_any_bin) {
+                     int n, int* d_any_bin, int stamp) {
     const bool vec = (w & 3) == 0 && ((((uintptr_t)g | (uintptr_t)mag | (uintptr_t)ori | (uintptr_t)prod) & 15u) == 0);
     if (vec) {
         const dim3 grid4((unsigned)((w / 4 + 255) / 256), (unsigned)((h + kGradRows - 1) / kGradRows), (unsigned)n);
-        hipLaunchKernelGGL(gradient4_kernel, grid4, dim3(256), 0, s, g, mag, ori, prod, w, h, d_any_bin);
+        hipLaunchKernelGGL(gradient4_kernel, grid4, dim3(256), 0, s, g, mag, ori, prod, w, h, d_any_bin, stamp);
         return;
     }
     const dim3 grid((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)n);
-    hipLaunchKernelGGL(gradient_kernel, grid, dim3(256), 0, s, g, mag, ori, prod, w, h, d_any_bin);
+    hipLaunchKernelGGL(gradient_kernel, grid, dim3(256), 0, s, g, mag, ori, prod, w, h, d_any_bin, stamp);
 }
 
 static int g_orient_dbg = 0;
@@ -463,14 +468,14 @@ void set_orient_dbg(int v) { g_orient_dbg = v; }
 
 void launch_orientation(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const Candidate* d_cands,
                         const OrientIn* d_oin, const int* d_list_cnt, int list_cap, OrientOut* d_out,
-                        float* d_peaks, int* d_next_group, const int* d_any_bin, int zero_counters) {
+                        float* d_peaks, int* d_next_group, const int* d_any_bin, int zero_counters, int stamp) {
     (void)d_cands;
     const dim3 grid(128, (unsigned)plan.n_images);
     const int dbg = g_orient_dbg;   // option "orient_dbg": timing ablations only
     // zero_counters: how many consecutive per-image counter arrays to clear first (0: the caller already did)
     (void)zero_counters;   // the groups are dealt statically: no counters to clear
     hipLaunchKernelGGL(orientation_kernel, grid, dim3(256), 0, s, d_plan, d_oin, d_list_cnt, list_cap, d_out,
-                       d_peaks, d_next_group, d_any_bin, dbg);
+                       d_peaks, d_next_group, d_any_bin, stamp, dbg);
 }
 
 // The runtime builds a translation unit's device code on the first launch of any of its kernels, and two host threads that make
