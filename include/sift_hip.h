@@ -92,9 +92,8 @@ void sift_hip_destroy(sift_hip_ctx* ctx);
  * and run beside the batch's extremum scans of the large octaves; only the scans of those octaves wait for them),
  * "tail_kernel" (0 default; those octaves as ONE launch of one 1024-thread workgroup per image, sift_amd/csrc/kernels_tail.hip,
  * instead of a launch per level: 1 - for batches of at least 16 images; 2 - whenever the levels fit the kernel.  Both were built
- * and measured in round 5, are bit-exact and do not shorten a step: DESIGN.md section 7), "extrema_per_cu" (4 default, process-wide:
- * persistent workgroups per CU of the fused extremum scan; 1 - 3 leave registers and LDS for other kernels' waves: measured, no gain).
- * These 18 names are all a release build knows; any other name returns SIFT_HIP_EINVAL.  The measurement build
+ * and measured in round 5, are bit-exact and do not shorten a step: DESIGN.md section 7).
+ * These 17 names are all a release build knows; any other name returns SIFT_HIP_EINVAL.  The measurement build
  * (libsift_hip_diag.so: make -C sift_amd/csrc diag, -DSIFT_HIP_DIAG) adds "desc_dbg" / "orient_dbg" (phases of a kernel
  * switched off: timing only, WRONG results), "stream_waves", "diag_repeat", "diag_pyramid_span", "diag_serial_gradient", "diag_skip_tail" and
  * "diag_cleanup_stamps" for the scripts under tools/.  The library reads no environment variable. */

@@ -1507,7 +1507,6 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
         return SIFT_HIP_OK;
     }
     if (!std::strcmp(name, "lazy_top")) { c->lazy_top = value != 0; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "extrema_per_cu")) { set_extrema_per_cu(value); return SIFT_HIP_OK; }
     if (!std::strcmp(name, "tail_async")) { c->tail_async = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "tail_kernel")) {
         if (value < 0 || value > 2) return SIFT_HIP_EINVAL;

@@ -601,10 +601,10 @@ void launch_extrema_mask(hipStream_t s, const DevPlan* d_plan, const DevPlan& pl
 }
 
 // the fused kernel stages 16-byte groups: every scanned octave's rows must be 16-byte aligned and at least one group wide
-// Persistent workgroups per CU of the fused scan (option "extrema_per_cu", process-wide; 4 = all the kernel's registers allow:
-// 122 VGPRs x 4 waves per SIMD is the whole register file, so nothing else runs on a CU while the scan holds it).
-static int g_extrema_per_cu = 4;
-void set_extrema_per_cu(int v) { g_extrema_per_cu = v >= 1 && v <= 4 ? v : 4; }
+// Persistent workgroups per CU of the fused scan: 4 = all the kernel's registers allow (122 VGPRs x 4 waves per SIMD is the whole
+// register file, so nothing else runs on a CU while the scan holds it).  Round 5 measured 3 and 2 (registers and LDS left for the
+// partner batch's descriptor kernel): 2.71 - 2.80 ms per step every way (profiles/r05_extrema_per_cu_ab.txt); the option is gone.
+constexpr int kExtremaPerCu = 4;
 
 bool extrema_edge_supported(const DevPlan& plan) {
     for (int k = 0; k < plan.n_scan; ++k) {
@@ -624,7 +624,7 @@ void launch_extrema_edge(hipStream_t s, const DevPlan& plan, unsigned long long*
     // others end and doubles the launch's time - so the grid leaves out the CUs another kernel is known to hold (the
     // pyramid's tail kernel: one workgroup per image, a whole CU each)
     const int cus = resident_cus();
-    int cap = g_extrema_per_cu * (cus > busy_cus + 8 ? cus - busy_cus : cus);
+    int cap = kExtremaPerCu * (cus > busy_cus + 8 ? cus - busy_cus : cus);
     cap &= ~7;
     int k = k_begin;
     while (k < k_end) {   // kFxMaxLevels scan levels per launch (the bench plan has four)
