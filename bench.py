@@ -205,6 +205,35 @@ def launch_ranks(n):
     return status
 
 
+VALU_PEAK_TLANEOPS = 256 * 64 * 2.4e9 / 1e12   # 256 CUs x 64 FP32 lanes per clock x 2.4 GHz: 39.3 T lane-operations/s (no FMA: a multiply and an add are two)
+
+
+def blur_lane_ops(nf, W, H, octaves, dogs, sigma, k):
+    """Lane-operations (FP32 multiplies + adds, the reference's unfused arithmetic) of one batch's pyramid as the kernels do it:
+    a level blur of radius R costs 2 (2R+1) per pixel in the row pass and (R+1) + (2R+1) in the column pass (one product serves
+    two slots: kernels_pyramid.hip) = 7R + 4; a kept-pixels reduction (2R+1) + (3R+2) / 4 per SOURCE pixel (kernels_reduce.hip).
+    Radii: (int)(3 sigma + 0.5) of Sift::_createDOGs' scale schedule (sift.cpp:388-411)."""
+    def radius(s):
+        return max(1, int(3.0 * float(np.float32(s)) + 0.5))
+    ops, exp = 0.0, 0
+    w, h = W, H
+    prev_scale = sigma
+    ops += w * h * (7 * radius(sigma) + 4)                      # g(0,0)
+    for o in range(octaves):
+        scales = []
+        for j in range(1, dogs + 1):
+            scales.append(float(np.float32((k ** exp) * sigma)))
+            exp += 1
+        for sc in scales:
+            ops += w * h * (7 * radius(sc) + 4)
+        if o < octaves - 1:
+            r = radius(scales[dogs - 2])                        # reduceToNextLevel(g(o, D-1), its scale)
+            ops += w * h * ((2 * r + 1) + (3 * r + 2) / 4.0)
+            exp -= 2
+            w, h = (w + 1) // 2, (h + 1) // 2
+    return ops * nf
+
+
 def whole_step_fraction(nf, W, H, keypoints, seconds):
     """All stages' algorithmic bytes of one step (4 octaves x 3 DoGs) over the step's time, against the 8 TB/s peak, with SURVEY.md
     section 8(d)'s per-unit figures: pyramid 4 B read + 4 B per level written per pixel (with lazy_top: g(o,1..2) and three DoGs
@@ -334,7 +363,11 @@ def main():
     rccl_ranks = 0
     if loopback:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29541")
+        if "MASTER_PORT" not in os.environ:   # a free port of this host (a fixed one can still be held by the run before)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
     if world > 1 or loopback:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -591,6 +624,17 @@ def main():
             t_ms, t_n, t_b = (sum(p[i] for p in tail_prof) for i in range(3))
             out["roofline"]["tail_kernel"] = {"launches": t_n, "avg_launch_ms": t_ms / t_n, "algorithmic_bytes_per_launch": t_b / t_n,
                                               "what": "pyramid_tail_kernel: octaves 2 - 3 of the batch, one workgroup per image (VALU-bound; not part of frac)"}
+        # The same launches against the OTHER roof: from radius 10 on a blur is bound by its arithmetic, not by HBM (DESIGN.md
+        # section 7, round 5) - the family's lane-operations over the same busy time, against the chip's FP32 issue rate
+        if not SUBPIXEL and busy_ms > 0 and launches:
+            batches_timed = launches / 16.0 if args.workload == "config4" else None   # 16 blur launches per batch of this plan
+            if batches_timed:
+                lane_ops = blur_lane_ops(nf, W, H, OCTAVES, DOGS, SIGMA, K_SQRT2) * batches_timed
+                out["roofline"]["valu"] = {"achieved": lane_ops / 1e12 / (busy_ms / 1e3), "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-op/s",
+                                           "frac": lane_ops / 1e12 / (busy_ms / 1e3) / VALU_PEAK_TLANEOPS,
+                                           "lane_ops_per_batch": lane_ops / batches_timed,
+                                           "what": "FP32 multiplies + adds of the blur launches (7R+4 per pixel and level, the reference's unfused arithmetic) over the "
+                                                   "same busy time, against 256 CUs x 64 lanes x 2.4 GHz: the launches of radius >= 10 are bound by this roof, not by HBM"}
         # the whole step against the same peak: every stage's algorithmic bytes over the step's time
         if args.workload == "config4" and not SUBPIXEL:
             out["roofline"]["whole_step"] = whole_step_fraction(nf, W, H, kps / max(args.steps, 1) / max(world, 1), dt / args.steps)

@@ -841,6 +841,28 @@ def test_cpp_dropin_example(ctx, tmp_path):
     assert "kernel longer than line" in out.stderr
 
 
+def test_cpp_dropin_example_large_result(ctx, tmp_path):
+    """examples/sift_points.cpp on a 1920x1080 frame (frame 1 of the bench batch, as an 8-bit PGM): 19 764 keypoints, so
+    sift::Sift::collect (include/sift/sift.hpp) takes its parallel path - the sparse lists expanded by the object's worker threads,
+    each into its own range of InterestPoints - and interstpoints.txt still equals, byte for byte, what main.cpp:78-89 writes for
+    the oracle's points."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "sift_points"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "sift_points.cpp"), "-L" + os.path.join(root, "sift_amd", "lib"),
+                           "-lsift_hip", "-Wl,-rpath," + os.path.join(root, "sift_amd", "lib"), "-o", str(exe)])
+    img = synth_frame(1920, 1080, 1)
+    assert (img == np.round(img)).all() and img.min() >= 0 and img.max() <= 255
+    with open(tmp_path / "frame.pgm", "wb") as f:
+        f.write(b"P5\n1920 1080\n255\n" + img.astype(np.uint8).tobytes())
+    out = subprocess.run([str(exe), "frame.pgm", "4", "3", "0"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    want, run = expected_result_file(tmp_path, img, 3, 4)
+    assert run.points("final")[0].size > 4096          # the parallel path of collect()
+    assert open(tmp_path / "interstpoints.txt", "rb").read() == want
+
+
 def test_cpp_gated_pair_example(ctx, tmp_path):
     """examples/sift_pipeline.cpp: two sift::Sift objects on two threads joined by a gate (sift_hip_gate_*, Sift::join)
     give, frame for frame, the single object's results."""
