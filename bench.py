@@ -236,18 +236,19 @@ def blur_lane_ops(nf, W, H, octaves, dogs, sigma, k):
 
 def whole_step_fraction(nf, W, H, keypoints, seconds):
     """All stages' algorithmic bytes of one step (4 octaves x 3 DoGs) over the step's time, against the 8 TB/s peak, with SURVEY.md
-    section 8(d)'s per-unit figures: pyramid 4 B read + 4 B per level written per pixel (with lazy_top: g(o,1..2) and three DoGs
-    per octave; a reduction reads its source and writes a quarter), gradient maps 12 B per pixel of level (0,0), extremum scan
-    12 B per pixel of every octave's middle DoG, descriptor stages 3.5 KB per keypoint."""
+    section 8(d)'s per-unit figures: pyramid 4 B read + 4 B written per pixel and level (round 5: Gaussian levels only, three per
+    octave; a reduction reads its source and writes a quarter), gradient maps 12 B per pixel of level (0,0), extremum scan 16 B
+    per pixel of every octave (it reads four Gaussian levels and forms the DoGs itself; 12 B when it read three DoG levels and the
+    pyramid wrote them: 7.87 GB per step in all, 7.54 now), descriptor stages 3.5 KB per keypoint."""
     px = [W * H] + [((W + (1 << o) - 1) >> o) * ((H + (1 << o) - 1) >> o) for o in range(1, 4)]
     pyramid = 0.0
     for o in range(4):
         pyramid += px[o] * (8 if o == 0 else 0)          # g(0,0) from the input
-        pyramid += px[o] * (12 + 12 + 8)                 # g(o,1) + dog, g(o,2) + dog, dog(o,2) alone (top level not kept)
+        pyramid += px[o] * (8 + 8 + 8)                   # g(o,1), g(o,2), g(o,3): no DoG level is written (option dog_in_extrema)
         if o < 3:
             pyramid += px[o] * 4 + px[o + 1] * 4         # reduceToNextLevel: source read, kept pixels written
     gradient = px[0] * 12
-    extrema = sum(px) * 12
+    extrema = sum(px) * 16
     descriptors = keypoints / nf * 3584
     total = nf * (pyramid + gradient + extrema + descriptors)
     return {"algorithmic_gbytes_per_step": total / 1e9, "achieved": total / 1e9 / seconds, "frac": total / 1e9 / seconds / HBM_PEAK_GBS,

@@ -93,7 +93,10 @@ void sift_hip_destroy(sift_hip_ctx* ctx);
  * "tail_kernel" (0 default; those octaves as ONE launch of one 1024-thread workgroup per image, sift_amd/csrc/kernels_tail.hip,
  * instead of a launch per level: 1 - for batches of at least 16 images; 2 - whenever the levels fit the kernel.  Both were built
  * and measured in round 5, are bit-exact and do not shorten a step: DESIGN.md section 7).
- * These 17 names are all a release build knows; any other name returns SIFT_HIP_EINVAL.  The measurement build
+ * "dog_in_extrema" (1 default since round 5: the pyramid writes Gaussian levels only - all of them - and the fused extremum scan
+ * fetches four Gaussian levels per scan level and forms its three DoG tiles on the way into LDS, 128.0f + (g[j+1] - g[j]); a DoG
+ * level sift_hip_level_copy is asked for is formed then; 0: every blur launch also writes its DoG level, as in rounds 1 - 4).
+ * These 18 names are all a release build knows; any other name returns SIFT_HIP_EINVAL.  The measurement build
  * (libsift_hip_diag.so: make -C sift_amd/csrc diag, -DSIFT_HIP_DIAG) adds "desc_dbg" / "orient_dbg" (phases of a kernel
  * switched off: timing only, WRONG results), "stream_waves", "diag_repeat", "diag_pyramid_span", "diag_serial_gradient", "diag_skip_tail" and
  * "diag_cleanup_stamps" for the scripts under tools/.  The library reads no environment variable. */

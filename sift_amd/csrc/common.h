@@ -196,7 +196,7 @@ void launch_extrema_scan(hipStream_t s, const DevPlan& plan, int* d_counts, int*
 bool extrema_edge_supported(const DevPlan& plan);
 // scan levels [k_begin, k_end) of the plan (k_end < 0: all the rest)
 void launch_extrema_edge(hipStream_t s, const DevPlan& plan, unsigned long long* d_masks, unsigned long long* d_fmasks,
-                         int* d_counts, int k_begin = 0, int k_end = -1, int busy_cus = 0);
+                         int* d_counts, int k_begin = 0, int k_end = -1, int busy_cus = 0, bool from_gauss = false);
 int resident_cus();   // CUs of the calling thread's device (kernels_pyramid.hip; 256 until sift_hip_create has asked)
 void launch_extrema_expand(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan,
                            const unsigned long long* d_masks, const int* d_offsets, Candidate* d_cands,

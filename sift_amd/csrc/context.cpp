@@ -157,6 +157,12 @@ struct sift_hip_ctx {
     // starts from the level below, sift.cpp:406-409; keypoints never refer to it) - unless it is a gradient level; a caller that
     // asks for it (sift_hip_level_copy) gets it formed then, by the same kernel
     bool lazy_top = true;
+    // option "dog_in_extrema" (round 5): the pyramid writes Gaussian levels only; the fused extremum scan fetches four of them per
+    // scan level and forms its three DoG tiles on the way into LDS (128.0f + (g[j+1] - g[j]): alg::dog's two roundings); a DoG level
+    // a caller asks for (sift_hip_level_copy) or the unfused scan needs is formed then
+    bool dog_in_extrema = true;
+    bool dogs_missing = false;       // this batch's DoG levels have not been written ...
+    std::vector<char> dog_formed;    // ... except the ones a caller has asked for since (sift_hip_level_copy)
     std::vector<char> top_missing;   // per octave: this batch's top Gaussian level has not been formed
     hipEvent_t ev_side_fork = nullptr, ev_side_join = nullptr;
     // option "tail_async" (round 5; measured, NOT the default - DESIGN.md section 7): the octaves from `Plan::tail_from` on - a
@@ -694,16 +700,18 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
                 // next octave's levels (fused kernels only: the two-pass fallback shares a scratch image with them).
                 const bool side = !in_tail && c->pyramid_side && c->ev_side_fork && op.j == D && op.octave + 1 < O && c->fused && op.radius >= 1 &&
                                   op.radius <= kMaxRadiusFused && std::find(P.grad_levels.begin(), P.grad_levels.end(), l) == P.grad_levels.end();
-                const bool skip = c->lazy_top && op.j == D && std::find(P.grad_levels.begin(), P.grad_levels.end(), l) == P.grad_levels.end();
+                const bool no_dogs = c->dogs_missing;   // option dog_in_extrema: every Gaussian level is kept, no DoG level is written
+                const bool skip = !no_dogs && c->lazy_top && op.j == D && std::find(P.grad_levels.begin(), P.grad_levels.end(), l) == P.grad_levels.end();
                 float* g_out = skip ? nullptr : dv.gauss[l];
+                float* dog_out = no_dogs ? nullptr : dv.dog[op.octave * D + op.j - 1];
                 if (skip) c->top_missing[(size_t)op.octave] = 1;
                 if (side) {
                     SIFT_HIP_CHECK(hipEventRecord(c->ev_side_fork, c->stream));
                     SIFT_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_side_fork, 0));
-                    run_blur(c, dv.gauss[l - 1], g_out, dv.dog[op.octave * D + op.j - 1], op.w, op.h, n, op.tap_off, op.radius, c->stream2);
+                    run_blur(c, dv.gauss[l - 1], g_out, dog_out, op.w, op.h, n, op.tap_off, op.radius, c->stream2);
                     side_used = true;
                 } else {
-                    run_blur(c, dv.gauss[l - 1], g_out, dv.dog[op.octave * D + op.j - 1], op.w, op.h, n, op.tap_off, op.radius, ms);
+                    run_blur(c, dv.gauss[l - 1], g_out, dog_out, op.w, op.h, n, op.tap_off, op.radius, ms);
                     if (!in_tail) early_w16(c, l);   // (no gradient level lies in the tail)
                 }
                 break;
@@ -1214,6 +1222,8 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
         c->tail_pending = false;
     }
     c->tail_in_kernel = false;
+    c->dog_formed.clear();
+    c->dogs_missing = c->dog_in_extrema && c->fused && c->fused_edge && extrema_edge_supported(dv) && !c->tail_async && c->tail_kernel == 0;
     run_pyramid(c, d_in);
     SIFT_HIP_CHECK(hipGetLastError());   // a rejected launch configuration must not go unnoticed
     if (c->gate) {
@@ -1259,9 +1269,10 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
         if (c->tail_pending)
             for (int k = dv.n_scan - 1; k >= 0 && dv.scan_octave[k] >= P.tail_from; --k) k_split = k;
         launch_extrema_edge(s, dv, c->d_masks.as<unsigned long long>(), c->d_fmasks.as<unsigned long long>(), c->d_counts.as<int>(), 0, k_split,
-                            c->tail_in_kernel ? n : 0);
+                            c->tail_in_kernel ? n : 0, c->dogs_missing);
         join_tail();
-        launch_extrema_edge(s, dv, c->d_masks.as<unsigned long long>(), c->d_fmasks.as<unsigned long long>(), c->d_counts.as<int>(), k_split, dv.n_scan);
+        launch_extrema_edge(s, dv, c->d_masks.as<unsigned long long>(), c->d_fmasks.as<unsigned long long>(), c->d_counts.as<int>(), k_split, dv.n_scan,
+                            0, c->dogs_missing);
         launch_extrema_scan(s, dv, c->d_counts.as<int>(), c->d_totals.as<int>());
         launch_extrema_expand(s, dpl, dv, c->d_masks.as<unsigned long long>(), c->d_counts.as<int>(), c->d_cands.as<Candidate>(),
                               c->d_fmasks.as<unsigned long long>(), c->d_flags.as<uint8_t>());
@@ -1507,6 +1518,7 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
         return SIFT_HIP_OK;
     }
     if (!std::strcmp(name, "lazy_top")) { c->lazy_top = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "dog_in_extrema")) { c->dog_in_extrema = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "tail_async")) { c->tail_async = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "tail_kernel")) {
         if (value < 0 || value > 2) return SIFT_HIP_EINVAL;
@@ -1998,6 +2010,30 @@ int sift_hip_level_copy(sift_hip_ctx* c, int image, int kind, int octave, int le
                 c->top_missing[(size_t)octave] = 0;
             }
             if (c->top_missing[(size_t)octave]) return (int)SIFT_HIP_EINVAL;   // the pyramid stopped before this level (precondition)
+        }
+        if (kind == 1 && c->dogs_missing) {
+            // option "dog_in_extrema": the batch wrote no DoG level (the extremum scan forms its tiles from the Gaussian levels);
+            // this one is formed now, by alg::dog's own kernel, from the two Gaussian levels it lies between
+            const Plan& P = c->plan;
+            const size_t di = (size_t)(octave * P.D + level);
+            if (c->dog_formed.size() != (size_t)(P.O * P.D)) c->dog_formed.assign((size_t)(P.O * P.D), 0);
+            if (!c->dog_formed[di]) {
+                auto formed = [&](int j) {   // did the batch's pyramid reach g(octave, j)?
+                    for (size_t k = 0; k < P.ops.size() && k < P.fail_op; ++k) {
+                        const BlurOp& op = P.ops[k];
+                        if (j == 0 ? ((octave == 0 && op.kind == 1) || (octave > 0 && op.kind == 3 && op.octave == octave - 1))
+                                   : (op.kind == 2 && op.octave == octave && op.j == j))
+                            return true;
+                    }
+                    return false;
+                };
+                if (!formed(level) || !formed(level + 1)) return (int)SIFT_HIP_EINVAL;   // the pyramid stopped before this level (precondition)
+                const int gl = octave * (P.D + 1) + level;
+                launch_dog(c->stream, P.dev.gauss[gl], P.dev.gauss[gl + 1], P.dev.dog[di], (size_t)w * (size_t)h * (size_t)P.n);
+                SIFT_HIP_CHECK(hipGetLastError());
+                SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
+                c->dog_formed[di] = 1;
+            }
         }
         const size_t px = (size_t)w * (size_t)h;
         SIFT_HIP_CHECK(hipMemcpy(out, p + (size_t)image * px, px * sizeof(float), hipMemcpyDeviceToHost));

@@ -312,6 +312,7 @@ struct FxLevel {
     const float* d0;
     const float* d1;
     const float* d2;
+    const float* d3;   // FROM_GAUSS: d0 .. d3 are four Gaussian levels, the three DoG tiles are formed on the way into LDS
     int w, h, nyb, word_base, tiles_x, tiles_img, tile_begin, pad;
 };
 struct FxPlan {
@@ -319,7 +320,8 @@ struct FxPlan {
     FxLevel lv[kFxMaxLevels];
 };
 
-__global__ __launch_bounds__(256) void extrema_edge_kernel(FxPlan plan, unsigned long long* __restrict__ masks,
+template <bool FROM_GAUSS>
+__global__ __launch_bounds__(256, 4) void extrema_edge_kernel(FxPlan plan, unsigned long long* __restrict__ masks,
                                                            unsigned long long* __restrict__ fmasks,
                                                            int* __restrict__ counts) {
     const int total_tiles = plan.total_tiles, words_per_image = plan.words_per_image;
@@ -352,9 +354,10 @@ __global__ __launch_bounds__(256) void extrema_edge_kernel(FxPlan plan, unsigned
     static_assert(kFxLoads == 3, "the prefetch registers are spelled out (an array here ends up in scratch memory)");
     const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float4 pa0 = z4, pa1 = z4, pa2 = z4, pb0 = z4, pb1 = z4, pb2 = z4, pc0 = z4, pc1 = z4, pc2 = z4;
+    float4 pd0 = z4, pd1 = z4, pd2 = z4;   // FROM_GAUSS: the fourth level
     // tile: rows ya-1 .. ya+64, columns x0-4 .. x0+35 as 16-byte groups (w is a multiple of 4 here).  Rows
     // and groups outside the image are clamped; clamped samples are only read by non-candidates.
-#define SIFT_FX_LOAD(I, A, B, C)                                                                     \
+#define SIFT_FX_LOAD(I, A, B, C, D)                                                                  \
     {                                                                                                \
         const int e = tid + 256 * (I);                                                               \
         if (e < kFxRows * kFxRow4) {                                                                 \
@@ -366,6 +369,7 @@ __global__ __launch_bounds__(256) void extrema_edge_kernel(FxPlan plan, unsigned
             A = *reinterpret_cast<const float4*>(d0 + o);                                            \
             B = *reinterpret_cast<const float4*>(d1 + o);                                            \
             C = *reinterpret_cast<const float4*>(d2 + o);                                            \
+            if (FROM_GAUSS) D = *reinterpret_cast<const float4*>(d3 + o);                            \
         }                                                                                            \
     }
 #define SIFT_FX_LOAD_TILE(TILE)                                                                      \
@@ -374,19 +378,27 @@ __global__ __launch_bounds__(256) void extrema_edge_kernel(FxPlan plan, unsigned
         const float* __restrict__ d0 = lv_.d0;                                                       \
         const float* __restrict__ d1 = lv_.d1;                                                       \
         const float* __restrict__ d2 = lv_.d2;                                                       \
+        const float* __restrict__ d3 = lv_.d3;                                                       \
         const int w = lv_.w, h = lv_.h, tl_ = (TILE) - lv_.tile_begin;                               \
         const int img_ = tl_ / lv_.tiles_img, rem_ = tl_ - img_ * lv_.tiles_img;                     \
         const int yb_ = rem_ / lv_.tiles_x, x0_ = (rem_ - yb_ * lv_.tiles_x) * kFxCols, ya_ = yb_ * 64; \
         const size_t img_off_ = (size_t)img_ * (size_t)w * (size_t)h;                                \
-        SIFT_FX_LOAD(0, pa0, pb0, pc0) SIFT_FX_LOAD(1, pa1, pb1, pc1) SIFT_FX_LOAD(2, pa2, pb2, pc2) \
+        SIFT_FX_LOAD(0, pa0, pb0, pc0, pd0) SIFT_FX_LOAD(1, pa1, pb1, pc1, pd1) SIFT_FX_LOAD(2, pa2, pb2, pc2, pd2) \
     }
-#define SIFT_FX_STORE(I, A, B, C)                                                                    \
+#define SIFT_FX_DOG(H, L) make_float4(128.0f + ((H).x - (L).x), 128.0f + ((H).y - (L).y), 128.0f + ((H).z - (L).z), 128.0f + ((H).w - (L).w))
+#define SIFT_FX_STORE(I, A, B, C, D)                                                                 \
     {                                                                                                \
         const int e = tid + 256 * (I);                                                               \
         if (e < kFxRows * kFxRow4) { /* r * kFxPitch + 4 * c4 == 4 * e */                            \
-            *reinterpret_cast<float4*>(&s_t[0][4 * e]) = A;                                          \
-            *reinterpret_cast<float4*>(&s_t[1][4 * e]) = B;                                          \
-            *reinterpret_cast<float4*>(&s_t[2][4 * e]) = C;                                          \
+            if (FROM_GAUSS) {   /* alg::dog (algorithms.cpp:52-64): 128 + (higher - lower), two roundings */ \
+                *reinterpret_cast<float4*>(&s_t[0][4 * e]) = SIFT_FX_DOG(B, A);                      \
+                *reinterpret_cast<float4*>(&s_t[1][4 * e]) = SIFT_FX_DOG(C, B);                      \
+                *reinterpret_cast<float4*>(&s_t[2][4 * e]) = SIFT_FX_DOG(D, C);                      \
+            } else {                                                                                 \
+                *reinterpret_cast<float4*>(&s_t[0][4 * e]) = A;                                      \
+                *reinterpret_cast<float4*>(&s_t[1][4 * e]) = B;                                      \
+                *reinterpret_cast<float4*>(&s_t[2][4 * e]) = C;                                      \
+            }                                                                                        \
         }                                                                                            \
     }
     if (t < t_end) SIFT_FX_LOAD_TILE(t)
@@ -396,7 +408,7 @@ __global__ __launch_bounds__(256) void extrema_edge_kernel(FxPlan plan, unsigned
         const int tl = t - lv.tile_begin;
         const int img = tl / tiles_img, rem = tl - img * tiles_img;
         const int yb = rem / tiles_x, x0 = (rem - yb * tiles_x) * kFxCols, ya = yb * 64;
-        SIFT_FX_STORE(0, pa0, pb0, pc0) SIFT_FX_STORE(1, pa1, pb1, pc1) SIFT_FX_STORE(2, pa2, pb2, pc2)
+        SIFT_FX_STORE(0, pa0, pb0, pc0, pd0) SIFT_FX_STORE(1, pa1, pb1, pc1, pd1) SIFT_FX_STORE(2, pa2, pb2, pc2, pd2)
         if (tid < kFxCols) { s_fm[tid] = 0ull; s_cm[tid] = 0ull; }
         if (tid < 4) s_qn[tid] = 0;
         if (tid == 4) s_n2 = 0;
@@ -618,7 +630,7 @@ bool extrema_edge_supported(const DevPlan& plan) {
 }
 
 void launch_extrema_edge(hipStream_t s, const DevPlan& plan, unsigned long long* d_masks, unsigned long long* d_fmasks,
-                         int* d_counts, int k_begin, int k_end, int busy_cus) {
+                         int* d_counts, int k_begin, int k_end, int busy_cus, bool from_gauss) {
     if (k_end < 0 || k_end > plan.n_scan) k_end = plan.n_scan;
     // persistent workgroups, 4 per CU, with EQUAL shares of the tiles: a workgroup that finds no CU free starts when the
     // others end and doubles the launch's time - so the grid leaves out the CUs another kernel is known to hold (the
@@ -636,7 +648,12 @@ void launch_extrema_edge(hipStream_t s, const DevPlan& plan, unsigned long long*
             const int o = plan.scan_octave[k], i = plan.scan_dog[k];
             const int l = o * plan.dogs + i;
             FxLevel& lv = fp.lv[fp.n_levels];
-            lv.d0 = plan.dog[l - 1]; lv.d1 = plan.dog[l]; lv.d2 = plan.dog[l + 1];
+            if (from_gauss) {   // DoG level j of the octave = 128 + (g[j + 1] - g[j]): the scan of (o, i) reads g(o, i-1 .. i+2)
+                const int gl = o * (plan.dogs + 1) + i;
+                lv.d0 = plan.gauss[gl - 1]; lv.d1 = plan.gauss[gl]; lv.d2 = plan.gauss[gl + 1]; lv.d3 = plan.gauss[gl + 2];
+            } else {
+                lv.d0 = plan.dog[l - 1]; lv.d1 = plan.dog[l]; lv.d2 = plan.dog[l + 1]; lv.d3 = nullptr;
+            }
             lv.w = plan.w[o]; lv.h = plan.h[o]; lv.nyb = plan.scan_nyb[k]; lv.word_base = plan.scan_word_base[k];
             lv.tiles_x = (lv.w + kFxCols - 1) / kFxCols;
             lv.tiles_img = lv.tiles_x * lv.nyb;
@@ -650,7 +667,8 @@ void launch_extrema_edge(hipStream_t s, const DevPlan& plan, unsigned long long*
         fp.total_tiles = (int)total;
         int grid = total < cap ? (int)total : cap;
         if (grid >= 8) grid &= ~7;
-        hipLaunchKernelGGL(extrema_edge_kernel, dim3((unsigned)grid), dim3(256), 0, s, fp, d_masks, d_fmasks, d_counts);
+        if (from_gauss) hipLaunchKernelGGL((extrema_edge_kernel<true>), dim3((unsigned)grid), dim3(256), 0, s, fp, d_masks, d_fmasks, d_counts);
+        else hipLaunchKernelGGL((extrema_edge_kernel<false>), dim3((unsigned)grid), dim3(256), 0, s, fp, d_masks, d_fmasks, d_counts);
     }
 }
 

@@ -362,6 +362,21 @@ def test_pipeline_parity_tail_kernel(ctx, report_dir, case):
         ctx.set_option("tail_async", 0)
 
 
+@pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[4]], ids=[CASES[1][0], CASES[2][0], CASES[4][0]])
+def test_pipeline_parity_dog_levels_written_by_the_pyramid(ctx, report_dir, case):
+    """Round 5's default leaves the DoG levels to the extremum scan (option dog_in_extrema: the pyramid writes Gaussian levels only, a
+    DoG level a caller asks for is formed then - which is what every other test's level comparison goes through).  The form of
+    rounds 1 - 4 - every blur launch writes its DoG level, the top Gaussian level of an octave is not kept - stays an option and is
+    compared here in full: levels, stage lists, descriptors."""
+    name, w, h, seed, dogs, octaves, subpixel = case
+    ctx.set_option("dog_in_extrema", 0)
+    try:
+        rep = compare_run(ctx, synth_frame(w, h, seed), dogs, octaves, subpixel, name + " [dog_in_extrema = 0]", report_dir, batch_of=2)
+        assert rep["final"] > 0
+    finally:
+        ctx.set_option("dog_in_extrema", 1)
+
+
 def test_top_gaussian_level_formed_on_demand(ctx):
     """Option lazy_top (default on): the launch that forms an octave's top Gaussian level stores its DoG only - nothing on the
     path reads the level again (sift.cpp:406-409) - and sift_hip_level_copy forms the level when asked.  Same keypoints and
@@ -370,6 +385,7 @@ def test_top_gaussian_level_formed_on_demand(ctx):
     frames = np.stack([synth_frame(640, 480, 70 + i) for i in range(3)])
     params = _lib.Params(4, 2, 1.6, O.K_SQRT2, 0)   # 4 DoGs per octave (Gaussian levels 0 .. 4), 2 octaves
     ctx.set_option("stream_min_waves", 1)
+    ctx.set_option("dog_in_extrema", 0)   # (with round 5's default the pyramid keeps every Gaussian level: nothing is lazy then)
     try:
         ctx.set_option("lazy_top", 0)
         ctx.calculate_batch(frames, params)
@@ -390,6 +406,7 @@ def test_top_gaussian_level_formed_on_demand(ctx):
             assert_bits_equal(ctx.level("gaussian", o, 4, 1), run.level("gaussian", o, 4), f"gaussian({o},4)")
     finally:
         ctx.set_option("lazy_top", 1)
+        ctx.set_option("dog_in_extrema", 1)
         ctx.set_option("stream_min_waves", 0)
 
 
@@ -1093,7 +1110,7 @@ def test_cli_result_file(ctx, tmp_path, monkeypatch):
     assert cli.main(["parrot_r.pgm", "--no-overlay"]) == 0 and not os.path.exists(tmp_path / "interstpoints.txt")
 
 
-@pytest.mark.parametrize("option", ["gate_schedule=0", "pyramid_side=0"])
+@pytest.mark.parametrize("option", ["gate_schedule=0", "pyramid_side=0", "dog_in_extrema=0"])
 def test_other_gate_schedules_leave_the_results_alone(ctx, option):
     """The other orders of the phase gate (sift_amd/csrc/phase_gate.h: schedule 0 keeps the pyramids alone on the chip) and the
     pyramid without its side stream (every launch on one stream) are options: same results."""

@@ -9,6 +9,8 @@ The plan (which blur runs on which level, with which radius) is rebuilt here fro
 Sift::_createDOGs schedules it (/root/reference/sift.cpp:388-411; radius = (int)(3 sigma + 0.5), Vigra initGaussian), and
 every launch is priced at its ALGORITHMIC bytes:
     g(0,0)                        4 B read + 4 B written per pixel                      8 N
+    level blur (round 5)          4 B read + 4 B written: no DoG level is written any more   8 N
+                                  (option dog_in_extrema, the default; --dog-in-extrema 0 prices the old plan:)
     level blur + DoG              4 B read + 4 B + 4 B written                          12 N
     top level of an octave        4 B read + 4 B written: the DoG only (option lazy_top,  8 N
                                   the default since round 4; --lazy-top 0 prices the old 12 N)
@@ -28,7 +30,7 @@ import numpy as np
 PEAK = 8000.0  # GB/s
 
 
-def plan(w, h, n, dogs, octaves, sigma, k, subpixel, lazy_top=True):
+def plan(w, h, n, dogs, octaves, sigma, k, subpixel, lazy_top=True, dog_in_extrema=True):
     """[(what, octave, level, radius, pixels per launch, algorithmic bytes if fused, ... unfused)]"""
     ops = []
     f32 = np.float32
@@ -53,7 +55,9 @@ def plan(w, h, n, dogs, octaves, sigma, k, subpixel, lazy_top=True):
     for o in range(octaves):
         px = ws[o] * hs[o] * n
         for j in range(1, dogs + 1):
-            if j == dogs and lazy_top:   # the top Gaussian level only feeds this DoG and is not written (context.cpp: lazy_top)
+            if dog_in_extrema:   # round 5's default: the pyramid writes Gaussian levels only, every level of them (context.cpp: dog_in_extrema)
+                ops.append((f"g({o},{j})", o, j, rad(gs[(o, j)]), px, 8.0 * px, 8.0 * px))
+            elif j == dogs and lazy_top:   # the top Gaussian level only feeds this DoG and is not written (context.cpp: lazy_top)
                 ops.append((f"dog({o},{j - 1}) [g({o},{j}) not kept]", o, j, rad(gs[(o, j)]), px, 8.0 * px, 8.0 * px))
             else:
                 ops.append((f"g({o},{j}) + dog({o},{j - 1})", o, j, rad(gs[(o, j)]), px, 12.0 * px, 12.0 * px))
@@ -83,13 +87,14 @@ def main():
     ap.add_argument("--h", type=int, default=1080)
     ap.add_argument("--n", type=int, default=32)
     ap.add_argument("--lazy-top", type=int, default=1, choices=[0, 1])
+    ap.add_argument("--dog-in-extrema", type=int, default=1, choices=[0, 1], help="1 (round 5's default): no blur launch writes a DoG level, 8 B per pixel each")
     ap.add_argument("--dogs", type=int, default=3)
     ap.add_argument("--octaves", type=int, default=4)
     ap.add_argument("--sigma", type=float, default=1.6)
     ap.add_argument("--k", type=float, default=float(np.float32(np.sqrt(2.0))))
     ap.add_argument("--subpixel", type=int, default=0)
     a = ap.parse_args()
-    ops = plan(a.w, a.h, a.n, a.dogs, a.octaves, a.sigma, a.k, a.subpixel, bool(a.lazy_top))
+    ops = plan(a.w, a.h, a.n, a.dogs, a.octaves, a.sigma, a.k, a.subpixel, bool(a.lazy_top), bool(a.dog_in_extrema))
     per_step_bytes = None
 
     if a.stats:
