@@ -25,7 +25,11 @@ timeout 900 python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> /dev/null
 timeout 600 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --pipeline-depth 1 > $O/bench_depth1.json 2> /dev/null
 timeout 600 python3 bench.py --workload config3 --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_config3.json 2> /dev/null
 timeout 600 python3 bench.py --workload config5 --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_config5.json 2> /dev/null
-timeout 600 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --rccl-loopback > $O/bench_rccl_loopback.json 2> $O/bench_rccl_loopback.err
+for try in 1 2 3; do   # (the first RCCL start of a box sometimes ends without a line: once more then)
+  timeout 600 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --rccl-loopback > $O/bench_rccl_loopback.json 2> $O/bench_rccl_loopback.err
+  [ -s $O/bench_rccl_loopback.json ] && break
+  echo "attempt $try: exit $?" >> $O/bench_rccl_loopback.err; sleep 5
+done
 # 3b. the host-buffer loop: kernels and copies of three batches in flight
 rm -rf gpurun_out/htrace
 timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/htrace -- python3 tools/host_trace.py 3 main > $O/host_trace.txt 2>/dev/null
