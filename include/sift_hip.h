@@ -96,7 +96,10 @@ void sift_hip_destroy(sift_hip_ctx* ctx);
  * "dog_in_extrema" (1 default since round 5: the pyramid writes Gaussian levels only - all of them - and the fused extremum scan
  * fetches four Gaussian levels per scan level and forms its three DoG tiles on the way into LDS, 128.0f + (g[j+1] - g[j]); a DoG
  * level sift_hip_level_copy is asked for is formed then; 0: every blur launch also writes its DoG level, as in rounds 1 - 4).
- * These 18 names are all a release build knows; any other name returns SIFT_HIP_EINVAL.  The measurement build
+ * "blur_pair" (1 default since round 5: g(0,0) and g(0,1) - two blurs with the same taps, the second of the first's result -
+ * are ONE launch whose second stage takes the first stage's rows from LDS, sift_amd/csrc/kernels_pair.hip; needs dog_in_extrema and a
+ * batch that fills the chip, else and with 0: two launches), "pair_waves" (waves that launch is cut into; 0 = the default 1536).
+ * These 20 names are all a release build knows; any other name returns SIFT_HIP_EINVAL.  The measurement build
  * (libsift_hip_diag.so: make -C sift_amd/csrc diag, -DSIFT_HIP_DIAG) adds "desc_dbg" / "orient_dbg" (phases of a kernel
  * switched off: timing only, WRONG results), "stream_waves", "diag_repeat", "diag_pyramid_span", "diag_serial_gradient", "diag_skip_tail" and
  * "diag_cleanup_stamps" for the scripts under tools/.  The library reads no environment variable. */

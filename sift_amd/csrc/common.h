@@ -182,6 +182,11 @@ void launch_io_copy(hipStream_t s, const void* src, void* dst, size_t bytes);   
 void launch_zero_ints(hipStream_t s, int* p, size_t n);
 // one empty launch per translation unit: makes the runtime build that unit's device code (see kernels_*.hip, sift_hip_create)
 void tu_touch_pyramid(hipStream_t s);
+void tu_touch_pair(hipStream_t s);
+// g0 = blur(in) and g1 = blur(g0) in one launch (kernels_pair.hip); false: not a shape that kernel takes
+bool launch_blur_pair(hipStream_t s, const float* in, float* g0, float* g1, int w, int h, int n, const float* taps,
+                      int radius, int min_waves, hipEvent_t ev_start, hipEvent_t ev_stop);
+void set_pair_waves(int v);  // <= 0 restores the default
 void tu_touch_reduce(hipStream_t s);
 void tu_touch_extrema(hipStream_t s);
 void tu_touch_orient(hipStream_t s);

@@ -161,6 +161,10 @@ struct sift_hip_ctx {
     // scan level and forms its three DoG tiles on the way into LDS (128.0f + (g[j+1] - g[j]): alg::dog's two roundings); a DoG level
     // a caller asks for (sift_hip_level_copy) or the unfused scan needs is formed then
     bool dog_in_extrema = true;
+    // option "blur_pair" (round 5, default on): the first two levels of the pyramid, g(0,0) and g(0,1), in one launch (kernels_pair.hip:
+    // the second blur reads the first one's rows from LDS) - when no DoG level is written (dog_in_extrema), the two levels share
+    // their taps and the batch fills the chip; otherwise two launches as before
+    bool blur_pair = true;
     bool dogs_missing = false;       // this batch's DoG levels have not been written ...
     std::vector<char> dog_formed;    // ... except the ones a caller has asked for since (sift_hip_level_copy)
     std::vector<char> top_missing;   // per octave: this batch's top Gaussian level has not been formed
@@ -689,10 +693,30 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
                 base = c->d_base.as<float>();
                 break;
             }
-            case 1:
+            case 1: {
+                // option "blur_pair": g(0,0) and g(0,1) in one launch (kernels_pair.hip) when no DoG level is written; the
+                // second blur then reads g(0,0) from LDS instead of HBM
+                if (c->blur_pair && c->fused && c->dogs_missing && k + 1 < P.ops.size() && k + 1 < P.fail_op) {
+                    const BlurOp& nx = P.ops[k + 1];
+                    if (nx.kind == 2 && nx.octave == 0 && nx.j == 1 && nx.radius == op.radius && nx.w == op.w && nx.h == op.h &&
+                        std::memcmp(P.taps.data() + op.tap_off, P.taps.data() + nx.tap_off, sizeof(float) * (size_t)(2 * op.radius + 1)) == 0) {
+                        hipEvent_t a = nullptr, b = nullptr;
+                        if (c->profile) { a = get_event(c); b = get_event(c); }
+                        if (launch_blur_pair(c->stream, base, dv.gauss[0], dv.gauss[1], op.w, op.h, n, c->d_taps.as<float>() + op.tap_off,
+                                             op.radius, stream_min_waves_now(), a, b)) {
+                            if (c->profile) c->pending.push_back({a, b, 0, (double)op.w * (double)op.h * (double)n * 12.0});   // one read, two levels written
+                            early_w16(c, 0);
+                            early_w16(c, 1);
+                            ++k;   // the next op was this launch's second half
+                            break;
+                        }
+                        if (c->profile) { c->event_pool.push_back(a); c->event_pool.push_back(b); }
+                    }
+                }
                 run_blur(c, base, dv.gauss[0], nullptr, op.w, op.h, n, op.tap_off, op.radius);
                 early_w16(c, 0);
                 break;
+            }
             case 2: {
                 const int l = op.octave * (D + 1) + op.j;
                 // The top level of an octave only feeds the octave's last DoG; the next octave starts from the level below it
@@ -1403,7 +1427,7 @@ int sift_hip_create(int device, sift_hip_ctx** out, char* err, int errlen) {
             static bool touched[64] = {false};
             std::lock_guard<std::mutex> lk(touch_lock);
             if (device < 64 && !touched[device]) {
-                tu_touch_pyramid(c->stream); tu_touch_tail(c->stream); tu_touch_reduce(c->stream); tu_touch_extrema(c->stream); tu_touch_orient(c->stream);
+                tu_touch_pyramid(c->stream); tu_touch_pair(c->stream); tu_touch_tail(c->stream); tu_touch_reduce(c->stream); tu_touch_extrema(c->stream); tu_touch_orient(c->stream);
                 tu_touch_desc(c->stream); tu_touch_cleanup(c->stream); tu_touch_wire(c->stream); tu_touch_io(c->stream);
                 SIFT_HIP_CHECK(hipGetLastError());
                 SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -1547,6 +1571,8 @@ int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     if (!std::strcmp(name, "profile")) { c->profile_every = value > 0 ? value : 0; c->profile_batches = 0; c->profile = false; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "orient_general")) { c->orient_general = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "stream_min_waves")) { set_stream_min_waves(value); return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "blur_pair")) { c->blur_pair = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "pair_waves")) { set_pair_waves(value); return SIFT_HIP_OK; }
     if (!std::strcmp(name, "host_threads")) { c->host_threads = value; return SIFT_HIP_OK; }
 #ifdef SIFT_HIP_DIAG
     // Measurement aids of tools/ (`make -C sift_amd/csrc diag` -> libsift_hip_diag.so): phases of kernels switched off for timing

@@ -167,9 +167,9 @@ CASES = [
 ]
 
 
-def compare_run(ctx, img, dogs, octaves, subpixel, name, report_dir, batch_of=1):
-    params = _lib.Params(dogs, octaves, 1.6, O.K_SQRT2, 1 if subpixel else 0)
-    run = O.OracleRun(img, dogs, octaves, subpixel=subpixel)
+def compare_run(ctx, img, dogs, octaves, subpixel, name, report_dir, batch_of=1, sigma=1.6):
+    params = _lib.Params(dogs, octaves, sigma, O.K_SQRT2, 1 if subpixel else 0)
+    run = O.OracleRun(img, dogs, octaves, sigma=sigma, subpixel=subpixel)
     assert run.status == 0, run.error
     imgs = np.stack([img] * batch_of)
     ctx.calculate_batch(imgs, params)
@@ -360,6 +360,39 @@ def test_pipeline_parity_tail_kernel(ctx, report_dir, case):
     finally:
         ctx.set_option("tail_kernel", 0)
         ctx.set_option("tail_async", 0)
+
+
+PAIR_CASES = [
+    # name, w, h, seed, dogs, octaves, subpixel, frames, sigma
+    ("pair 640x480 (three strips, the last pulled left)", 640, 480, 1, 3, 4, False, 2, 1.6),
+    ("pair 240x100 (one strip, both edges in it)", 240, 100, 2, 3, 2, False, 1, 1.6),
+    ("pair 244x120 (second strip 4 columns in: a left halo partly outside)", 244, 120, 3, 3, 2, False, 2, 1.6),
+    ("pair 484x200 (middle strip's right halo outside the image)", 484, 200, 4, 3, 2, False, 1, 1.6),
+    ("pair 320x240 subpixel (the doubled image is the input)", 320, 240, 5, 3, 3, True, 1, 1.6),
+    ("pair 1920x1080 config 3's frame", 1920, 1080, 6, 3, 4, False, 2, 1.6),
+    ("pair 400x300 sigma 1.0 (radius 3)", 400, 300, 7, 3, 2, False, 1, 1.0),
+    ("pair 400x300 sigma 1.3 (radius 4)", 400, 300, 8, 3, 2, False, 2, 1.3),
+    ("pair 400x1000 sigma 2.0 (radius 6, tall: many chunks)", 400, 1000, 9, 4, 2, False, 1, 2.0),
+]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES, ids=[c[0] for c in PAIR_CASES])
+def test_pipeline_parity_first_two_levels_in_one_launch(ctx, report_dir, case):
+    """Option blur_pair (default on; taken by batches that fill the chip): g(0,0) and g(0,1) from one launch (kernels_pair.hip: the
+    second blur reads the first one's rows from LDS, reflected columns and rows included), forced onto small inputs and cut into
+    many chunks: every level, stage list and the descriptors against the oracle."""
+    name, w, h, seed, dogs, octaves, subpixel, frames, sigma = case
+    ctx.set_option("blur_pair", 1)
+    ctx.set_option("stream_min_waves", 1)
+    ctx.set_option("pair_waves", 64 * frames)
+    try:
+        rep = compare_run(ctx, synth_frame(w, h, seed), dogs, octaves, subpixel, name, report_dir, batch_of=frames, sigma=sigma)
+        assert rep["final"] > 0
+        ctx.set_option("pair_waves", 0)
+        compare_run(ctx, synth_frame(w, h, seed), dogs, octaves, subpixel, name + " [default cut]", report_dir, batch_of=frames, sigma=sigma)
+    finally:
+        ctx.set_option("stream_min_waves", 0)
+        ctx.set_option("pair_waves", 0)
 
 
 @pytest.mark.parametrize("case", [CASES[1], CASES[2], CASES[4]], ids=[CASES[1][0], CASES[2][0], CASES[4][0]])

@@ -30,7 +30,7 @@ import numpy as np
 PEAK = 8000.0  # GB/s
 
 
-def plan(w, h, n, dogs, octaves, sigma, k, subpixel, lazy_top=True, dog_in_extrema=True):
+def plan(w, h, n, dogs, octaves, sigma, k, subpixel, lazy_top=True, dog_in_extrema=True, blur_pair=True):
     """[(what, octave, level, radius, pixels per launch, algorithmic bytes if fused, ... unfused)]"""
     ops = []
     f32 = np.float32
@@ -51,10 +51,17 @@ def plan(w, h, n, dogs, octaves, sigma, k, subpixel, lazy_top=True, dog_in_extre
             gs[(i + 1, 0)] = gs[(i, dogs - 1)]
             exp -= 2
     rad = lambda s: max(1, int(3.0 * float(s) + 0.5))  # noqa: E731
-    ops.append(("g(0,0)", 0, 0, rad(gs[(0, 0)]), ws[0] * hs[0] * n, 8.0 * ws[0] * hs[0] * n, 8.0 * ws[0] * hs[0] * n))
+    # option blur_pair (with dog_in_extrema): the first two levels are one launch, one read and two levels written (kernels_pair.hip)
+    pair = blur_pair and dog_in_extrema and rad(gs[(0, 0)]) == rad(gs[(0, 1)]) and 3 <= rad(gs[(0, 0)]) <= 6
+    if pair:
+        ops.append(("pair: g(0,0) and g(0,1)", 0, 0, rad(gs[(0, 0)]), ws[0] * hs[0] * n, 12.0 * ws[0] * hs[0] * n, 12.0 * ws[0] * hs[0] * n))
+    else:
+        ops.append(("g(0,0)", 0, 0, rad(gs[(0, 0)]), ws[0] * hs[0] * n, 8.0 * ws[0] * hs[0] * n, 8.0 * ws[0] * hs[0] * n))
     for o in range(octaves):
         px = ws[o] * hs[o] * n
         for j in range(1, dogs + 1):
+            if pair and o == 0 and j == 1:
+                continue
             if dog_in_extrema:   # round 5's default: the pyramid writes Gaussian levels only, every level of them (context.cpp: dog_in_extrema)
                 ops.append((f"g({o},{j})", o, j, rad(gs[(o, j)]), px, 8.0 * px, 8.0 * px))
             elif j == dogs and lazy_top:   # the top Gaussian level only feeds this DoG and is not written (context.cpp: lazy_top)
@@ -71,6 +78,9 @@ def parse_name(name):
     m = re.search(r"blur_reduce_kernel<(\d+), (\d+)>", name)   # reduceToNextLevel, kept pixels only (kernels_reduce.hip)
     if m:
         return {"form": "reduce", "R": int(m.group(1)), "dog": False, "dec": True}
+    m = re.search(r"blur_pair_kernel<(\d+)>", name)   # the first two levels in one launch (kernels_pair.hip)
+    if m:
+        return {"form": "pair", "R": int(m.group(1)), "dog": False, "dec": False}
     m = re.search(r"blur_(stream|fused)_kernel<(\d+), (true|false)(?:, (\d+))?(?:, (true|false))?>", name)
     if not m:
         return None
@@ -88,13 +98,14 @@ def main():
     ap.add_argument("--n", type=int, default=32)
     ap.add_argument("--lazy-top", type=int, default=1, choices=[0, 1])
     ap.add_argument("--dog-in-extrema", type=int, default=1, choices=[0, 1], help="1 (round 5's default): no blur launch writes a DoG level, 8 B per pixel each")
+    ap.add_argument("--blur-pair", type=int, default=1, choices=[0, 1], help="1 (the default build): g(0,0) and g(0,1) are one launch, 12 B per pixel")
     ap.add_argument("--dogs", type=int, default=3)
     ap.add_argument("--octaves", type=int, default=4)
     ap.add_argument("--sigma", type=float, default=1.6)
     ap.add_argument("--k", type=float, default=float(np.float32(np.sqrt(2.0))))
     ap.add_argument("--subpixel", type=int, default=0)
     a = ap.parse_args()
-    ops = plan(a.w, a.h, a.n, a.dogs, a.octaves, a.sigma, a.k, a.subpixel, bool(a.lazy_top), bool(a.dog_in_extrema))
+    ops = plan(a.w, a.h, a.n, a.dogs, a.octaves, a.sigma, a.k, a.subpixel, bool(a.lazy_top), bool(a.dog_in_extrema), bool(a.blur_pair))
     per_step_bytes = None
 
     if a.stats:
@@ -143,6 +154,8 @@ def main():
                 p = parse_name(name)
                 def fits(op):
                     has_dog, is_reduce = "dog(" in op[0], op[0].startswith("reduce")
+                    if (p["form"] == "pair") != op[0].startswith("pair"):
+                        return False
                     return op[3] == p["R"] and ((p["dog"] and has_dog) or (p["dec"] and is_reduce) or (not p["dog"] and not p["dec"] and not has_dog))
                 k = next((i for i in free if fits(ops[i])), None)
                 assert k is not None, f"{name} matches no launch of the plan that is still open in its pyramid"
