@@ -156,7 +156,8 @@ def pmc_traffic_live(extra_args):  # noqa: C901
             s, n = 0.0, 0
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if row.get("Counter_Name") == c and ("blur_stream_kernel" in row["Kernel_Name"] or "blur_fused_kernel" in row["Kernel_Name"]):
+                    # every launch of the family the roofline is about: streaming / tile blurs, the kept-pixels reductions, the pair launch
+                    if row.get("Counter_Name") == c and any(k in row["Kernel_Name"] for k in ("blur_stream_kernel", "blur_fused_kernel", "blur_reduce_kernel", "blur_pair_kernel")):
                         s += float(row["Counter_Value"])
                         n += 1
             if not n:
@@ -182,7 +183,7 @@ def launch_ranks(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else sys.stderr))
+                                      stdout=_JSON_FD if r == 0 else sys.stderr))   # (this process's fd 1 points at stderr: see the end of the file)
     status = 0
     try:
         pending = dict(enumerate(procs))
@@ -205,7 +206,13 @@ def launch_ranks(n):
     return status
 
 
-VALU_PEAK_TLANEOPS = 256 * 64 * 2.4e9 / 1e12   # 256 CUs x 64 FP32 lanes per clock x 2.4 GHz: 39.3 T lane-operations/s (no FMA: a multiply and an add are two)
+# FP32 vector peak of the data sheet, 157.3 TFLOP/s, counts a packed FMA as 4: 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz = 78.6 T
+# lane-operations/s where a multiply and an add are two operations (the reference's unfused arithmetic, -ffp-contract=off).
+# What the issue logic sustains was measured (tools/probe/valu_rate_probe.hip, profiles/r05_valu_rate.txt): v_pk_mul_f32 /
+# v_pk_add_f32 streams reach 59 T at two waves per SIMD (where the streaming blurs run: 140 - 240 VGPRs), 64 at three, 72 at
+# eight.  (Rounds 4 - 5 priced this roof at 39.3 T - 64 lanes per clock and CU - which was a factor of two too low.)
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+VALU_ISSUE_CEILING_2_WAVES = 59.0
 
 
 def blur_lane_ops(nf, W, H, octaves, dogs, sigma, k):
@@ -628,14 +635,20 @@ def main():
         # The same launches against the OTHER roof: from radius 10 on a blur is bound by its arithmetic, not by HBM (DESIGN.md
         # section 7, round 5) - the family's lane-operations over the same busy time, against the chip's FP32 issue rate
         if not SUBPIXEL and busy_ms > 0 and launches:
-            batches_timed = launches / 16.0 if args.workload == "config4" else None   # 16 blur launches per batch of this plan
+            # blur launches per batch of this plan: 16, or 15 with the first two levels in one launch (option blur_pair)
+            per_batch = 15.0 if (options.get("blur_pair", 1) and options.get("dog_in_extrema", 1) and not options.get("tail_async", 0)
+                                 and not options.get("tail_kernel", 0) and options.get("fused_blur", 1) and options.get("fused_edge", 1)) else 16.0
+            batches_timed = launches / per_batch if args.workload == "config4" else None
             if batches_timed:
                 lane_ops = blur_lane_ops(nf, W, H, OCTAVES, DOGS, SIGMA, K_SQRT2) * batches_timed
                 out["roofline"]["valu"] = {"achieved": lane_ops / 1e12 / (busy_ms / 1e3), "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-op/s",
                                            "frac": lane_ops / 1e12 / (busy_ms / 1e3) / VALU_PEAK_TLANEOPS,
+                                           "issue_ceiling_at_2_waves_per_simd": VALU_ISSUE_CEILING_2_WAVES,
+                                           "frac_of_issue_ceiling": lane_ops / 1e12 / (busy_ms / 1e3) / VALU_ISSUE_CEILING_2_WAVES,
                                            "lane_ops_per_batch": lane_ops / batches_timed,
                                            "what": "FP32 multiplies + adds of the blur launches (7R+4 per pixel and level, the reference's unfused arithmetic) over the "
-                                                   "same busy time, against 256 CUs x 64 lanes x 2.4 GHz: the launches of radius >= 10 are bound by this roof, not by HBM"}
+                                                   "same busy time, against the data sheet's 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz and against what packed multiply / add "
+                                                   "streams were measured to issue at two waves per SIMD (tools/probe/valu_rate_probe.hip); bookkeeping instructions not counted"}
         # the whole step against the same peak: every stage's algorithmic bytes over the step's time
         if args.workload == "config4" and not SUBPIXEL:
             out["roofline"]["whole_step"] = whole_step_fraction(nf, W, H, kps / max(args.steps, 1) / max(world, 1), dt / args.steps)
@@ -791,11 +804,18 @@ def main():
             out["parity_spot_check"] = bool(ok)
             out["parity_spot_check_what"] = (f"frames 1..{len(per_frame)} of one more step of this batch: per-image keypoint count and SHA-256 over "
                                             "(x, y, octave, index, scale, orientation, 128-float descriptors) equal the oracle's")
-        print(json.dumps(out), flush=True)
+        os.write(_JSON_FD, (json.dumps(out) + "\n").encode())
     pipe.close()
     if world > 1 or loopback:
         dist.destroy_process_group()
 
 
+# The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints its version banner to stdout when a communicator is
+# created), so the line goes to a private copy of the original stdout and file descriptor 1 is pointed at stderr for everything else.
+_JSON_FD = 1
+
 if __name__ == "__main__":
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     main()

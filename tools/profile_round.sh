@@ -41,6 +41,7 @@ DBGS="" bash tools/desc_probe.sh 2>&1 | grep -vE "^dbg" > $O/pmc_sq_counters.txt
 rm -rf gpurun_out/pmck_* gpurun_out/pmc_d1 gpurun_out/pmc_d2
 # 5. round 4: the practical HBM ceiling, both descriptor kernels, the N > 1 per-rank step on one GPU
 ./tools/probe/hbm_copy_probe > $O/hbm_copy.txt 2>&1
+./tools/probe/valu_rate_probe > $O/valu_rate.txt 2>&1   # (built here: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off, see the file's header)
 STEPS=20 bash tools/desc_ab.sh > $O/desc_ab.txt 2>&1
 bash tools/pmc_one.sh descriptor_tile --set desc_kernel=2 > $O/pmc_desc_tile.txt 2>&1
 bash tools/loopback_ab.sh > $O/loopback_ab.txt 2>&1
