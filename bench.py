@@ -625,15 +625,15 @@ def main():
                          "achieved_over_sum_of_durations": achieved_sum, "frac_over_sum_of_durations": achieved_sum / HBM_PEAK_GBS,
                          "sum_of_durations_ms_per_launch": ms / launches if launches else None},
         }
-        # The tail kernel (option tail_kernel, off by default) is a launch of its own class: arithmetic-bound on one CU per image
+        # The tail kernel (option tail_kernel, off by default) is a launch of its own class: issue-bound on one CU per image
         # by design, it is reported beside the bandwidth-bound launches, never mixed into their fraction
         tail_prof = [c.profile(2) for c in ctxs]
         if sum(p[1] for p in tail_prof) > 0:
             t_ms, t_n, t_b = (sum(p[i] for p in tail_prof) for i in range(3))
             out["roofline"]["tail_kernel"] = {"launches": t_n, "avg_launch_ms": t_ms / t_n, "algorithmic_bytes_per_launch": t_b / t_n,
-                                              "what": "pyramid_tail_kernel: octaves 2 - 3 of the batch, one workgroup per image (VALU-bound; not part of frac)"}
-        # The same launches against the OTHER roof: from radius 10 on a blur is bound by its arithmetic, not by HBM (DESIGN.md
-        # section 7, round 5) - the family's lane-operations over the same busy time, against the chip's FP32 issue rate
+                                              "what": "pyramid_tail_kernel: octaves 2 - 3 of the batch, one workgroup per image (issue-bound on its CU; not part of frac)"}
+        # The same launches against the OTHER roof: from radius 7 on a blur is bound by instruction issue, not by HBM (DESIGN.md
+        # section 7, round 5) - the family's lane-operations over the same busy time, against the chip's FP32 vector rate
         if not SUBPIXEL and busy_ms > 0 and launches:
             # blur launches per batch of this plan: 16, or 15 with the first two levels in one launch (option blur_pair)
             per_batch = 15.0 if (options.get("blur_pair", 1) and options.get("dog_in_extrema", 1) and not options.get("tail_async", 0)

@@ -178,7 +178,7 @@ struct sift_hip_ctx {
     bool tail_async = false;
     // option "tail_kernel" (round 5; measured, NOT the default): those octaves as ONE launch of one workgroup per image
     // (kernels_tail.hip) on that stream, started before the extrema pass so that it holds its CUs.  Bit-exact; ~0.93 ms on 32
-    // CUs (arithmetic-bound: the reference's 2 (2R+1) multiply-adds per pixel and level at 64 lanes per clock and CU), which
+    // CUs (issue-bound on the one CU an image gets: the reference's 2 (2R+1) multiply-adds per pixel and level, sixteen waves), which
     // the phase it runs beside pays for in full: 2.74 - 2.81 against 2.73 - 2.78 ms per step, 3.31 against 3.12 one batch at
     // a time.  0: never; 1: for batches of at least kTailKernelImages images; 2: whenever the plan allows (tests).  Implies
     // tail_async for the batches it takes.

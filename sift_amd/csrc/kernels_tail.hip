@@ -7,7 +7,7 @@
 // round 4) while the chip stands idle; as a tile chain with inter-workgroup flags (round 3's blur_chain_kernel) they were
 // slower still.  Here a dependency never leaves its workgroup: a level is complete when the workgroup's threads have passed
 // a barrier, the next level reads it back through the CU's own L1 / the XCD's L2 (workgroup scope: no cache maintenance, no
-// flags), and the kernel is arithmetic-bound on the ~n CUs it occupies - 2 (2R+1) multiply-adds per pixel and level, the
+// flags), and the kernel is bound by instruction issue on the ~n CUs it occupies - 2 (2R+1) multiply-adds per pixel and level, the
 // reference's own count - while the rest of the chip runs the partner batch's descriptors and this batch's extremum scans of
 // the large octaves (context.cpp: option "tail_kernel", the stream it is launched on, what waits for it).
 //
