@@ -234,6 +234,9 @@ static bool launch_pair_r(hipStream_t s, const float* in, float* g0, float* g1, 
     int chunks = g_pair_waves / (n * strips);
     if (chunks < 1) chunks = 1;
     int chunk_h = (h + chunks - 1) / chunks;
+    // short chunks pay stage 1's and stage 2's run-in (3R + RI rows) too often: batches of 4 - 8 frames of 1080p are no faster
+    // this way than as two launches (profiles/r05_pair_ab.txt); the tests' forced mode (min_waves = 1) takes any chunk
+    if (min_waves > 1 && chunk_h < 64) return false;
     if (chunk_h < 3 * RI) chunk_h = 3 * RI;
     if (chunk_h > h) chunk_h = h;
     chunks = (h + chunk_h - 1) / chunk_h;
