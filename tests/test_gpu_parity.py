@@ -549,8 +549,8 @@ def test_bench_starts_its_own_ranks():
                         "--steps", "2", "--warmup", "1", "--frames", "4", "--no-cpu-baseline", "--no-extras"],
                        env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout   # ONE line on stdout: RCCL's banner and the other ranks' output go to stderr
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["config"]["frames_total"] == 8
     assert out["config"]["gather_steps_on_rank0"] == 2
@@ -562,6 +562,23 @@ def test_bench_starts_its_own_ranks():
                         "--steps", "1", "--warmup", "0", "--frames", "2", "--no-cpu-baseline", "--no-extras", "--set", "no_such_option=1"],
                        env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode != 0
+
+
+def test_bench_rccl_loopback_prints_one_line():
+    """`bench.py --rccl-loopback`: the N > 1 per-rank step on one GPU, the keypoint lists looped through RCCL.  RCCL prints its
+    version banner to stdout when the communicator is created; the bench's contract is ONE JSON line there, so the line goes to a
+    private copy of stdout and everything else to stderr."""
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rccl-loopback", "--steps", "3", "--warmup", "1", "--frames", "4",
+                        "--no-cpu-baseline", "--no-extras"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
+    out = json.loads(lines[0])
+    assert out["config"]["gather_steps_on_rank0"] >= 3 and out["value"] > 0
 
 
 @pytest.mark.parametrize("host_loop", ["stream", "dispatch"])
@@ -580,8 +597,8 @@ def test_bench_eight_ranks_sharing_the_gpu(host_loop):
                         "--host-loop", host_loop],
                        env=env, cwd=root, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout   # ONE line on stdout: RCCL's banner and the other ranks' output go to stderr
     out = json.loads(lines[0])
     cfg = out["config"]
     assert out["n_gpus"] == 8 and out["steps"] == 3 and cfg["frames_total"] == 32 and cfg["host_loop"] == host_loop
