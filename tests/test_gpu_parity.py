@@ -1093,6 +1093,22 @@ for wire in (1, 0):
         assert kp.tobytes() == wkp.tobytes() and desc.tobytes() == wdesc.tobytes()
         cms, gms, nbytes = g.timing()
         assert nbytes == (34 if wire else 532) * kp.size + (4 * int((desc.view(np.uint32) != 0).sum()) if wire else 0), (nbytes, kp.size)
+# two batches in flight over RCCL, the second one larger (its buffers grow while the first one's send may still be waiting for its
+# peer: no device-wide wait may sit under a lock another shard's first calls need - ADVICE r04), then a third, larger still
+g.set_option('gather_wire', 1)
+grow = [np.stack([synth_frame(320, 240, 900 + 16 * b + i) for i in range(2 * 3 ** b)]) for b in range(3)]      # 2, 6, 18 frames
+got = []
+g.submit(grow[0], params)
+for b in range(1, len(grow) + 1):
+    if b < len(grow):
+        g.submit(grow[b], params)
+    g.collect()
+    got.append((g.counts().copy(),) + tuple(a.copy() for a in g.results()))
+for b, (counts, kp, desc) in zip(grow, got):
+    c.calculate_batch(b, params)
+    wkp, wdesc = c.results()
+    assert counts.tolist() == c.counts().tolist()
+    assert kp.tobytes() == wkp.tobytes() and desc.tobytes() == wdesc.tobytes()
 g.close(); c.close()
 print('rccl loopback ok:', why)
 """
@@ -1101,7 +1117,8 @@ print('rccl loopback ok:', why)
 def test_group_gather_over_rccl_on_one_gpu(ctx):
     """The native RCCL gather of sift_hip_group on a box with one GPU: a group of one shard with option gather_loopback sends its
     packed lists (and, with gather_wire = 0, its plain arrays) through ncclSend / ncclRecv to the same rank - communicator from
-    ncclCommInitAll, grouped point-to-point, arrival area, unpack - and returns the single context's results."""
+    ncclCommInitAll, grouped point-to-point, arrival area, unpack - and returns the single context's results; then submit, submit,
+    collect with batches that grow (2, 6, 18 frames) over the same communicator."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
