@@ -251,7 +251,7 @@ def whole_step_fraction(nf, W, H, keypoints, seconds):
     pyramid = 0.0
     for o in range(4):
         pyramid += px[o] * (8 if o == 0 else 0)          # g(0,0) from the input
-        pyramid += px[o] * (8 + 8 + 8)                   # g(o,1), g(o,2), g(o,3): no DoG level is written (option dog_in_extrema)
+        pyramid += px[o] * (8 + 8 + 8)                   # g(o,1), g(o,2), g(o,3): no DoG level is written (the extremum scan forms them)
         if o < 3:
             pyramid += px[o] * 4 + px[o + 1] * 4         # reduceToNextLevel: source read, kept pixels written
     gradient = px[0] * 12
@@ -321,7 +321,7 @@ def main():
     ap.add_argument("--wire", default="sparse", choices=["sparse", "packed", "full"],
                     help="N > 1, descriptors on the wire (all lossless): sparse = presence bits + the floats that are set (about a third), "
                          "packed = the 112 floats that can carry information, full = 128 floats")
-    ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE", help="library option (sift_hip_set_option), e.g. fused_edge=0")
+    ap.add_argument("--set", action="append", default=[], metavar="OPTION=VALUE", help="library option (sift_hip_set_option), e.g. pair_waves=2048; SIFT_HIP_LIBRARY=libsift_hip_diag.so adds the forcing options")
     ap.add_argument("--pipeline-depth", type=int, default=2,
                     help="batches in flight per GPU (sift_amd.pipeline.BatchPipeline: one context and host thread per slot).\n"
                          "2 (default): consecutive steps overlap under the phase gate - this step's cleanup chain (one workgroup\n"
@@ -576,8 +576,7 @@ def main():
     if rank == 0:
         prof = [c.profile(0) for c in ctxs]
         ms, launches, nbytes = (sum(p[i] for p in prof) for i in range(3))
-        # The top Gaussian level of an octave runs on the side stream beside the next octave's first launches (option
-        # pyramid_side, default): launches overlap, so the family's rate is its bytes over the time during which at least one
+        # The top Gaussian level of an octave runs on the side stream beside the next octave's first launches: launches overlap, so the family's rate is its bytes over the time during which at least one
         # blur launch was running (union of the launches' [start, stop] intervals, from the same events), not over the sum of
         # the durations, which counts the overlapped time twice.
         busy_ms = sum(c.profile_busy_ms(0) for c in ctxs)
@@ -625,21 +624,30 @@ def main():
                          "achieved_over_sum_of_durations": achieved_sum, "frac_over_sum_of_durations": achieved_sum / HBM_PEAK_GBS,
                          "sum_of_durations_ms_per_launch": ms / launches if launches else None},
         }
-        # The tail kernel (option tail_kernel, off by default) is a launch of its own class: issue-bound on one CU per image
-        # by design, it is reported beside the bandwidth-bound launches, never mixed into their fraction
-        tail_prof = [c.profile(2) for c in ctxs]
-        if sum(p[1] for p in tail_prof) > 0:
-            t_ms, t_n, t_b = (sum(p[i] for p in tail_prof) for i in range(3))
-            out["roofline"]["tail_kernel"] = {"launches": t_n, "avg_launch_ms": t_ms / t_n, "algorithmic_bytes_per_launch": t_b / t_n,
-                                              "what": "pyramid_tail_kernel: octaves 2 - 3 of the batch, one workgroup per image (issue-bound on its CU; not part of frac)"}
+        # The three kernels of the OTHER phase of a step (E || D: the extremum scan and the gradient maps of one batch beside the
+        # partner batch's descriptors), from the same kind of events on their own dispatch packets: strict (bytes over the sum of
+        # the launches' durations) and union (over the time at least one launch of the class was running) in the timed region;
+        # `alone` is added below from the steps run one at a time.  Algorithmic bytes: SURVEY.md section 8(d).
+        batches_timed = sum(c.profile_batches() for c in ctxs)
+        kp_per_batch = kps / max(args.steps, 1) / max(world, 1)
+        for key, which, kernel in (("descriptor", 2, "descriptor_wave_kernel"), ("extrema", 3, "extrema_edge_kernel"), ("gradient", 4, "gradient4_kernel")):
+            pk = [c.profile(which) for c in ctxs]
+            k_ms, k_n, k_b = (sum(q[i] for q in pk) for i in range(3))
+            k_busy = sum(c.profile_busy_ms(which) for c in ctxs)
+            if not k_n or k_ms <= 0:
+                continue
+            if which == 2:
+                k_b = 3584.0 * kp_per_batch * batches_timed     # 3.5 KB per keypoint, the keypoints of the instrumented batches
+            out["roofline"][key] = {"kernel": kernel, "launches": k_n, "algorithmic_bytes_per_launch": k_b / k_n,
+                                    "avg_launch_ms": k_ms / k_n,
+                                    "frac_over_sum_of_durations": k_b / 1e9 / (k_ms / 1e3) / HBM_PEAK_GBS,
+                                    "frac": k_b / 1e9 / (k_busy / 1e3) / HBM_PEAK_GBS if k_busy > 0 else None}
         # The same launches against the OTHER roof: from radius 7 on a blur is bound by instruction issue, not by HBM (DESIGN.md
         # section 7, round 5) - the family's lane-operations over the same busy time, against the chip's FP32 vector rate
         if not SUBPIXEL and busy_ms > 0 and launches:
-            # blur launches per batch of this plan: 16, or 15 with the first two levels in one launch (option blur_pair)
-            per_batch = 15.0 if (options.get("blur_pair", 1) and options.get("dog_in_extrema", 1) and not options.get("tail_async", 0)
-                                 and not options.get("tail_kernel", 0) and options.get("fused_blur", 1) and options.get("fused_edge", 1)) else 16.0
-            batches_timed = launches / per_batch if args.workload == "config4" else None
-            if batches_timed:
+            # (the number of instrumented batches comes from the library - sift_hip_profile_batches -, not from an assumed
+            # number of launches per batch: a batch whose first two levels do not take the pair launch makes 16, not 15)
+            if batches_timed and args.workload == "config4":
                 lane_ops = blur_lane_ops(nf, W, H, OCTAVES, DOGS, SIGMA, K_SQRT2) * batches_timed
                 out["roofline"]["valu"] = {"achieved": lane_ops / 1e12 / (busy_ms / 1e3), "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-op/s",
                                            "frac": lane_ops / 1e12 / (busy_ms / 1e3) / VALU_PEAK_TLANEOPS,
@@ -679,6 +687,13 @@ def main():
             ctx.set_option("profile", 0)
             ms_a, launches_a, nbytes_a = ctx.profile(0)
             busy_a = ctx.profile_busy_ms(0)
+            for key, which in (("descriptor", 2), ("extrema", 3), ("gradient", 4)):
+                k_ms, k_n, k_b = ctx.profile(which)
+                if key in out["roofline"] and k_n and k_ms > 0:
+                    if which == 2:
+                        k_b = 3584.0 * kp_per_batch * ctx.profile_batches()
+                    out["roofline"][key]["avg_launch_ms_alone"] = k_ms / k_n
+                    out["roofline"][key]["frac_alone"] = k_b / 1e9 / (k_ms / 1e3) / HBM_PEAK_GBS
             if busy_a > 0:
                 out["roofline"]["achieved_alone"] = (nbytes_a / 1e9) / (busy_a / 1e3)
                 out["roofline"]["frac_alone"] = out["roofline"]["achieved_alone"] / HBM_PEAK_GBS

@@ -67,42 +67,33 @@ typedef struct sift_hip_keypoint {
 /* One context per GPU / worker thread (a Sift instance is not re-entrant either, sift.hpp:46-56). */
 int sift_hip_create(int device, sift_hip_ctx** out, char* err, int errlen);
 void sift_hip_destroy(sift_hip_ctx* ctx);
-/* Option knobs: "fused_blur" (1 default: single-kernel blur + DoG, streaming or LDS-tiled; 0: two-pass
- * row/col kernels), "fused_edge" (1 default: extremum scan and edge-response filter in one LDS-tiled pass;
- * 0: mask kernel + thread-per-candidate filter), "fused_reduce" (1 default: reduceToNextLevel's blur stores only the
- * pixels the decimation keeps; 0: blur into a temporary, then the resampling kernel), "gpu_cleanup" (1 default: cleanup steps as GPU kernels;
- * 0: std::sort on the host), "host_threads", "profile" (N > 0: the blur launches of every N-th batch carry timing
- * events on their dispatch packets, read with sift_hip_profile_get; the events keep consecutive launches ~10 us apart, which
- * is why a measurement run samples, e.g. N = 4; 0: off), "stream_min_waves" (process-wide; smallest launch, in waves, that takes the streaming blur instead of
- * the LDS-tiled one; default 1024, <= 0 restores it; the parity tests set 1 to run the streaming form on small
- * inputs), "orient_general" (0 default; 1: orientationHistogram36 reads every sample's bin even when the gradient pass
- * found all bins of the frame to be 0, which is what the reference's radians-as-degrees maps always give), "wire_count"
- * (0 default; 1: the descriptor kernel also counts the floats the sparse wire format will carry, so that
- * sift_hip_result_sparse_size needs no pass of its own over the descriptors: for hosts that gather every batch),
- * "desc_kernel" (1 default: one wave per keypoint over a grid of 16 px cells; 2: one wave per 32 x 32 px tile of keypoint
- * locations, its gradient samples held in LDS; other values: SIFT_HIP_EINVAL), "gate_schedule" (order of the phases of batches
- * joined by a gate, sift_amd/csrc/phase_gate.h: 1 default - the cleanup steps under the next batch's pyramid, the descriptors
- * under its extrema / gradient pass; 0 - no pyramid shares the chip, the order of rounds 1 - 2), "pyramid_side" (1 default: the
- * top Gaussian level of an octave, which only feeds the octave's last DoG, is formed on the side stream beside the reduction
- * and the next octave's small launches; 0: every launch on one stream), "reduce_kept" (1 default: reduceToNextLevel evaluates
- * the kept pixels only), "lazy_top" (1 default: the top Gaussian level of an octave is not written at all by the batch - nothing
- * on the path reads it again - and is formed when sift_hip_level_copy asks for it; 0: every level is written), "spin_wait" (1 default: the end of a batch is awaited by polling its event - tens of microseconds per batch sooner than
- * sleeping in hipStreamSynchronize, which is what 0 selects), "tail_async" (0 default; 1: the pyramid's small octaves - a level of at
- * most 6 Mpx over the whole batch, octaves 2 and 3 of 32 1080p frames - leave the main stream at the reduction that feeds them
- * and run beside the batch's extremum scans of the large octaves; only the scans of those octaves wait for them),
- * "tail_kernel" (0 default; those octaves as ONE launch of one 1024-thread workgroup per image, sift_amd/csrc/kernels_tail.hip,
- * instead of a launch per level: 1 - for batches of at least 16 images; 2 - whenever the levels fit the kernel.  Both were built
- * and measured in round 5, are bit-exact and do not shorten a step: DESIGN.md section 7).
- * "dog_in_extrema" (1 default since round 5: the pyramid writes Gaussian levels only - all of them - and the fused extremum scan
- * fetches four Gaussian levels per scan level and forms its three DoG tiles on the way into LDS, 128.0f + (g[j+1] - g[j]); a DoG
- * level sift_hip_level_copy is asked for is formed then; 0: every blur launch also writes its DoG level, as in rounds 1 - 4).
- * "blur_pair" (1 default since round 5: g(0,0) and g(0,1) - two blurs with the same taps, the second of the first's result -
- * are ONE launch whose second stage takes the first stage's rows from LDS, sift_amd/csrc/kernels_pair.hip; needs dog_in_extrema and a
- * batch that fills the chip, else and with 0: two launches), "pair_waves" (waves that launch is cut into; 0 = the default 1536).
- * These 20 names are all a release build knows; any other name returns SIFT_HIP_EINVAL.  The measurement build
- * (libsift_hip_diag.so: make -C sift_amd/csrc diag, -DSIFT_HIP_DIAG) adds "desc_dbg" / "orient_dbg" (phases of a kernel
- * switched off: timing only, WRONG results), "stream_waves", "diag_repeat", "diag_pyramid_span", "diag_serial_gradient", "diag_skip_tail" and
- * "diag_cleanup_stamps" for the scripts under tools/.  The library reads no environment variable. */
+/* Options.  The shipped library knows EIGHT names (any other returns SIFT_HIP_EINVAL); values belong to the context they are
+ * set on, nothing is process-wide, and the library reads no environment variable:
+ *   "profile"          N > 0: the blur launches of every N-th batch carry timing events on their dispatch packets, read with
+ *                      sift_hip_profile_get (the events keep consecutive launches ~10 us apart, so a measurement run samples,
+ *                      e.g. N = 4); 0 (default): off
+ *   "wire_count"       1: the descriptor kernel also counts the floats the sparse wire format will carry, so that
+ *                      sift_hip_result_sparse_size needs no pass of its own (hosts that gather every batch); 0 default
+ *   "host_threads"     threads of the host-side copies and of the std::sort fallback (0 default: the hardware's)
+ *   "spin_wait"        1 default: the end of a batch is awaited by polling its event (tens of microseconds sooner than
+ *                      sleeping in hipStreamSynchronize, which 0 selects)
+ *   "orient_general"   1: orientationHistogram36 reads every sample's bin even when the gradient pass found all bins of the
+ *                      frame to be 0 - which is what the reference's radians-as-degrees maps always give (0 default)
+ *   "stream_min_waves" smallest launch, in waves, that takes the streaming blur instead of the LDS-tiled one (0 = the default,
+ *                      1024; the parity tests set 1 to run the streaming kernels on small inputs)
+ *   "blur_pair"        1 default: g(0,0) and g(0,1) - two blurs with the same taps, the second of the first's result - are ONE
+ *                      launch whose second stage takes the first stage's rows from LDS (sift_amd/csrc/kernels_pair.hip) when
+ *                      the batch fills the chip; 0: two launches
+ *   "pair_waves"       waves that launch is cut into (0 = the default, 1536)
+ * Everything else the library decides by itself from the shape: rows that are not 16-byte aligned get the unfused extremum
+ * scan over DoG levels the pyramid writes, radii beyond 32 the two-pass blur, index maps without a parity split the streaming
+ * decimating blur, an introsort that hits its depth limit libstdc++'s std::sort on the host.  The names that FORCE those paths
+ * ("fused_blur", "fused_edge", "fused_reduce", "reduce_kept", "dog_in_extrema", "gpu_cleanup", "pyramid_side",
+ * "gate_schedule") and the host-side measurement aids ("diag_repeat", "diag_pyramid_span", "diag_serial_gradient",
+ * "stream_waves") exist only in libsift_hip_diag.so - the shipped kernels with context.cpp compiled -DSIFT_HIP_DIAG, built by
+ * `make -C sift_amd/csrc`, used by tests/diag_fallbacks.py and tools/ -, the switches inside kernels ("desc_dbg", "orient_dbg",
+ * "diag_cleanup_stamps": timing only, WRONG results) only in `make ablate`'s libsift_hip_ablate.so.  Removed in round 6 with
+ * their kernels (measured, not kept: DESIGN.md section 7): "tail_async", "tail_kernel", "desc_kernel", "lazy_top". */
 int sift_hip_set_option(sift_hip_ctx* ctx, const char* name, int value);
 
 /* ---- several batches in flight on one GPU --------------------------------------------------------
@@ -110,8 +101,7 @@ int sift_hip_set_option(sift_hip_ctx* ctx, const char* name, int value);
  * every batch in flight a context of its own (one host thread each) and join the contexts with a gate: the gate
  * orders the phases of consecutive batches on the device: this batch's cleanup steps (one workgroup per image,
  * sift.cpp:37-54), which cannot fill the chip, run under the next batch's pyramid and its descriptors under the next
- * extrema / gradient pass; no two pyramids and no two descriptor stages share the chip (sift_amd/csrc/phase_gate.h;
- * option "gate_schedule" = 0: no pyramid shares the chip with anything).  Results are unchanged.  Batches take their
+ * extrema / gradient pass; no two pyramids and no two descriptor stages share the chip (sift_amd/csrc/phase_gate.h).  Results are unchanged.  Batches take their
  * place in the order in which their calculate calls begin. */
 typedef struct sift_hip_gate sift_hip_gate;
 int sift_hip_gate_create(int device, sift_hip_gate** out);
@@ -318,13 +308,20 @@ void sift_hip_overlay_box(const sift_hip_keypoint* kp, int subpixel, uint16_t* c
 int sift_hip_overlay_draw(uint8_t* bgr, int w, int h, const sift_hip_keypoint* kps, long long n, int subpixel);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
-/* HIP-event timings of the pyramid kernels collected while option "profile" is 1.
- * which: 0 = fused blur(+DoG) kernel, 1 = everything else in the pyramid stage.
- * Returns accumulated milliseconds, launches and ALGORITHMIC bytes since reset. */
+/* HIP-event timings collected while option "profile" is N > 0 (every N-th batch of the context carries a start / stop event pair
+ * on the dispatch packets of the kernels below; no reference counterpart - sift.cpp has no timers).
+ * which: 0 = the fused blur family (streaming / LDS-tiled / kept-pixels reduction / the launch of the first two levels),
+ *        1 = the two-pass blur fallback, 2 = descriptor_wave_kernel, 3 = extrema_edge_kernel, 4 = the gradient maps' kernel.
+ * Returns accumulated milliseconds (the SUM of the launches' durations), launches and ALGORITHMIC bytes (SURVEY.md section 8(d)'s
+ * per-unit figures; class 2 reports 0 bytes: its unit is the keypoint, 3.5 KB each, and the caller knows
+ * the count) since the last reset. */
 int sift_hip_profile_get(sift_hip_ctx* ctx, int which, double* ms, int64_t* launches, double* bytes);
 /* Milliseconds during which at least one launch of the class was running (the union of the launches' intervals): equal to the
- * sum above while launches follow one another, smaller when launches of two streams overlap (option "pyramid_side"). */
+ * sum above while launches follow one another, smaller when launches of two streams overlap (an octave's top level runs on
+ * the side stream). */
 int sift_hip_profile_get_busy(sift_hip_ctx* ctx, int which, double* busy_ms);
+/* Batches whose launches carried the events since the last reset (what the per-batch figures divide by). */
+int sift_hip_profile_batches(sift_hip_ctx* ctx, int64_t* batches);
 int sift_hip_profile_reset(sift_hip_ctx* ctx);
 
 const char* sift_hip_version(void);

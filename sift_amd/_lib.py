@@ -25,7 +25,7 @@ SYMBOLS = [
     "sift_hip_stage_count", "sift_hip_stage_copy", "sift_hip_gauss_taps", "sift_hip_convolve_with_gauss",
     "sift_hip_reduce_to_next_level", "sift_hip_increase_to_next_level", "sift_hip_dog", "sift_hip_gradient",
     "sift_hip_edge_responses", "sift_hip_vertex_parabola", "sift_hip_sort_by_filter", "sift_hip_cleanup_survivors", "sift_hip_profile_get", "sift_hip_profile_get_busy",
-    "sift_hip_profile_reset", "sift_hip_version", "sift_hip_gate_create", "sift_hip_gate_destroy", "sift_hip_set_gate",
+    "sift_hip_profile_reset", "sift_hip_profile_batches", "sift_hip_version", "sift_hip_gate_create", "sift_hip_gate_destroy", "sift_hip_set_gate",
     "sift_hip_result_sparse_size", "sift_hip_result_sparse_pack", "sift_hip_result_sparse_pack_async", "sift_hip_result_pack_wait", "sift_hip_sparse_unpack",
     "sift_hip_host_alloc", "sift_hip_host_free",
     "sift_hip_group_create", "sift_hip_group_destroy", "sift_hip_group_shards", "sift_hip_group_set_option", "sift_hip_group_calculate",
@@ -131,6 +131,7 @@ def load():
     L.sift_hip_profile_get.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     L.sift_hip_profile_get_busy.argtypes = [vp, ci, C.POINTER(C.c_double)]
     L.sift_hip_profile_reset.argtypes = [vp]
+    L.sift_hip_profile_batches.argtypes = [vp, C.POINTER(C.c_int64)]
     ll = C.c_longlong
     L.sift_hip_group_create.argtypes = [ip, ci, C.POINTER(vp), cs, ci]
     L.sift_hip_group_destroy.argtypes = [vp]

@@ -71,9 +71,9 @@ hipError_t combined_last_error();
 namespace sift_hip {
 
 // Measurement switches inside kernels (options desc_dbg, orient_dbg, the cleanup stamps): phases switched off for timing - the
-// results are then WRONG.  They exist in the measurement build only (-DSIFT_HIP_DIAG, `make diag`); in the shipped library the
-// mask is 0 and the compiler removes every branch that tests them.
-#ifdef SIFT_HIP_DIAG
+// results are then WRONG.  They exist in the ablation build only (-DSIFT_HIP_ABLATE, `make ablate`); in the shipped library and in
+// libsift_hip_diag.so (whose kernels ARE the shipped ones) the mask is 0 and the compiler removes every branch that tests them.
+#ifdef SIFT_HIP_ABLATE
 constexpr int kDiagMask = ~0;
 #else
 constexpr int kDiagMask = 0;
@@ -116,6 +116,12 @@ struct DevPlan {
     int scan_nyb[kMaxLevels];        // 64-row blocks per column
     int scan_word_base[kMaxLevels];  // first mask word of the level inside one image
     int words_per_image;
+    // the fused scan's tiles (32 columns x one 64-row block) numbered in CANDIDATE order at strip granularity - scan level,
+    // 32-column strip, 64-row block: a strip's candidates follow those of all tiles numbered before its first one
+    int scan_tiles_x[kMaxLevels];    // 32-column strips of the level
+    int scan_strip_base[kMaxLevels]; // first strip of the level among the image's strips
+    int scan_tile_base[kMaxLevels];  // first tile of the level among the image's tiles
+    int strips_per_image, tiles_per_image;
     long long cand_capacity;         // per image
     // grid of 16 px cells over the levels some keypoint scale selects (descriptor kernels): cells across / down, first cell of the level
     int desc_cell_base[kMaxLevels], desc_cw[kMaxLevels], desc_ch[kMaxLevels];
@@ -163,20 +169,22 @@ struct FinalKp {             // one entry per keypoint entering _createDecriptor
 static_assert(sizeof(FinalKp) == 16, "FinalKp packing");
 
 // ---- kernel launchers (defined in the .hip files) ------------------------------------------------
+// min_waves: smallest launch, in waves, that takes the streaming form (kStreamMinWaves unless the context's option
+// "stream_min_waves" says otherwise: a value of the calling context, not of the process)
+constexpr int kStreamMinWaves = 1024;  // below one wave per SIMD the tile kernel's finer work units win
 void launch_blur(hipStream_t s, bool fused, const float* in, float* tmp, float* out, float* dog, int w,
-                 int h, int n, const float* d_taps, int radius, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                 int h, int n, const float* d_taps, int radius, int min_waves = kStreamMinWaves, hipEvent_t ev_start = nullptr,
+                 hipEvent_t ev_stop = nullptr);
 bool launch_blur_reduce(hipStream_t s, const float* in, float* dst, int w, int h, int wd, int hd, int n, const float* d_taps,
-                        int radius, const int* d_inv_x, const int* d_inv_y, float* d_dump, hipEvent_t ev_start = nullptr,
-                        hipEvent_t ev_stop = nullptr);
-void set_stream_min_waves(int v);  // <= 0 restores the default
-void set_stream_waves(int v);      // < 0 restores the default; 0 = tile kernel only
+                        int radius, const int* d_inv_x, const int* d_inv_y, float* d_dump, int min_waves = kStreamMinWaves,
+                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+void set_stream_waves(int v);      // measurement build: < 0 restores the default; 0 = tile kernel only (process-wide)
 void set_orient_dbg(int v);        // timing ablations of the orientation kernel (results are wrong when != 0)
 void launch_resample(hipStream_t s, const float* src, float* dst, int ws, int hs, int wd, int hd, int n,
                      const int* d_lutx, const int* d_luty);
 void launch_dog(hipStream_t s, const float* lower, const float* higher, float* out, size_t count);
 bool launch_blur_reduce_kept(hipStream_t s, const float* in, float* dst, int w, int h, int wd, int hd, int n, const float* d_taps, int radius,
                              int sx, int sy, int min_waves, hipEvent_t ev_start, hipEvent_t ev_stop);
-int stream_min_waves_now();
 void launch_widen_u8(hipStream_t s, const uint8_t* in, float* out, size_t count);
 void launch_io_copy(hipStream_t s, const void* src, void* dst, size_t bytes);      // kernels_io.hip: device-to-device copies as small kernels (group.cpp)
 void launch_zero_ints(hipStream_t s, int* p, size_t n);
@@ -185,8 +193,7 @@ void tu_touch_pyramid(hipStream_t s);
 void tu_touch_pair(hipStream_t s);
 // g0 = blur(in) and g1 = blur(g0) in one launch (kernels_pair.hip); false: not a shape that kernel takes
 bool launch_blur_pair(hipStream_t s, const float* in, float* g0, float* g1, int w, int h, int n, const float* taps,
-                      int radius, int min_waves, hipEvent_t ev_start, hipEvent_t ev_stop);
-void set_pair_waves(int v);  // <= 0 restores the default
+                      int radius, int min_waves, int pair_waves, hipEvent_t ev_start, hipEvent_t ev_stop);
 void tu_touch_reduce(hipStream_t s);
 void tu_touch_extrema(hipStream_t s);
 void tu_touch_orient(hipStream_t s);
@@ -199,9 +206,14 @@ void launch_extrema_mask(hipStream_t s, const DevPlan* d_plan, const DevPlan& pl
                          unsigned long long* d_masks, int* d_counts);
 void launch_extrema_scan(hipStream_t s, const DevPlan& plan, int* d_counts, int* d_totals);
 bool extrema_edge_supported(const DevPlan& plan);
-// scan levels [k_begin, k_end) of the plan (k_end < 0: all the rest)
+// every scan level of the plan in one launch (from_gauss: the scan forms its DoG tiles from four Gaussian levels)
 void launch_extrema_edge(hipStream_t s, const DevPlan& plan, unsigned long long* d_masks, unsigned long long* d_fmasks,
-                         int* d_counts, int k_begin = 0, int k_end = -1, int busy_cus = 0, bool from_gauss = false);
+                         int* d_tile_counts, bool from_gauss = false, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// candidate records, flag bytes and per-image totals from the fused scan's words and per-tile counts: no scan launch in between
+void launch_extrema_expand_tiles(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const unsigned long long* d_masks,
+                                 const unsigned long long* d_fmasks, const int* d_tile_counts, Candidate* d_cands, uint8_t* d_flags,
+                                 int* d_totals);
+constexpr int kFxCols = 32;   // columns of a tile of the fused scan (kernels_extrema.hip)
 int resident_cus();   // CUs of the calling thread's device (kernels_pyramid.hip; 256 until sift_hip_create has asked)
 void launch_extrema_expand(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan,
                            const unsigned long long* d_masks, const int* d_offsets, Candidate* d_cands,
@@ -213,7 +225,7 @@ void launch_edge_filter_points(hipStream_t s, const float* d0, const float* d1, 
 void launch_vertex_parabola(hipStream_t s, const uint16_t* lnx, const float* lny, const uint16_t* px,
                             const float* py, const uint16_t* rnx, const float* rny, int m, float* out);
 void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, float* prod, int w, int h,
-                     int n, int* d_any_bin = nullptr, int stamp = 1);
+                     int n, int* d_any_bin = nullptr, int stamp = 1, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void launch_orientation(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const Candidate* d_cands,
                         const OrientIn* d_oin, const int* d_list_cnt, int list_cap, OrientOut* d_out,
                         float* d_peaks, int* d_next_group, const int* d_any_bin = nullptr, int zero_counters = 1, int stamp = 1);
@@ -241,12 +253,8 @@ void launch_desc_grid(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan,
                       bool compute_base, sift_hip_keypoint* d_kp_out, float* d_desc_out, long long out_cap);
 void launch_descriptors_wave(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level, const int* d_cell_off,
                              const FinalKp* d_pool, int pool_cap, const long long* d_out_base, sift_hip_keypoint* d_kp_out,
-                             float* d_desc_out, long long out_cap, int dbg = 0, int* d_wire_sums = nullptr);
-
-void launch_descriptors_tile(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level, const int* d_cell_off,
-                             const FinalKp* d_pool, int pool_cap, const long long* d_out_base, sift_hip_keypoint* d_kp_out,
-                             float* d_desc_out, long long out_cap, int* d_wire_sums, int* d_sched);
-size_t desc_tile_sched_ints(int n_images);
+                             float* d_desc_out, long long out_cap, int dbg = 0, int* d_wire_sums = nullptr, hipEvent_t ev_start = nullptr,
+                             hipEvent_t ev_stop = nullptr);
 
 // wire format of the keypoint gather (kernels_wire.hip)
 size_t wire_blocks(long long total);

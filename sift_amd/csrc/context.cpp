@@ -18,7 +18,6 @@
 
 #include "common.h"
 #include "phase_gate.h"
-#include "tail_plan.h"
 #include "host_glue.h"
 
 using namespace sift_hip;
@@ -27,8 +26,6 @@ namespace {
 
 constexpr int kPoolCap = 65536;  // records of the descriptor stage's cell grid: every keypoint once (u16_t size, sift.cpp:53)
 constexpr int kListCap = 65536;  // cleanup keeps at most 65535 points (u16_t size, sift.cpp:41)
-constexpr int kTailKernelImages = 16;
-constexpr long long kTailPixels = 6ll << 20;   // a level of the pyramid's tail: at most this many pixels over the whole batch (1080p x 32: octaves 2 and 3)
 
 struct DevBuf {
     void* p = nullptr;
@@ -102,13 +99,11 @@ struct Plan {
     std::vector<size_t> lut_x_off, lut_y_off;  // per octave transition (index o -> o+1); [O] = subpixel
     std::vector<size_t> inv_x_off, inv_y_off;  // inverse maps (source -> destination or -1) of the decimations
     std::vector<int> red_sx, red_sy;           // decimation o -> o+1: first destination column / row kept from source index 2 i + 1 (-1: the map has another form)
+    bool dogs_carved = true;          // the arena holds the DoG levels (false: the fused extremum scan forms its DoG tiles from Gaussian levels)
     int fail_status = 0;              // plan-time precondition failure (depends only on sizes/params)
     size_t fail_op = (size_t)-1;      // first op that cannot run
     std::string fail_msg;
     std::vector<int> grad_levels;     // levels some keypoint scale selects
-    int tail_from = 0;                // first octave of the pyramid's tail (option "tail_async"); O: no tail
-    TailPlan tail{};                  // ... as the argument block of pyramid_tail_kernel; n_ops == 0: the kernel cannot take it
-    double tail_bytes = 0;            // algorithmic bytes of the tail's ops over the whole batch
     std::vector<float> taps16;        // taps of convolveWithGauss(level, 1.6f) (sift.cpp:87)
     int radius16 = 0;
     size_t max_level_floats = 0;      // per image, largest level
@@ -140,23 +135,17 @@ struct sift_hip_ctx {
     Plan plan;
     DevBuf arena, d_plan, d_taps, d_luts, d_taps16, d_input, d_input_u8, d_base, d_tmp, d_tmp2;
     DevBuf d_sparse_rec, d_sparse_val;   // sift_hip_result_copy_sparse: the packed lists on their way to the host
-    DevBuf d_masks, d_fmasks, d_counts, d_totals, d_cands, d_flags;
+    DevBuf d_masks, d_fmasks, d_counts, d_tile_counts, d_totals, d_cands, d_flags;
     DevBuf d_wk, d_wi, d_wi2, d_wp, d_status, d_pool;
     DevBuf d_order;
     HostBuf h_stage[2];              // pinned staging of pageable caller memory (host <-> device in chunks)
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
     DevBuf d_cell_cnt, d_cell_off;   // descriptor grid: keypoints per 16 px cell, exclusive scan (+ total)
-    DevBuf d_desc_sched;             // tile-per-wave descriptor kernel: draw counters
-    bool desc_tile = false;          // option "desc_kernel": 1 wave-per-keypoint kernel (the default), 2 tile-per-wave kernel
     int diag_repeat = 1;             // option "diag_repeat" (diagnostics, sift_hip_calculate_batch_device only)
     int gate_schedule = 1;           // option "gate_schedule" (phase_gate.h; 1 since round 3): applies to the gate this context is joined to
     // option "pyramid_side" (default on): the top Gaussian level of an octave (it only feeds the octave's last DoG) is formed on
     // the side stream, beside the reduction and the first levels of the next octave, which are too small to fill the chip alone
     bool pyramid_side = true;
-    // option "lazy_top" (default on): that top level is not WRITTEN at all - nothing on the path reads it again (the next octave
-    // starts from the level below, sift.cpp:406-409; keypoints never refer to it) - unless it is a gradient level; a caller that
-    // asks for it (sift_hip_level_copy) gets it formed then, by the same kernel
-    bool lazy_top = true;
     // option "dog_in_extrema" (round 5): the pyramid writes Gaussian levels only; the fused extremum scan fetches four of them per
     // scan level and forms its three DoG tiles on the way into LDS (128.0f + (g[j+1] - g[j]): alg::dog's two roundings); a DoG level
     // a caller asks for (sift_hip_level_copy) or the unfused scan needs is formed then
@@ -165,28 +154,11 @@ struct sift_hip_ctx {
     // the second blur reads the first one's rows from LDS) - when no DoG level is written (dog_in_extrema), the two levels share
     // their taps and the batch fills the chip; otherwise two launches as before
     bool blur_pair = true;
-    bool dogs_missing = false;       // this batch's DoG levels have not been written ...
-    std::vector<char> dog_formed;    // ... except the ones a caller has asked for since (sift_hip_level_copy)
-    std::vector<char> top_missing;   // per octave: this batch's top Gaussian level has not been formed
+    bool dogs_missing = false;       // this batch's DoG levels have not been written (the plan then has no room for them) ...
+    int dog_in_scratch = -1;         // ... except the one a caller asked for last (sift_hip_level_copy forms it in d_tmp2)
+    int stream_min_waves = 0;        // option "stream_min_waves" (0: the default, 1024): smallest launch, in waves, that takes the streaming blur
+    int pair_waves = 0;              // option "pair_waves" (0: the default, 1536): waves the launch of the first two levels is cut into
     hipEvent_t ev_side_fork = nullptr, ev_side_join = nullptr;
-    // option "tail_async" (round 5; measured, NOT the default - DESIGN.md section 7): the octaves from `Plan::tail_from` on - a
-    // few tiles per CU and launch, 5 % of the pyramid's bytes in a fifth of its time - leave the main stream: they run on a
-    // stream of their own from the reduction that feeds them on, beside the rest of the batch (and beside the partner batch's
-    // descriptors), and only the extremum scans of THOSE octaves wait for them.  The pyramid phase the gate orders (P) then ends
-    // with the last launch of the octaves in front.  Not running the tail at all would be worth 0.21 ms of a 2.79 ms step;
-    // moved aside, its launches starve behind the extrema pass's persistent workgroups and the step does not move.
-    bool tail_async = false;
-    // option "tail_kernel" (round 5; measured, NOT the default): those octaves as ONE launch of one workgroup per image
-    // (kernels_tail.hip) on that stream, started before the extrema pass so that it holds its CUs.  Bit-exact; ~0.93 ms on 32
-    // CUs (issue-bound on the one CU an image gets: the reference's 2 (2R+1) multiply-adds per pixel and level, sixteen waves), which
-    // the phase it runs beside pays for in full: 2.74 - 2.81 against 2.73 - 2.78 ms per step, 3.31 against 3.12 one batch at
-    // a time.  0: never; 1: for batches of at least kTailKernelImages images; 2: whenever the plan allows (tests).  Implies
-    // tail_async for the batches it takes.
-    int tail_kernel = 0;
-    hipStream_t stream3 = nullptr;
-    hipEvent_t ev_tail_fork = nullptr, ev_tail_done = nullptr;
-    bool tail_pending = false;       // this batch has launches on stream3 that the main stream has not waited for yet
-    bool tail_in_kernel = false;     // ... as the tail kernel: one workgroup per image holds a CU while it runs
     int bin_stamp = 0;               // this batch's value of the gradient pass's "some bin != 0" flags (kernels_orient.hip: launch_gradient)
     DevBuf d_list, d_list_cnt, d_orient, d_peaks, d_final, d_final_cnt, d_out_base, d_kp, d_desc;
     DevBuf d_wire_sums, d_wire_off;   // sparse wire format: floats per block of keypoints, their exclusive scan
@@ -206,7 +178,6 @@ struct sift_hip_ctx {
     bool spin_wait = true;    // poll an event instead of sleeping in hipStreamSynchronize (tens of microseconds per batch)
     // diagnostics (options "diag_pyramid_span", "diag_serial_gradient", "diag_cleanup_stamps"): all off by default
     bool diag_pyramid_span = false, diag_serial_gradient = false, diag_cleanup_stamps = false;
-    bool diag_skip_tail = false;   // timing only (results WRONG): the tail's launches are not made at all
     // results of the last batch
     std::vector<int32_t> status, counts;
     std::vector<std::string> messages;
@@ -225,11 +196,14 @@ struct sift_hip_ctx {
     struct EvPair { hipEvent_t a, b; int which; double bytes; };
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> event_pool;
-    // classes: 0 the fused blur launches (streaming / tile / kept-pixels reduction), 1 the two-pass fallback, 2 the tail kernel
-    double prof_ms[3] = {0, 0, 0};
-    long long prof_launches[3] = {0, 0, 0};
-    double prof_bytes[3] = {0, 0, 0};
-    double prof_busy_ms[3] = {0, 0, 0};   // time during which at least one launch of the class was running (union of the launches' intervals)
+    // classes: 0 the fused blur launches (streaming / tile / kept-pixels reduction / the pair launch), 1 the two-pass fallback,
+    // 2 descriptor_wave_kernel, 3 extrema_edge_kernel, 4 the gradient maps' kernel (round 6: the E || D phase's three kernels)
+    static constexpr int kProfClasses = 5;
+    double prof_ms[kProfClasses] = {0, 0, 0, 0, 0};
+    long long prof_launches[kProfClasses] = {0, 0, 0, 0, 0};
+    double prof_bytes[kProfClasses] = {0, 0, 0, 0, 0};
+    double prof_busy_ms[kProfClasses] = {0, 0, 0, 0, 0};   // time during which at least one launch of the class was running (union of the launches' intervals)
+    long long prof_batches = 0;           // batches whose launches carried the events since the last reset
 };
 
 namespace {
@@ -264,7 +238,7 @@ void resolve_events(sift_hip_ctx* c) {
         for (auto& p : c->pending) { float ms = 0; (void)hipEventElapsedTime(&ms, p.a, p.b); sum += ms; }
         std::fprintf(stderr, "pyramid span %.3f ms, sum of blur kernels %.3f ms, launches %zu\n", span, sum, c->pending.size());
     }
-    std::vector<std::pair<float, float>> iv[3];   // launch intervals, milliseconds after the batch's first launch began
+    std::vector<std::pair<float, float>> iv[sift_hip_ctx::kProfClasses];   // launch intervals, milliseconds after the batch's first launch began
     for (auto& p : c->pending) {
         float ms = 0, t0 = 0;
         SIFT_HIP_CHECK(hipEventSynchronize(p.b));
@@ -275,7 +249,7 @@ void resolve_events(sift_hip_ctx* c) {
         if (&p != &c->pending.front()) SIFT_HIP_CHECK(hipEventElapsedTime(&t0, c->pending.front().a, p.a));
         iv[p.which].emplace_back(t0, t0 + ms);
     }
-    for (int wch = 0; wch < 3; ++wch) {   // launches on two streams overlap (option "pyramid_side"): count that time once
+    for (int wch = 0; wch < sift_hip_ctx::kProfClasses; ++wch) {   // launches on two streams overlap (option "pyramid_side"): count that time once
         std::sort(iv[wch].begin(), iv[wch].end());
         float end = -1e30f;
         for (auto& x : iv[wch]) {
@@ -291,6 +265,8 @@ void resolve_events(sift_hip_ctx* c) {
     c->pending.clear();
 }
 
+int min_waves(const sift_hip_ctx* c) { return c->stream_min_waves > 0 ? c->stream_min_waves : kStreamMinWaves; }
+
 // Blur with optional event bracket.  Algorithmic bytes: 4 B read + 4 B written per
 // pixel, + 4 B when the DoG is written too.
 void run_blur(sift_hip_ctx* c, const float* in, float* out, float* dog, int w, int h, int n, size_t tap_off,
@@ -304,7 +280,7 @@ void run_blur(sift_hip_ctx* c, const float* in, float* out, float* dog, int w, i
     // the events ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL): start/stop are the
     // kernel's begin/end timestamps and back-to-back launches stay back-to-back
     launch_blur(st ? st : c->stream, c->fused, in, c->d_tmp.as<float>(), out, dog, w, h, n, c->d_taps.as<float>() + tap_off,
-                radius, a, b);
+                radius, min_waves(c), a, b);
     if (c->profile) {
         const double px = (double)w * (double)h * (double)n;
         c->pending.push_back({a, b, is_fused ? 0 : 1, px * (4.0 + (out ? 4.0 : 0.0) + (dog ? 4.0 : 0.0))});   // algorithmic bytes: read + levels written
@@ -316,9 +292,18 @@ void run_blur(sift_hip_ctx* c, const float* in, float* out, float* dog, int w, i
 // pyramid can trip, in execution order.
 int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm, std::string& msg) {
     Plan& P = c->plan;
-    if (P.valid && P.n == n && P.in_w == w && P.in_h == h && std::memcmp(&P.params, &prm, sizeof(prm)) == 0)
+    // Does the batch write DoG levels?  Not when the fused extremum scan can take its DoG tiles from four Gaussian levels
+    // (kernels_extrema.hip: rows of every scanned octave 16-byte aligned) - the plan then carves none (1 GB for 32 x 1080p).
+    bool carve_dogs = !(c->dog_in_extrema && c->fused && c->fused_edge);
+    {
+        int ow = prm.subpixel ? 2 * w : w;
+        for (int o = 0; o < prm.octaves && !carve_dogs; ++o, ow = (ow + 1) / 2)
+            if (prm.dogs_per_epoch >= 3 && (ow % 4 != 0 || ow < 4)) carve_dogs = true;
+    }
+    if (P.valid && P.n == n && P.in_w == w && P.in_h == h && std::memcmp(&P.params, &prm, sizeof(prm)) == 0 && P.dogs_carved == carve_dogs)
         return SIFT_HIP_OK;
     P = Plan();
+    P.dogs_carved = carve_dogs;
     if (n <= 0 || w <= 0 || h <= 0 || w >= 32768 || h >= 32768) {  // i16 loop counters, sift.cpp:354-355
         msg = "sift_hip: bad batch geometry";
         return SIFT_HIP_EINVAL;
@@ -471,6 +456,11 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
             dv.scan_nyb[s] = (dv.h[o] + 63) / 64;
             dv.scan_word_base[s] = words;
             words += dv.w[o] * dv.scan_nyb[s];
+            dv.scan_tiles_x[s] = (dv.w[o] + kFxCols - 1) / kFxCols;
+            dv.scan_strip_base[s] = dv.strips_per_image;
+            dv.scan_tile_base[s] = dv.tiles_per_image;
+            dv.strips_per_image += dv.scan_tiles_x[s];
+            dv.tiles_per_image += dv.scan_tiles_x[s] * dv.scan_nyb[s];
             cap += (long long)std::max(0, dv.w[o] - 2) * (long long)std::max(0, dv.h[o] - 2);
             if (std::find(P.grad_levels.begin(), P.grad_levels.end(), dv.nearest_level[o * D + i]) == P.grad_levels.end())
                 P.grad_levels.push_back(dv.nearest_level[o * D + i]);
@@ -489,23 +479,6 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
     dv.words_per_image = std::max(words, 1);
     dv.cand_capacity = (std::max(cap, 1LL) + 15) / 16 * 16;   // every image's flag bytes start 16-byte aligned
     gauss_taps(1.6f, P.taps16, P.radius16);
-    // The pyramid's tail (option "tail_async"): the octaves whose levels are a few tiles per CU for the whole batch.  They must
-    // not hold a gradient level (the gradient maps and W16 are launched beside the main stream's octaves) and every blur of
-    // theirs must have a fused kernel (the two-pass fallback shares the context's scratch image).
-    P.tail_from = O;
-    if (P.fail_status == 0) {
-        int from = O;
-        for (int o = O - 1; o >= 1; --o) {
-            if ((long long)dv.w[o] * dv.h[o] * n > kTailPixels) break;
-            bool ok_o = true;
-            for (int lvl : P.grad_levels) ok_o = ok_o && lvl / (D + 1) != o;
-            for (const BlurOp& op : P.ops)
-                if ((op.kind == 2 || op.kind == 3) && op.octave == o) ok_o = ok_o && op.radius >= 1 && op.radius <= kMaxRadiusFused;
-            if (!ok_o) break;
-            from = o;
-        }
-        P.tail_from = from;
-    }
 
     // ---- device memory ----------------------------------------------------------------------------
     size_t total = 0;
@@ -515,7 +488,8 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
     for (int o = 0; o < O; ++o) {
         const size_t px = (size_t)dv.w[o] * (size_t)dv.h[o] * (size_t)n;
         for (int j = 0; j < D + 1; ++j) goff[(size_t)(o * (D + 1) + j)] = carve(px);
-        for (int j = 0; j < D; ++j) doff[(size_t)(o * D + j)] = carve(px);
+        if (P.dogs_carved)
+            for (int j = 0; j < D; ++j) doff[(size_t)(o * D + j)] = carve(px);
     }
     for (size_t g = 0; g < P.grad_levels.size(); ++g) {
         const int o = P.grad_levels[g] / (D + 1);
@@ -528,7 +502,11 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
     c->arena.ensure(total + 256);   // slack: the kept-pixels decimating blur may read the float after a level's last row (kernels_reduce.hip)
     char* base = c->arena.as<char>();
     for (size_t l = 0; l < goff.size(); ++l) dv.gauss[l] = reinterpret_cast<float*>(base + goff[l]);
-    for (size_t l = 0; l < doff.size(); ++l) dv.dog[l] = reinterpret_cast<float*>(base + doff[l]);
+    for (size_t l = 0; l < doff.size(); ++l) dv.dog[l] = P.dogs_carved ? reinterpret_cast<float*>(base + doff[l]) : nullptr;
+    if (!P.dogs_carved && !extrema_edge_supported(dv)) {   // (cannot happen: the widths were checked above and every carve is 256-byte aligned)
+        msg = "sift_hip: plan without DoG levels for a shape the fused extremum scan does not take";
+        return SIFT_HIP_EINVAL;
+    }
     for (size_t g = 0; g < P.grad_levels.size(); ++g) {
         dv.mag[P.grad_levels[g]] = reinterpret_cast<float*>(base + moff[g]);
         dv.ori[P.grad_levels[g]] = reinterpret_cast<float*>(base + ooff[g]);
@@ -553,6 +531,7 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
     c->d_masks.ensure(nw * sizeof(unsigned long long));
     c->d_fmasks.ensure(nw * sizeof(unsigned long long));
     c->d_counts.ensure(nw * sizeof(int));
+    c->d_tile_counts.ensure((size_t)std::max(dv.tiles_per_image, 1) * (size_t)n * sizeof(int));
     c->d_totals.ensure((size_t)n * sizeof(int));
     c->d_cands.ensure((size_t)dv.cand_capacity * (size_t)n * sizeof(Candidate));
     c->d_flags.ensure((size_t)dv.cand_capacity * (size_t)n);
@@ -571,7 +550,6 @@ int build_plan(sift_hip_ctx* c, int n, int w, int h, const sift_hip_params& prm,
     c->d_pool.ensure((size_t)kPoolCap * (size_t)n * sizeof(FinalKp));
     c->d_cell_cnt.ensure((size_t)(dv.desc_cells_per_image + 1) * (size_t)n * sizeof(int));
     c->d_cell_off.ensure((size_t)(dv.desc_cells_per_image + 1) * (size_t)n * sizeof(int));
-    c->d_desc_sched.ensure(desc_tile_sched_ints(n) * sizeof(int));
     SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
     P.valid = true;
     return SIFT_HIP_OK;
@@ -587,53 +565,6 @@ void early_w16(sift_hip_ctx* c, int level) {
     launch_w16(c->stream2, P.dev, level, c->d_taps16.as<float>(), P.radius16);
 }
 
-// The ops from P.ops[first] on as the argument block of pyramid_tail_kernel (kernels_tail.hip).  false: a level does not fit
-// the kernel's LDS, a reduction's index maps have no inverse-free form here, or there are more ops than the block holds - the
-// tail then stays a launch per level.
-bool make_tail_plan(sift_hip_ctx* c, size_t first, TailPlan& tp, double& bytes, std::vector<int>& skipped_tops) {
-    Plan& P = c->plan;
-    const DevPlan& dv = P.dev;
-    const int n = P.n, O = P.O, D = P.D;
-    tp.n_ops = 0;
-    bytes = 0;
-    skipped_tops.clear();
-    for (size_t k = first; k < P.ops.size() && k < P.fail_op; ++k) {
-        const BlurOp& op = P.ops[k];
-        if (op.kind != 2 && op.kind != 3) return false;
-        if (tp.n_ops >= kMaxTailOps) return false;
-        TailOp& t = tp.op[tp.n_ops++];
-        t = TailOp{};
-        t.kind = op.kind;
-        t.w = op.w; t.h = op.h;
-        t.radius = op.radius;
-        t.tap_off = (int)op.tap_off;
-        t.band = tail_band_rows(op.w, op.h, op.radius);
-        if (t.band <= 0) return false;
-        const double px = (double)op.w * (double)op.h * (double)n;
-        if (op.kind == 2) {
-            const int l = op.octave * (D + 1) + op.j;
-            const bool skip = c->lazy_top && op.j == D && std::find(P.grad_levels.begin(), P.grad_levels.end(), l) == P.grad_levels.end();
-            t.wd = op.w; t.hd = op.h;
-            t.src = dv.gauss[l - 1];
-            t.dst = skip ? nullptr : dv.gauss[l];
-            t.dog = dv.dog[op.octave * D + op.j - 1];
-            if (skip) skipped_tops.push_back(op.octave);
-            bytes += px * (4.0 + (t.dst ? 4.0 : 0.0) + 4.0);
-        } else {
-            const int o = op.octave;
-            if (o + 1 >= O) return false;
-            t.wd = dv.w[o + 1]; t.hd = dv.h[o + 1];
-            t.src = dv.gauss[o * (D + 1) + D - 1];
-            t.dst = dv.gauss[(o + 1) * (D + 1)];
-            t.dog = nullptr;
-            t.lut_x = (int)P.lut_x_off[(size_t)o];
-            t.lut_y = (int)P.lut_y_off[(size_t)o];
-            bytes += px * 4.0 + (double)t.wd * (double)t.hd * (double)n * 4.0;
-        }
-    }
-    return tp.n_ops > 0;
-}
-
 // ---- pyramid (Sift::_createDOGs, sift.cpp:381-417) ---------------------------------------------
 void run_pyramid(sift_hip_ctx* c, const float* d_in) {
     Plan& P = c->plan;
@@ -641,17 +572,7 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
     const int n = P.n, O = P.O, D = P.D;
     const float* base = d_in;
     bool side_used = false;
-    // the pyramid's tail runs on a stream of its own (option "tail_async"; Plan::tail_from)
-    const bool want_kernel = c->tail_kernel == 2 || (c->tail_kernel == 1 && n >= kTailKernelImages);
-    const bool use_tail = (c->tail_async || want_kernel) && c->stream3 && c->fused && P.tail_from < O;
     hipStream_t ms = c->stream;   // stream of the launches that are not the side stream's
-    bool in_tail = false;
-    struct TailMark {   // the tail's end, recorded however the loop ends
-        sift_hip_ctx* c; bool* in_tail;
-        ~TailMark() {
-            if (*in_tail) (void)hipEventRecord(c->ev_tail_done, c->stream3);
-        }
-    } tail_mark{c, &in_tail};
     struct SideJoin {   // whatever ran on the side stream is part of the pyramid: the main stream goes on after it
         sift_hip_ctx* c; bool* used;
         ~SideJoin() {
@@ -663,28 +584,6 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
     for (size_t k = 0; k < P.ops.size(); ++k) {
         if (k >= P.fail_op) break;
         const BlurOp& op = P.ops[k];
-        if (c->diag_skip_tail && (op.kind == 2 || op.kind == 3) && op.octave >= P.tail_from) continue;
-        if (use_tail && !in_tail && (op.kind == 2 || op.kind == 3) && op.octave >= P.tail_from) {
-            SIFT_HIP_CHECK(hipEventRecord(c->ev_tail_fork, c->stream));
-            SIFT_HIP_CHECK(hipStreamWaitEvent(c->stream3, c->ev_tail_fork, 0));
-            in_tail = true;
-            c->tail_pending = true;
-            ms = c->stream3;
-            // ... as ONE launch, a workgroup per image (option "tail_kernel"), where the plan and the batch allow it
-            if (want_kernel) {
-                std::vector<int> tops;
-                double bytes = 0;
-                if (make_tail_plan(c, k, P.tail, bytes, tops)) {
-                    hipEvent_t a = nullptr, b = nullptr;
-                    if (c->profile) { a = get_event(c); b = get_event(c); }
-                    launch_pyramid_tail(c->stream3, P.tail, n, c->d_taps.as<float>(), c->d_luts.as<int>(), a, b);
-                    if (c->profile) c->pending.push_back({a, b, 2, bytes});
-                    for (int o : tops) c->top_missing[(size_t)o] = 1;
-                    c->tail_in_kernel = true;
-                    break;   // every op from here on was the tail's
-                }
-            }
-        }
         switch (op.kind) {
             case 0: {  // increaseToNextLevel(img, 1.0): blur then 2x nearest upsample
                 run_blur(c, d_in, c->d_tmp2.as<float>(), nullptr, op.w, op.h, n, op.tap_off, op.radius);
@@ -703,7 +602,7 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
                         hipEvent_t a = nullptr, b = nullptr;
                         if (c->profile) { a = get_event(c); b = get_event(c); }
                         if (launch_blur_pair(c->stream, base, dv.gauss[0], dv.gauss[1], op.w, op.h, n, c->d_taps.as<float>() + op.tap_off,
-                                             op.radius, stream_min_waves_now(), a, b)) {
+                                             op.radius, min_waves(c), c->pair_waves, a, b)) {
                             if (c->profile) c->pending.push_back({a, b, 0, (double)op.w * (double)op.h * (double)n * 12.0});   // one read, two levels written
                             early_w16(c, 0);
                             early_w16(c, 1);
@@ -722,13 +621,11 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
                 // The top level of an octave only feeds the octave's last DoG; the next octave starts from the level below it
                 // (sift.cpp:406-409).  Option "pyramid_side": it is formed on the side stream beside the reduction and the
                 // next octave's levels (fused kernels only: the two-pass fallback shares a scratch image with them).
-                const bool side = !in_tail && c->pyramid_side && c->ev_side_fork && op.j == D && op.octave + 1 < O && c->fused && op.radius >= 1 &&
+                const bool side = c->pyramid_side && c->ev_side_fork && op.j == D && op.octave + 1 < O && c->fused && op.radius >= 1 &&
                                   op.radius <= kMaxRadiusFused && std::find(P.grad_levels.begin(), P.grad_levels.end(), l) == P.grad_levels.end();
                 const bool no_dogs = c->dogs_missing;   // option dog_in_extrema: every Gaussian level is kept, no DoG level is written
-                const bool skip = !no_dogs && c->lazy_top && op.j == D && std::find(P.grad_levels.begin(), P.grad_levels.end(), l) == P.grad_levels.end();
-                float* g_out = skip ? nullptr : dv.gauss[l];
+                float* g_out = dv.gauss[l];
                 float* dog_out = no_dogs ? nullptr : dv.dog[op.octave * D + op.j - 1];
-                if (skip) c->top_missing[(size_t)op.octave] = 1;
                 if (side) {
                     SIFT_HIP_CHECK(hipEventRecord(c->ev_side_fork, c->stream));
                     SIFT_HIP_CHECK(hipStreamWaitEvent(c->stream2, c->ev_side_fork, 0));
@@ -736,7 +633,7 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
                     side_used = true;
                 } else {
                     run_blur(c, dv.gauss[l - 1], g_out, dog_out, op.w, op.h, n, op.tap_off, op.radius, ms);
-                    if (!in_tail) early_w16(c, l);   // (no gradient level lies in the tail)
+                    early_w16(c, l);
                 }
                 break;
             }
@@ -753,11 +650,11 @@ void run_pyramid(sift_hip_ctx* c, const float* d_in) {
                     // that stores the kept quarter of a full-resolution result
                     if (c->reduce_kept && P.red_sx[(size_t)o] >= 0 && P.red_sy[(size_t)o] >= 0)
                         done = launch_blur_reduce_kept(ms, src, dst, op.w, op.h, dv.w[o + 1], dv.h[o + 1], n, c->d_taps.as<float>() + op.tap_off,
-                                                       op.radius, P.red_sx[(size_t)o], P.red_sy[(size_t)o], std::min(stream_min_waves_now(), 256), a, b);
+                                                       op.radius, P.red_sx[(size_t)o], P.red_sy[(size_t)o], std::min(min_waves(c), 256), a, b);
                     if (!done)
                         done = launch_blur_reduce(ms, src, dst, op.w, op.h, dv.w[o + 1], dv.h[o + 1], n,
                                               c->d_taps.as<float>() + op.tap_off, op.radius, c->d_luts.as<int>() + P.inv_x_off[(size_t)o],
-                                              c->d_luts.as<int>() + P.inv_y_off[(size_t)o], c->d_tmp.as<float>(), a, b);
+                                              c->d_luts.as<int>() + P.inv_y_off[(size_t)o], c->d_tmp.as<float>(), min_waves(c), a, b);
                     if (c->profile) {
                         if (done) {
                             const double px = (double)op.w * (double)op.h * (double)n, pd = (double)dv.w[o + 1] * (double)dv.h[o + 1] * (double)n;
@@ -948,15 +845,15 @@ void launch_descriptor_stage(sift_hip_ctx* c, bool base_on_device = false) {
         wire_sums = c->d_wire_sums.as<int>();
         c->wire_counted = true;
     }
-    for (int lvl : P.grad_levels)
-        if (c->desc_tile)
-            launch_descriptors_tile(c->stream, c->d_plan.as<DevPlan>(), dv, lvl, c->d_cell_off.as<int>(), c->d_pool.as<FinalKp>(), kPoolCap,
-                                    c->d_out_base.as<long long>(), c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->out_cap,
-                                    wire_sums, c->d_desc_sched.as<int>());
-        else
-            launch_descriptors_wave(c->stream, c->d_plan.as<DevPlan>(), dv, lvl, c->d_cell_off.as<int>(), c->d_pool.as<FinalKp>(), kPoolCap,
-                                    c->d_out_base.as<long long>(), c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->out_cap, c->desc_dbg,
-                                    wire_sums);
+    for (int lvl : P.grad_levels) {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (c->profile) { a = get_event(c); b = get_event(c); }
+        launch_descriptors_wave(c->stream, c->d_plan.as<DevPlan>(), dv, lvl, c->d_cell_off.as<int>(), c->d_pool.as<FinalKp>(), kPoolCap,
+                                c->d_out_base.as<long long>(), c->d_kp.as<sift_hip_keypoint>(), c->d_desc.as<float>(), c->out_cap, c->desc_dbg,
+                                wire_sums, a, b);
+        // (bytes: SURVEY 8(d)'s 3.5 KB per keypoint - the keypoint count is not on the host yet, the caller prices the launches)
+        if (c->profile) c->pending.push_back({a, b, 2, 0.0});
+    }
     c->wire_scanned = false;
     if (c->wire_counted) {
         // ... and the scan of the per-block counts, over the blocks of the arrays' CAPACITY (the number of keypoints is not on
@@ -1229,6 +1126,7 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     c->wire_counted = false;
     c->wire_scanned = false;
     c->profile = c->profile_every > 0 && (c->profile_batches++ % c->profile_every) == 0;
+    if (c->profile) c->prof_batches++;
 
     // Batches of several contexts in flight on this GPU: the gate orders their phases (phase_gate.h).  Whatever
     // this batch owes its partners is released when the scope ends, however it ends.
@@ -1240,27 +1138,15 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
         }
     } gate_scope{c};
     c->gate_ticket = c->gate ? c->gate->begin_batch(s) : -1;
-    c->top_missing.assign((size_t)P.O, 0);
-    if (c->tail_pending) {   // a batch that ended early left its tail behind: nothing of it may run beside this pyramid
-        SIFT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_tail_done, 0));
-        c->tail_pending = false;
-    }
-    c->tail_in_kernel = false;
-    c->dog_formed.clear();
-    c->dogs_missing = c->dog_in_extrema && c->fused && c->fused_edge && extrema_edge_supported(dv) && !c->tail_async && c->tail_kernel == 0;
+    c->dog_in_scratch = -1;
+    c->dogs_missing = !P.dogs_carved;
     run_pyramid(c, d_in);
     SIFT_HIP_CHECK(hipGetLastError());   // a rejected launch configuration must not go unnoticed
     if (c->gate) {
         c->gate->mark(c->gate_ticket, sift_hip::PhaseGate::kP, s);
     }
     c->have_pyramid = true;
-    auto join_tail = [&]() {   // the main stream goes on behind the tail's last launch
-        if (!c->tail_pending) return;
-        SIFT_HIP_CHECK(hipStreamWaitEvent(s, c->ev_tail_done, 0));
-        c->tail_pending = false;
-    };
     if (P.fail_status) {
-        join_tail();
         SIFT_HIP_CHECK(hipStreamSynchronize(s));
         resolve_events(c);
         for (int i = 0; i < n; ++i) { c->status[(size_t)i] = P.fail_status; c->messages[(size_t)i] = P.fail_msg; }
@@ -1281,27 +1167,28 @@ int run_batch(sift_hip_ctx* c, const float* d_in, char* err, int errlen) {
     c->bin_stamp = (c->bin_stamp % 0x3fffffff) + 1;
     for (int lvl : P.grad_levels) {
         const int o = lvl / (P.D + 1);
+        hipEvent_t a = nullptr, b = nullptr;
+        if (c->profile) { a = get_event(c); b = get_event(c); }
         launch_gradient(gs, dv.gauss[lvl], dv.mag[lvl], dv.ori[lvl], dv.prod[lvl], dv.w[o], dv.h[o], n,
-                        (c->orient_general ? nullptr : c->d_ocnt.as<int>() + 4 * n), c->bin_stamp);
+                        (c->orient_general ? nullptr : c->d_ocnt.as<int>() + 4 * n), c->bin_stamp, a, b);
+        if (c->profile) c->pending.push_back({a, b, 4, (double)dv.w[o] * (double)dv.h[o] * (double)n * 12.0});   // grad_mag_ori 12 N
     }
     if (c->gate) SIFT_HIP_CHECK(hipEventRecord(c->ev_grad, gs));
     // extrema + edge responses (sift.cpp:33-34)
     if (c->fused_edge && extrema_edge_supported(dv)) {
         // one pass over the DoG levels: extremum test and edge-response filter from LDS tiles
-        // (the scans of the tail's octaves wait for the tail; the others do not)
-        int k_split = dv.n_scan;
-        if (c->tail_pending)
-            for (int k = dv.n_scan - 1; k >= 0 && dv.scan_octave[k] >= P.tail_from; --k) k_split = k;
-        launch_extrema_edge(s, dv, c->d_masks.as<unsigned long long>(), c->d_fmasks.as<unsigned long long>(), c->d_counts.as<int>(), 0, k_split,
-                            c->tail_in_kernel ? n : 0, c->dogs_missing);
-        join_tail();
-        launch_extrema_edge(s, dv, c->d_masks.as<unsigned long long>(), c->d_fmasks.as<unsigned long long>(), c->d_counts.as<int>(), k_split, dv.n_scan,
-                            0, c->dogs_missing);
-        launch_extrema_scan(s, dv, c->d_counts.as<int>(), c->d_totals.as<int>());
-        launch_extrema_expand(s, dpl, dv, c->d_masks.as<unsigned long long>(), c->d_counts.as<int>(), c->d_cands.as<Candidate>(),
-                              c->d_fmasks.as<unsigned long long>(), c->d_flags.as<uint8_t>());
+        hipEvent_t a = nullptr, b = nullptr;
+        if (c->profile) { a = get_event(c); b = get_event(c); }
+        launch_extrema_edge(s, dv, c->d_masks.as<unsigned long long>(), c->d_fmasks.as<unsigned long long>(), c->d_tile_counts.as<int>(), c->dogs_missing, a, b);
+        if (c->profile) {   // 12 N per scanned middle level read as three DoG levels; 16 N when the scan reads four Gaussian levels
+            double px = 0;
+            for (int k = 0; k < dv.n_scan; ++k) px += (double)dv.w[dv.scan_octave[k]] * (double)dv.h[dv.scan_octave[k]];
+            c->pending.push_back({a, b, 3, px * (double)n * (c->dogs_missing ? 16.0 : 12.0)});
+        }
+        // (no scan launch: the expansion finds a strip's first slot from the per-tile counts of the tiles in front of it)
+        launch_extrema_expand_tiles(s, dpl, dv, c->d_masks.as<unsigned long long>(), c->d_fmasks.as<unsigned long long>(), c->d_tile_counts.as<int>(),
+                                    c->d_cands.as<Candidate>(), c->d_flags.as<uint8_t>(), c->d_totals.as<int>());
     } else {
-        join_tail();
         launch_extrema_mask(s, dpl, dv, c->d_masks.as<unsigned long long>(), c->d_counts.as<int>());
         launch_extrema_scan(s, dv, c->d_counts.as<int>(), c->d_totals.as<int>());
         launch_extrema_expand(s, dpl, dv, c->d_masks.as<unsigned long long>(), c->d_counts.as<int>(), c->d_cands.as<Candidate>());
@@ -1410,9 +1297,6 @@ int sift_hip_create(int device, sift_hip_ctx** out, char* err, int errlen) {
         c->device = device;
         SIFT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         SIFT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-        SIFT_HIP_CHECK(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
-        SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_tail_fork, hipEventDisableTiming));
-        SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_tail_done, hipEventDisableTiming));
         SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork0, hipEventDisableTiming));
         SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         SIFT_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -1427,7 +1311,7 @@ int sift_hip_create(int device, sift_hip_ctx** out, char* err, int errlen) {
             static bool touched[64] = {false};
             std::lock_guard<std::mutex> lk(touch_lock);
             if (device < 64 && !touched[device]) {
-                tu_touch_pyramid(c->stream); tu_touch_pair(c->stream); tu_touch_tail(c->stream); tu_touch_reduce(c->stream); tu_touch_extrema(c->stream); tu_touch_orient(c->stream);
+                tu_touch_pyramid(c->stream); tu_touch_pair(c->stream); tu_touch_reduce(c->stream); tu_touch_extrema(c->stream); tu_touch_orient(c->stream);
                 tu_touch_desc(c->stream); tu_touch_cleanup(c->stream); tu_touch_wire(c->stream); tu_touch_io(c->stream);
                 SIFT_HIP_CHECK(hipGetLastError());
                 SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -1446,8 +1330,8 @@ void sift_hip_destroy(sift_hip_ctx* c) {
     (void)sift_hip_set_gate(c, nullptr);
     ApiGuard api;
     for (DevBuf* b : {&c->arena, &c->d_plan, &c->d_taps, &c->d_luts, &c->d_taps16, &c->d_input, &c->d_input_u8, &c->d_sparse_rec, &c->d_sparse_val, &c->d_base, &c->d_tmp, &c->d_tmp2,
-                      &c->d_wk, &c->d_wi, &c->d_wi2, &c->d_wp, &c->d_status, &c->d_pool, &c->d_order, &c->d_masks, &c->d_fmasks, &c->d_counts, &c->d_totals, &c->d_cands, &c->d_flags, &c->d_list, &c->d_list_cnt, &c->d_orient,
-                      &c->d_peaks, &c->d_final, &c->d_final_cnt, &c->d_out_base, &c->d_kp, &c->d_desc, &c->d_lrank, &c->d_ochunk, &c->d_ocnt, &c->d_recs, &c->d_wire_sums, &c->d_wire_off, &c->d_unpack_sums, &c->d_unpack_off, &c->d_cell_cnt, &c->d_cell_off, &c->d_desc_sched})
+                      &c->d_wk, &c->d_wi, &c->d_wi2, &c->d_wp, &c->d_status, &c->d_pool, &c->d_order, &c->d_masks, &c->d_fmasks, &c->d_counts, &c->d_tile_counts, &c->d_totals, &c->d_cands, &c->d_flags, &c->d_list, &c->d_list_cnt, &c->d_orient,
+                      &c->d_peaks, &c->d_final, &c->d_final_cnt, &c->d_out_base, &c->d_kp, &c->d_desc, &c->d_lrank, &c->d_ochunk, &c->d_ocnt, &c->d_recs, &c->d_wire_sums, &c->d_wire_off, &c->d_unpack_sums, &c->d_unpack_off, &c->d_cell_cnt, &c->d_cell_off})
         b->release();
     for (HostBuf* b : {&c->h_flags, &c->h_orient, &c->h_peaks, &c->h_status, &c->h_wire, &c->h_stage[0], &c->h_stage[1]}) b->release();
     for (auto& e : c->ev_stage) if (e) (void)hipEventDestroy(e);
@@ -1461,9 +1345,6 @@ void sift_hip_destroy(sift_hip_ctx* c) {
     if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
     if (c->ev_side_fork) (void)hipEventDestroy(c->ev_side_fork);
     if (c->ev_side_join) (void)hipEventDestroy(c->ev_side_join);
-    if (c->ev_tail_fork) (void)hipEventDestroy(c->ev_tail_fork);
-    if (c->ev_tail_done) (void)hipEventDestroy(c->ev_tail_done);
-    if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
     (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1531,60 +1412,43 @@ int sift_hip_set_gate(sift_hip_ctx* c, sift_hip_gate* g) {
 
 int sift_hip_set_option(sift_hip_ctx* c, const char* name, int value) {
     if (!c || !name) return SIFT_HIP_EINVAL;
-    if (!std::strcmp(name, "fused_blur")) { c->fused = value != 0; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "fused_edge")) { c->fused_edge = value != 0; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "fused_reduce")) { c->fused_reduce = value != 0; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "reduce_kept")) { c->reduce_kept = value != 0; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "spin_wait")) { c->spin_wait = value != 0; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "desc_kernel")) {
-        if (value != 1 && value != 2) return SIFT_HIP_EINVAL;
-        c->desc_tile = value == 2;
-        return SIFT_HIP_OK;
-    }
-    if (!std::strcmp(name, "lazy_top")) { c->lazy_top = value != 0; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "dog_in_extrema")) { c->dog_in_extrema = value != 0; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "tail_async")) { c->tail_async = value != 0; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "tail_kernel")) {
-        if (value < 0 || value > 2) return SIFT_HIP_EINVAL;
-        c->tail_kernel = value;
-        return SIFT_HIP_OK;
-    }
+    // ---- the eight options of the shipped library (include/sift_hip.h) ----
+    if (!std::strcmp(name, "profile")) { c->profile_every = value > 0 ? value : 0; c->profile_batches = 0; c->profile = false; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "wire_count")) { c->wire_count = value != 0; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "pyramid_side")) {
-        ApiGuard api;
-        if (value != 0 && !c->ev_side_fork) {
-            if (hipSetDevice(c->device) != hipSuccess ||
-                hipEventCreateWithFlags(&c->ev_side_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&c->ev_side_join, hipEventDisableTiming) != hipSuccess)
-                return SIFT_HIP_EHIP;
-        }
-        c->pyramid_side = value != 0;
-        return SIFT_HIP_OK;
-    }
-    if (!std::strcmp(name, "gate_schedule")) {
+    if (!std::strcmp(name, "host_threads")) { c->host_threads = value; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "spin_wait")) { c->spin_wait = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "orient_general")) { c->orient_general = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "stream_min_waves")) { c->stream_min_waves = value > 0 ? value : 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "blur_pair")) { c->blur_pair = value != 0; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "pair_waves")) { c->pair_waves = value > 0 ? value : 0; return SIFT_HIP_OK; }
+#ifdef SIFT_HIP_DIAG
+    // ---- libsift_hip_diag.so (`make -C sift_amd/csrc diag`: this file alone compiled with -DSIFT_HIP_DIAG, the kernels are the
+    // shipped ones).  Names that FORCE a fallback path the library otherwise takes by itself when a shape does not fit the
+    // default kernels - tests/diag_fallbacks.py runs them against the oracle - and host-side measurement aids of tools/.
+    if (!std::strcmp(name, "fused_blur")) { c->fused = value != 0; return SIFT_HIP_OK; }                 // 0: two-pass row / column kernels (radius 0 and > 32)
+    if (!std::strcmp(name, "fused_edge")) { c->fused_edge = value != 0; return SIFT_HIP_OK; }            // 0: mask kernel + thread-per-candidate filter (rows not 16-byte aligned)
+    if (!std::strcmp(name, "fused_reduce")) { c->fused_reduce = value != 0; return SIFT_HIP_OK; }        // 0: blur into a temporary, then the resampling kernel (index maps without an inverse)
+    if (!std::strcmp(name, "reduce_kept")) { c->reduce_kept = value != 0; return SIFT_HIP_OK; }          // 0: the streaming blur that stores the kept quarter (maps without a parity split)
+    if (!std::strcmp(name, "dog_in_extrema")) { c->dog_in_extrema = value != 0; return SIFT_HIP_OK; }    // 0: every blur launch writes its DoG level (rows not 16-byte aligned)
+    if (!std::strcmp(name, "gpu_cleanup")) { c->gpu_cleanup = value != 0; return SIFT_HIP_OK; }          // 0: std::sort on the host (introsort depth limit, several orientation peaks)
+    if (!std::strcmp(name, "pyramid_side")) { c->pyramid_side = value != 0; return SIFT_HIP_OK; }        // 0: every pyramid launch on one stream
+    if (!std::strcmp(name, "gate_schedule")) {                                                           // 0: no pyramid shares the chip (rounds 1 - 2)
         if (value < 0 || value > 1) return SIFT_HIP_EINVAL;
         c->gate_schedule = value;
         if (c->gate) c->gate->set_schedule(value);
         return SIFT_HIP_OK;
     }
-    if (!std::strcmp(name, "gpu_cleanup")) { c->gpu_cleanup = value != 0; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "profile")) { c->profile_every = value > 0 ? value : 0; c->profile_batches = 0; c->profile = false; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "orient_general")) { c->orient_general = value != 0; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "stream_min_waves")) { set_stream_min_waves(value); return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "blur_pair")) { c->blur_pair = value != 0; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "pair_waves")) { set_pair_waves(value); return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "host_threads")) { c->host_threads = value; return SIFT_HIP_OK; }
-#ifdef SIFT_HIP_DIAG
-    // Measurement aids of tools/ (`make -C sift_amd/csrc diag` -> libsift_hip_diag.so): phases of kernels switched off for timing
-    // (the results are then WRONG), stamps, the batch repeated inside one call.  The shipped library does not know these names.
-    if (!std::strcmp(name, "desc_dbg")) { c->desc_dbg = value; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "diag_repeat")) { c->diag_repeat = value > 1 ? value : 1; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "stream_waves")) { set_stream_waves(value); return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "orient_dbg")) { set_orient_dbg(value); return SIFT_HIP_OK; }
     if (!std::strcmp(name, "diag_pyramid_span")) { c->diag_pyramid_span = value != 0; return SIFT_HIP_OK; }
     if (!std::strcmp(name, "diag_serial_gradient")) { c->diag_serial_gradient = value != 0; return SIFT_HIP_OK; }
+#endif
+#ifdef SIFT_HIP_ABLATE
+    // ---- libsift_hip_ablate.so (`make ablate`: every file with -DSIFT_HIP_DIAG -DSIFT_HIP_ABLATE): phases INSIDE kernels switched
+    // off for timing - the results are then WRONG - and stamps.  Scripts under tools/ only.
+    if (!std::strcmp(name, "desc_dbg")) { c->desc_dbg = value; return SIFT_HIP_OK; }
+    if (!std::strcmp(name, "orient_dbg")) { set_orient_dbg(value); return SIFT_HIP_OK; }
     if (!std::strcmp(name, "diag_cleanup_stamps")) { c->diag_cleanup_stamps = value != 0; return SIFT_HIP_OK; }
-    if (!std::strcmp(name, "diag_skip_tail")) { c->diag_skip_tail = value != 0; return SIFT_HIP_OK; }
 #endif
     return SIFT_HIP_EINVAL;
 }
@@ -2003,7 +1867,7 @@ static float* level_ptr(sift_hip_ctx* c, int kind, int o, int i, int* w, int* h)
     *h = P.dev.h[o];
     switch (kind) {
         case 0: return P.dev.gauss[o * (P.D + 1) + i];
-        case 1: return P.dev.dog[o * P.D + i];
+        case 1: return P.dogs_carved ? P.dev.dog[o * P.D + i] : c->d_tmp2.as<float>();   // not carved: formed on demand (sift_hip_level_copy)
         case 2: return P.dev.mag[o * (P.D + 1) + i];
         case 3: return P.dev.ori[o * (P.D + 1) + i];
     }
@@ -2024,26 +1888,12 @@ int sift_hip_level_copy(sift_hip_ctx* c, int image, int kind, int octave, int le
     if (!p) return SIFT_HIP_EINVAL;
     return guarded(nullptr, 0, [&]() {
         SIFT_HIP_CHECK(hipSetDevice(c->device));
-        if (kind == 0 && level == c->plan.D && (size_t)octave < c->top_missing.size() && c->top_missing[(size_t)octave]) {
-            // option "lazy_top": the batch did not write this level; the launch that would have, now without the DoG
-            const Plan& P = c->plan;
-            for (size_t k = 0; k < P.ops.size() && k < P.fail_op; ++k) {
-                const BlurOp& op = P.ops[k];
-                if (op.kind != 2 || op.octave != octave || op.j != P.D) continue;
-                const int l = octave * (P.D + 1) + P.D;
-                run_blur(c, P.dev.gauss[l - 1], P.dev.gauss[l], nullptr, op.w, op.h, P.n, op.tap_off, op.radius);
-                SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
-                c->top_missing[(size_t)octave] = 0;
-            }
-            if (c->top_missing[(size_t)octave]) return (int)SIFT_HIP_EINVAL;   // the pyramid stopped before this level (precondition)
-        }
         if (kind == 1 && c->dogs_missing) {
-            // option "dog_in_extrema": the batch wrote no DoG level (the extremum scan forms its tiles from the Gaussian levels);
-            // this one is formed now, by alg::dog's own kernel, from the two Gaussian levels it lies between
+            // the batch wrote no DoG level (the extremum scan forms its tiles from the Gaussian levels) and the plan holds none:
+            // this one is formed now, by alg::dog's own kernel, from the two Gaussian levels it lies between, in the scratch image
             const Plan& P = c->plan;
-            const size_t di = (size_t)(octave * P.D + level);
-            if (c->dog_formed.size() != (size_t)(P.O * P.D)) c->dog_formed.assign((size_t)(P.O * P.D), 0);
-            if (!c->dog_formed[di]) {
+            const int di = octave * P.D + level;
+            if (c->dog_in_scratch != di) {
                 auto formed = [&](int j) {   // did the batch's pyramid reach g(octave, j)?
                     for (size_t k = 0; k < P.ops.size() && k < P.fail_op; ++k) {
                         const BlurOp& op = P.ops[k];
@@ -2055,10 +1905,10 @@ int sift_hip_level_copy(sift_hip_ctx* c, int image, int kind, int octave, int le
                 };
                 if (!formed(level) || !formed(level + 1)) return (int)SIFT_HIP_EINVAL;   // the pyramid stopped before this level (precondition)
                 const int gl = octave * (P.D + 1) + level;
-                launch_dog(c->stream, P.dev.gauss[gl], P.dev.gauss[gl + 1], P.dev.dog[di], (size_t)w * (size_t)h * (size_t)P.n);
+                launch_dog(c->stream, P.dev.gauss[gl], P.dev.gauss[gl + 1], p, (size_t)w * (size_t)h * (size_t)P.n);
                 SIFT_HIP_CHECK(hipGetLastError());
                 SIFT_HIP_CHECK(hipStreamSynchronize(c->stream));
-                c->dog_formed[di] = 1;
+                c->dog_in_scratch = di;
             }
         }
         const size_t px = (size_t)w * (size_t)h;
@@ -2188,7 +2038,7 @@ int op_blur_resample(sift_hip_ctx* c, const float* in, int w, int h, float sigma
         float* d_tmp = s.dev<float>(px);
         float* d_out = s.dev<float>(px);
         float* d_taps = s.upload(taps.data(), taps.size());
-        launch_blur(c->stream, c->fused, d_in, d_tmp, d_out, nullptr, w, h, 1, d_taps, r);
+        launch_blur(c->stream, c->fused, d_in, d_tmp, d_out, nullptr, w, h, 1, d_taps, r, min_waves(c));
         if (resample) {
             const std::vector<int> lx = resize_index_map(w, wd), ly = resize_index_map(h, hd);
             int* d_lx = s.upload(lx.data(), lx.size());
@@ -2377,7 +2227,7 @@ int sift_hip_cleanup_survivors(sift_hip_ctx* c, const uint8_t* flags, int n, int
 }
 
 int sift_hip_profile_get(sift_hip_ctx* c, int which, double* ms, int64_t* launches, double* bytes) {
-    if (!c || which < 0 || which > 2) return SIFT_HIP_EINVAL;
+    if (!c || which < 0 || which >= sift_hip_ctx::kProfClasses) return SIFT_HIP_EINVAL;
     if (ms) *ms = c->prof_ms[which];
     if (launches) *launches = c->prof_launches[which];
     if (bytes) *bytes = c->prof_bytes[which];
@@ -2385,13 +2235,19 @@ int sift_hip_profile_get(sift_hip_ctx* c, int which, double* ms, int64_t* launch
 }
 
 int sift_hip_profile_get_busy(sift_hip_ctx* c, int which, double* busy_ms) {
-    if (!c || which < 0 || which > 2 || !busy_ms) return SIFT_HIP_EINVAL;
+    if (!c || which < 0 || which >= sift_hip_ctx::kProfClasses || !busy_ms) return SIFT_HIP_EINVAL;
     *busy_ms = c->prof_busy_ms[which];
     return SIFT_HIP_OK;
 }
 int sift_hip_profile_reset(sift_hip_ctx* c) {
     if (!c) return SIFT_HIP_EINVAL;
-    for (int i = 0; i < 3; ++i) { c->prof_ms[i] = 0; c->prof_launches[i] = 0; c->prof_bytes[i] = 0; c->prof_busy_ms[i] = 0; }
+    for (int i = 0; i < sift_hip_ctx::kProfClasses; ++i) { c->prof_ms[i] = 0; c->prof_launches[i] = 0; c->prof_bytes[i] = 0; c->prof_busy_ms[i] = 0; }
+    c->prof_batches = 0;
+    return SIFT_HIP_OK;
+}
+int sift_hip_profile_batches(sift_hip_ctx* c, int64_t* batches) {
+    if (!c || !batches) return SIFT_HIP_EINVAL;
+    *batches = c->prof_batches;
     return SIFT_HIP_OK;
 }
 

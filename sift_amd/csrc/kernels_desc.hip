@@ -9,12 +9,11 @@
 // `ori += p.orientation` and `mag += W(lx, ly)` where W is the top-left 16x16 of
 // convolveWithGauss(level, 1.6) indexed by WINDOW-LOCAL coordinates.  A later keypoint whose
 // window overlaps sees the accumulated values, so each pixel carries an order-dependent float
-// chain.  Two kernels reproduce those chains exactly and in parallel (nothing is written back to HBM
-// except the descriptors: the reference's mutated pyramids are private state):
-//   * descriptor_wave_kernel (the default): one wave per keypoint recomputes the chains of its window's 256
-//     pixels from the initial maps and the preceding neighbours, found through a grid of 16 px cells;
-//   * descriptor_tile_kernel (option desc_kernel = 2): one wave per 32x32 tile of keypoint locations keeps
-//     the tile's pixels in LDS and applies the keypoints that touch it in vector order.
+// chain.  descriptor_wave_kernel reproduces those chains exactly and in parallel (nothing is written back to HBM
+// except the descriptors: the reference's mutated pyramids are private state): one wave per keypoint recomputes
+// the chains of its window's 256 pixels from the initial maps and the preceding neighbours, found through a grid
+// of 16 px cells.  (A tile-per-wave form - a wave owning a 32x32 tile of keypoint locations with the tile's pixels
+// in LDS - was built in round 4, lost in the pipeline and was removed in round 6: DESIGN.md section 4.)
 #include <cstdio>
 
 #include "common.h"
@@ -569,515 +568,6 @@ __global__ __launch_bounds__(256, 8) void descriptor_wave_kernel(const DevPlan* 
     }   // units
 }
 
-// =====================================================================================================
-// Tile-per-wave form (round 4; option desc_kernel = 2, NOT the default: context.cpp).  The wave-per-keypoint kernel above recomputes, for every keypoint, the float
-// chains of its 256 window pixels from the initial maps: a keypoint's additions are applied once for itself and once more
-// for each of the ~8.5 later keypoints whose window overlaps its own, and three quarters of those lane-pixel updates fall
-// outside the neighbour's window.  Here ONE WAVE owns a core of 32 x CH pixels of keypoint locations ("home" keypoints)
-// and keeps the (orientation, magnitude) pairs of the (32 + 15) x (CH + 15) pixels their windows can touch in ITS OWN
-// slice of LDS (~18 KB; a workgroup is one wave, eight of them share a CU).  It sorts the keypoints whose window meets
-// that extended tile by vector index (they are found through the same grid of 16 px cells: 4 x (CH/16 + 2) cells, one
-// run of consecutive records per cell row) and applies them IN VECTOR ORDER, exactly as the reference's in-place
-// updates (sift.cpp:80-92):
-//   * every keypoint's update is made in ITS OWN window frame: lane l owns the pixels (l & 15, (l >> 4) + 4 i), i = 0..3,
-//     of the window, so the weighting value it adds (sift.cpp:87-90: window-local) is the same register for every keypoint
-//     of the image - no table - and an update is four 8-byte LDS reads, eight additions and four 8-byte LDS writes; the
-//     LDS executes a wave's operations in order, which IS the chain order, and no two lanes of an instruction share a
-//     pixel.  (LDS float atomics would need no wait at all, and ds_add_f32 is the same round-to-nearest-even add as
-//     v_add_f32, denormals kept - tools/probe/lds_atomic_probe.hip -, but it takes ~190 cycles per wave-instruction,
-//     22 times the read-add-write form: tools/probe/lds_rate_probe.hip.)  A window that leaves the extended tile is
-//     clipped per pixel (the rest of it belongs to the chains of other tiles): the clipped pixels' reads and writes go to a
-//     scratch line instead, so the code is branch-free;
-//   * after a home keypoint's own update its window is read back in the histogram layout of the kernel above (lane = four
-//     consecutive x of one row, a DPP quad = the four rows of a 4x4 cell) and the 16 cell histograms, the L1
-//     normalisation and the stores are that kernel's.
-// A keypoint is applied in the ~3.75 tiles (CH = 32) its window can meet instead of ~9.5 neighbours' waves, at about half the
-// instructions a time, and every lane-pixel update is a real one.  The row stride of the tile is 47 pixels (odd): an update
-// instruction (two window rows of 16 consecutive pixels per half-wave) and a read-back (16 rows x 2 column groups) meet a
-// bank at most twice.
-// Keypoints after the last home keypoint of the vector cannot change anything the tile emits and are dropped before the
-// sort.  Neighbourhoods of more than kDtListCap records (the blob lattice of the B-7 pin) take the records in order by
-// repeated wave minimum instead of the sorted list.
-// =====================================================================================================
-constexpr int kDtListCap = 192;
-constexpr int kDtRecs = kDtListCap / 64;   // records a lane holds during the sort
-constexpr int kDtCW = 32;                  // core width in pixels of keypoint location (two grid cells)
-constexpr int kDtS = kDtCW + 15;           // row stride of the tile in LDS = its width (odd: see above)
-
-__device__ __forceinline__ int wave_max_int(int v) {
-    v = max(v, __builtin_amdgcn_update_dpp((int)0x80000000, v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
-    v = max(v, __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
-    v = max(v, __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x141, 0xf, 0xf, false));   // row_half_mirror
-    v = max(v, __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x140, 0xf, 0xf, false));   // row_mirror
-    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-}
-
-// the compiler must not move LDS accesses across this point (the hardware keeps a wave's LDS operations in order)
-__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
-
-template <int CH>
-__global__ __launch_bounds__(64) void descriptor_tile_kernel(const DevPlan* __restrict__ plan, DescGridLevel lv,
-                                                             const int* __restrict__ cell_off,
-                                                             const FinalKp* __restrict__ pool, int pool_cap,
-                                                             const long long* __restrict__ out_base,
-                                                             sift_hip_keypoint* __restrict__ kp_out,
-                                                             float* __restrict__ desc_out, long long out_cap, int n_images,
-                                                             int chunks, int* __restrict__ sched) {
-    constexpr int CW = kDtCW, S = kDtS, EW = CW + 15, EH = CH + 15;
-    constexpr int NCX = CW / 16, NCY = CH / 16, NROW = NCY + 2;
-    constexpr int TRASH = EH * S;                    // 32 scratch pixels behind the tile (clipped window pixels)
-    constexpr int R4 = 12;                           // 16-byte groups per tile row and map (the 48th float is dropped)
-    constexpr int NLOAD = 3 * ((EH + 15) / 16);      // groups per lane: 16 rows x 4 groups per wave-instruction
-    __shared__ float2 s_tile[EH * S + 32];           // (orientation, magnitude) per pixel
-    __shared__ uint2 s_list[kDtListCap];             // influencing keypoints in vector order: orientation bits, x | y << 16 | home << 15
-    __shared__ unsigned s_kio[kDtListCap];           // same order: vector index k | octave << 16 | index << 24 (read for home keypoints)
-    static_assert(sizeof(s_tile) + sizeof(s_list) + sizeof(s_kio) <= 20480, "eight waves per CU");
-    static_assert(sizeof(unsigned) * (kDtListCap + 4) <= sizeof(s_tile), "the sort's keys borrow the tile");
-    unsigned* const s_keys = reinterpret_cast<unsigned*>(s_tile);
-
-    const int lane = threadIdx.x;
-    const int w = lv.w, h = lv.h, D = lv.dogs;
-    const int colU = lane & 15, rowU = lane >> 4;             // update frame: column lane & 15, rows (lane >> 4) + 4 i
-    const int baseU = rowU * S + colU;
-    const int baseH = (lane & 15) * S + 4 * (lane >> 4);      // histogram frame: row lane & 15, columns 4 (lane >> 4) + i
-    const int trash = TRASH + (lane & 31);
-    const unsigned b0 = 2u * (unsigned)(lane & 3), b1 = b0 + 1u;
-    const int ntx = (w + CW - 1) / CW, nty = (h + CH - 1) / CH;
-    const int tiles = ntx * nty;
-    const bool vec = (w & 3) == 0 && ((((uintptr_t)lv.mag | (uintptr_t)lv.ori) & 15u) == 0);
-    // The 16-byte groups of the tile this lane fetches (constant over the launch).  A wave-instruction takes 16 rows x 4
-    // consecutive groups: its 16 lanes that store together (8-byte LDS stores, one pixel of each group at a time) then hit 16
-    // different rows, 94 dwords apart - all banks distinct; 16 consecutive groups of one row would meet every bank four times.
-    int grp_row[NLOAD], grp_c4[NLOAD];
-#pragma unroll
-    for (int j = 0; j < NLOAD; ++j) {
-        grp_row[j] = 16 * (j / 3) + (lane & 15);
-        grp_c4[j] = 4 * (j % 3) + (lane >> 4);
-    }
-    // DoG scales by octave * D + index, for the records of the emitted keypoints: lane l holds entry l (a lookup is one
-    // v_readlane; a scalar load inside the walk would make every LDS wait of the loop a wait for everything)
-    const float scale_tbl = plan->dog_scale[min(lane, kMaxLevels - 1)];
-
-    // Work units = (image, chunk of the image's tiles) as in the kernel above: the waves of one XCD sweep the same image
-    // in tile order, so the 15-pixel overlap of neighbouring tiles comes out of that XCD's L2.
-    // Inside a unit the tiles are DRAWN (one counter per unit, each on a cache line of its own, zeroed before the launch):
-    // a tile's cost varies with its keypoints - the top-left corner of the level also holds the keypoints of the coarser
-    // octaves (App. B-10) -, and dealt round-robin the slowest wave took half as long again as the average one.
-    const int xcd = (int)blockIdx.x & 7;
-    for (int unit = xcd; unit < n_images * chunks; unit += 8) {
-    const int img = unit / chunks, chunk = unit - img * chunks;
-    const int t_begin = (int)((long long)tiles * chunk / chunks), t_end = (int)((long long)tiles * (chunk + 1) / chunks);
-    int* const ctr = sched + 32 * unit;
-    auto draw = [&]() {   // lane 0 holds the drawn index; it is only looked at when the next tile starts
-        int v = 0;
-        if (lane == 0) v = atomicAdd(ctr, 1);
-        return v;
-    };
-    int drawn = draw();
-    if (t_begin + __builtin_amdgcn_readfirstlane(drawn) >= t_end) continue;
-    const int* __restrict__ coff = cell_off + (size_t)img * (size_t)(lv.cells_per_image + 1) + lv.cell_base;
-    const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
-    const float* __restrict__ gm = lv.mag + img_off;
-    const float* __restrict__ go = lv.ori + img_off;
-    const float* __restrict__ gg = lv.gauss + img_off;
-    const FinalKp* __restrict__ pl = pool + (size_t)img * (size_t)pool_cap;
-    const long long obase = out_base[img];
-    float wU[4];   // weighting(x, y) (sift.cpp:87-90) at this lane's four pixels of the update frame
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wU[i] = lv.w16[(size_t)img * 256 + (size_t)(colU + 16 * (rowU + 4 * i))];
-
-    for (;;) {
-        const int t = t_begin + __builtin_amdgcn_readfirstlane(drawn);
-        if (t >= t_end) break;
-        drawn = draw();
-        const int ty = t / ntx, tx = t - ty * ntx;
-        const int X0 = tx * CW, Y0 = ty * CH, ex0 = X0 - kRegion, ey0 = Y0 - kRegion;
-        const int hcx = tx * NCX, hcy = ty * NCY;
-        // ---- the cells: home records (skip the tile if none), then the runs of the influence region --------------
-        {
-            const int hx1 = min(hcx + NCX, lv.cw);
-            int n_home_rec = 0;
-#pragma unroll
-            for (int j = 0; j < NCY; ++j) {
-                const int cy = min(hcy + j, lv.ch - 1);
-                const int a = coff[cy * lv.cw + hcx], b = coff[cy * lv.cw + hx1];
-                n_home_rec += hcy + j < lv.ch ? b - a : 0;
-            }
-            if (n_home_rec == 0) continue;
-        }
-        int rs[NROW], rp[NROW + 1];   // first record of each run, records before it
-        rp[0] = 0;
-        {
-            const int c0 = max(hcx - 1, 0), c1 = min(hcx + NCX, lv.cw - 1);
-#pragma unroll
-            for (int j = 0; j < NROW; ++j) {
-                const int cy = hcy - 1 + j;
-                const int cyc = min(max(cy, 0), lv.ch - 1);
-                const int a = coff[cyc * lv.cw + c0], b = coff[cyc * lv.cw + c1 + 1];
-                rs[j] = a;
-                rp[j + 1] = rp[j] + ((cy >= 0 && cy < lv.ch) ? b - a : 0);
-            }
-        }
-        const int T = rp[NROW];
-        auto entry_of = [&](int i) {
-            int e = rs[0] + i;
-#pragma unroll
-            for (int j = 1; j < NROW; ++j) e = i >= rp[j] ? rs[j] + (i - rp[j]) : e;
-            return e;
-        };
-        auto influences = [&](unsigned xy) {   // its window meets the extended tile
-            return (unsigned)((int)(xy & 0xffffu) - (X0 - 15)) < (unsigned)(CW + 30) && (unsigned)((int)(xy >> 16) - (Y0 - 15)) < (unsigned)(CH + 30);
-        };
-        auto is_home = [&](unsigned xy) {
-            return (unsigned)((int)(xy & 0xffffu) - X0) < (unsigned)CW && (unsigned)((int)(xy >> 16) - Y0) < (unsigned)CH;
-        };
-
-        // ---- the tile's pixels: fetched into registers now, stored behind the sort (whose keys borrow the tile) ----
-        f4u to[NLOAD], tm[NLOAD];
-        if (vec) {
-#pragma unroll
-            for (int j = 0; j < NLOAD; ++j) {
-                to[j] = (f4u)(0.0f); tm[j] = (f4u)(0.0f);
-                const int X = ex0 + 4 * grp_c4[j], Y = ey0 + grp_row[j];
-                if (grp_row[j] < EH && X >= 0 && X < w && Y >= 0 && Y < h) {   // ex0 and w are multiples of 4
-                    const size_t o = (size_t)Y * (size_t)w + (size_t)X;
-                    to[j] = *reinterpret_cast<const f4u*>(go + o);
-                    tm[j] = *reinterpret_cast<const f4u*>(gm + o);
-                }
-            }
-        }
-        auto store_tile = [&]() {
-            if (vec) {
-#pragma unroll
-                for (int j = 0; j < NLOAD; ++j)
-                    if (grp_row[j] < EH) {
-                        float2* d = s_tile + grp_row[j] * S + 4 * grp_c4[j];
-                        d[0] = make_float2(to[j].x, tm[j].x);
-                        d[1] = make_float2(to[j].y, tm[j].y);
-                        d[2] = make_float2(to[j].z, tm[j].z);
-                        if (grp_c4[j] < R4 - 1) d[3] = make_float2(to[j].w, tm[j].w);   // the row's 48th pixel does not exist
-                    }
-            } else {
-                for (int idx = lane; idx < EH * EW; idx += 64) {
-                    const int ry = idx / EW, rx = idx - ry * EW;
-                    const int X = ex0 + rx, Y = ey0 + ry;
-                    if (X >= 0 && X < w && Y >= 0 && Y < h) {
-                        const size_t o = (size_t)Y * (size_t)w + (size_t)X;
-                        s_tile[ry * S + rx] = make_float2(go[o], gm[o]);
-                    }
-                }
-            }
-            lds_order();
-        };
-
-        // ---- one keypoint of the ordered walk -------------------------------------------------------------------------
-        // xy (x | y << 16) and home are wave-uniform.  An update is split in two so that the walk can run the address
-        // arithmetic of keypoint e + 1 while the LDS reads of keypoint e are on their way:
-        //   addresses(): the tile indices of this lane's four pixels of the window (update frame), the scratch line for pixels
-        //   that a clipped window leaves outside the tile;  then four 8-byte reads, add(), four 8-byte writes.
-        auto addresses = [&](unsigned xy, bool home, int (&a)[4]) {
-            const int wx = (int)(xy & 0xffffu) - kRegion - ex0, wy = (int)(xy >> 16) - kRegion - ey0;   // window origin inside the tile: -15 .. CW + 14
-            const int at = wy * S + wx + baseU;
-            if (home) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a[i] = at + 4 * i * S;
-            } else {   // clipped: only the pixels of the window that lie in the tile
-                const bool colok = (unsigned)(wx + colU) < (unsigned)EW;
-                const int ry = wy + rowU;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a[i] = (colok && (unsigned)(ry + 4 * i) < (unsigned)EH) ? at + 4 * i * S : trash;
-            }
-        };
-        auto add = [&](float theta, float2 (&v)[4]) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[i].x = v[i].x + theta;    // sift.cpp:82
-                v[i].y = v[i].y + wU[i];    // sift.cpp:90
-            }
-        };
-        auto update = [&](float theta, unsigned xy, bool home) {   // the whole update at once (crowded path)
-            int a[4];
-            addresses(xy, home, a);
-            float2 v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = s_tile[a[i]];
-            add(theta, v);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s_tile[a[i]] = v[i];
-            lds_order();
-        };
-        // the home keypoint whose update was just made: histograms of its window as the reference sees it now
-        // om = the window's (orientation, magnitude) pairs read back in the histogram frame (window_back);
-        // kio: vector index | octave << 16 | index << 24;  vg4 = its window of the Gaussian level (histogram frame)
-        auto window_back = [&](unsigned xy, float2 (&om)[4]) {
-            const float2* p = s_tile + ((int)(xy >> 16) - kRegion - ey0) * S + ((int)(xy & 0xffffu) - kRegion - ex0) + baseH;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) om[i] = p[i];
-        };
-        auto emit = [&](float theta, unsigned xy, unsigned kio, const float2 (&om)[4], const f4u& vg4) {
-            const int px = (int)(xy & 0xffffu), py = (int)(xy >> 16);
-            float val[4];
-            unsigned bin[4];
-            {
-                const float vg[4] = {vg4.x, vg4.y, vg4.z, vg4.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    val[i] = om[i].y * vg[i];          // algorithms.cpp:147
-                    bin[i] = hist8_bin(om[i].x);
-                }
-            }
-            // ---- 16 cell histograms: a quad holds one cell; samples in x-outer / y-inner order -------------------------
-            float h0 = 0.0f, h1 = 0.0f;
-            cell_histograms(val, bin, lane, b0, b1, h0, h1);
-            // alg::normalizeVector (algorithms.cpp:210-223): length = ((0 + b0) + b1) + ... + b7, handed along the quad
-            float run = 0.0f;
-            run += h0; run += h1;
-            float acc = run;
-#pragma unroll
-            for (int step = 1; step < 4; ++step) {
-                const float prev = quad_prev_f(acc);
-                float tt = prev;
-                tt += h0; tt += h1;
-                acc = ((lane & 3) == step) ? tt : acc;
-            }
-            const float length = quad_bcast_f<3>(acc);
-            if (!(length == 0.0f)) {
-                h0 = h0 / length;
-                h1 = h1 / length;
-            }
-            const long long ok = obase + (long long)(kio & 0xffffu);
-            const unsigned lvl_idx = ((kio >> 16) & 0xffu) * (unsigned)D + (kio >> 24);
-            const float my_scale = lvl_idx < 64u ? __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(scale_tbl), (int)lvl_idx))
-                                                 : plan->dog_scale[lvl_idx];
-            if (ok < out_cap) {   // (the output arrays are sized before the final counts reach the host: see run_batch)
-                *reinterpret_cast<float2*>(desc_out + (size_t)ok * 128 + (size_t)(2 * lane)) = make_float2(h0, h1);
-                if (lv.wire_sums != nullptr) {
-                    // the counting pass of the sparse wire format (kernels_wire.hip: wire_count_kernel) while the 128 floats
-                    // are still in registers
-                    const bool s0 = __float_as_uint(h0) != 0u, odd7 = (lane & 3) == 3;
-                    const bool s1 = !odd7 && __float_as_uint(h1) != 0u;
-                    const int nset = __popcll(__ballot(s0)) + __popcll(__ballot(s1));
-                    const unsigned long long bin7 = __ballot(odd7 && __float_as_uint(h1) != 0u);
-                    if (lane == 0) {
-                        atomicAdd(&lv.wire_sums[1 + (ok >> 6)], nset);
-                        if (bin7 != 0ull) atomicOr(&lv.wire_sums[0], 1);
-                    }
-                }
-                if (lane == 0) {
-                    const unsigned oct = (kio >> 16) & 0xffu, idx = kio >> 24;
-                    sift_hip_keypoint r;
-                    r.scale = my_scale;
-                    r.orientation = theta;
-                    r.x = (uint16_t)px; r.y = (uint16_t)py;
-                    r.octave = (uint16_t)oct; r.index = (uint16_t)idx;
-                    r.filtered = 0; r.has_descriptor = 1; r.reserved = 0;
-                    kp_out[ok] = r;
-                }
-            }
-        };
-        auto load_gauss = [&](unsigned xy) {   // histogram frame; the window of a grid keypoint lies inside the image
-            const size_t o = (size_t)((int)(xy >> 16) - kRegion + (lane & 15)) * (size_t)w + (size_t)((int)(xy & 0xffffu) - kRegion + 4 * (lane >> 4));
-            return *reinterpret_cast<const f4u*>(gg + o);
-        };
-        // a record's vector index fits 16 bits (u16_t size, sift.cpp:41,53), octave and index 8 bits each (kMaxOctaves, kMaxDogs)
-        auto kio_of = [](const uint4& c) { return (c.x & 0xffffu) | ((c.w & 0xffu) << 16) | (((c.w >> 16) & 0xffu) << 24); };
-        if (T <= kDtListCap) {
-            // ---- the records: kDtRecs per lane -------------------------------------------------------------------------
-            uint4 rec[kDtRecs];
-            bool hm[kDtRecs], pass[kDtRecs];
-            int khome = -1;
-#pragma unroll
-            for (int u = 0; u < kDtRecs; ++u) {
-                const int i = lane + 64 * u;
-                rec[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (i < T) rec[u] = *reinterpret_cast<const uint4*>(&pl[entry_of(i)]);
-                pass[u] = i < T && influences(rec[u].z);
-                hm[u] = pass[u] && is_home(rec[u].z);
-                if (hm[u]) khome = max(khome, (int)rec[u].x);
-            }
-            const int kmax = wave_max_int(khome);   // >= 0: the home cells hold a record
-            // ---- which of them matter: the home keypoints, and every earlier keypoint whose window overlaps a home
-            // keypoint's (an addition no emitted window ever sees need not be made).  The home keypoints' (index, x | y << 16)
-            // pairs go to LDS (they borrow the tile) and every lane tests its records against them.
-            int nh = 0;
-            {
-                int hp[kDtRecs];
-#pragma unroll
-                for (int u = 0; u < kDtRecs; ++u) {
-                    const unsigned long long m = __ballot(hm[u]);
-                    hp[u] = nh + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    nh += __popcll(m);
-                }
-#pragma unroll
-                for (int u = 0; u < kDtRecs; ++u)
-                    if (hm[u]) *reinterpret_cast<uint2*>(s_keys + 2 * hp[u]) = make_uint2(rec[u].x, rec[u].z);
-                if (lane == 0) *reinterpret_cast<uint2*>(s_keys + 2 * nh) = make_uint2(0u, 0u);   // the last 16-byte read's second half: index 0 is later than nothing
-                lds_order();
-                bool need[kDtRecs];
-#pragma unroll
-                for (int u = 0; u < kDtRecs; ++u) need[u] = hm[u];
-                for (int j = 0; j < nh; j += 2) {
-                    const uint4 h2 = *reinterpret_cast<const uint4*>(s_keys + 2 * j);
-#pragma unroll
-                    for (int u = 0; u < kDtRecs; ++u) {
-                        const int qx = (int)(rec[u].z & 0xffffu), qy = (int)(rec[u].z >> 16);
-                        need[u] = need[u] || (h2.x > rec[u].x && (unsigned)(qx - (int)(h2.y & 0xffffu) + 15) < 31u && (unsigned)(qy - (int)(h2.y >> 16) + 15) < 31u) ||
-                                  (h2.z > rec[u].x && (unsigned)(qx - (int)(h2.w & 0xffffu) + 15) < 31u && (unsigned)(qy - (int)(h2.w >> 16) + 15) < 31u);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < kDtRecs; ++u) pass[u] = pass[u] && need[u] && (int)rec[u].x <= kmax;
-                lds_order();
-            }
-            // ---- sort: ranked by counting the smaller keys ------------------------------------------------------------------
-            int n = 0, pos[kDtRecs];
-#pragma unroll
-            for (int u = 0; u < kDtRecs; ++u) {
-                const unsigned long long m = __ballot(pass[u]);
-                pos[u] = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                n += __popcll(m);
-            }
-#pragma unroll
-            for (int u = 0; u < kDtRecs; ++u)
-                if (pass[u]) s_keys[pos[u]] = rec[u].x;
-            if (lane < 4) s_keys[n + lane] = 0xffffffffu;   // the last 16-byte read may run past the keys: never smaller
-            lds_order();
-            int rank[kDtRecs];
-#pragma unroll
-            for (int u = 0; u < kDtRecs; ++u) rank[u] = 0;
-            for (int ch = 0; ch < n; ch += 4) {
-                const uint4 k4 = *reinterpret_cast<const uint4*>(s_keys + ch);
-#pragma unroll
-                for (int u = 0; u < kDtRecs; ++u)
-                    rank[u] += (k4.x < rec[u].x ? 1 : 0) + (k4.y < rec[u].x ? 1 : 0) + (k4.z < rec[u].x ? 1 : 0) + (k4.w < rec[u].x ? 1 : 0);
-            }
-#pragma unroll
-            for (int u = 0; u < kDtRecs; ++u)
-                if (pass[u]) {
-                    s_list[rank[u]] = make_uint2(rec[u].y, rec[u].z | (hm[u] ? 0x8000u : 0u));   // x < 32768 (App. B-17)
-                    s_kio[rank[u]] = kio_of(rec[u]);
-                }
-            lds_order();
-            store_tile();   // (the keys are dead: every lane's reads of them have returned)
-            // which entries of the ordered list are home keypoints: one bit each, in scalar registers
-            unsigned long long hmask[kDtRecs];
-#pragma unroll
-            for (int u = 0; u < kDtRecs; ++u) {
-                const int e = lane + 64 * u;
-                hmask[u] = __ballot(e < n && (s_list[min(e, kDtListCap - 1)].y & 0x8000u) != 0u);
-            }
-            auto next_home = [&](int from) {   // first home entry at or behind `from`, n if none
-                int r = n;
-#pragma unroll
-                for (int u = kDtRecs - 1; u >= 0; --u) {
-                    const int sh = from - 64 * u;
-                    const unsigned long long m = sh <= 0 ? hmask[u] : (sh >= 64 ? 0ull : hmask[u] & (~0ull << sh));
-                    if (m != 0ull) r = 64 * u + (int)__builtin_ctzll(m);
-                }
-                return r;
-            };
-            // the first home keypoint's Gaussian window; the following ones are fetched one home keypoint ahead
-            int hnext = next_home(0);
-            f4u gnext = load_gauss((unsigned)__builtin_amdgcn_readfirstlane((int)s_list[hnext].y) & 0xffff7fffu);
-            // ---- the walk, software-pipelined: while the LDS reads of keypoint e are on their way the addresses of keypoint
-            // e + 1 are worked out; its reads are issued right behind the writes of keypoint e (the LDS keeps a wave's
-            // operations in order, so they see them) and BEFORE the histograms of keypoint e, which hide their latency; list
-            // entries are fetched two keypoints ahead.
-            auto decode = [](const uint2& q, unsigned& xy, bool& home) {
-                const unsigned xyf = (unsigned)__builtin_amdgcn_readfirstlane((int)q.y);
-                home = (xyf & 0x8000u) != 0u;
-                xy = xyf & 0xffff7fffu;
-            };
-            unsigned xy_c, kio_c;
-            bool home_c;
-            int a_c[4];
-            float th_c;
-            float2 v[4];
-            {
-                const uint2 q = s_list[0];
-                kio_c = s_kio[0];
-                decode(q, xy_c, home_c);
-                th_c = __uint_as_float(q.x);
-                addresses(xy_c, home_c, a_c);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = s_tile[a_c[i]];
-            }
-            uint2 qn = s_list[min(1, n - 1)];
-            unsigned kion = s_kio[min(1, n - 1)];
-            for (int e = 0; e < n; ++e) {
-                // keypoint e + 1 (the last keypoint once more behind the end: read, never written)
-                unsigned xy_n;
-                bool home_n;
-                int a_n[4];
-                decode(qn, xy_n, home_n);
-                const float th_n = __uint_as_float(qn.x);
-                const unsigned kio_n = kion;
-                addresses(xy_n, home_n, a_n);
-                qn = s_list[min(e + 2, n - 1)];
-                kion = s_kio[min(e + 2, n - 1)];
-                // keypoint e: additions and writes
-                add(th_c, v);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) s_tile[a_c[i]] = v[i];
-                lds_order();
-                float2 om[4];
-                if (home_c) window_back(xy_c, om);
-                lds_order();
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = s_tile[a_n[i]];
-                lds_order();
-                if (home_c) {
-                    const f4u gcur = gnext;
-                    hnext = next_home(e + 1);
-                    if (hnext < n) gnext = load_gauss((unsigned)__builtin_amdgcn_readfirstlane((int)s_list[hnext].y) & 0xffff7fffu);
-                    emit(th_c, xy_c, (unsigned)__builtin_amdgcn_readfirstlane((int)kio_c), om, gcur);
-                }
-                xy_c = xy_n; home_c = home_n; th_c = th_n; kio_c = kio_n;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a_c[i] = a_n[i];
-            }
-            lds_order();   // the list and the tile are rewritten for the wave's next tile
-        } else {
-            // ---- crowded neighbourhood: the records in vector order by repeated wave minimum ---------------------
-            store_tile();
-            int khome = -1;
-            for (int i = lane; i < T; i += 64) {
-                const uint4 c = *reinterpret_cast<const uint4*>(&pl[entry_of(i)]);
-                if (is_home(c.z)) khome = max(khome, (int)c.x);
-            }
-            const int kmax = wave_max_int(khome);
-            int last = -1;
-            for (;;) {
-                int bk = 0x7fffffff;
-                unsigned bxy = 0u, bth = 0u, bio = 0u;
-                for (int i = lane; i < T; i += 64) {
-                    const uint4 c = *reinterpret_cast<const uint4*>(&pl[entry_of(i)]);
-                    if (influences(c.z) && (int)c.x > last && (int)c.x <= kmax && (int)c.x < bk) { bk = (int)c.x; bxy = c.z; bth = c.y; bio = kio_of(c); }
-                }
-                const int m = wave_min_nonneg(bk);
-                if (m == 0x7fffffff) break;
-                const int src = (int)__builtin_ctzll(__ballot(bk == m));
-                const unsigned xy = (unsigned)__builtin_amdgcn_readlane((int)bxy, src);
-                const unsigned th = (unsigned)__builtin_amdgcn_readlane((int)bth, src);
-                const unsigned kio = (unsigned)__builtin_amdgcn_readlane((int)bio, src);
-                const bool home = is_home(xy);
-                const float theta = __uint_as_float(th);
-                update(theta, xy, home);
-                if (home) {
-                    float2 om[4];
-                    window_back(xy, om);
-                    lds_order();
-                    emit(theta, xy, kio, om, load_gauss(xy));
-                }
-                last = m;
-            }
-            lds_order();
-        }
-    }
-    }   // units
-}
-
 void launch_w16(hipStream_t s, const DevPlan& plan, int level, const float* d_taps16, int radius16) {
     const int oct = level / (plan.dogs + 1);
     hipLaunchKernelGGL(w16_kernel, dim3((unsigned)plan.n_images), dim3(256), 0, s,
@@ -1099,7 +589,7 @@ void launch_desc_grid(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan,
 
 void launch_descriptors_wave(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level, const int* d_cell_off,
                              const FinalKp* d_pool, int pool_cap, const long long* d_out_base, sift_hip_keypoint* d_kp_out,
-                             float* d_desc_out, long long out_cap, int dbg, int* d_wire_sums) {
+                             float* d_desc_out, long long out_cap, int dbg, int* d_wire_sums, hipEvent_t ev_start, hipEvent_t ev_stop) {
     DescGridLevel lv;
     const int oct = level / (plan.dogs + 1);
     lv.w = plan.w[oct]; lv.h = plan.h[oct]; lv.dogs = plan.dogs;
@@ -1110,28 +600,8 @@ void launch_descriptors_wave(hipStream_t s, const DevPlan* d_plan, const DevPlan
     // 2048 workgroups of four waves (8 per CU); whole images per XCD when there are at least 8, eighths of an image otherwise
     const int chunks = plan.n_images >= 8 ? 1 : 8;
     const unsigned nwg = (dbg & kDiagMask & 64) ? 512u : ((dbg & kDiagMask & 32) ? 1024u : 2048u);   // timing only (measurement build): fewer resident waves
-    hipLaunchKernelGGL(descriptor_wave_kernel, dim3(nwg), dim3(256), 0, s, d_plan, lv, d_cell_off, d_pool, pool_cap, d_out_base,
+    hipExtLaunchKernelGGL(descriptor_wave_kernel, dim3(nwg), dim3(256), 0, s, ev_start, ev_stop, 0, d_plan, lv, d_cell_off, d_pool, pool_cap, d_out_base,
                        d_kp_out, d_desc_out, out_cap, plan.n_images, chunks, dbg);
-}
-
-// ints of the tile kernel's draw counters (one per work unit, 128 bytes apart)
-size_t desc_tile_sched_ints(int n_images) { return (size_t)32 * (size_t)(n_images >= 8 ? n_images : 8 * n_images); }
-
-// tile-per-wave form: 2048 one-wave workgroups (eight per CU), whole images per XCD when there are at least 8
-void launch_descriptors_tile(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, int level, const int* d_cell_off,
-                             const FinalKp* d_pool, int pool_cap, const long long* d_out_base, sift_hip_keypoint* d_kp_out,
-                             float* d_desc_out, long long out_cap, int* d_wire_sums, int* d_sched) {
-    DescGridLevel lv;
-    const int oct = level / (plan.dogs + 1);
-    lv.w = plan.w[oct]; lv.h = plan.h[oct]; lv.dogs = plan.dogs;
-    lv.cw = plan.desc_cw[level]; lv.ch = plan.desc_ch[level]; lv.cell_base = plan.desc_cell_base[level];
-    lv.cells_per_image = plan.desc_cells_per_image;
-    lv.mag = plan.mag[level]; lv.ori = plan.ori[level]; lv.gauss = plan.gauss[level]; lv.w16 = plan.w16[level];
-    lv.wire_sums = d_wire_sums;
-    const int chunks = plan.n_images >= 8 ? 1 : 8;
-    launch_zero_ints(s, d_sched, desc_tile_sched_ints(plan.n_images));
-    hipLaunchKernelGGL(descriptor_tile_kernel<32>, dim3(2048), dim3(64), 0, s, d_plan, lv, d_cell_off, d_pool, pool_cap, d_out_base,
-                           d_kp_out, d_desc_out, out_cap, plan.n_images, chunks, d_sched);
 }
 
 // The runtime builds a translation unit's device code on the first launch of any of its kernels, and two host threads that make

@@ -197,6 +197,84 @@ __global__ __launch_bounds__(256) void extrema_expand_kernel(const DevPlan* __re
     }
 }
 
+// Expansion of the FUSED scan's words (round 6): one workgroup per (image, scan level, 32-column strip) - the columns of one
+// tile column of extrema_edge_kernel, whose mask words are contiguous in the reference's candidate order (octave, dog, x outer,
+// y inner: sift.cpp:352-373).  Where the strip's candidates start is the sum of the per-tile counts the scan kernel left for the
+// tiles numbered in front of it (level, strip, 64-row block: a few thousand ints per image, L2-resident) - so the
+// one-workgroup-per-image scan launch between the two kernels (rounds 1 - 5: 190 us alone for 11 MB, every lane walking a
+// 176-byte chunk of its own) is gone, and so is the per-word count array.  Then the strip's words in order: popcount, block
+// scan, every thread writes its word's run of records and flag bytes.  The image's last strip also leaves the image's total.
+__global__ __launch_bounds__(256) void extrema_expand_tiles_kernel(const DevPlan* __restrict__ plan,
+                                                                   const unsigned long long* __restrict__ masks,
+                                                                   const unsigned long long* __restrict__ fmasks,
+                                                                   const int* __restrict__ tile_counts,
+                                                                   Candidate* __restrict__ cands, uint8_t* __restrict__ flags,
+                                                                   int* __restrict__ totals) {
+    __shared__ int s_part[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int spi = plan->strips_per_image;
+    const int img = (int)blockIdx.x / spi, sg = (int)blockIdx.x - img * spi;
+    int sl = 0;
+    for (int k = 1; k < plan->n_scan; ++k)
+        if (sg >= plan->scan_strip_base[k]) sl = k;
+    const int strip = sg - plan->scan_strip_base[sl];
+    const int nyb = plan->scan_nyb[sl];
+    const int w = plan->w[plan->scan_octave[sl]];
+    const int x0 = strip * kFxCols;
+    const int cols = min(kFxCols, w - x0);
+    // candidates in front of the strip: the tiles of the levels before, and of this level's strips before
+    const int pre = plan->scan_tile_base[sl] + strip * nyb;
+    const int* __restrict__ tc = tile_counts + (size_t)img * (size_t)plan->tiles_per_image;
+    int sum = 0;
+    for (int i = tid; i < pre; i += 256) sum += tc[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) s_part[wv] = sum;
+    __syncthreads();
+    int run = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    __syncthreads();
+    const size_t w0 = (size_t)img * (size_t)plan->words_per_image + (size_t)plan->scan_word_base[sl] + (size_t)x0 * (size_t)nyb;
+    const int nwords = cols * nyb;
+    Candidate c;
+    c.octave = (uint16_t)plan->scan_octave[sl];
+    c.index = (uint16_t)plan->scan_dog[sl];
+    const size_t cbase = (size_t)img * (size_t)plan->cand_capacity;
+    for (int i0 = 0; i0 < nwords; i0 += 256) {
+        const int i = i0 + tid;
+        unsigned long long m = i < nwords ? masks[w0 + i] : 0ull;
+        const int cnt = __popcll(m);
+        int incl = cnt;   // inclusive scan over the wave, then over the four waves
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) s_part[wv] = incl;
+        __syncthreads();
+        int before = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) before += k < wv ? s_part[k] : 0;
+        const int all = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        if (m) {
+            const int xc = i / nyb, yb = i - xc * nyb;
+            c.x = (uint16_t)(x0 + xc);
+            const unsigned long long fm = fmasks[w0 + i];
+            size_t o = cbase + (size_t)(run + before + incl - cnt);
+            while (m) {
+                const int bit = __ffsll((long long)m) - 1;
+                c.y = (uint16_t)(yb * 64 + bit);
+                cands[o] = c;
+                flags[o] = (uint8_t)((fm >> bit) & 1ull);
+                ++o;
+                m &= m - 1ull;
+            }
+        }
+        run += all;
+        __syncthreads();
+    }
+    if (sg == spi - 1 && tid == 0) totals[img] = run;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Body of the per-point loop of _eliminateEdgeResponses (sift.cpp:295-345).  true => filtered.
 // d0/d1/d2 = dogs(octave, index-1 / index / index+1) of one image, row pitch w.
@@ -288,7 +366,7 @@ __device__ __forceinline__ bool edge_response_filtered(const float* __restrict__
 //     word of `filtered` bits; the expansion turns both into the candidate records and flag bytes in
 //     the reference's octave / dog / x / y order.
 // ---------------------------------------------------------------------------------------------
-constexpr int kFxCols = 32;
+// (kFxCols = 32 columns per tile: common.h)
 constexpr int kFxLead = 4;                      // columns staged left of the tile (16-byte aligned loads)
 constexpr int kFxPitch = kFxCols + 2 * kFxLead; // 40 floats per staged row: x0-4 .. x0+35
 constexpr int kFxRows = 64 + 2;
@@ -313,17 +391,19 @@ struct FxLevel {
     const float* d1;
     const float* d2;
     const float* d3;   // FROM_GAUSS: d0 .. d3 are four Gaussian levels, the three DoG tiles are formed on the way into LDS
-    int w, h, nyb, word_base, tiles_x, tiles_img, tile_begin, pad;
+    int w, h, nyb, word_base, tiles_x, tiles_img, tile_begin;
+    int cnt_base;      // the level's first tile among the image's tiles in candidate order (DevPlan::scan_tile_base)
 };
 struct FxPlan {
-    int n_levels, total_tiles, words_per_image, pad;
+    int n_levels, total_tiles, words_per_image;
+    int tiles_per_image;   // DevPlan::tiles_per_image: stride of the per-tile counts
     FxLevel lv[kFxMaxLevels];
 };
 
 template <bool FROM_GAUSS>
 __global__ __launch_bounds__(256, 4) void extrema_edge_kernel(FxPlan plan, unsigned long long* __restrict__ masks,
                                                            unsigned long long* __restrict__ fmasks,
-                                                           int* __restrict__ counts) {
+                                                           int* __restrict__ tile_counts) {
     const int total_tiles = plan.total_tiles, words_per_image = plan.words_per_image;
     // level of a tile (tiles are numbered level after level; wave-uniform: a scalar loop over at most 16 entries)
     auto level_of = [&](int tile) {
@@ -541,13 +621,21 @@ __global__ __launch_bounds__(256, 4) void extrema_edge_kernel(FxPlan plan, unsig
         qr_body((int)(e & 31u), (int)(e >> 5));
     }
     fx_lds_barrier();
-    if (tid < kFxCols && x0 + tid < w) {
-        const unsigned long long m = s_cm[tid];
-        const size_t wi = (size_t)img * (size_t)words_per_image + (size_t)word_base + (size_t)(x0 + tid) * (size_t)nyb +
-                          (size_t)yb;
-        masks[wi] = m;
-        fmasks[wi] = s_fm[tid];
-        counts[wi] = __popcll(m);
+    if (wv == 0) {
+        int cnt = 0;
+        if (tid < kFxCols && x0 + tid < w) {
+            const unsigned long long m = s_cm[tid];
+            const size_t wi = (size_t)img * (size_t)words_per_image + (size_t)word_base + (size_t)(x0 + tid) * (size_t)nyb +
+                              (size_t)yb;
+            masks[wi] = m;
+            fmasks[wi] = s_fm[tid];
+            cnt = __popcll(m);
+        }
+        // the tile's candidates: what the expansion sums over the tiles in front of a strip (no scan launch, no atomics; every
+        // tile of the plan writes its count in every batch, so nothing needs clearing)
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+        if (tid == 0) tile_counts[(size_t)img * (size_t)plan.tiles_per_image + (size_t)(lv.cnt_base + (x0 / kFxCols) * nyb + yb)] = cnt;
     }
         t = tn;
     }
@@ -618,31 +706,35 @@ void launch_extrema_mask(hipStream_t s, const DevPlan* d_plan, const DevPlan& pl
 // partner batch's descriptor kernel): 2.71 - 2.80 ms per step every way (profiles/r05_extrema_per_cu_ab.txt); the option is gone.
 constexpr int kExtremaPerCu = 4;
 
+// rows of every scanned octave 16-byte aligned (width a multiple of 4; the level buffers are carved 256-byte aligned, which
+// the launch checks for the pointers the selected variant reads)
 bool extrema_edge_supported(const DevPlan& plan) {
     for (int k = 0; k < plan.n_scan; ++k) {
         const int o = plan.scan_octave[k];
         if (plan.w[o] % 4 != 0 || plan.w[o] < 4) return false;
-        const int l = o * plan.dogs + plan.scan_dog[k];
+        const int l = o * plan.dogs + plan.scan_dog[k], gl = o * (plan.dogs + 1) + plan.scan_dog[k];
         for (int j = -1; j <= 1; ++j)
             if ((uintptr_t)plan.dog[l + j] & 15u) return false;
+        for (int j = -1; j <= 2; ++j)
+            if ((uintptr_t)plan.gauss[gl + j] & 15u) return false;
     }
     return true;
 }
 
 void launch_extrema_edge(hipStream_t s, const DevPlan& plan, unsigned long long* d_masks, unsigned long long* d_fmasks,
-                         int* d_counts, int k_begin, int k_end, int busy_cus, bool from_gauss) {
-    if (k_end < 0 || k_end > plan.n_scan) k_end = plan.n_scan;
+                         int* d_tile_counts, bool from_gauss, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    const int k_end = plan.n_scan;
     // persistent workgroups, 4 per CU, with EQUAL shares of the tiles: a workgroup that finds no CU free starts when the
-    // others end and doubles the launch's time - so the grid leaves out the CUs another kernel is known to hold (the
-    // pyramid's tail kernel: one workgroup per image, a whole CU each)
-    const int cus = resident_cus();
-    int cap = kExtremaPerCu * (cus > busy_cus + 8 ? cus - busy_cus : cus);
-    cap &= ~7;
-    int k = k_begin;
+    // others end and doubles the launch's time
+    int cap = kExtremaPerCu * resident_cus();
+    cap = cap >= 8 ? (cap & ~7) : (cap > 0 ? cap : 1);
+    int k = 0;
+    bool k_first = true;
     while (k < k_end) {   // kFxMaxLevels scan levels per launch (the bench plan has four)
         FxPlan fp;
         std::memset(&fp, 0, sizeof(fp));
         fp.words_per_image = plan.words_per_image;
+        fp.tiles_per_image = plan.tiles_per_image;
         long long total = 0;
         for (; k < k_end && fp.n_levels < kFxMaxLevels; ++k) {
             const int o = plan.scan_octave[k], i = plan.scan_dog[k];
@@ -660,6 +752,7 @@ void launch_extrema_edge(hipStream_t s, const DevPlan& plan, unsigned long long*
             const long long tiles = (long long)lv.tiles_img * plan.n_images;
             if (total + tiles > 0x7fffffffLL) break;   // (tile numbers are ints)
             lv.tile_begin = (int)total;
+            lv.cnt_base = plan.scan_tile_base[k];
             total += tiles;
             ++fp.n_levels;
         }
@@ -667,8 +760,11 @@ void launch_extrema_edge(hipStream_t s, const DevPlan& plan, unsigned long long*
         fp.total_tiles = (int)total;
         int grid = total < cap ? (int)total : cap;
         if (grid >= 8) grid &= ~7;
-        if (from_gauss) hipLaunchKernelGGL((extrema_edge_kernel<true>), dim3((unsigned)grid), dim3(256), 0, s, fp, d_masks, d_fmasks, d_counts);
-        else hipLaunchKernelGGL((extrema_edge_kernel<false>), dim3((unsigned)grid), dim3(256), 0, s, fp, d_masks, d_fmasks, d_counts);
+        // (timing events: a plan of more than kFxMaxLevels scan levels makes several launches; the events bracket them all)
+        hipEvent_t ea = k_first ? ev_start : nullptr, eb = k >= k_end ? ev_stop : nullptr;
+        k_first = false;
+        if (from_gauss) hipExtLaunchKernelGGL((extrema_edge_kernel<true>), dim3((unsigned)grid), dim3(256), 0, s, ea, eb, 0, fp, d_masks, d_fmasks, d_tile_counts);
+        else hipExtLaunchKernelGGL((extrema_edge_kernel<false>), dim3((unsigned)grid), dim3(256), 0, s, ea, eb, 0, fp, d_masks, d_fmasks, d_tile_counts);
     }
 }
 
@@ -686,6 +782,14 @@ void launch_extrema_expand(hipStream_t s, const DevPlan* d_plan, const DevPlan& 
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(extrema_expand_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d_plan, d_masks,
                        d_offsets, d_cands, d_fmasks, d_flags);
+}
+
+void launch_extrema_expand_tiles(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const unsigned long long* d_masks,
+                                 const unsigned long long* d_fmasks, const int* d_tile_counts, Candidate* d_cands, uint8_t* d_flags,
+                                 int* d_totals) {
+    const unsigned grid = (unsigned)plan.strips_per_image * (unsigned)plan.n_images;
+    hipLaunchKernelGGL(extrema_expand_tiles_kernel, dim3(grid), dim3(256), 0, s, d_plan, d_masks, d_fmasks, d_tile_counts, d_cands,
+                       d_flags, d_totals);
 }
 
 void launch_edge_filter(hipStream_t s, const DevPlan* d_plan, const DevPlan& plan, const Candidate* d_cands,

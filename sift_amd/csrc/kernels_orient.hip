@@ -452,15 +452,15 @@ __global__ __launch_bounds__(256) void orientation_kernel(const DevPlan* __restr
 // gradient pass behind it); a stale word that happens to equal the stamp only sends the image down the general path, which is
 // always right.
 void launch_gradient(hipStream_t s, const float* g, float* mag, float* ori, float* prod, int w, int h,
-                     int n, int* d_any_bin, int stamp) {
+                     int n, int* d_any_bin, int stamp, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const bool vec = (w & 3) == 0 && ((((uintptr_t)g | (uintptr_t)mag | (uintptr_t)ori | (uintptr_t)prod) & 15u) == 0);
     if (vec) {
         const dim3 grid4((unsigned)((w / 4 + 255) / 256), (unsigned)((h + kGradRows - 1) / kGradRows), (unsigned)n);
-        hipLaunchKernelGGL(gradient4_kernel, grid4, dim3(256), 0, s, g, mag, ori, prod, w, h, d_any_bin, stamp);
+        hipExtLaunchKernelGGL(gradient4_kernel, grid4, dim3(256), 0, s, ev_start, ev_stop, 0, g, mag, ori, prod, w, h, d_any_bin, stamp);
         return;
     }
     const dim3 grid((unsigned)((w + 255) / 256), (unsigned)h, (unsigned)n);
-    hipLaunchKernelGGL(gradient_kernel, grid, dim3(256), 0, s, g, mag, ori, prod, w, h, d_any_bin, stamp);
+    hipExtLaunchKernelGGL(gradient_kernel, grid, dim3(256), 0, s, ev_start, ev_stop, 0, g, mag, ori, prod, w, h, d_any_bin, stamp);
 }
 
 static int g_orient_dbg = 0;

@@ -219,19 +219,19 @@ __global__ __launch_bounds__(64) void blur_pair_kernel(const float* __restrict__
 #undef SIFT_PAIR_FETCH
 }
 
-static int g_pair_waves = 1536;   // option "pair_waves": waves a launch is cut into.  The chip holds 2048 of this kernel's waves (two per SIMD); alone 2048 is fastest (180 us), beside the other batch's kernels 1536 - 1792 (profiles/r05_pair_ab.txt)
-
-void set_pair_waves(int v) { g_pair_waves = v < 1 ? 1536 : v; }
+// waves a launch is cut into (option "pair_waves" of the calling context; <= 0: this default).  The chip holds 2048 of this kernel's
+// waves (two per SIMD); alone 2048 is fastest (180 us), beside the other batch's kernels 1536 - 1792 (profiles/r05_pair_ab.txt)
+constexpr int kPairWaves = 1536;
 
 template <int R>
 static bool launch_pair_r(hipStream_t s, const float* in, float* g0, float* g1, int w, int h, int n, const float* taps,
-                          int min_waves, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                          int min_waves, int pair_waves, hipEvent_t ev_start, hipEvent_t ev_stop) {
     constexpr int SWU = pair_useful(R);
     constexpr int RI = pair_runin(R);
     if (w % 4 != 0 || w < SWU || h < 4 * R + 2) return false;
     if ((((uintptr_t)in | (uintptr_t)g0 | (uintptr_t)g1) & 15u) != 0) return false;
     const int strips = (w + SWU - 1) / SWU;
-    int chunks = g_pair_waves / (n * strips);
+    int chunks = (pair_waves > 0 ? pair_waves : kPairWaves) / (n * strips);
     if (chunks < 1) chunks = 1;
     int chunk_h = (h + chunks - 1) / chunks;
     // short chunks pay stage 1's and stage 2's run-in (3R + RI rows) too often: batches of 4 - 8 frames of 1080p are no faster
@@ -250,12 +250,12 @@ static bool launch_pair_r(hipStream_t s, const float* in, float* g0, float* g1, 
 // g0 = blur(in), g1 = blur(g0), both with the same taps.  false: the shape is not one this kernel takes (the caller runs
 // the two blurs one after the other).
 bool launch_blur_pair(hipStream_t s, const float* in, float* g0, float* g1, int w, int h, int n, const float* taps,
-                      int radius, int min_waves, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                      int radius, int min_waves, int pair_waves, hipEvent_t ev_start, hipEvent_t ev_stop) {
     switch (radius) {
-        case 3: return launch_pair_r<3>(s, in, g0, g1, w, h, n, taps, min_waves, ev_start, ev_stop);
-        case 4: return launch_pair_r<4>(s, in, g0, g1, w, h, n, taps, min_waves, ev_start, ev_stop);
-        case 5: return launch_pair_r<5>(s, in, g0, g1, w, h, n, taps, min_waves, ev_start, ev_stop);
-        case 6: return launch_pair_r<6>(s, in, g0, g1, w, h, n, taps, min_waves, ev_start, ev_stop);
+        case 3: return launch_pair_r<3>(s, in, g0, g1, w, h, n, taps, min_waves, pair_waves, ev_start, ev_stop);
+        case 4: return launch_pair_r<4>(s, in, g0, g1, w, h, n, taps, min_waves, pair_waves, ev_start, ev_stop);
+        case 5: return launch_pair_r<5>(s, in, g0, g1, w, h, n, taps, min_waves, pair_waves, ev_start, ev_stop);
+        case 6: return launch_pair_r<6>(s, in, g0, g1, w, h, n, taps, min_waves, pair_waves, ev_start, ev_stop);
         default: return false;
     }
 }

@@ -559,14 +559,10 @@ void set_stream_waves(int v) { g_stream_waves = v < 0 ? kStreamWaves : v; }
 static int stream_waves() { return g_stream_waves; }
 
 constexpr int kMaxRadiusStream = 14;   // beyond: the 2R+1 partial sums per column no longer fit the register file
-constexpr int kMinStreamWaves = 1024;  // below one wave per SIMD the tile kernel's finer work units win
-static int g_stream_min_waves = kMinStreamWaves;  // option "stream_min_waves": tests lower it to run the streaming form on small inputs
-void set_stream_min_waves(int v) { g_stream_min_waves = v < 1 ? kMinStreamWaves : v; }
-int stream_min_waves_now() { return g_stream_min_waves; }
 
 template <int R, int CPL>
 static bool launch_stream_rc(hipStream_t s, const float* in, float* out, float* dog, int w, int h, int n,
-                             const float* d_taps, const StreamDecimate* dec = nullptr) {
+                             const float* d_taps, int min_waves, const StreamDecimate* dec = nullptr) {
     const int target = stream_waves();
     if (target <= 0) return false;
     const bool aligned = (((uintptr_t)in | (dec ? 0 : (uintptr_t)out) | (uintptr_t)dog) & (4u * CPL - 1u)) == 0;
@@ -584,7 +580,7 @@ static bool launch_stream_rc(hipStream_t s, const float* in, float* out, float* 
     if (chunk_h > h) return false;
     chunks = (h + chunk_h - 1) / chunk_h;
     const int total = n * strips * chunks;
-    if (total < g_stream_min_waves) return false;
+    if (total < min_waves) return false;
     const int grid = (total + 3) / 4;
     const StreamDecimate none{nullptr, nullptr, 0, 0, nullptr};
     if (dec)
@@ -603,25 +599,24 @@ static bool launch_stream_rc(hipStream_t s, const float* in, float* out, float* 
 // arithmetic per row grows and the halved register footprint buys the waves to overlap it with HBM.
 template <int R>
 static bool launch_stream_r(hipStream_t s, const float* in, float* out, float* dog, int w, int h, int n,
-                            const float* d_taps, const StreamDecimate* dec = nullptr) {
+                            const float* d_taps, int min_waves, const StreamDecimate* dec = nullptr) {
     if constexpr (R > kMaxRadiusStream) {
         return false;
     } else if constexpr (R <= 5) {
-        if (launch_stream_rc<R, 4>(s, in, out, dog, w, h, n, d_taps, dec)) return true;
-        return false;
+        return launch_stream_rc<R, 4>(s, in, out, dog, w, h, n, d_taps, min_waves, dec);
     } else {
-        return launch_stream_rc<R, 2>(s, in, out, dog, w, h, n, d_taps, dec);
+        return launch_stream_rc<R, 2>(s, in, out, dog, w, h, n, d_taps, min_waves, dec);
     }
 }
 
 #define SIFT_FUSED_CASE(R) \
     case R:                \
-        if (launch_stream_r<R>(s, in, out, dog, w, h, n, d_taps)) return; \
+        if (launch_stream_r<R>(s, in, out, dog, w, h, n, d_taps, min_waves)) return; \
         launch_fused_r<R>(s, in, out, dog, w, h, n, d_taps); \
         return;
 
 void launch_blur(hipStream_t s, bool fused, const float* in, float* tmp, float* out, float* dog, int w,
-                 int h, int n, const float* d_taps, int radius, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                 int h, int n, const float* d_taps, int radius, int min_waves, hipEvent_t ev_start, hipEvent_t ev_stop) {
     struct Scope {
         Scope(hipEvent_t a, hipEvent_t b) { t_ev_start = a; t_ev_stop = b; }
         ~Scope() { t_ev_start = t_ev_stop = nullptr; }
@@ -654,12 +649,12 @@ void launch_blur(hipStream_t s, bool fused, const float* in, float* tmp, float* 
 
 #define SIFT_REDUCE_CASE(R) \
     case R:                 \
-        return launch_stream_r<R>(s, in, dst, nullptr, w, h, n, d_taps, &dec);
+        return launch_stream_r<R>(s, in, dst, nullptr, w, h, n, d_taps, min_waves, &dec);
 
 // Blur + nearest-neighbour decimation in one pass (streaming kernel only).  false: the caller runs the blur into a
 // temporary and the resampling kernel after it.
 bool launch_blur_reduce(hipStream_t s, const float* in, float* dst, int w, int h, int wd, int hd, int n, const float* d_taps,
-                        int radius, const int* d_inv_x, const int* d_inv_y, float* d_dump, hipEvent_t ev_start,
+                        int radius, const int* d_inv_x, const int* d_inv_y, float* d_dump, int min_waves, hipEvent_t ev_start,
                         hipEvent_t ev_stop) {
     struct Scope {
         Scope(hipEvent_t a, hipEvent_t b) { t_ev_start = a; t_ev_stop = b; }

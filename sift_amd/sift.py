@@ -337,6 +337,12 @@ class Context:
         self._L.sift_hip_profile_get_busy(self._h, which, C.byref(ms))
         return ms.value
 
+    def profile_batches(self) -> int:
+        """Batches whose launches carried timing events since the last profile_reset()."""
+        n = C.c_int64()
+        self._L.sift_hip_profile_batches(self._h, C.byref(n))
+        return int(n.value)
+
     def profile_reset(self):
         self._L.sift_hip_profile_reset(self._h)
 

@@ -1,4 +1,4 @@
-import os as _os; _os.environ.setdefault("SIFT_HIP_LIBRARY", "libsift_hip_diag.so")   # measurement options: `make -C sift_amd/csrc diag`
+import os as _os; _os.environ.setdefault("SIFT_HIP_LIBRARY", "libsift_hip_ablate.so")   # measurement options: `make -C sift_amd/csrc ablate`
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,5 +1,7 @@
 #!/bin/bash
-export SIFT_HIP_LIBRARY=libsift_hip_diag.so   # measurement options (desc_dbg, orient_dbg, diag_*, stream_waves): make -C sift_amd/csrc diag
+# DBGS="" (tools/profile_round.sh): only the SQ counters of the shipped library; otherwise the ablation build (options desc_dbg,
+# orient_dbg: `make -C sift_amd/csrc ablate`)
+[ -n "${DBGS-0 1 2 3}" ] && export SIFT_HIP_LIBRARY=libsift_hip_ablate.so
 # descriptor_wave_kernel: time with phases switched off (desc_dbg bits: 1 no neighbour chains, 2 no histograms; WRONG results) and SQ counters
 export TMPDIR=/tmp
 mkdir -p gpurun_out

@@ -4,7 +4,7 @@
 # window loads (wrong pixels, fewer lines touched).  Results are wrong with any of them; timing only.
 #   bash tools/desc_traffic_probe.sh > gpurun_out/desc_traffic_probe.txt
 cd "$(dirname "$0")/.."
-export SIFT_HIP_LIBRARY="$PWD/sift_amd/lib/libsift_hip_diag.so"
+export SIFT_HIP_LIBRARY="$PWD/sift_amd/lib/libsift_hip_ablate.so"
 line() { python3 bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline "$@" 2>/dev/null | grep '^{' | python3 -c '
 import json, sys
 d = json.loads(sys.stdin.read())

@@ -1,5 +1,5 @@
 #!/bin/bash
-export SIFT_HIP_LIBRARY=libsift_hip_diag.so   # measurement options (desc_dbg, orient_dbg, diag_*, stream_waves): make -C sift_amd/csrc diag
+export SIFT_HIP_LIBRARY=libsift_hip_ablate.so   # measurement options (desc_dbg, orient_dbg, diag_*, stream_waves): make -C sift_amd/csrc ablate
 export TMPDIR=/tmp
 for d in 0 1 2 4 7; do
   rm -rf gpurun_out/prof_o

@@ -1,5 +1,5 @@
 #!/bin/bash
-export SIFT_HIP_LIBRARY=libsift_hip_diag.so   # measurement options (desc_dbg, orient_dbg, diag_*, stream_waves): make -C sift_amd/csrc diag
+export SIFT_HIP_LIBRARY=libsift_hip_ablate.so   # measurement options (desc_dbg, orient_dbg, diag_*, stream_waves): make -C sift_amd/csrc ablate
 # orientation_kernel: time with phases switched off (orient_dbg bits: 1 no peak search, 2 no ordered sums, 4 no window loads; WRONG results)
 export TMPDIR=/tmp
 mkdir -p gpurun_out

@@ -39,15 +39,13 @@ rm -rf gpurun_out/htrace
 bash tools/pmc_kernel.sh > $O/pmc_hbm_traffic.txt 2>&1
 DBGS="" bash tools/desc_probe.sh 2>&1 | grep -vE "^dbg" > $O/pmc_sq_counters.txt
 rm -rf gpurun_out/pmck_* gpurun_out/pmc_d1 gpurun_out/pmc_d2
-# 5. round 4: the practical HBM ceiling, both descriptor kernels, the N > 1 per-rank step on one GPU
+# 5. round 4: the practical HBM ceiling, the N > 1 per-rank step on one GPU
 ./tools/probe/hbm_copy_probe > $O/hbm_copy.txt 2>&1
 ./tools/probe/valu_rate_probe > $O/valu_rate.txt 2>&1   # (built here: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off, see the file's header)
-STEPS=20 bash tools/desc_ab.sh > $O/desc_ab.txt 2>&1
-bash tools/pmc_one.sh descriptor_tile --set desc_kernel=2 > $O/pmc_desc_tile.txt 2>&1
 bash tools/loopback_ab.sh > $O/loopback_ab.txt 2>&1
 python3 tools/gather_probe.py 40 2>&1 | grep "ms/step" > $O/gather_probe.txt
-# 6. round 5: the pyramid's tail as one launch per image / on a stream of its own against the launches in line
-bash tools/tail_kernel_ab.sh 1 > $O/tail_kernel_ab.txt 2>&1
+# 6. round 6: registers, scratch, occupancy and LDS of every kernel of THIS build (compiled on the box: hipcc remarks)
+bash tools/kernel_resources.sh > $O/kernel_resources.txt 2>&1
 rm -rf gpurun_out/prof_d1 gpurun_out/prof_d2
 cat $O/roofline.txt; python3 -c "
 import json

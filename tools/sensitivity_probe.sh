@@ -3,7 +3,7 @@
 # build, timing only, wrong results): desc_dbg 1 = no neighbour chains (the kernel alone: 0.85 -> 0.50 ms), 2 = no histograms (-> 0.76), 15 = nothing.
 #   bash tools/sensitivity_probe.sh > gpurun_out/sens.txt
 cd "$(dirname "$0")/.."
-export SIFT_HIP_LIBRARY="$PWD/sift_amd/lib/libsift_hip_diag.so"
+export SIFT_HIP_LIBRARY="$PWD/sift_amd/lib/libsift_hip_ablate.so"
 line() { python3 bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline "$@" 2>/dev/null | grep '^{' | python3 -c '
 import json, sys
 d = json.loads(sys.stdin.read())
