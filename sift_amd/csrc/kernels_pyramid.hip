@@ -17,17 +17,11 @@
 
 #include "common.h"
 #include "lds_tile.h"
+#include "blur_stream.h"   // reflect_clamp, blur_stream_kernel
 
 #pragma clang fp contract(off)
 
 namespace sift_hip {
-
-__device__ __forceinline__ int reflect_clamp(int p, int n) {
-    p = p < 0 ? -p : p;
-    p = p >= n ? 2 * (n - 1) - p : p;
-    // lanes that only feed outputs outside the image may still be out of range: keep them legal
-    return p < 0 ? 0 : (p >= n ? n - 1 : p);
-}
 
 // ---------------------------------------------------------------------------------------------
 // Fused blur, tile form (radii above 14, small levels, small batches; the streaming form further down takes the
@@ -241,198 +235,6 @@ __global__ __launch_bounds__(256, (R <= 8 ? 3 : ((R <= 24 || (TH <= 48 && R <= 2
 }
 
 // ---------------------------------------------------------------------------------------------
-// Streaming blur (small radii, rows that are 16-byte aligned).  Every WAVE is on its own: it owns a
-// strip of up to 256 columns (4 per lane) and a chunk of rows, and walks the chunk top to bottom:
-//   * the source row (plus RA reflected halo columns each side) is fetched PF rows ahead into
-//     registers, then dropped into a per-wave LDS row (a ring of R+1 rows when the DoG needs the
-//     source again R rows later);
-//   * row pass: ds_read_b128 window -> 4 consecutive outputs per lane, the reference's order;
-//   * column pass in REGISTERS: the 2R+1 partial sums of the lane's 4 columns slide by one each row,
-//         A[j] = A[j+1] + tap[j] * mid      (A[2R] = 0 + tap[2R] * mid)
-//     so output row y receives its terms for source rows y-R .. y+R in ascending order from 0.0f,
-//     exactly the reference's sequence; A[0] is complete after the step and is stored.
-// No workgroup barrier, no intermediate tile in LDS, no vertical halo inside a chunk: HBM sees each
-// source row once per chunk (+2R rows of run-in) and LDS traffic is the row windows only.
-// ---------------------------------------------------------------------------------------------
-constexpr int kStreamPF = 4;  // source rows in flight per wave (registers)
-// run-in rows before the first output: 2R rounded up to whole unrolled bodies (the extra leading rows
-// only feed partial sums that are never stored)
-constexpr int stream_runin(int r) { return (2 * r + kStreamPF - 1) / kStreamPF * kStreamPF; }
-// waves per SIMD the register budget is cut for (512 VGPRs per lane per SIMD)
-constexpr int stream_occ(int r, int cpl) { return cpl == 4 ? (r <= 8 ? 3 : 2) : (r <= 8 ? 4 : r <= 12 ? 3 : 2); }
-
-// decimation of the blurred image on the way out (alg::reduceToNextLevel, algorithms.cpp:24-36): only the pixels the
-// nearest-neighbour resampling keeps are stored, straight into the next octave's first level
-struct StreamDecimate {
-    const int* inv_x;   // source column -> destination column, or -1
-    const int* inv_y;   // source row -> destination row, or -1
-    int wd, hd;         // destination size
-    float* dump;        // >= 64 * CPL floats nobody reads: where the unselected pixels go (no branch around a store)
-};
-
-template <int R, bool DOG, int CPL, bool DEC = false>
-__global__ __launch_bounds__(256, stream_occ(R, CPL)) void blur_stream_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                          float* __restrict__ dog, int w, int h, int strips,
-                                                          int strip_w, int chunks, int chunk_h, int total_units,
-                                                          const float* __restrict__ taps, StreamDecimate dec) {
-    static_assert(!(DEC && DOG), "the decimating variant has no DoG output");
-    constexpr int PF = kStreamPF;
-    constexpr int RI = stream_runin(R);
-    constexpr int E = RI - 2 * R;
-    constexpr int RA = (R + CPL - 1) / CPL * CPL;  // halo columns each side, a whole number of lane vectors
-    constexpr int PAD = RA - R;
-    constexpr int NT = 2 * R + 1;
-    constexpr int ROWF = 64 * CPL + 2 * RA;  // floats per LDS row
-    constexpr int DP = DOG ? R + 2 : 1;  // ring depth: rows s-R .. s+1 are live when the DoG reads its source
-    constexpr int NV = PAD + CPL + 2 * R;
-    constexpr int NV4 = (NV + CPL - 1) / CPL;  // lane vectors per window
-    __shared__ __attribute__((aligned(16))) float s_ring[4][DP * ROWF];
-    typedef float f4v __attribute__((ext_vector_type(CPL)));  // CPL consecutive columns of one row
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int unit = (int)blockIdx.x * 4 + wave;
-    if (unit >= total_units) return;
-    const int per_img = strips * chunks;
-    const int img = unit / per_img;
-    const int rem = unit - img * per_img;
-    const int chunk = rem / strips;
-    const int strip = rem - chunk * strips;
-    const int xs = strip * strip_w;
-    const int sw = min(strip_w, w - xs);
-    // every chunk is chunk_h rows (a multiple of PF); the last one is pulled up to end at the image's
-    // last row and rewrites a few rows of its neighbour with the same values
-    const int y0 = min(chunk * chunk_h, h - chunk_h);
-    const int nsteps = chunk_h + RI;
-    const int p0 = y0 - R - E;  // source row of stream index 0 (reflected)
-
-    const float* __restrict__ src = in + (size_t)img * (size_t)w * (size_t)h;
-    const size_t img_off = (size_t)img * (size_t)w * (size_t)h;
-    float* ring = s_ring[wave];
-
-    // Lanes beyond the strip shadow its last lane (same addresses, same values): every lane runs the
-    // same instruction stream and no global access sits under a branch, which keeps the compiler's
-    // vmcnt bookkeeping exact and the prefetched rows really in flight.
-    const int el = min(lane, sw / CPL - 1);
-    const int mcol = xs + CPL * el;
-    // halo: lanes < 2*RA fetch one reflected column each (the others repeat lane 0's and drop it)
-    const bool has_halo = lane < 2 * RA;
-    const int hl = has_halo ? lane : 0;
-    const int hcol = reflect_clamp(hl < RA ? xs - RA + hl : xs + sw + (hl - RA), w);
-    const int hslot = hl < RA ? hl : RA + sw + (hl - RA);
-    // uniform row base (SGPR pair) + 32-bit per-lane byte offset: no 64-bit per-lane addresses to keep
-    const unsigned moff = 4u * (unsigned)mcol, hoff = 4u * (unsigned)hcol;
-    int dcol[CPL];   // DEC: destination column of each of this lane's source columns (-1: dropped)
-#pragma unroll
-    for (int e = 0; e < CPL; ++e) dcol[e] = DEC ? dec.inv_x[mcol + e] : 0;
-
-    float tp[NT];
-#pragma unroll
-    for (int k = 0; k < NT; ++k) tp[k] = taps[k];
-
-    f4v A[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) A[j] = (f4v)(0.0f);
-
-    f4v pm[PF];
-    float ph[PF];
-    f4v W[NV4];
-    // rows past the end of the stream are clamped to a legal row and never used
-#define SIFT_STREAM_FETCH(T, U)                                                                                       \
-    {                                                                                                                 \
-        const char* rowp_ = reinterpret_cast<const char*>(src + (size_t)reflect_clamp(p0 + (T), h) * (size_t)w);      \
-        pm[U] = *reinterpret_cast<const f4v*>(rowp_ + moff);                                                          \
-        ph[U] = *reinterpret_cast<const float*>(rowp_ + hoff);                                                        \
-    }
-    // LDS stage of stream row T (held in pm[U]): into the ring, refill pm[U] from HBM, read the window
-#define SIFT_STREAM_LDS(T, U)                                                                                         \
-    {                                                                                                                 \
-        float* row_ = ring + wslot * ROWF;                                                                            \
-        *reinterpret_cast<f4v*>(row_ + RA + CPL * el) = pm[U];                                                          \
-        if (has_halo) row_[hslot] = ph[U];                                                                            \
-        __builtin_amdgcn_wave_barrier();                                                                              \
-        SIFT_STREAM_FETCH((T) + PF, U)                                                                                \
-        const f4v* p4_ = reinterpret_cast<const f4v*>(row_) + el;                                                     \
-        _Pragma("unroll") for (int c = 0; c < NV4; ++c) W[c] = p4_[c];                                                \
-        wslot = wslot + 1 == DP ? 0 : wslot + 1;                                                                      \
-    }
-#pragma unroll
-    for (int u = 0; u < PF; ++u) SIFT_STREAM_FETCH(u, u)
-
-    int wslot = 0;                 // ring slot the next LDS stage writes
-    int pslot = DP > 1 ? 2 : 0;    // ring slot of stream row s - R   (-R mod (R + 2))
-    SIFT_STREAM_LDS(0, 0)
-
-    // one step: row pass of stream row S from the window read a step earlier; the next row's LDS stage
-    // is issued before the column pass so that its latency hides under it
-#define SIFT_STREAM_STEP(S, U, STORE)                                                                                 \
-    {                                                                                                                 \
-        f4v m = (f4v)(0.0f);                                                                                          \
-        {                                                                                                             \
-            float v[NV4 * CPL];                                                                                       \
-            _Pragma("unroll") for (int c = 0; c < NV4; ++c)                                                           \
-                _Pragma("unroll") for (int e = 0; e < CPL; ++e) v[CPL * c + e] = W[c][e];                             \
-            _Pragma("unroll") for (int k = 0; k < NT; ++k) {                                                          \
-                const float tap = tp[NT - 1 - k];                                                                     \
-                _Pragma("unroll") for (int e = 0; e < CPL; ++e) m[e] += tap * v[PAD + k + e];                         \
-            }                                                                                                         \
-        }                                                                                                             \
-        f4v prev = (f4v)(0.0f);                                                                                       \
-        if (DOG && (STORE)) prev = *reinterpret_cast<const f4v*>(ring + pslot * ROWF + RA + CPL * el);                  \
-        __builtin_amdgcn_wave_barrier();                                                                              \
-        SIFT_STREAM_LDS((S) + 1, ((U) + 1) % PF)                                                                      \
-        /* The taps are symmetric (tap[j] == tap[2R-j] bit for bit: initGaussian evaluates x*x), so the product  */   \
-        /* tap[j] * mid is the same float for slots j and 2R-j: one multiply serves both additions.             */   \
-        {                                                                                                             \
-            f4v An[NT];                                                                                               \
-            _Pragma("unroll") for (int i = 0; i <= R; ++i) {                                                          \
-                const f4v pr = tp[i] * m;                                                                             \
-                An[i] = A[i + 1] + pr;            /* i + 1 <= R + 1 <= 2R for R >= 1 */                               \
-                if (2 * R - i != i) An[2 * R - i] = (2 * R - i + 1 < NT ? A[2 * R - i + 1] : (f4v)(0.0f)) + pr;       \
-            }                                                                                                         \
-            _Pragma("unroll") for (int j = 0; j < NT; ++j) A[j] = An[j];                                              \
-        }                                                                                                             \
-        if (STORE) {                                                                                                  \
-            const int y = y0 + (S) - RI;                                                                              \
-            const size_t o = img_off + (size_t)y * (size_t)w;                                                         \
-            if (DOG) {                                                                                                \
-                const f4v dif = A[0] - prev;                                                                          \
-                __builtin_nontemporal_store((f4v)(128.0f + dif), reinterpret_cast<f4v*>(reinterpret_cast<char*>(dog + o) + moff)); \
-            }                                                                                                         \
-            if (DEC) {                                                                                                \
-                const int jd = dec.inv_y[y];   /* wave-uniform: half of the rows are dropped */                       \
-                if (jd >= 0) {                                                                                        \
-                    float* drow = out + ((size_t)img * (size_t)dec.hd + (size_t)jd) * (size_t)dec.wd;                 \
-                    _Pragma("unroll") for (int e = 0; e < CPL; ++e)                                                   \
-                        if (dcol[e] >= 0) drow[dcol[e]] = A[0][e];   /* consecutive lanes, consecutive columns */     \
-                }                                                                                                     \
-            } else if (out) {   /* out == nullptr: only the DoG is wanted (wave-uniform) */                            \
-                __builtin_nontemporal_store(A[0], reinterpret_cast<f4v*>(reinterpret_cast<char*>(out + o) + moff));   \
-            }                                                                                                         \
-        }                                                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                            \
-        pslot = pslot + 1 == DP ? 0 : pslot + 1;                                                                      \
-    }
-
-    // run-in: RI rows that only feed the partial sums
-    int s0 = 0;
-#pragma unroll 1
-    for (; s0 < RI; s0 += PF) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) SIFT_STREAM_STEP(s0 + u, u, false)
-    }
-    // steady state: every step completes one output row (chunk_h is a multiple of PF: no tail)
-#pragma unroll 1
-    for (; s0 < nsteps; s0 += PF) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) SIFT_STREAM_STEP(s0 + u, u, true)
-    }
-#undef SIFT_STREAM_STEP
-#undef SIFT_STREAM_LDS
-#undef SIFT_STREAM_FETCH
-}
-
-// ---------------------------------------------------------------------------------------------
 // Two-pass fallback for any radius (r = 0 and r > kMaxRadiusFused included): the reference's own
 // structure, X pass into tmp then Y pass.  Taps in LDS.
 // ---------------------------------------------------------------------------------------------
@@ -595,6 +397,37 @@ static bool launch_stream_rc(hipStream_t s, const float* in, float* out, float* 
     return true;
 }
 
+// Rows in pairs (blur_stream.h: blur_stream2_kernel; round 6): the level launches of radius 6 .. 14 that write a Gaussian level
+// only - no DoG, no decimation -, i.e. every streaming launch of the default plan beyond the first two levels.
+// waves such a launch is cut into: one round of the slots its registers leave - three waves per SIMD up to radius 12 (3072 slots;
+// 2880 waves for 32 x 1080p), two beyond (tools/probe/blur_probe.hip, profiles/r06_blur_probe.txt: R 10 alone 172 us as columns
+// packed, 149 us at 1920 waves, 147 at 2880, 157 at 2400 - a round and a sixth)
+constexpr int stream2_waves(int r) { return stream2_occ(r) >= 3 ? 3072 : 2048; }
+template <int R>
+static bool launch_stream2_r(hipStream_t s, const float* in, float* out, int w, int h, int n, const float* d_taps, int min_waves) {
+    const int target = stream_waves() == kStreamWaves ? stream2_waves(R) : stream_waves();
+    if (target <= 0) return false;
+    const bool aligned = (((uintptr_t)in | (uintptr_t)out) & 7u) == 0;
+    if (!(w % 2 == 0 && aligned) || w < 2 || h < R + 1 || w < R + 1) return false;
+    if ((long long)w * h * 4 > 0x7fffffffLL) return false;   // an image's rows are addressed by 32-bit byte offsets (buffer descriptors)
+    constexpr int SW = 128;
+    const int strips = (w + SW - 1) / SW;
+    const int strip_w = (((w + strips - 1) / strips) + 1) / 2 * 2;
+    constexpr int RI = stream_runin(R);
+    int chunks = target / (n * strips);
+    if (chunks < 1) chunks = 1;
+    int chunk_h = (h + chunks - 1) / chunks;
+    if (chunk_h < 3 * RI) chunk_h = 3 * RI;  // keep the run-in rows a minor share
+    chunk_h = (chunk_h + 3) / 4 * 4;         // whole unrolled bodies (two row pairs)
+    if (chunk_h > h) return false;
+    chunks = (h + chunk_h - 1) / chunk_h;
+    const int total = n * strips * chunks;
+    if (total < min_waves) return false;
+    hipExtLaunchKernelGGL((blur_stream2_kernel<R, 1>), dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, t_ev_start, t_ev_stop, 0, in, out, w, h, strips,
+                          strip_w, chunks, chunk_h, total, d_taps);
+    return true;
+}
+
 // 4 columns per lane while the kernel is HBM-bound (r <= 5); 2 columns per lane beyond, where the
 // arithmetic per row grows and the halved register footprint buys the waves to overlap it with HBM.
 template <int R>
@@ -605,6 +438,7 @@ static bool launch_stream_r(hipStream_t s, const float* in, float* out, float* d
     } else if constexpr (R <= 5) {
         return launch_stream_rc<R, 4>(s, in, out, dog, w, h, n, d_taps, min_waves, dec);
     } else {
+        if (!dog && out && !dec && launch_stream2_r<R>(s, in, out, w, h, n, d_taps, min_waves)) return true;
         return launch_stream_rc<R, 2>(s, in, out, dog, w, h, n, d_taps, min_waves, dec);
     }
 }
