@@ -113,6 +113,28 @@ SIFT_HD float fdlibm_atan2f(float y, float x) {
     }
 }
 
+// a / b, correctly rounded, for operands and quotients well inside the exponent range (round 6).  The division the compiler
+// emits for `a / b` is this very sequence - reciprocal estimate, one Newton step on it, quotient, two residual corrections -
+// wrapped in v_div_scale_f32 (twice) and v_div_fixup_f32, which only move the exponents out of harm's way and patch
+// infinities, zeros and NaNs: 12 instructions where 9 do the arithmetic.  With |a|, |b| in [2^-60, 2^60] (the caller checks;
+// everything else takes fdlibm_atan2f's own division) no intermediate leaves the normal range, the scaling is the identity
+// and the result is the same correctly rounded quotient.  a == 0 gives the zero `a / b` gives.  On the host the estimate is
+// 1.0f / b: any estimate within an ulp refines to the same quotient (tests/test_host_math.py compares with `/` on 10^8 pairs).
+SIFT_HD float div_in_range(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = __builtin_amdgcn_rcpf(b);
+#else
+    float r = 1.0f / b;
+#endif
+    const float e = __builtin_fmaf(-b, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = a * r;
+    float rem = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(rem, r, q);
+    rem = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(rem, r, q);
+}
+
 // Branch-free evaluation of the same algorithm for the common case, for the GPU: the four argument
 // reductions of atanf differ only in the numerator and denominator of their single division, so they are
 // selected first and divided once; the polynomial and the quadrant fix-up are the same operations in the
@@ -122,10 +144,13 @@ SIFT_HD bool fdlibm_atan2f_common(float y, float x, float& out) {
     const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
     const int32_t hx = f2i(x), hy = f2i(y);
     const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    // (round 6: both divisions as div_in_range - |x|, |y| in [2^-60, 2^60], which also keeps the exponent gap k within
+    // +-120 > 60, checked below; the reduced argument's numerator and denominator lie in [2^-29, 2^25] by construction)
     const int32_t k = (iy - ix) >> 23;
-    const float t = fabs_bits(y / x);
+    const float t = fabs_bits(div_in_range(y, x));
     const int32_t it = f2i(t);
-    const bool common = ix < 0x7f800000 && iy < 0x7f800000 && ix != 0 && iy != 0 && hx != 0x3f800000 && k <= 60 &&
+    const bool common = (uint32_t)(ix - 0x21800000) <= (uint32_t)(0x5d800000 - 0x21800000) &&
+                        (uint32_t)(iy - 0x21800000) <= (uint32_t)(0x5d800000 - 0x21800000) && hx != 0x3f800000 && k <= 60 &&
                         k >= -60 && it < 0x4c000000 && it >= 0x31000000;
     // argument reduction: x' = num / den
     const bool c_small = it < 0x3ee00000, c0 = it < 0x3f300000, c1 = it < 0x3f980000, c2 = it < 0x401c0000;
@@ -137,7 +162,7 @@ SIFT_HD bool fdlibm_atan2f_common(float y, float x, float& out) {
                 aT3 = -1.1111110449e-01f, aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f,
                 aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f, aT8 = 4.9768779427e-02f,
                 aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
-    const float xr = num / den;
+    const float xr = div_in_range(num, den);
     const float z = xr * xr;
     const float w = z * z;
     const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "fdlibm_atan2f.h"
+#include "grad_math.h"
 #include "hist_bins.h"
 #include "linalg3.h"
 
@@ -21,6 +22,23 @@ int hostmath_atan2f_sel_array(const float* y, const float* x, int n, float* out)
         out[i] = sift_hip::fdlibm_atan2f_sel(y[i], x[i]);
     }
     return common;
+}
+// alg::gradientMagnitude as the gradient kernels compute it (grad_math.h); returns how many inputs took the exact routine
+long long hostmath_magnitude_array(const float* dx, const float* dy, long long n, float* out) {
+    long long slow = 0;
+    for (long long i = 0; i < n; ++i) {
+        out[i] = sift_hip::gradient_magnitude(dx[i], dy[i]);
+    }
+    return slow;
+}
+// a / b as the atan2f restatement divides (fdlibm_atan2f.h: div_in_range); mismatches against the compiler's division
+long long hostmath_div_mismatches(const float* a, const float* b, long long n) {
+    long long bad = 0;
+    for (long long i = 0; i < n; ++i) {
+        const float q = sift_hip::div_in_range(a[i], b[i]), w = a[i] / b[i];
+        bad += sift_hip::f2i(q) != sift_hip::f2i(w) ? 1 : 0;
+    }
+    return bad;
 }
 // matrices row-fastest like vigra::Matrix: a[i + 3*j] = A(i, j)
 int hostmath_inverse3(const float* a, float* res) {

@@ -14,6 +14,7 @@
 
 #include "common.h"
 #include "linalg3.h"
+#include "grad_math.h"
 
 #pragma clang fp contract(off)
 
@@ -50,8 +51,8 @@ __device__ __forceinline__ void gradient_pixel(bool interior, float left, float 
     if (interior) {   // border pixels stay 0
         const float dx = right - left;
         const float dy = down - up;
-        // std::sqrt(std::pow(dx, 2) + std::pow(dy, 2)) evaluated in double (algorithms.cpp:109-110)
-        m = (float)__builtin_sqrt((double)dx * (double)dx + (double)dy * (double)dy);
+        // std::sqrt(std::pow(dx, 2) + std::pow(dy, 2)) evaluated in double (algorithms.cpp:109-110): grad_math.h
+        m = gradient_magnitude(dx, dy);
         // std::fmod(atan2f(dy, dx) + 360.f, 360.) (algorithms.cpp:114-115); atan2f in [-pi, pi] so the
         // double fmod reduces to one conditional subtraction, which is exact.
         // branch-free common path (one division for every argument range); rare inputs take the full routine

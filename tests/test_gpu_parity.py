@@ -125,6 +125,33 @@ def test_dog_and_gradient(ctx):
     gm, go = ctx.gradient(c)
     assert_bits_equal(gm, mag, "gradient magnitude (wide range)")
     assert_bits_equal(go, ori, "gradient orientation (wide range)")
+    # round 6: the magnitude takes one Newton round on the hardware's reciprocal-square-root estimate and the correctly
+    # rounded routine only near a float rounding boundary (sift_amd/csrc/grad_math.h).  A lattice of pixels whose (dx, dy)
+    # put sqrt(dx^2 + dy^2) within ~2^-47 of the midpoint of two floats - just above, just below, and as close as float
+    # inputs get - plus random pairs in between; every pixel against the oracle, magnitudes also against numpy's sqrt.
+    from test_host_math import midpoint_pairs
+    rng = np.random.default_rng(6)
+    side = 1024
+    k = (side // 4) ** 2
+    d = np.zeros((side, side), np.float32)
+    dxs, dys = [], []
+    for steps in (0, 1):
+        dxa, dya, _ = midpoint_pairs(rng, k // 8, steps)
+        for bump in (0, 1, -1):
+            dxs.append(dxa)
+            dys.append((dya.view(np.int32) + bump).view(np.float32))
+    rest = k - sum(a.size for a in dxs)
+    dxs.append((rng.standard_normal(rest) * 10.0 ** rng.integers(-5, 3, rest)).astype(np.float32))
+    dys.append((rng.standard_normal(rest) * 10.0 ** rng.integers(-5, 3, rest)).astype(np.float32))
+    dxs, dys = np.concatenate(dxs).reshape(side // 4, side // 4), np.concatenate(dys).reshape(side // 4, side // 4)
+    d[1::4, 2::4] = dxs          # right neighbour of pixel (4i+1, 4j+1); its left, up neighbours stay 0
+    d[2::4, 1::4] = dys          # down neighbour
+    O.lib().oracle_gradient(d, side, side, mag := np.empty_like(d), ori := np.empty_like(d))
+    gm, go = ctx.gradient(d)
+    assert_bits_equal(gm, mag, "gradient magnitude (pairs at float rounding boundaries)")
+    assert_bits_equal(go, ori, "gradient orientation (pairs at float rounding boundaries)")
+    want = np.sqrt(dxs.astype(np.float64) ** 2 + dys.astype(np.float64) ** 2).astype(np.float32)
+    assert_bits_equal(gm[1::4, 1::4], want, "gradient magnitude against numpy's correctly rounded square root")
 
 
 def test_edge_responses_and_parabola(ctx):

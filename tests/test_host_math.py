@@ -15,8 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def hm():
     path = os.path.join(ROOT, "sift_amd", "lib", "libsift_hostmath.so")
-    if not os.path.exists(path):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "sift_amd", "csrc"), "../lib/libsift_hostmath.so"])
+    # (always through make: a no-op when the library is newer than the headers it is built from)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "sift_amd", "csrc"), "../lib/libsift_hostmath.so"])
     H = C.CDLL(path)
     fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
     H.hostmath_atan2f_array.argtypes = [fp, fp, C.c_int, fp]
@@ -28,7 +28,79 @@ def hm():
     H.hostmath_vertex_parabola.argtypes = [C.c_uint16, C.c_float, C.c_uint16, C.c_float, C.c_uint16, C.c_float]
     H.hostmath_hist8_bin_mismatches.restype = C.c_longlong
     H.hostmath_hist8_bin_mismatches.argtypes = [C.c_ulonglong, C.c_ulonglong, C.POINTER(C.c_uint)]
+    H.hostmath_magnitude_array.argtypes = [fp, fp, C.c_longlong, fp]
+    H.hostmath_magnitude_array.restype = C.c_longlong
+    H.hostmath_div_mismatches.argtypes = [fp, fp, C.c_longlong]
+    H.hostmath_div_mismatches.restype = C.c_longlong
     return H
+
+
+def midpoint_pairs(rng, k, dx_steps_below=0):
+    """(dx, dy) whose sqrt(dx^2 + dy^2) lies within ~2^-47 (relative) of the MIDPOINT of two neighbouring floats - where
+    (float)sqrt(double) is decided by the last bits of the double square root: dx the float below the midpoint m (or a few
+    floats lower), dy = sqrt(m^2 - dx^2) rounded to float."""
+    base = (rng.random(k) * 2.0 ** rng.integers(-10, 10, k)).astype(np.float32)
+    nxt = np.nextafter(base, np.float32(np.inf))
+    m = (base.astype(np.float64) + nxt.astype(np.float64)) / 2
+    dx = base.copy()
+    for _ in range(dx_steps_below):
+        dx = np.nextafter(dx, np.float32(0))
+    dy = np.sqrt(np.maximum(m * m - dx.astype(np.float64) ** 2, 0)).astype(np.float32)
+    return dx, dy, m
+
+
+def test_gradient_magnitude_is_the_double_square_root_rounded_to_float(hm):
+    """alg::gradientMagnitude (/root/reference/algorithms.cpp:108-111) is (float)sqrt((double)dx*dx + (double)dy*dy).  The
+    gradient kernels take ONE Newton round on a 24-bit reciprocal-square-root estimate and fall back to the correctly rounded
+    routine where a float rounding boundary lies within the round's error bound (sift_amd/csrc/grad_math.h); the host build
+    of that function (its estimate truncated to 24 bits: the device's worst case) against numpy's correctly rounded sqrt."""
+    rng = np.random.default_rng(11)
+    n = 4_000_000
+    dx = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 3, n)).astype(np.float32)
+    dy = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 3, n)).astype(np.float32)
+    dx[:1000] = 0.0                       # flat rows / columns, and dx = dy = 0
+    dy[500:1500] = 0.0
+    dx[2000:3000] = np.round(dx[2000:3000] * 8)   # integer differences: exact squares (3, 4 -> 5)
+    dy[2000:3000] = np.round(dy[2000:3000] * 8)
+    out = np.empty(n, np.float32)
+    hm.hostmath_magnitude_array(dx, dy, n, out)
+    want = np.sqrt(dx.astype(np.float64) ** 2 + dy.astype(np.float64) ** 2).astype(np.float32)
+    assert (out.view(np.uint32) == want.view(np.uint32)).all()
+    k = 1_000_000
+    for steps in (0, 1):
+        dxa, dya, m = midpoint_pairs(rng, k, steps)
+        for bump in (0, 1, -1):           # dy one float up / down: results decided just above / just below the midpoint
+            dyb = (dya.view(np.int32) + bump).view(np.float32)
+            s = dxa.astype(np.float64) ** 2 + dyb.astype(np.float64) ** 2
+            want = np.sqrt(s).astype(np.float32)
+            near = np.abs(np.sqrt(s) - m) / m < 2.0 ** -44
+            assert near.mean() > 0.2, (steps, bump, near.mean())
+            hm.hostmath_magnitude_array(dxa, dyb, k, out[:k])
+            assert (out[:k].view(np.uint32) == want.view(np.uint32)).all(), (steps, bump)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, 3.4e38, 1e-30, 1.0], np.float32)
+    ys, xs = np.meshgrid(special, special)
+    ys, xs = np.ascontiguousarray(ys.ravel()), np.ascontiguousarray(xs.ravel())
+    hm.hostmath_magnitude_array(xs, ys, xs.size, out[:xs.size])
+    with np.errstate(all="ignore"):
+        want = np.sqrt(xs.astype(np.float64) ** 2 + ys.astype(np.float64) ** 2).astype(np.float32)
+    g = out[:xs.size]
+    assert ((g.view(np.uint32) == want.view(np.uint32)) | (np.isnan(g) & np.isnan(want))).all()
+
+
+def test_division_without_exponent_scaling_is_the_ieee_division(hm):
+    """fdlibm_atan2f.h: div_in_range - the compiler's own division sequence without v_div_scale / v_div_fixup - for operands in
+    [2^-60, 2^60]: the quotient `a / b` gives, bit for bit (what atanf's argument reduction divides is covered separately by
+    test_atan2f_matches_libm, which runs the whole restatement against glibc)."""
+    rng = np.random.default_rng(12)
+    n = 10_000_000
+    a = (rng.standard_normal(n) * 10.0 ** rng.integers(-15, 15, n)).astype(np.float32)
+    b = (rng.standard_normal(n) * 10.0 ** rng.integers(-15, 15, n)).astype(np.float32)
+    a[:100000] = rng.integers(-2550, 2550, 100000).astype(np.float32)      # exact quotients, zeros
+    b[:100000] = rng.integers(1, 256, 100000).astype(np.float32)
+    ok = (np.abs(b) > 2.0 ** -60) & (np.abs(b) < 2.0 ** 60) & ((a == 0) | ((np.abs(a) > 2.0 ** -60) & (np.abs(a) < 2.0 ** 60)))
+    a, b = np.ascontiguousarray(a[ok]), np.ascontiguousarray(b[ok])
+    assert a.size > n // 2
+    assert hm.hostmath_div_mismatches(a, b, a.size) == 0
 
 
 def test_hist8_bin_without_division_all_inputs(hm):
