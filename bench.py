@@ -157,7 +157,7 @@ def pmc_traffic_live(extra_args):  # noqa: C901
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
                     # every launch of the family the roofline is about: streaming / tile blurs, the kept-pixels reductions, the pair launch
-                    if row.get("Counter_Name") == c and any(k in row["Kernel_Name"] for k in ("blur_stream_kernel", "blur_fused_kernel", "blur_reduce_kernel", "blur_pair_kernel")):
+                    if row.get("Counter_Name") == c and any(k in row["Kernel_Name"] for k in ("blur_stream_kernel", "blur_stream2_kernel", "blur_fused_kernel", "blur_reduce_kernel", "blur_pair_kernel")):
                         s += float(row["Counter_Value"])
                         n += 1
             if not n:
@@ -610,7 +610,7 @@ def main():
                        "gather": ("RCCL p2p of keypoint records + descriptors to rank 0, no per-step collective (sizes ride one step ahead), overlapped with the following steps; "
                                   + {"full": "128 floats per descriptor", "packed": "descriptors on the wire as 112 of 128 floats (bin 7 of each cell is structurally +0.0f; lossless)",
                                      "sparse": "descriptors on the wire as 112 presence bits + the floats that are not +0.0f (about a third; lossless)"}[args.wire]) if gatherer is not None else "none (1 GPU)"},
-            "roofline": {"kernel": "blur_stream_kernel / blur_fused_kernel (separable Gaussian + DoG; every launch of the pyramid)",
+            "roofline": {"kernel": "blur_pair_kernel / blur_stream2_kernel / blur_reduce_kernel / blur_fused_kernel (separable Gaussian: every launch of the pyramid)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                          "timing": "hipEventElapsedTime over start/stop events attached to each blur dispatch (hipExtLaunchKernelGGL) on the library's streams, inside the timed region; "

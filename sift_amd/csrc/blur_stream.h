@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256, stream_occ(R, CPL)) void blur_stream_kernel(co
 // Bit-identical to blur_stream_kernel by construction (the same operations in the same order per output); the probe and
 // the parity tests check it.
 // ---------------------------------------------------------------------------------------------
-constexpr int stream2_occ(int r) { return r <= 12 ? 3 : 2; }
+constexpr int stream2_occ(int r) { return r <= 10 ? 3 : 2; }   // (R 11, 12 would spill at the 168 registers three waves leave)
 
 template <int R, int VAR = 0>
 __global__ __launch_bounds__(256, stream2_occ(R)) void blur_stream2_kernel(const float* __restrict__ in, float* __restrict__ out, int w,

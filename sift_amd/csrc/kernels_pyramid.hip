@@ -399,7 +399,7 @@ static bool launch_stream_rc(hipStream_t s, const float* in, float* out, float* 
 
 // Rows in pairs (blur_stream.h: blur_stream2_kernel; round 6): the level launches of radius 6 .. 14 that write a Gaussian level
 // only - no DoG, no decimation -, i.e. every streaming launch of the default plan beyond the first two levels.
-// waves such a launch is cut into: one round of the slots its registers leave - three waves per SIMD up to radius 12 (3072 slots;
+// waves such a launch is cut into: one round of the slots its registers leave - three waves per SIMD up to radius 10 (3072 slots;
 // 2880 waves for 32 x 1080p), two beyond (tools/probe/blur_probe.hip, profiles/r06_blur_probe.txt: R 10 alone 172 us as columns
 // packed, 149 us at 1920 waves, 147 at 2880, 157 at 2400 - a round and a sixth)
 constexpr int stream2_waves(int r) { return stream2_occ(r) >= 3 ? 3072 : 2048; }

@@ -28,7 +28,7 @@ for name, v in sorted(res.items(), key=lambda kv: -(kv[1]["FETCH_SIZE_KB"] + kv[
     write = v["WRITE_SIZE_KB"] * 1024
     out[name] = {"launches": n, "read_bytes_per_launch_x2_corrected": read / n, "write_bytes_per_launch": write / n,
                  "hbm_bytes_per_launch": (read + write) / n}
-blur = {k: v for k, v in out.items() if k.startswith(("blur_fused_kernel", "blur_stream_kernel"))}
+blur = {k: v for k, v in out.items() if k.startswith(("blur_fused_kernel", "blur_stream_kernel", "blur_stream2_kernel", "blur_reduce_kernel", "blur_pair_kernel"))}
 if blur:
     tot_l = sum(v["launches"] for v in blur.values())
     out["_blur_fused_all"] = {"launches": tot_l,

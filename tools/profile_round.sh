@@ -44,8 +44,10 @@ rm -rf gpurun_out/pmck_* gpurun_out/pmc_d1 gpurun_out/pmc_d2
 ./tools/probe/valu_rate_probe > $O/valu_rate.txt 2>&1   # (built here: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off, see the file's header)
 bash tools/loopback_ab.sh > $O/loopback_ab.txt 2>&1
 python3 tools/gather_probe.py 40 2>&1 | grep "ms/step" > $O/gather_probe.txt
-# 6. round 6: registers, scratch, occupancy and LDS of every kernel of THIS build (compiled on the box: hipcc remarks)
-bash tools/kernel_resources.sh > $O/kernel_resources.txt 2>&1
+# 6. round 6: the streaming blur kernels alone (old against new packing, bit for bit); registers / scratch / occupancy of every kernel
+# come from `bash tools/kernel_resources.sh > profiles/rNN_kernel_resources.txt` in the build container (hipcc's remarks need no GPU)
+[ -x tools/probe/blur_probe ] && timeout 300 ./tools/probe/blur_probe > $O/blur_probe.txt 2>&1
+bash tools/single_trace.sh > $O/single_trace.txt 2>&1
 rm -rf gpurun_out/prof_d1 gpurun_out/prof_d2
 cat $O/roofline.txt; python3 -c "
 import json

@@ -81,6 +81,9 @@ def parse_name(name):
     m = re.search(r"blur_pair_kernel<(\d+)>", name)   # the first two levels in one launch (kernels_pair.hip)
     if m:
         return {"form": "pair", "R": int(m.group(1)), "dog": False, "dec": False}
+    m = re.search(r"blur_stream2_kernel<(\d+), (\d+)>", name)   # round 6: rows packed in pairs, a Gaussian level out (blur_stream.h)
+    if m:
+        return {"form": "stream", "R": int(m.group(1)), "dog": False, "dec": False}
     m = re.search(r"blur_(stream|fused)_kernel<(\d+), (true|false)(?:, (\d+))?(?:, (true|false))?>", name)
     if not m:
         return None
