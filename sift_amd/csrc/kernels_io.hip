@@ -1,6 +1,5 @@
-// Plumbing kernels and the launch locks: device-to-device copies as a kernel of the library (the one-process multi-GPU gather,
-// group.cpp), the few counters cleared between kernels of a stream, and the per-device locks every HIP call of the library is
-// made under (launch_guard.h).  Transfers between page-locked host memory and HBM as kernels of our own (options "io_kernels",
+// Plumbing kernels: device-to-device copies as a kernel of the library (the one-process multi-GPU gather, group.cpp) and the few
+// counters cleared between kernels of a stream.  Transfers between page-locked host memory and HBM as kernels of our own (options "io_kernels",
 // "stage_kernels") were measured in rounds 2 - 3, lost to the runtime's copies (6.5 - 6.8 ms a step against
 // 4.5 - 5.5 ms; reads over the link reach ~28 GB/s with this much in flight) and were removed in round 4.
 #include <algorithm>
@@ -15,62 +14,7 @@
 
 namespace sift_hip {
 
-// ---- launch locks (launch_guard.h) -------------------------------------------------------------------------------------
-constexpr int kMaxLockDevices = 64;
-std::recursive_mutex& launch_lock_of(int device) {
-    static std::recursive_mutex m[kMaxLockDevices];
-    return m[(unsigned)device % (unsigned)kMaxLockDevices];
-}
-static thread_local int t_device = 0;
-int set_device_tracked(int device) {
-    const hipError_t e = (hipSetDevice)(device);
-    if (e == hipSuccess) t_device = device;
-    return (int)e;
-}
-int tracked_device() { return t_device; }
-int current_device_refreshed() {
-    int d = t_device;
-    if (hipGetDevice(&d) == hipSuccess) t_device = d;
-    else (void)hipGetLastError();
-    return t_device;
-}
-std::recursive_mutex& launch_lock() { return launch_lock_of(t_device); }
-static std::atomic<long long> g_lock_wait_ns{0};
-double launch_lock_wait_ms() { return (double)g_lock_wait_ns.load(std::memory_order_relaxed) / 1e6; }
-static void lock_accounted(std::recursive_mutex& m) {
-    if (m.try_lock()) return;
-    const auto t0 = std::chrono::steady_clock::now();
-    m.lock();
-    g_lock_wait_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
-}
-LaunchGuard::LaunchGuard() : m(launch_lock()) { lock_accounted(m); }
-
-// ---- function objects of the library's kernels, per device (launch_cache.h) ------------------------------------------------
-static std::unordered_map<const void*, hipFunction_t> g_functions[kMaxLockDevices];   // each under its device's launch lock
-hipFunction_t cached_function(const void* host_stub) {
-    auto& table = g_functions[(unsigned)t_device % (unsigned)kMaxLockDevices];
-    const auto it = table.find(host_stub);
-    if (it != table.end()) return it->second;
-    hipFunction_t f = nullptr;
-    if (hipGetFuncBySymbol(&f, host_stub) != hipSuccess || !f) {
-        (void)(hipGetLastError)();
-        return nullptr;
-    }
-    table.emplace(host_stub, f);
-    return f;
-}
-static thread_local hipError_t t_launch_error = hipSuccess;
-void note_launch_error(hipError_t e) { if (t_launch_error == hipSuccess) t_launch_error = e; }
-hipError_t take_launch_error() {
-    const hipError_t e = t_launch_error;
-    t_launch_error = hipSuccess;
-    return e;
-}
-hipError_t combined_last_error() {
-    const hipError_t mine = take_launch_error(), runtime = (hipGetLastError)();
-    return mine != hipSuccess ? mine : runtime;
-}
-LaunchGuard::LaunchGuard(int device) : m(launch_lock_of(device)) { lock_accounted(m); }
+// (the launch locks, the thread's tracked device and the table of cached function objects are host code: launch_guard.cpp)
 
 constexpr int kIoWorkgroups = 16;
 constexpr int kIoUnroll = 4;

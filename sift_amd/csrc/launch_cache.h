@@ -34,6 +34,13 @@ inline void launch_cached_impl(void (*kernel)(KArgs...), dim3 grid, dim3 block, 
     static_assert(sizeof...(KArgs) == sizeof...(Args), "kernel launched with the wrong number of arguments");
     std::tuple<KArgs...> a{static_cast<KArgs>(std::forward<Args>(args))...};
     void* ptrs[sizeof...(KArgs) > 0 ? sizeof...(KArgs) : 1] = {const_cast<void*>(static_cast<const void*>(&std::get<I>(a)))...};
+    // the module launch takes the grid in THREADS per dimension, as 32-bit numbers: a launch of 2^32 threads or more along a
+    // dimension (the runtime's own path accepted 2^31 blocks) must fail, not wrap
+    if ((unsigned long long)grid.x * block.x > 0xffffffffull || (unsigned long long)grid.y * block.y > 0xffffffffull ||
+        (unsigned long long)grid.z * block.z > 0xffffffffull) {
+        note_launch_error(hipErrorInvalidConfiguration);
+        return;
+    }
     LaunchGuard guard;
     hipFunction_t f = cached_function(reinterpret_cast<const void*>(kernel));
     if (!f) { note_launch_error(hipErrorInvalidDeviceFunction); return; }

@@ -19,8 +19,10 @@
 #include "../../include/sift_hip.h"
 #include "../../sift_amd/csrc/launch_guard.h"
 
-// ---- launch locks (the shipped implementation lives in kernels_io.hip, a device source) --------------------------------------
+// ---- launch locks: the shipped implementation is sift_amd/csrc/launch_guard.cpp; the group / gate drivers link this small copy,
+// the collect driver (-DSIFT_FAKE_WITH_REAL_LAUNCH_GUARD) links the real file ---------------------------------------------------
 namespace sift_hip {
+#ifndef SIFT_FAKE_WITH_REAL_LAUNCH_GUARD
 std::recursive_mutex& launch_lock_of(int device) {
     static std::recursive_mutex m[64];
     return m[(unsigned)device % 64u];
@@ -33,14 +35,32 @@ std::recursive_mutex& launch_lock() { return launch_lock_of(t_device); }
 double launch_lock_wait_ms() { return 0.0; }
 LaunchGuard::LaunchGuard() : m(launch_lock()) { m.lock(); }
 LaunchGuard::LaunchGuard(int device) : m(launch_lock_of(device)) { m.lock(); }
+static int& fake_device() { return t_device; }
+#else
+static int& fake_device() { static thread_local int d = 0; return d; }
+#endif
 }  // namespace sift_hip
 
 // ---- the runtime ----------------------------------------------------------------------------------------------------------------
 static std::atomic<long long> g_live_allocs{0};
 extern "C" {
 hipError_t hipGetDeviceCount(int* n) { *n = 4; return hipSuccess; }
-hipError_t hipSetDevice(int d) { sift_hip::t_device = d; return hipSuccess; }
-hipError_t hipGetDevice(int* d) { *d = sift_hip::t_device; return hipSuccess; }
+hipError_t hipSetDevice(int d) { sift_hip::fake_device() = d; return hipSuccess; }
+hipError_t hipGetDevice(int* d) { *d = sift_hip::fake_device(); return hipSuccess; }
+// a function object per (device, host stub): the address of a cell in a per-device table, filled on first use WITHOUT a lock of its
+// own - the real runtime's table is what the library's launch lock protects, and a second thread inside it would be the bug
+hipError_t hipGetFuncBySymbol(hipFunction_t* f, const void* stub) {
+    static const void* seen[4][64];
+    const int d = sift_hip::fake_device() & 3;
+    for (int i = 0; i < 64; ++i) {
+        if (seen[d][i] == stub || seen[d][i] == nullptr) {
+            seen[d][i] = stub;
+            *f = reinterpret_cast<hipFunction_t>(&seen[d][i]);
+            return hipSuccess;
+        }
+    }
+    return hipErrorInvalidDeviceFunction;
+}
 hipError_t hipGetLastError(void) { return hipSuccess; }
 const char* hipGetErrorString(hipError_t) { return "fake"; }
 hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); g_live_allocs++; return *p ? hipSuccess : hipErrorOutOfMemory; }
@@ -78,8 +98,8 @@ struct sift_hip_ctx {
     int64_t nnz = 0;
 };
 
-static void fake_points(float v, std::vector<sift_hip_keypoint>& kp, std::vector<float>& desc) {
-    const int n = 1 + ((int)v % 7 + 7) % 7;
+static void fake_points(float v, std::vector<sift_hip_keypoint>& kp, std::vector<float>& desc, int count = 0) {
+    const int n = count > 0 ? count : 1 + ((int)v % 7 + 7) % 7;
     for (int j = 0; j < n; ++j) {
         sift_hip_keypoint r;
         std::memset(&r, 0, sizeof(r));
@@ -115,7 +135,9 @@ int sift_hip_calculate_batch(sift_hip_ctx* c, const float* imgs, int n, int w, i
             continue;
         }
         const size_t before = c->kp.size();
-        fake_points(v, c->kp, c->desc);
+        // (a frame whose SECOND pixel is >= 1000 asks for that many records: the large results sift::Sift::collect() shares out)
+        const float second = (size_t)w * (size_t)h > 1 ? imgs[(size_t)i * (size_t)w * (size_t)h + 1] : 0.0f;
+        fake_points(v, c->kp, c->desc, second >= 1000.0f ? (int)second : 0);
         c->counts[(size_t)i] = (int32_t)(c->kp.size() - before);
     }
     c->have = true;
@@ -163,6 +185,30 @@ int sift_hip_sparse_unpack(sift_hip_ctx*, const void* rec, const void* val, int6
     return SIFT_HIP_OK;
 }
 int sift_hip_internal_copy(void*, const void* src, void* dst, size_t bytes) { std::memcpy(dst, src, bytes); return 0; }
+// ---- what include/sift/sift.hpp calls beside the above (collect_main.cpp) ----
+int sift_hip_calculate_batch_u8(sift_hip_ctx* c, const uint8_t* imgs, int n, int w, int h, const sift_hip_params* p, char* err, int errlen) {
+    std::vector<float> f((size_t)n * (size_t)w * (size_t)h);
+    for (size_t i = 0; i < f.size(); ++i) f[i] = (float)imgs[i];
+    return sift_hip_calculate_batch(c, f.data(), n, w, h, p, err, errlen);
+}
+int sift_hip_result_copy(sift_hip_ctx* c, sift_hip_keypoint* kp, float* desc) {
+    if (kp) std::copy(c->kp.begin(), c->kp.end(), kp);
+    if (desc) std::copy(c->desc.begin(), c->desc.end(), desc);
+    return SIFT_HIP_OK;
+}
+int sift_hip_result_copy_sparse(sift_hip_ctx* c, void* rec, float* val) { return sift_hip_result_sparse_pack(c, rec, val); }
+int sift_hip_sparse_unpack_host(const void* rec, const float* val, int64_t n, sift_hip_keypoint* kp, float* desc, int) {
+    // (the caller may pass either output; the device form above wants both)
+    std::vector<sift_hip_keypoint> k2(kp ? 0 : (size_t)n);
+    std::vector<float> d2(desc ? 0 : (size_t)n * 128);
+    return sift_hip_sparse_unpack(nullptr, rec, val, n, kp ? (void*)kp : (void*)k2.data(), desc ? (void*)desc : (void*)d2.data());
+}
+int sift_hip_image_dims(sift_hip_ctx*, int* w, int* h) { *w = *h = 0; return SIFT_HIP_EINVAL; }
+int sift_hip_image_copy(sift_hip_ctx*, int, float*) { return SIFT_HIP_EINVAL; }
+struct sift_hip_gate { int device; };
+int sift_hip_gate_create(int device, sift_hip_gate** out) { *out = new sift_hip_gate{device}; return SIFT_HIP_OK; }
+void sift_hip_gate_destroy(sift_hip_gate* g) { delete g; }
+int sift_hip_set_gate(sift_hip_ctx*, sift_hip_gate*) { return SIFT_HIP_OK; }
 void* sift_hip_host_alloc(size_t n) { return std::malloc(n ? n : 1); }
 void sift_hip_host_free(void* p) { std::free(p); }
 }

@@ -18,10 +18,10 @@ pytestmark = pytest.mark.skipif(shutil.which("g++") is None or not os.path.exist
                                 reason="needs g++ and the HIP headers")
 
 
-def _build(tmp_path, name, sanitize, sources):
+def _build(tmp_path, name, sanitize, sources, defines=()):
     exe = str(tmp_path / name)
     cmd = ["g++", "-std=c++17", "-O1", "-g", f"-fsanitize={sanitize}", "-fno-sanitize-recover=all", "-pthread", "-D__HIP_PLATFORM_AMD__",
-           "-I" + HIP_INCLUDE] + sources + ["-ldl", "-o", exe]
+           "-I" + HIP_INCLUDE] + ["-D" + d for d in defines] + sources + ["-ldl", "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     if r.returncode != 0 and ("cannot find" in r.stderr or "unrecognized" in r.stderr):
         pytest.skip("this toolchain has no " + sanitize + " runtime: " + r.stderr[-200:])
@@ -56,3 +56,20 @@ def test_phase_gate_under_thread_sanitizer(tmp_path):
     """PhaseGate: 2 - 4 host threads taking tickets from one gate, both schedules, batches that end early."""
     exe = _build(tmp_path, "gate_tsan", "thread", [os.path.join(SRC, "gate_main.cpp"), os.path.join(SRC, "fake_hip.cpp")])
     assert "gate ok" in _run(exe, [], 600)
+
+
+# include/sift/sift.hpp's collect() worker pool and sift_amd/csrc/launch_guard.cpp as it ships (ADVICE r05)
+COLLECT_SOURCES = [os.path.join(SRC, "collect_main.cpp"), os.path.join(SRC, "fake_hip.cpp"), os.path.join(ROOT, "sift_amd", "csrc", "launch_guard.cpp")]
+
+
+def test_collect_pool_and_launch_cache_under_thread_sanitizer(tmp_path):
+    """sift::Sift::collect(): small and large results through one object (the pool starts at the first large one and parks between
+    calls and at destruction), two objects on two threads; the launch locks and the table of cached function objects: threads of two
+    devices resolving the same kernels, the per-thread launch error."""
+    exe = _build(tmp_path, "collect_tsan", "thread", COLLECT_SOURCES, defines=("SIFT_FAKE_WITH_REAL_LAUNCH_GUARD",))
+    assert "collect ok" in _run(exe, ["22"], 900)
+
+
+def test_collect_pool_and_launch_cache_under_address_sanitizer(tmp_path):
+    exe = _build(tmp_path, "collect_asan", "address,undefined", COLLECT_SOURCES, defines=("SIFT_FAKE_WITH_REAL_LAUNCH_GUARD",))
+    assert "collect ok" in _run(exe, ["22"], 900)
