@@ -1305,7 +1305,7 @@ def test_library_before_torch_in_one_process(tmp_path):
         "assert c.total() == n and n > 0 and t == 28\n"
         "print('ok', n)\n"
     )
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
