@@ -92,15 +92,16 @@ def cpu_baseline(frames, faithful=True):
     faith = None
     if faithful:
         # bounded: the cost is O(candidates x pixels), a whole 1080p frame takes this mode 456 s on the MI355X box's EPYC 9575F
-        # (profiles/r02_bench_full.json; 19764 keypoints: 43 keypoints/s) — its top-left 480x270 sixteenth a few tens of seconds
+        # (profiles/r02_bench_full.json; 19764 keypoints: 43 keypoints/s) - its top-left 960x540 quarter ~25 s there (round 6; until
+        # round 5 the sample was the 480x270 sixteenth: 1.5 s, 750 - 800 keypoints/s, 18 x the whole frame's rate)
         h, w = frames[0].shape
-        crop = np.ascontiguousarray(frames[0][:h // 4, :w // 4])
+        crop = np.ascontiguousarray(frames[0][:h // 2, :w // 2])
         run = O.OracleRun(crop, DOGS, OCTAVES, SIGMA, faithful=True)
         n = run.points("final")[0].size
         faith = {"value": n / run.seconds, "unit": "keypoints/s", "cores": 1, "seconds": run.seconds, "keypoints": int(n),
-                 "sample": f"the top-left {w // 4}x{h // 4} sixteenth of frame 1, oracle in faithful mode (the reference's own cost structure: "
+                 "sample": f"the top-left {w // 2}x{h // 2} quarter of frame 1, oracle in faithful mode (the reference's own cost structure: "
                            "three DoG images copied per extremum candidate, a level re-blurred per keypoint), timed on this box; the cost "
-                           "grows with candidates x pixels, so a whole 1080p frame is several times slower per keypoint (measured once on "
+                           "grows with candidates x pixels, so a whole 1080p frame is still ~4 x slower per keypoint (measured once on "
                            "this box type: 456 s for frame 1, 43 keypoints/s, profiles/r02_bench_full.json)"}
         run.close()
     ref = None
