@@ -5,7 +5,8 @@ Not collected by `pytest tests/` (the file name does not match): a run takes as 
 the suite were chosen for the kernels' known boundaries; this draws the rest of the space - widths of every residue
 modulo 2 / 4 / 64 / 128, strips that end inside the image, chunks of odd row counts, levels close to the smallest the
 reference accepts, batches of 1 - 3.
-    python3 tests/soak_parity.py [seconds=600] [seed=1]
+    python3 tests/soak_parity.py [seconds=600] [seed=1] [big]
+("big": shapes 1000..4096 x 700..2200, batches of 1 - 6 - launches large enough to take the streaming kernels by themselves.)
 Prints one line per case and a summary; exits 1 if any case differed.
 """
 import os
@@ -24,6 +25,16 @@ from sift_amd import _lib                                  # noqa: E402
 from sift_amd.sift import Context                          # noqa: E402
 from sift_amd.synthetic import blob_frame, synth_frame     # noqa: E402
 from test_gpu_parity import compare_run                    # noqa: E402
+
+
+def draw_big(rng):
+    w = int(rng.integers(1000, 4097))
+    h = int(rng.integers(700, 2201))
+    if rng.random() < 0.5:
+        w = w // 4 * 4
+    frames = int(rng.choice([1, 2, 3, 4, 6])) if w * h < 3000 * 1000 else int(rng.choice([1, 2]))
+    return dict(w=w, h=h, dogs=int(rng.choice([3, 3, 4])), octaves=int(rng.integers(2, 6)), sigma=float(rng.choice([1.6, 1.6, 1.2])), subpixel=False,
+                frames=frames, streaming=0, blobs=False, seed=int(rng.integers(1, 1 << 20)))
 
 
 def draw(rng):
@@ -50,12 +61,13 @@ def draw(rng):
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"
     ctx = Context(0)
     report_dir = tempfile.mkdtemp(prefix="soak_")
     t_end = time.time() + budget
     done, failed, skipped = 0, [], 0
     while time.time() < t_end:
-        c = draw(rng)
+        c = draw_big(rng) if big else draw(rng)
         name = "soak %(w)dx%(h)d dogs %(dogs)d oct %(octaves)d sigma %(sigma)g sub %(subpixel)d x%(frames)d stream %(streaming)d blobs %(blobs)d seed %(seed)d" % c
         img = blob_frame(c["w"], c["h"], 3 + c["seed"] % 5) if c["blobs"] else synth_frame(c["w"], c["h"], c["seed"])
         ctx.set_option("stream_min_waves", 1 if c["streaming"] else 0)
